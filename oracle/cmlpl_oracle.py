@@ -1,0 +1,387 @@
+"""CPU oracle for the CMLPL training hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU (fp32) restatement of the reference's per-step
+training computation.  It is *the checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The shipped path (``cmlpl_amd``) never imports anything from ``oracle/`` and
+fails loudly when the HIP library is missing.
+
+Pinning: ``tests/golden/make_golden.py`` runs the *reference itself*
+(``/root/reference/tools/models.py:BaseNet2`` imported, ``train.py:150-279``
+text-exec'd on CPU) on closed-form seeded inputs and stores its outputs as
+small ``.npz`` fixtures; ``tests/test_oracle_golden.py`` checks this restatement
+against those fixtures.  Parity is therefore pinned by outputs of the reference
+run in the build container (the reference ships no tests or golden vectors of
+its own for this path -- SURVEY.md section 4).
+
+Reference lines restated (all under /root/reference/):
+  * BaseNet2.forward ............ tools/models.py:130-152 (Normalize :87-90)
+  * input augmentation .......... train.py:157-158,163-164,170-171,181-182
+  * supervised CE / accuracy .... train.py:191-194,278
+  * pseudo-label smoothing ...... train.py:203-219
+  * adaptive threshold .......... train.py:147-148,220-222,227-228
+  * memory bank update .......... train.py:138-145,223-237 (incl. the ptr1 quirk :237)
+  * mutual soft-target CE ....... train.py:239-242
+  * similarity softmax .......... train.py:243-247,257-258
+  * pseudo-label graph .......... train.py:249-256
+  * contrastive loss ............ train.py:260-265
+  * totals / backward / Adam .... train.py:131-132,266-272
+  * logged row .................. train.py:274-278
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FEAT_DIM = 1024          # tools/models.py:119 (n_fc1)
+CONV_CH = 64             # tools/models.py:102-107
+
+
+@dataclass(frozen=True)
+class NetShape:
+    """Shape parameters of one BaseNet2.
+
+    The reference hard-codes C=60 and a 2624-wide classifier
+    (tools/models.py:102,127), which only fits 20..23-pixel windows; the
+    generalisation derives both from (C, H, W).
+    """
+    C: int = 60          # input channels of conv0 (PCA components / bands)
+    H: int = 20          # window height
+    W: int = 20          # window width
+    bands: int = 103     # spectral vector length (num_features)
+    K: int = 9           # classes
+
+    @property
+    def H2(self): return self.H // 2          # AvgPool2d(2,2) floors (models.py:110)
+    @property
+    def W2(self): return self.W // 2
+    @property
+    def H4(self): return self.H2 // 2
+    @property
+    def W4(self): return self.W2 // 2
+    @property
+    def spatial_feat(self): return CONV_CH * self.H4 * self.W4
+    @property
+    def cls_in(self): return self.spatial_feat + FEAT_DIM
+
+
+@dataclass
+class HyperParams:
+    """Flags of train.py:356-379 plus the literals hard-coded in the step."""
+    lr: float = 5e-4             # train.py:365
+    num_epochs: int = 20         # train.py:366
+    thr: float = 1.0             # train.py:369
+    alpha: float = 0.95          # train.py:371
+    queue_batch: float = 17      # train.py:372
+    temperature: float = 0.3     # train.py:374
+    dropout: float = 0.8         # train.py:377
+    noise: float = 0.5           # train.py:378
+    w_contrast: float = 0.5      # literal, train.py:266,270
+    w_mutual: float = 4.0        # literal, train.py:266,270
+    pos_thr: float = 0.8         # literal, train.py:251
+    neg_thr: float = 0.3         # literal, train.py:254
+    bank_step: int = 256         # literal pointer advance, train.py:234,237
+    bank_mult: int = 5           # queue_size = 5 * labeled_batch_size * 2, train.py:138
+    beta1: float = 0.9           # torch.optim.Adam defaults (train.py:131)
+    beta2: float = 0.999
+    eps: float = 1e-8
+
+    def adap_thr(self, epoch: int) -> float:
+        # train.py:147-148  (numpy float64 scalar)
+        decay = epoch / self.num_epochs
+        return float(np.exp(-0.5 * (decay ** 2)))
+
+
+# --------------------------------------------------------------------------- #
+# parameters
+# --------------------------------------------------------------------------- #
+LIVE_KEYS = ("conv0.weight", "conv0.bias", "conv1.weight", "conv1.bias",
+             "conv2.weight", "conv2.bias", "feat_spe.weight", "feat_spe.bias",
+             "classifier.weight", "classifier.bias")
+
+
+def param_shapes(s: NetShape) -> "OrderedDict[str, tuple]":
+    """The 16 state_dict keys of BaseNet2 in registration order (models.py:98-128)."""
+    return OrderedDict([
+        ("conv0.weight", (CONV_CH, s.C, 1, 1)), ("conv0.bias", (CONV_CH,)),
+        ("conv1.weight", (CONV_CH, CONV_CH, 3, 3)), ("conv1.bias", (CONV_CH,)),
+        ("conv2.weight", (CONV_CH, CONV_CH, 3, 3)), ("conv2.bias", (CONV_CH,)),
+        ("feat_spe.weight", (FEAT_DIM, s.bands)), ("feat_spe.bias", (FEAT_DIM,)),
+        ("feat_ss.weight", (256, FEAT_DIM)), ("feat_ss.bias", (256,)),
+        ("feat_ss2.weight", (64, FEAT_DIM)), ("feat_ss2.bias", (64,)),
+        ("feat_ss3.weight", (64, 256)), ("feat_ss3.bias", (64,)),
+        ("classifier.weight", (s.K, s.cls_in)), ("classifier.bias", (s.K,)),
+    ])
+
+
+def closed_form_params(s: NetShape, seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic parameters from numpy PCG64 (no torch RNG, so fixtures do not
+    depend on the torch version).  Same distribution as torch's default init:
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = OrderedDict()
+    shapes = param_shapes(s)
+    for key, shp in shapes.items():
+        mod = key.split(".")[0]
+        wshape = shapes[mod + ".weight"]
+        fan_in = int(np.prod(wshape[1:]))
+        b = 1.0 / math.sqrt(fan_in)
+        out[key] = torch.from_numpy(rng.uniform(-b, b, size=shp).astype(np.float32))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# BaseNet2.forward  (tools/models.py:130-152)
+# --------------------------------------------------------------------------- #
+def l2norm(x: torch.Tensor) -> torch.Tensor:
+    # Normalize.forward, models.py:87-90 -- no epsilon (0/0 -> NaN is reference behaviour)
+    norm = x.pow(2).sum(1, keepdim=True).pow(0.5)
+    return x.div(norm)
+
+
+def basenet2_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor,
+                     dropmask: Optional[torch.Tensor] = None):
+    """x: [n,C,H,W], y: [n,bands].  ``dropmask`` is the explicit dropout
+    multiplier ([n, cls_in], values 0 or 1/(1-p)); None = eval / p==0.
+    Returns (logits [n,K], feat [n,1024])."""
+    x = F.conv2d(x, p["conv0.weight"], p["conv0.bias"])                    # :132
+    x_res = x
+    x = F.conv2d(x, p["conv1.weight"], p["conv1.bias"], padding=1)         # :134
+    x = F.relu(x + x_res)                                                   # :135
+    x = F.avg_pool2d(x, 2, 2)                                               # :136
+    x_res = x
+    x = F.conv2d(x, p["conv2.weight"], p["conv2.bias"], padding=1)         # :138
+    x = F.relu(x + x_res)                                                   # :139
+    x = F.avg_pool2d(x, 2, 2)                                               # :140
+    x = x.reshape(x.size(0), -1)                                            # :141
+    y = F.relu(F.linear(y, p["feat_spe.weight"], p["feat_spe.bias"]))      # :142-143
+    cat = torch.cat([x, y], 1)                                              # :144
+    feat = l2norm(y)                                                        # :145-146
+    if dropmask is not None:
+        cat = cat * dropmask                                                # :147-148
+    logits = F.linear(cat, p["classifier.weight"], p["classifier.bias"])   # :150
+    return logits, feat
+
+
+# --------------------------------------------------------------------------- #
+# training state
+# --------------------------------------------------------------------------- #
+@dataclass
+class AdamState:
+    m: Dict[str, torch.Tensor]
+    v: Dict[str, torch.Tensor]
+    t: int = 0
+
+
+@dataclass
+class StepState:
+    shape: NetShape
+    params: List[Dict[str, torch.Tensor]]            # [Base, Base1]
+    adam: List[AdamState]
+    bank_feats: List[torch.Tensor]                   # [queue_feats, queue_feats1]
+    bank_probs: List[torch.Tensor]                   # [queue_probs, queue_probs1]
+    ptr: List[int] = field(default_factory=lambda: [0, 0])
+
+    @staticmethod
+    def create(shape: NetShape, params0, params1, labeled_batch_size: int,
+               hp: Optional[HyperParams] = None) -> "StepState":
+        hp = hp or HyperParams()
+        q = hp.bank_mult * labeled_batch_size * 2                           # train.py:138,142
+        ps = [OrderedDict((k, v.clone()) for k, v in params0.items()),
+              OrderedDict((k, v.clone()) for k, v in params1.items())]
+        adam = [AdamState({k: torch.zeros_like(v) for k, v in pp.items() if k in LIVE_KEYS},
+                          {k: torch.zeros_like(v) for k, v in pp.items() if k in LIVE_KEYS})
+                for pp in ps]
+        return StepState(shape, ps, adam,
+                         [torch.zeros(q, FEAT_DIM), torch.zeros(q, FEAT_DIM)],   # :139,143
+                         [torch.zeros(q, shape.K), torch.zeros(q, shape.K)])     # :140,144
+
+
+def adam_update(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
+                t: int, hp: HyperParams) -> None:
+    """torch.optim.Adam single-tensor update (defaults: no amsgrad, no weight
+    decay), in place; ``t`` is the 1-based step count."""
+    m.lerp_(g, 1.0 - hp.beta1)
+    v.mul_(hp.beta2).addcmul_(g, g, value=1.0 - hp.beta2)
+    bc1 = 1.0 - hp.beta1 ** t
+    bc2 = 1.0 - hp.beta2 ** t
+    step_size = hp.lr / bc1
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(hp.eps)
+    p.addcdiv_(m, denom, value=-step_size)
+
+
+def bank_write(bank: torch.Tensor, ptr: int, rows: torch.Tensor) -> None:
+    """queue[ptr:ptr+n] = rows (train.py:232-236), written modulo the bank size
+    where the reference's slice-assign would raise (documented generalisation,
+    SURVEY.md section 8a A9); identical whenever ptr+n <= Q."""
+    q = bank.shape[0]
+    idx = (torch.arange(rows.shape[0]) + ptr) % q
+    bank[idx] = rows
+
+
+# --------------------------------------------------------------------------- #
+# the loss block (train.py:191-266), differentiable w.r.t. logits / feats
+# --------------------------------------------------------------------------- #
+def loss_block(z_s, f_s, z_w, f_w, Y, bt: int, bank_feats, bank_probs,
+               smooth: bool, adap_mask: float, hp: HyperParams):
+    """z_*: logits [n,K]; f_*: l2-normalised feats [n,1024] of Base (s) / Base1 (w);
+    rows [:bt] labelled, [bt:] unlabelled.  Returns a dict with the two total
+    losses (autograd-connected) and every intermediate the tests compare."""
+    K = z_s.shape[1]
+    T = hp.temperature
+    zL_s, zU_s = z_s[:bt], z_s[bt:]
+    zL_w, zU_w = z_w[:bt], z_w[bt:]
+    fL_s, fU_s = f_s[:bt], f_s[bt:]
+    fL_w, fU_w = f_w[:bt], f_w[bt:]
+    btu = zU_s.shape[0]
+
+    cls_s = F.cross_entropy(zL_s, Y)                                        # :191
+    cls_w = F.cross_entropy(zL_w, Y)                                        # :192
+    pred_w = zL_w.argmax(1)                                                 # :194
+    acc = (pred_w == Y).float().mean()                                      # :278
+
+    with torch.no_grad():
+        p_w = torch.softmax(zU_w.detach(), dim=1)                           # :203  ("probs")
+        p_w0 = p_w.clone()                                                  # :205
+        p_s = torch.softmax(zU_s.detach(), dim=1)                           # :209  ("probs1")
+        p_s0 = p_s.clone()                                                  # :210
+        if smooth:                                                          # :212
+            A = torch.exp(torch.mm(fU_w.detach(), bank_feats[0].t()) / T)   # :213
+            A = A / A.sum(1, keepdim=True)                                  # :214
+            p_w = hp.alpha * p_w + (1 - hp.alpha) * torch.mm(A, bank_probs[0])   # :215
+            A1 = torch.exp(torch.mm(fU_s.detach(), bank_feats[1].t()) / T)  # :217
+            A1 = A1 / A1.sum(1, keepdim=True)                               # :218
+            p_s = hp.alpha * p_s + (1 - hp.alpha) * torch.mm(A1, bank_probs[1])  # :219
+        mask_w = p_w.max(1)[0].ge(adap_mask).float()                        # :220-222 ("mask")
+        mask_s = p_s.max(1)[0].ge(adap_mask).float()                        # :227-228 ("masks")
+        onehot = torch.zeros(bt, K).scatter(1, Y.view(-1, 1), 1)            # :224
+        # rows written to the banks (:223,225,229,230): unlabelled feats of one net
+        # stacked on LABELLED feats of the OTHER net
+        bank0_rows = (torch.cat([fU_w.detach(), fL_s.detach()], 0), torch.cat([p_w0, onehot], 0))
+        bank1_rows = (torch.cat([fU_s.detach(), fL_w.detach()], 0), torch.cat([p_s0, onehot], 0))
+
+    con_s = (-(F.log_softmax(zU_s, dim=1) * p_w).sum(1) * mask_w).mean()    # :239,241
+    con_w = (-(F.log_softmax(zU_w, dim=1) * p_s).sum(1) * mask_s).mean()    # :240,242
+
+    sim = torch.exp(torch.mm(fU_s, fU_w.detach().t()) / T)                  # :246
+    P = sim / sim.sum(1, keepdim=True)                                      # :247
+    with torch.no_grad():
+        Q0 = torch.mm(p_s, p_w.t())                                         # :249
+        Q0.fill_diagonal_(1)                                                # :250
+        Q = Q0 * (Q0 >= hp.pos_thr).float()                                 # :251-252
+        Q = Q / Q.sum(1, keepdim=True)                                      # :253
+        Qn = (1 - Q0) * (Q0 <= hp.neg_thr).float()                          # :254-255
+        Qn = Qn / (Qn.sum(1, keepdim=True) + 1e-8)                          # :256
+    sim1 = torch.exp(torch.mm(fU_s.detach(), fU_w.t()) / T)                 # :257
+    P1 = sim1 / sim1.sum(1, keepdim=True)                                   # :258
+
+    ctr_s = (-(torch.log(P) * Q).sum(1)).mean() + ((torch.log(P + 1) * Qn).sum(1)).mean()     # :260-262
+    ctr_w = (-(torch.log(P1) * Q).sum(1)).mean() + ((torch.log(P1 + 1) * Qn).sum(1)).mean()   # :263-265
+
+    total_s = cls_s + hp.w_contrast * ctr_s + hp.w_mutual * con_s           # :266
+    total_w = cls_w + hp.w_contrast * ctr_w + hp.w_mutual * con_w           # :270
+    return dict(total_s=total_s, total_w=total_w, cls_s=cls_s, cls_w=cls_w,
+                con_s=con_s, con_w=con_w, ctr_s=ctr_s, ctr_w=ctr_w, acc=acc,
+                p_w=p_w, p_s=p_s, p_w0=p_w0, p_s0=p_s0, mask_w=mask_w, mask_s=mask_s,
+                Q=Q, Qn=Qn, P=P.detach(), bank0_rows=bank0_rows, bank1_rows=bank1_rows)
+
+
+# --------------------------------------------------------------------------- #
+# one training step  (train.py:150-278)
+# --------------------------------------------------------------------------- #
+def train_step(state: StepState, XPl, Xl, Y, XPu, Xu, noise: Sequence[torch.Tensor],
+               dropmask: Sequence[Optional[torch.Tensor]], epoch: int, batch_index: int,
+               hp: Optional[HyperParams] = None, apply_update: bool = True):
+    """``noise``: the 8 N(0,1) draws in reference order
+        [XPl->Base, Xl->Base, XPl->Base1, Xl->Base1, XPu->Base, Xu->Base, XPu->Base1, Xu->Base1]
+    (train.py:157,158,163,164,170,171,181,182).  ``dropmask``: per-network
+    explicit dropout multiplier [n, cls_in] (or None).  Mutates ``state``."""
+    hp = hp or HyperParams()
+    bt = XPl.shape[0]
+    btu = XPu.shape[0]
+    n = bt + btu
+    sg = hp.noise
+    XP_b_all = torch.cat([XPl + noise[0] * sg, XPu + noise[4] * sg], 0)     # :157,170,173
+    X_b_all = torch.cat([Xl + noise[1] * sg, Xu + noise[5] * sg], 0)        # :158,171,174
+    XP_e_all = torch.cat([XPl + noise[2] * sg, XPu + noise[6] * sg], 0)     # :163,181,183
+    X_e_all = torch.cat([Xl + noise[3] * sg, Xu + noise[7] * sg], 0)        # :164,182,184
+
+    ps = []
+    for net in range(2):
+        ps.append({k: (v.detach().clone().requires_grad_(True) if k in LIVE_KEYS else v)
+                   for k, v in state.params[net].items()})
+    z_s, f_s = basenet2_forward(ps[0], XP_b_all, X_b_all, dropmask[0])      # :175
+    z_w, f_w = basenet2_forward(ps[1], XP_e_all, X_e_all, dropmask[1])      # :185
+
+    smooth = (epoch > 0) or (batch_index > hp.queue_batch)                  # :212
+    adap_mask = hp.thr * hp.adap_thr(epoch)                                 # :221
+    lb = loss_block(z_s, f_s, z_w, f_w, Y, bt, state.bank_feats, state.bank_probs,
+                    smooth, adap_mask, hp)
+
+    # bank update happens after the smoothing read (:232-237)
+    bank_write(state.bank_feats[0], state.ptr[0], lb["bank0_rows"][0])      # :232
+    bank_write(state.bank_probs[0], state.ptr[0], lb["bank0_rows"][1])      # :233
+    q = state.bank_feats[0].shape[0]
+    new_ptr0 = (state.ptr[0] + hp.bank_step) % q                            # :234
+    bank_write(state.bank_feats[1], state.ptr[1], lb["bank1_rows"][0])      # :235
+    bank_write(state.bank_probs[1], state.ptr[1], lb["bank1_rows"][1])      # :236
+    new_ptr1 = (new_ptr0 + hp.bank_step) % q                                # :237 (uses queue_ptr!)
+    state.ptr = [new_ptr0, new_ptr1]
+
+    g_s = torch.autograd.grad(lb["total_s"], [ps[0][k] for k in LIVE_KEYS])    # :267
+    g_w = torch.autograd.grad(lb["total_w"], [ps[1][k] for k in LIVE_KEYS])    # :271
+    grads = [dict(zip(LIVE_KEYS, g_s)), dict(zip(LIVE_KEYS, g_w))]
+    if apply_update:
+        for net in range(2):                                                # :268,272
+            st = state.adam[net]
+            st.t += 1
+            for k in LIVE_KEYS:
+                adam_update(state.params[net][k], grads[net][k], st.m[k], st.v[k], st.t, hp)
+
+    out = dict(lb)
+    out.update(logits=[z_s.detach(), z_w.detach()], feats=[f_s.detach(), f_w.detach()],
+               grads=grads, smooth=smooth, adap_mask=adap_mask, n=n,
+               # loss_hist row, train.py:274-278
+               hist=[float(lb[k].detach()) for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc")])
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# deterministic synthetic batches (shared by fixtures, tests, bench)
+# --------------------------------------------------------------------------- #
+def synthetic_batch(shape: NetShape, bt: int, btu: int, seed: int, with_noise: bool = True,
+                    dropout: float = 0.8, separable: float = 0.0):
+    """Closed-form batch from numpy PCG64: XP, X ~ N(0,1) (real data is z-scored,
+    tools/hyper_tools.py:289-292), Y ~ U{0..K-1}, 8 noise draws, 2 dropout masks.
+    ``separable`` > 0 adds a class-dependent offset so predictions become peaky."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    XPl = rng.standard_normal((bt, shape.C, shape.H, shape.W))
+    Xl = rng.standard_normal((bt, shape.bands))
+    Y = rng.integers(0, shape.K, size=(bt,))
+    XPu = rng.standard_normal((btu, shape.C, shape.H, shape.W))
+    Xu = rng.standard_normal((btu, shape.bands))
+    if separable > 0:
+        Yu = rng.integers(0, shape.K, size=(btu,))
+        proto_p = rng.standard_normal((shape.K, shape.C, 1, 1)) * separable
+        proto_x = rng.standard_normal((shape.K, shape.bands)) * separable
+        XPl = XPl + proto_p[Y]; Xl = Xl + proto_x[Y]
+        XPu = XPu + proto_p[Yu]; Xu = Xu + proto_x[Yu]
+    out = dict(XPl=f32(XPl), Xl=f32(Xl), Y=torch.from_numpy(Y.astype(np.int64)),
+               XPu=f32(XPu), Xu=f32(Xu))
+    if with_noise:
+        shp = [XPl.shape, Xl.shape, XPl.shape, Xl.shape, XPu.shape, Xu.shape, XPu.shape, Xu.shape]
+        out["noise"] = [f32(rng.standard_normal(s)) for s in shp]
+        n = bt + btu
+        if dropout > 0:
+            keep = 1.0 - dropout
+            out["dropmask"] = [f32((rng.random((n, shape.cls_in)) < keep) / keep) for _ in range(2)]
+        else:
+            out["dropmask"] = [None, None]
+    return out

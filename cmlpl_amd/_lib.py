@@ -1,0 +1,130 @@
+"""ctypes binding of libcmlpl_hip.so (include/cmlpl.h).
+
+The HIP library is the product: there is no CPU fallback.  ``load()`` raises
+``CmlplLibraryError`` when the shared object is missing or does not export the
+full C ABI; every compute entry point raises on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcmlpl_hip.so")
+ABI_VERSION = 1
+NUM_TENSORS = 16
+NUM_LIVE = 10
+
+# state_dict keys of BaseNet2 in the order of the flat buffer (live tensors first)
+TENSOR_KEYS = (
+    "conv0.weight", "conv0.bias", "conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias",
+    "feat_spe.weight", "feat_spe.bias", "classifier.weight", "classifier.bias",
+    "feat_ss.weight", "feat_ss.bias", "feat_ss2.weight", "feat_ss2.bias", "feat_ss3.weight", "feat_ss3.bias",
+)
+
+EXPORTS = (
+    "cmlpl_abi_version", "cmlpl_layout", "cmlpl_workspace_bytes", "cmlpl_pack_weights", "cmlpl_augment",
+    "cmlpl_basenet2_fwd", "cmlpl_basenet2_bwd", "cmlpl_loss_fwd_bwd", "cmlpl_adam_step", "cmlpl_train_step",
+)
+
+
+class CmlplLibraryError(RuntimeError):
+    pass
+
+
+class CmlplError(RuntimeError):
+    def __init__(self, fn, rc):
+        names = {-1: "CMLPL_E_ARG", -2: "CMLPL_E_SHAPE", -3: "CMLPL_E_WORKSPACE"}
+        what = names.get(rc, f"hipError_t {rc}" if rc > 0 else str(rc))
+        super().__init__(f"{fn} failed: {what}")
+        self.rc = rc
+
+
+class Shape(C.Structure):
+    _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("bands", C.c_int32), ("K", C.c_int32)]
+
+
+class HParams(C.Structure):
+    _fields_ = [(k, C.c_float) for k in (
+        "lr", "beta1", "beta2", "eps", "temperature", "alpha", "noise_sigma", "dropout_p",
+        "w_contrast", "w_mutual", "pos_thr", "neg_thr")]
+
+
+class Layout(C.Structure):
+    _fields_ = [("param_off", C.c_int64 * NUM_TENSORS), ("param_numel", C.c_int64 * NUM_TENSORS),
+                ("param_total", C.c_int64), ("param_live", C.c_int64), ("packed_total", C.c_int64),
+                ("cls_in", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Banks(C.Structure):
+    _fields_ = [("d_feats", C.c_void_p * 2), ("d_probs", C.c_void_p * 2), ("Q", C.c_int32),
+                ("ptr", C.c_int32 * 2)]
+
+
+class StepIO(C.Structure):
+    _fields_ = [
+        ("d_xpl", C.c_void_p), ("d_xl", C.c_void_p), ("d_labels", C.c_void_p),
+        ("d_xpu", C.c_void_p), ("d_xu", C.c_void_p),
+        ("noise8", C.POINTER(C.c_void_p)), ("d_dropmask", C.c_void_p),
+        ("d_params", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_grads", C.c_void_p),
+        ("d_packed", C.c_void_p),
+        ("banks", Banks),
+        ("d_scalars", C.c_void_p), ("d_logits", C.c_void_p), ("d_feat", C.c_void_p),
+        ("d_workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("bt", C.c_int32), ("btu", C.c_int32), ("smooth", C.c_int32), ("adap_mask", C.c_float),
+        ("adam_t", C.c_int64), ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("apply_update", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load(path: str = LIB_PATH):
+    """Load the HIP library once; fail loudly if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise CmlplLibraryError(
+            f"{path} not found: build it with `python -m cmlpl_amd.build_ext` (hipcc, gfx950). "
+            "cmlpl_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise CmlplLibraryError(f"cannot load {path}: {e}") from e
+    missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise CmlplLibraryError(f"{path} does not export {missing}")
+    vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+    SP, HP = C.POINTER(Shape), C.POINTER(HParams)
+    lib.cmlpl_abi_version.restype = i32
+    lib.cmlpl_layout.argtypes = [SP, C.POINTER(Layout)]
+    lib.cmlpl_workspace_bytes.argtypes = [SP, i32, i32, i32]
+    lib.cmlpl_workspace_bytes.restype = sz
+    lib.cmlpl_pack_weights.argtypes = [SP, i32, vp, i64, vp, vp]
+    lib.cmlpl_augment.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp), f32, u64, u64, vp, vp, vp]
+    lib.cmlpl_basenet2_fwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, u64, u64, vp, vp, vp, sz, vp]
+    lib.cmlpl_basenet2_bwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, vp, vp, vp, i64, vp, sz, vp]
+    lib.cmlpl_loss_fwd_bwd.argtypes = [SP, i32, i32, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp,
+                                       vp, sz, vp]
+    lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
+    lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
+    for s in EXPORTS[1:]:
+        if s != "cmlpl_workspace_bytes":
+            getattr(lib, s).restype = i32
+    if lib.cmlpl_abi_version() != ABI_VERSION:
+        raise CmlplLibraryError(f"ABI version mismatch: library {lib.cmlpl_abi_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(fn: str, rc: int):
+    if rc != 0:
+        raise CmlplError(fn, rc)
+
+
+def layout(shape: Shape) -> Layout:
+    out = Layout()
+    check("cmlpl_layout", load().cmlpl_layout(C.byref(shape), C.byref(out)))
+    return out

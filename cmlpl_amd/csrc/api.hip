@@ -1,0 +1,297 @@
+// C-ABI entry points (include/cmlpl.h): argument checking, workspace carving and the launch
+// sequence of one training step.  No allocation, no synchronisation, graph-capturable.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/cmlpl.h"
+#include "kernels.hpp"
+
+using namespace cmlpl;
+
+namespace {
+
+inline int64_t up4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Dims {
+  int C, H, W, bands, K, HW, H2, W2, P2, H4, W4, P4, SF, F;
+};
+
+bool make_dims(const cmlpl_shape* s, Dims* d) {
+  if (!s) return false;
+  d->C = s->C; d->H = s->H; d->W = s->W; d->bands = s->bands; d->K = s->K;
+  if (d->C < 1 || d->C > 256 || d->H < 4 || d->W < 4 || d->bands < 1 || d->K < 1 || d->K > 64) return false;
+  d->HW = d->H * d->W; d->H2 = d->H / 2; d->W2 = d->W / 2; d->P2 = d->H2 * d->W2;
+  d->H4 = d->H2 / 2; d->W4 = d->W2 / 2; d->P4 = d->H4 * d->W4;
+  d->SF = 64 * d->P4; d->F = d->SF + 1024;
+  return d->P4 >= 1;
+}
+
+// workspace of the network forward/backward (all sizes in bytes, 256-B aligned regions)
+struct NetWs {
+  float *a0, *p1, *p2, *y, *ynorm, *catd, *dropgen, *dy, *dp2, *dp1, *da0, *part1, *part2, *part0;
+  uint8_t *m1, *m2;
+  size_t bytes;
+};
+
+bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up256(bytes); return p; };
+  const size_t N = (size_t)nets * n;
+  Wgrad3Plan w1, w2;
+  if (!plan_wgrad3(n, d.H, d.W, &w1) || !plan_wgrad3(n, d.H2, d.W2, &w2)) return false;
+  Conv3Plan c;
+  if (!plan_conv3(0, d.H, d.W, nets * n, &c) || !plan_conv3(1, d.H, d.W, nets * n, &c) ||
+      !plan_conv3(0, d.H2, d.W2, nets * n, &c) || !plan_conv3(1, d.H2, d.W2, nets * n, &c)) return false;
+  const int G0 = plan_conv0_wgrad_G(n, d.C, d.HW);
+  const int Ct = ((d.C + 31) / 32) * 32;
+  w->a0 = (float*)take(N * d.HW * 64 * 4);
+  w->p1 = (float*)take(N * d.P2 * 64 * 4);
+  w->m1 = (uint8_t*)take(N * d.P2 * 64);
+  w->p2 = (float*)take(N * d.P4 * 64 * 4);
+  w->m2 = (uint8_t*)take(N * d.P4 * 64);
+  w->y = (float*)take(N * 1024 * 4);
+  w->ynorm = (float*)take(N * 4);
+  w->catd = (float*)take(N * d.F * 4);
+  w->dropgen = (float*)take(N * d.F * 4);
+  w->dy = (float*)take(N * 1024 * 4);
+  w->dp2 = (float*)take(N * d.P4 * 64 * 4);
+  w->dp1 = (float*)take(N * d.P2 * 64 * 4);
+  w->da0 = (float*)take(N * d.HW * 64 * 4);
+  w->part1 = (float*)take((size_t)nets * w1.G * PART3 * 4);
+  w->part2 = (float*)take((size_t)nets * w2.G * PART3 * 4);
+  w->part0 = (float*)take((size_t)nets * G0 * ((size_t)Ct * 64 + 64) * 4);
+  w->bytes = off;
+  return true;
+}
+
+// extra regions used only by cmlpl_train_step / cmlpl_loss_fwd_bwd
+struct StepWs {
+  float *xn, *sn, *dlogits, *dfeat, *loss;
+  size_t bytes;
+};
+
+void carve_step(const Dims& d, int n, int bank_rows, char* base, StepWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up256(bytes); return p; };
+  w->xn = (float*)take((size_t)2 * n * d.C * d.HW * 4);
+  w->sn = (float*)take((size_t)2 * n * d.bands * 4);
+  w->dlogits = (float*)take((size_t)2 * n * d.K * 4);
+  w->dfeat = (float*)take((size_t)2 * n * 1024 * 4);
+  w->loss = (float*)take(loss_ws_floats(n, n, d.K, bank_rows > n ? bank_rows : n) * 4);
+  w->bytes = off;
+}
+
+int chk(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+}  // namespace
+
+extern "C" {
+
+int cmlpl_abi_version(void) { return CMLPL_ABI_VERSION; }
+
+int cmlpl_layout(const cmlpl_shape* shape, cmlpl_layout_t* out) {
+  Dims d;
+  if (!out) return CMLPL_E_ARG;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  const int64_t numel[CMLPL_NUM_TENSORS] = {
+      64LL * d.C, 64, 36864, 64, 36864, 64, 1024LL * d.bands, 1024, (int64_t)d.K * d.F, d.K,
+      256LL * 1024, 256, 64LL * 1024, 64, 64LL * 256, 64};
+  int64_t off = 0;
+  for (int i = 0; i < CMLPL_NUM_TENSORS; ++i) {
+    out->param_off[i] = off;
+    out->param_numel[i] = numel[i];
+    off = up4(off + numel[i]);
+    if (i == CMLPL_NUM_LIVE - 1) out->param_live = off;
+  }
+  out->param_total = off;
+  out->packed_total = PACK_PER_NET;
+  out->cls_in = d.F;
+  out->reserved = 0;
+  return 0;
+}
+
+size_t cmlpl_workspace_bytes(const cmlpl_shape* shape, int nets, int n, int bank_rows) {
+  Dims d;
+  if (!make_dims(shape, &d) || nets < 1 || nets > 2 || n < 1) return 0;
+  NetWs nw;
+  if (!carve_net(d, nets, n, nullptr, &nw)) return 0;
+  StepWs sw;
+  carve_step(d, n, bank_rows, nullptr, &sw);
+  return nw.bytes + sw.bytes + 256;
+}
+
+int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params, int64_t param_stride,
+                       float* d_packed, void* stream) {
+  cmlpl_layout_t L;
+  int rc = cmlpl_layout(shape, &L);
+  if (rc) return rc;
+  if (!d_params || !d_packed || nets < 1 || nets > 2) return CMLPL_E_ARG;
+  return chk(launch_pack_weights(nets, d_params, param_stride, L.param_off[2], L.param_off[4], d_packed,
+                                 (hipStream_t)stream));
+}
+
+int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const float* d_xpl, const float* d_xl,
+                  const float* d_xpu, const float* d_xu, const float* const* noise8, float sigma, uint64_t seed,
+                  uint64_t step, float* d_xn, float* d_sn, void* stream) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  if (nets < 1 || nets > 2 || bt < 0 || btu < 0 || bt + btu < 1 || !d_xn || !d_sn) return CMLPL_E_ARG;
+  if ((bt > 0 && (!d_xpl || !d_xl)) || (btu > 0 && (!d_xpu || !d_xu))) return CMLPL_E_ARG;
+  const long long e = (long long)d.C * d.HW;
+  return chk(launch_augment(nets, bt * e, btu * e, (long long)bt * d.bands, (long long)btu * d.bands, d_xpl, d_xl,
+                            d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn, (hipStream_t)stream));
+}
+
+int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
+                       const float* d_packed, const float* d_xn, const float* d_sn, const float* d_dropmask,
+                       float dropout_p, int train, uint64_t seed, uint64_t step, float* d_logits, float* d_feat,
+                       void* d_workspace, size_t workspace_bytes, void* stream) {
+  Dims d;
+  cmlpl_layout_t L;
+  if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
+  if (nets < 1 || nets > 2 || n < 1 || !d_params || !d_packed || !d_xn || !d_sn || !d_logits || !d_feat ||
+      !d_workspace)
+    return CMLPL_E_ARG;
+  if (dropout_p < 0.f || dropout_p >= 1.f) return CMLPL_E_ARG;
+  NetWs w;
+  if (!carve_net(d, nets, n, (char*)d_workspace, &w)) return CMLPL_E_SHAPE;
+  if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if ((rc = chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_params + L.param_off[0], d_params + L.param_off[1],
+                                 param_stride, w.a0, st)))) return rc;
+  if ((rc = chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV, PACK_PER_NET,
+                             d_params + L.param_off[3], param_stride, w.p1, w.m1, st)))) return rc;
+  if ((rc = chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + 2 * PACK_CONV, PACK_PER_NET,
+                             d_params + L.param_off[5], param_stride, w.p2, w.m2, st)))) return rc;
+  if ((rc = chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6], d_params + L.param_off[7],
+                               param_stride, w.y, st)))) return rc;
+  return chk(launch_head_fwd(nets, n, d.P4, d.K, w.p2, w.y, d_dropmask, w.dropgen, dropout_p, train, seed, step,
+                             d_params + L.param_off[8], d_params + L.param_off[9], param_stride, w.catd, w.ynorm,
+                             d_logits, d_feat, st));
+}
+
+int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
+                       const float* d_packed, const float* d_xn, const float* d_sn, const float* d_dropmask,
+                       float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
+                       int64_t grad_stride, void* d_workspace, size_t workspace_bytes, void* stream) {
+  Dims d;
+  cmlpl_layout_t L;
+  if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
+  if (nets < 1 || nets > 2 || n < 1 || !d_params || !d_packed || !d_xn || !d_sn || !d_dlogits || !d_grads ||
+      !d_workspace)
+    return CMLPL_E_ARG;
+  NetWs w;
+  if (!carve_net(d, nets, n, (char*)d_workspace, &w)) return CMLPL_E_SHAPE;
+  if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
+  int rc;
+  // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
+  if ((rc = chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask, d_params + L.param_off[8],
+                                param_stride, w.y, w.ynorm, w.dy, w.dp2, st)))) return rc;
+  GemmTN g;
+  // dW_cls[k][f] = sum_n dlogits[n][k] * catd[n][f] ; db_cls[k] = sum_n dlogits[n][k]
+  g.A = d_dlogits; g.a_bstride = (long long)n * d.K; g.lda = d.K; g.M = d.K;
+  g.B = w.catd; g.b_bstride = (long long)n * d.F; g.ldb = d.F; g.N = d.F;
+  g.C = d_grads + L.param_off[8]; g.c_bstride = grad_stride; g.ldc = d.F;
+  g.bias = d_grads + L.param_off[9]; g.bias_bstride = grad_stride;
+  g.R = n; g.batches = nets; g.scale = 1.f;
+  if ((rc = chk(launch_gemm_tn(g, st)))) return rc;
+  // dW_spe[o][b] = sum_n dy[n][o] * sn[n][b] ; db_spe[o] = sum_n dy[n][o]
+  g.A = w.dy; g.a_bstride = (long long)n * 1024; g.lda = 1024; g.M = 1024;
+  g.B = d_sn; g.b_bstride = (long long)n * d.bands; g.ldb = d.bands; g.N = d.bands;
+  g.C = d_grads + L.param_off[6]; g.ldc = d.bands;
+  g.bias = d_grads + L.param_off[7];
+  if ((rc = chk(launch_gemm_tn(g, st)))) return rc;
+  // spatial branch
+  if ((rc = chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + 3 * PACK_CONV, PACK_PER_NET, nullptr, 0,
+                             w.dp1, nullptr, st)))) return rc;
+  if ((rc = chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, d_grads + L.param_off[4],
+                              d_grads + L.param_off[5], grad_stride, st)))) return rc;
+  if ((rc = chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV, PACK_PER_NET, nullptr, 0,
+                             w.da0, nullptr, st)))) return rc;
+  if ((rc = chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, d_grads + L.param_off[2],
+                              d_grads + L.param_off[3], grad_stride, st)))) return rc;
+  return chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, d_grads + L.param_off[0],
+                                d_grads + L.param_off[1], grad_stride, st));
+}
+
+int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
+                       const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
+                       const cmlpl_hparams* hp, float* d_scalars, float* d_dlogits, float* d_dfeat,
+                       float* d_probs_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  if (bt < 1 || btu < 1 || btu > 2048 || !d_logits || !d_feat || !d_labels || !banks || !hp || !d_scalars ||
+      !d_dlogits || !d_dfeat || !d_workspace)
+    return CMLPL_E_ARG;
+  if (banks->Q < bt + btu || !banks->d_feats[0] || !banks->d_feats[1] || !banks->d_probs[0] || !banks->d_probs[1])
+    return CMLPL_E_ARG;
+  if (loss_ws_floats(bt, btu, d.K, banks->Q) * 4 > workspace_bytes) return CMLPL_E_WORKSPACE;
+  LossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.logits = d_logits; a.feat = d_feat; a.labels = d_labels;
+  for (int i = 0; i < 2; ++i) {
+    a.bank_f[i] = banks->d_feats[i]; a.bank_p[i] = banks->d_probs[i];
+    a.bank_fw[i] = banks->d_feats[i]; a.bank_pw[i] = banks->d_probs[i];
+  }
+  a.Q = banks->Q; a.ptr0 = ((banks->ptr[0] % a.Q) + a.Q) % a.Q; a.ptr1 = ((banks->ptr[1] % a.Q) + a.Q) % a.Q;
+  a.bt = bt; a.btu = btu; a.K = d.K; a.smooth = smooth;
+  a.adap_mask = adap_mask; a.T = hp->temperature; a.alpha = hp->alpha;
+  a.w_contrast = hp->w_contrast; a.w_mutual = hp->w_mutual; a.pos_thr = hp->pos_thr; a.neg_thr = hp->neg_thr;
+  a.scalars = d_scalars; a.dlogits = d_dlogits; a.dfeat = d_dfeat; a.probs_out = d_probs_out;
+  loss_ws_carve(a, (float*)d_workspace);
+  return chk(launch_loss(a, (hipStream_t)stream));
+}
+
+int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t param_stride,
+                    const float* d_grads, int64_t grad_stride, float* d_m, float* d_v, int64_t t,
+                    const cmlpl_hparams* hp, float* d_packed, void* stream) {
+  cmlpl_layout_t L;
+  int rc = cmlpl_layout(shape, &L);
+  if (rc) return rc;
+  if (nets < 1 || nets > 2 || !d_params || !d_grads || !d_m || !d_v || !hp || t < 1) return CMLPL_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = chk(launch_adam(nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v, L.param_live, t, hp->lr,
+                            hp->beta1, hp->beta2, hp->eps, st)))) return rc;
+  if (d_packed)
+    return chk(launch_pack_weights(nets, d_params, param_stride, L.param_off[2], L.param_off[4], d_packed, st));
+  return 0;
+}
+
+int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io, void* stream) {
+  Dims d;
+  cmlpl_layout_t L;
+  if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
+  if (!hp || !io || io->bt < 1 || io->btu < 1 || !io->d_workspace || !io->d_params || !io->d_grads ||
+      !io->d_packed || !io->d_logits || !io->d_feat || !io->d_scalars || !io->d_labels)
+    return CMLPL_E_ARG;
+  if (io->apply_update && (!io->d_m || !io->d_v)) return CMLPL_E_ARG;
+  const int n = io->bt + io->btu;
+  NetWs nw;
+  if (!carve_net(d, 2, n, (char*)io->d_workspace, &nw)) return CMLPL_E_SHAPE;
+  StepWs sw;
+  carve_step(d, n, io->banks.Q, (char*)io->d_workspace + nw.bytes, &sw);
+  if (nw.bytes + sw.bytes > io->workspace_bytes) return CMLPL_E_WORKSPACE;
+  const int train = 1;
+  int rc;
+  if ((rc = cmlpl_augment(shape, 2, io->bt, io->btu, io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->noise8,
+                          hp->noise_sigma, io->seed, io->step, sw.xn, sw.sn, stream))) return rc;
+  if ((rc = cmlpl_basenet2_fwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn,
+                               io->d_dropmask, hp->dropout_p, train, io->seed, io->step, io->d_logits, io->d_feat,
+                               io->d_workspace, nw.bytes, stream))) return rc;
+  if ((rc = cmlpl_loss_fwd_bwd(shape, io->bt, io->btu, io->d_logits, io->d_feat, io->d_labels, &io->banks,
+                               io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, nullptr, sw.loss,
+                               loss_ws_floats(n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream))) return rc;
+  if ((rc = cmlpl_basenet2_bwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn, io->d_dropmask,
+                               hp->dropout_p, train, sw.dlogits, sw.dfeat, io->d_grads, L.param_total,
+                               io->d_workspace, nw.bytes, stream))) return rc;
+  if (io->apply_update)
+    return cmlpl_adam_step(shape, 2, io->d_params, L.param_total, io->d_grads, L.param_total, io->d_m, io->d_v,
+                           io->adam_t, hp, io->d_packed, stream);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Shared device helpers for the CMLPL gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmlpl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH = 64;        // conv channels (tools/models.py:102-107)
+constexpr int FD = 1024;      // spectral feature width (tools/models.py:119)
+
+// v_mfma_f32_32x32x2_f32: exact fp32 (fmaf chain), 64 cycles/SIMD.
+//   A: lane l holds A[i = l&31][k = l>>5];  B: lane l holds B[k = l>>5][j = l&31]
+//   D: reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 32 lanes of each half-wave (lanes sharing l>>5)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct Philox {
+  static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  __device__ static __forceinline__ uint4 gen(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+      uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+      c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+      k.x += W0; k.y += W1;
+    }
+    return c;
+  }
+};
+// 4 standard normals from one Philox block (Box-Muller)
+__device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t step, uint32_t stream, uint64_t idx) {
+  uint4 c = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)step);
+  uint2 k = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
+  uint4 r = Philox::gen(c, k);
+  const float s = 2.3283064365386963e-10f;  // 2^-32
+  float u0 = ((float)r.x + 1.0f) * s, u1 = (float)r.y * s;
+  float u2 = ((float)r.z + 1.0f) * s, u3 = (float)r.w * s;
+  u0 = fminf(u0, 1.0f); u2 = fminf(u2, 1.0f);
+  float r0 = sqrtf(-2.0f * __logf(u0)), r1 = sqrtf(-2.0f * __logf(u2));
+  float s0, c0, s1, c1;
+  __sincosf(6.283185307179586f * u1, &s0, &c0);
+  __sincosf(6.283185307179586f * u3, &s1, &c1);
+  return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+}
+__device__ __forceinline__ float4 philox_uniform4(uint64_t seed, uint64_t step, uint32_t stream, uint64_t idx) {
+  uint4 c = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)step);
+  uint2 k = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
+  uint4 r = Philox::gen(c, k);
+  const float s = 2.3283064365386963e-10f;
+  return make_float4((float)r.x * s, (float)r.y * s, (float)r.z * s, (float)r.w * s);
+}
+
+constexpr uint32_t STREAM_NOISE_XP = 0x100;   // + net
+constexpr uint32_t STREAM_NOISE_X = 0x200;    // + net
+constexpr uint32_t STREAM_DROPOUT = 0x300;    // + net
+
+}  // namespace cmlpl

@@ -1,0 +1,490 @@
+// 3x3 / pad 1 / 64->64 convolutions of BaseNet2 (tools/models.py:104-107,134-140) as
+// LDS-staged implicit GEMMs on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   conv3x3_kernel<FWD>   : z = conv(in)+bias+in ; r = relu(z) ; out = avgpool2(r) ; mask = (r>0) nibble
+//                           (models.py:134-136 / 138-140, fused)
+//   conv3x3_kernel<DGRAD> : dz = mask * upsample(dpool)/4 (avgpool+relu backward, formed while staging)
+//                           out = conv_transpose(dz) + dz      (residual branch adds dz itself)
+//   wgrad3_kernel         : dW[s][ci][co] = sum_pix in[pix+s][ci] * dz[pix][co], db[co] = sum dz
+//
+// Data layout: activations are pixel-major / channel-last  [net][sample][pixel][64] so that
+// the 64 channels of a pixel are one 256-B line; the padded image of S samples sits in LDS
+// with a zero border, so the 9 taps are pure address offsets.  Weights are re-packed once per
+// step (pack_weights_kernel) to [tap][ci/4][co][4] so that both MFMA operands are ds_read_b128.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace cmlpl {
+
+constexpr int CS = 68;  // LDS pixel stride in floats (64 + 4): conflict-free ds_read_b128 over 16 pixels
+
+// ------------------------------------------------------------------------------------------
+// weight packing: canonical W[co][ci][kh][kw] ->
+//   fwd  : wf[s][q][co][r] = W[co][4q+r][kh][kw]            s = kh*3+kw
+//   dgrad: wd[s][q][ci][r] = W[4q+r][ci][2-kh][2-kw]        (transposed + flipped)
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ params, long long pstride, long long off_w1,
+                                    long long off_w2, float* __restrict__ packed) {
+  const int net = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 4*PACK_CONV
+  if (e >= PACK_PER_NET) return;
+  const int which = e / PACK_CONV;          // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
+  const int i = e - which * PACK_CONV;
+  const int r = i & 3, oc = (i >> 2) & 63, q = (i >> 8) & 15, s = i >> 12;
+  const int kh = s / 3, kw = s - kh * 3;
+  const float* W = params + (long long)net * pstride + ((which < 2) ? off_w1 : off_w2);
+  const int k = 4 * q + r;
+  float v;
+  if ((which & 1) == 0) v = W[((oc * 64 + k) * 3 + kh) * 3 + kw];                    // co=oc, ci=k
+  else                  v = W[((k * 64 + oc) * 3 + (2 - kh)) * 3 + (2 - kw)];        // co=k, ci=oc
+  packed[(long long)net * PACK_PER_NET + e] = v;
+}
+
+hipError_t launch_pack_weights(int nets, const float* params, long long pstride, long long off_w1,
+                               long long off_w2, float* packed, hipStream_t st) {
+  dim3 grid((PACK_PER_NET + 255) / 256, nets);
+  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, params, pstride, off_w1, off_w2, packed);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ------------------------------------------------------------------------------------------
+struct Conv3Args {
+  const float* in; const uint8_t* mask_in; const float* wpk; const float* bias;
+  float* out; uint8_t* mask_out;
+  long long in_ns, mask_in_ns, wpk_ns, bias_ns, out_ns, mask_out_ns;  // per-net strides (elements)
+  int n, H, W, S;
+};
+
+template <int MODE, int MTW>
+__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int net = blockIdx.y, s0 = blockIdx.x * a.S;
+  const int H = a.H, W = a.W, HW = H * W, PW = W + 2, IMG = (H + 2) * PW;
+  const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
+  const int RO = (MODE == 0) ? 2 * H2 : H, CO = (MODE == 0) ? 2 * W2 : W;
+  const int PX = RO * CO, S = a.S, npx = S * PX;
+  float* img = smem;                       // [S][IMG][CS]
+  float* wbuf = img + (size_t)S * IMG * CS;  // [16][64][4]
+  int* lut = (int*)(wbuf + 4096);          // [MTW*128] padded-image position of output pixel m
+
+  {  // zero the padded images (border must be zero; interior overwritten below)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* p = (float4*)img;
+    const int tot = S * IMG * (CS / 4);
+    for (int i = tid; i < tot; i += 256) p[i] = z;
+  }
+  for (int m = tid; m < MTW * 128; m += 256) {
+    const int mm = (m < npx) ? m : 0;
+    const int s = mm / PX, rem = mm - s * PX, r = rem / CO, c = rem - r * CO;
+    lut[m] = s * IMG + (r + 1) * PW + (c + 1);
+  }
+  const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
+  float4 wr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wr[r] = wg[tid + 256 * r];
+  __syncthreads();
+
+  if (MODE == 0) {
+    const float* src = a.in + (long long)net * a.in_ns;
+    const int tot = S * HW * 16;
+    for (int idx = tid; idx < tot; idx += 256) {
+      const int c4 = idx & 15, p = idx >> 4;
+      const int s = p / HW, pix = p - s * HW, h = pix / W, w = pix - h * W;
+      const int sample = s0 + s;
+      if (sample < a.n) {
+        const float4 v = *(const float4*)(src + ((size_t)sample * HW + pix) * 64 + c4 * 4);
+        *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+      }
+    }
+  } else {
+    const float* dp = a.in + (long long)net * a.in_ns;
+    const uint8_t* mk = a.mask_in + (long long)net * a.mask_in_ns;
+    const int tot = S * P2 * 64;
+    for (int idx = tid; idx < tot; idx += 256) {
+      const int c4 = idx & 15, sub = (idx >> 4) & 3, pp = idx >> 6;
+      const int s = pp / P2, q = pp - s * P2, ph = q / W2, pw = q - ph * W2;
+      const int sample = s0 + s;
+      if (sample < a.n) {
+        const size_t g = ((size_t)sample * P2 + q) * 64 + c4 * 4;
+        const float4 d = *(const float4*)(dp + g);
+        const uint32_t m4 = *(const uint32_t*)(mk + g);
+        float4 v;
+        v.x = ((m4 >> sub) & 1u) ? d.x * 0.25f : 0.f;
+        v.y = ((m4 >> (8 + sub)) & 1u) ? d.y * 0.25f : 0.f;
+        v.z = ((m4 >> (16 + sub)) & 1u) ? d.z * 0.25f : 0.f;
+        v.w = ((m4 >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
+        const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
+        *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+      }
+    }
+  }
+
+  const int MT = (npx + 31) >> 5;
+  int abase[MTW];
+  f32x16 acc[MTW][2];
+#pragma unroll
+  for (int t = 0; t < MTW; ++t) {
+    abase[t] = lut[(wave + 4 * t) * 32 + l31] * CS + 4 * hh;
+    acc[t][0] = zero16();
+    acc[t][1] = zero16();
+  }
+
+  for (int s = 0; s < 9; ++s) {
+    __syncthreads();  // everyone done with wbuf of tap s-1 (and, for s==0, the image is complete)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ((float4*)wbuf)[tid + 256 * r] = wr[r];
+    __syncthreads();
+    if (s + 1 < 9) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wr[r] = wg[(s + 1) * 1024 + tid + 256 * r];
+    }
+    const int kh = s / 3, kw = s - kh * 3;
+    const int shoff = ((kh - 1) * PW + (kw - 1)) * CS;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float4 b0 = *(const float4*)(wbuf + ((2 * kk + hh) * 64 + l31) * 4);
+      const float4 b1 = *(const float4*)(wbuf + ((2 * kk + hh) * 64 + 32 + l31) * 4);
+#pragma unroll
+      for (int t = 0; t < MTW; ++t) {
+        if (wave + 4 * t < MT) {  // wave-uniform
+          const float4 av = *(const float4*)(img + abase[t] + shoff + kk * 8);
+          acc[t][0] = mfma32(av.x, b0.x, acc[t][0]);
+          acc[t][1] = mfma32(av.x, b1.x, acc[t][1]);
+          acc[t][0] = mfma32(av.y, b0.y, acc[t][0]);
+          acc[t][1] = mfma32(av.y, b1.y, acc[t][1]);
+          acc[t][0] = mfma32(av.z, b0.z, acc[t][0]);
+          acc[t][1] = mfma32(av.z, b1.z, acc[t][1]);
+          acc[t][0] = mfma32(av.w, b0.w, acc[t][0]);
+          acc[t][1] = mfma32(av.w, b1.w, acc[t][1]);
+        }
+      }
+    }
+  }
+  __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
+
+  if (MODE == 0) {
+    const float* bias = a.bias + (long long)net * a.bias_ns;
+    const float bv0 = bias[l31], bv1 = bias[32 + l31];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < MT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = tile * 32 + acc_row(r, lane);
+          if (m < npx) {
+            float* p = img + (size_t)lut[m] * CS;
+            const float v0 = acc[t][0][r] + bv0 + p[l31];
+            const float v1 = acc[t][1][r] + bv1 + p[32 + l31];
+            p[l31] = fmaxf(v0, 0.f);
+            p[32 + l31] = fmaxf(v1, 0.f);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* out = a.out + (long long)net * a.out_ns;
+    uint8_t* mo = a.mask_out + (long long)net * a.mask_out_ns;
+    const int tot = S * P2 * 64;
+    for (int idx = tid; idx < tot; idx += 256) {
+      const int co = idx & 63, pp = idx >> 6;
+      const int s = pp / P2, q = pp - s * P2, ph = q / W2, pw = q - ph * W2;
+      const int sample = s0 + s;
+      if (sample < a.n) {
+        const float* p = img + (size_t)(s * IMG + (2 * ph + 1) * PW + 2 * pw + 1) * CS + co;
+        const float v00 = p[0], v01 = p[CS], v10 = p[PW * CS], v11 = p[PW * CS + CS];
+        const size_t g = ((size_t)sample * P2 + q) * 64 + co;
+        out[g] = (v00 + v01 + v10 + v11) * 0.25f;
+        mo[g] = (uint8_t)((v00 > 0.f ? 1 : 0) | (v01 > 0.f ? 2 : 0) | (v10 > 0.f ? 4 : 0) | (v11 > 0.f ? 8 : 0));
+      }
+    }
+  } else {
+    float* out = a.out + (long long)net * a.out_ns;
+    const int nvalid = (a.n - s0 < S ? a.n - s0 : S) * PX;  // rows that map to real samples
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < MT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = tile * 32 + acc_row(r, lane);
+          if (m < nvalid) {
+            const float* p = img + (size_t)lut[m] * CS;
+            float* o = out + ((size_t)s0 * HW + m) * 64;
+            o[l31] = acc[t][0][r] + p[l31];
+            o[32 + l31] = acc[t][1][r] + p[32 + l31];
+          }
+        }
+      }
+    }
+  }
+}
+
+static size_t conv3_lds(int S, int H, int W, int MTW) {
+  return ((size_t)S * (H + 2) * (W + 2) * CS + 4096 + (size_t)MTW * 128) * 4;
+}
+
+// Pick samples-per-workgroup S: maximise MFMA slot use subject to LDS, favouring grids >= 256 WGs.
+bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
+  const int PX = (mode == 0) ? (2 * (H / 2)) * (2 * (W / 2)) : H * W;
+  if (PX <= 0) return false;
+  double best = 1e30;
+  bool ok = false;
+  for (int S = 1; S <= 16; ++S) {
+    const int MT = (S * PX + 31) / 32, MTW = (MT + 3) / 4;
+    if (MTW > 4) break;
+    const size_t lds = conv3_lds(S, H, W, MTW);
+    if (lds > LDS_MAX) break;
+    const long long wgs = (rows + S - 1) / S;
+    const long long rounds = (wgs + 255) / 256;
+    const double cost = (double)rounds * (MTW + 0.35);   // tile-times per CU + fixed staging overhead
+    if (cost < best - 1e-9) { best = cost; p->S = S; p->MTW = MTW; p->lds = lds; ok = true; }
+  }
+  return ok;
+}
+
+template <int MODE, int MTW>
+static hipError_t launch_conv3_t(const Conv3Args& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<MODE, MTW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<MODE, MTW>), grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in, const uint8_t* mask_in,
+                        const float* wpk, long long wpk_ns, const float* bias, long long bias_ns,
+                        float* out, uint8_t* mask_out, hipStream_t st) {
+  Conv3Plan pl;
+  if (!plan_conv3(mode, H, W, nets * n, &pl)) return hipErrorInvalidValue;
+  const int HW = H * W, P2 = (H / 2) * (W / 2);
+  Conv3Args a;
+  a.in = in; a.mask_in = mask_in; a.wpk = wpk; a.bias = bias; a.out = out; a.mask_out = mask_out;
+  a.wpk_ns = wpk_ns; a.bias_ns = bias_ns;
+  if (mode == 0) { a.in_ns = (long long)n * HW * 64; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns; a.mask_in_ns = 0; }
+  else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
+  a.n = n; a.H = H; a.W = W; a.S = pl.S;
+  dim3 grid((n + pl.S - 1) / pl.S, nets);
+#define CMLPL_DISPATCH(M)                                                      \
+  switch (pl.MTW) {                                                            \
+    case 1: return launch_conv3_t<M, 1>(a, grid, pl.lds, st);                  \
+    case 2: return launch_conv3_t<M, 2>(a, grid, pl.lds, st);                  \
+    case 3: return launch_conv3_t<M, 3>(a, grid, pl.lds, st);                  \
+    default: return launch_conv3_t<M, 4>(a, grid, pl.lds, st);                 \
+  }
+  if (mode == 0) { CMLPL_DISPATCH(0) } else { CMLPL_DISPATCH(1) }
+#undef CMLPL_DISPATCH
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+struct Wgrad3Args {
+  const float* in; const float* dpool; const uint8_t* mask; float* part;
+  long long in_ns, dpool_ns, part_ns;
+  int n, H, W, RU, U, G;
+};
+
+__global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int net = blockIdx.y, g = blockIdx.x;
+  const int H = a.H, W = a.W, HW = H * W, PW = W + 2;
+  const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2, RO = 2 * H2, CO = 2 * W2;
+  const int RU = a.RU, U = a.U;
+  const int IMGU = (RU + 2) * PW;          // padded rows of one unit
+  const int DU = RU * CO;                  // dz slots per unit
+  const int D = U * DU;                    // dz slots per pass
+  const int UPS = (RO + RU - 1) / RU;      // units per sample
+  const int NU = a.n * UPS;
+  const int UPG = (NU + a.G - 1) / a.G;
+  const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
+
+  float* img = smem;                        // [U][IMGU][64]
+  float* dz = img + (size_t)U * IMGU * 64;  // [D+1][64]
+  int* lut = (int*)(dz + (size_t)(D + 1) * 64);  // [D+2]
+  float* red = (float*)(lut + ((D + 2 + 3) & ~3));  // [256]
+
+  for (int i = tid; i < U * IMGU * 64; i += 256) img[i] = 0.f;
+  for (int i = tid; i < 64; i += 256) dz[(size_t)D * 64 + i] = 0.f;
+  for (int d = tid; d < D + 2; d += 256) {
+    const int dd = (d < D) ? d : 0;
+    const int u = dd / DU, rem = dd - u * DU, r = rem / CO, c = rem - r * CO;
+    lut[d] = u * IMGU + (r + 1) * PW + (c + 1);
+  }
+  const float* src = a.in + (long long)net * a.in_ns;
+  const float* dp = a.dpool + (long long)net * a.dpool_ns;
+  const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
+
+  const int ct = wave & 1, it = wave >> 1;
+  f32x16 acc[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) acc[s] = zero16();
+  float dbacc = 0.f;
+  int shoff[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) shoff[s] = ((s / 3 - 1) * PW + (s % 3 - 1)) * 64;
+
+  for (int ub = ubeg; ub < uend; ub += U) {
+    __syncthreads();  // previous pass finished reading img/dz
+    // stage the input rows (row0-1 .. row0+RU) of each unit; rows outside the image are zero
+    {
+      const int tot = U * (RU + 2) * W * 16;
+      for (int idx = tid; idx < tot; idx += 256) {
+        const int c4 = idx & 15, p = idx >> 4;
+        const int u = p / ((RU + 2) * W), rem = p - u * (RU + 2) * W, ir = rem / W, w = rem - ir * W;
+        const int uid = ub + u;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (uid < uend) {
+          const int sample = uid / UPS, j = uid - sample * UPS;
+          const int row = j * RU - 1 + ir;
+          if (row >= 0 && row < H) v = *(const float4*)(src + ((size_t)sample * HW + row * W + w) * 64 + c4 * 4);
+        }
+        *(float4*)(img + (size_t)(u * IMGU + ir * PW + w + 1) * 64 + c4 * 4) = v;
+      }
+    }
+    // stage dz = mask * dpool / 4 for the unit's output rows
+    {
+      const int tot = D * 16;
+      for (int idx = tid; idx < tot; idx += 256) {
+        const int c4 = idx & 15, d = idx >> 4;
+        const int u = d / DU, rem = d - u * DU, r = rem / CO, c = rem - r * CO;
+        const int uid = ub + u;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (uid < uend) {
+          const int sample = uid / UPS, j = uid - sample * UPS;
+          const int row = j * RU + r;
+          if (row < RO) {
+            const size_t gi = ((size_t)sample * P2 + (row >> 1) * W2 + (c >> 1)) * 64 + c4 * 4;
+            const float4 dv = *(const float4*)(dp + gi);
+            const uint32_t m4 = *(const uint32_t*)(mk + gi);
+            const int sub = (row & 1) * 2 + (c & 1);
+            v.x = ((m4 >> sub) & 1u) ? dv.x * 0.25f : 0.f;
+            v.y = ((m4 >> (8 + sub)) & 1u) ? dv.y * 0.25f : 0.f;
+            v.z = ((m4 >> (16 + sub)) & 1u) ? dv.z * 0.25f : 0.f;
+            v.w = ((m4 >> (24 + sub)) & 1u) ? dv.w * 0.25f : 0.f;
+          }
+        }
+        *(float4*)(dz + (size_t)d * 64 + c4 * 4) = v;
+      }
+    }
+    __syncthreads();
+    {  // bias gradient: column sums of dz
+      const int co = tid & 63;
+      for (int d = tid >> 6; d < D; d += 4) dbacc += dz[(size_t)d * 64 + co];
+    }
+    const int pairs = (D + 1) >> 1;
+    const float* arow = img + it * 32 + l31;
+    const float* brow = dz + ct * 32 + l31;
+#pragma unroll 2
+    for (int t = 0; t < pairs; ++t) {
+      const int d = 2 * t + hh;
+      const int pos = lut[d] * 64;
+      const float b = brow[(size_t)d * 64];
+#pragma unroll
+      for (int s = 0; s < 9; ++s) acc[s] = mfma32(arow[pos + shoff[s]], b, acc[s]);
+    }
+  }
+
+  float* part = a.part + (long long)net * a.part_ns + (size_t)g * PART3;
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = it * 32 + acc_row(r, lane);
+      part[s * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r];
+    }
+  }
+  __syncthreads();
+  red[tid] = dbacc;
+  __syncthreads();
+  if (tid < 64) part[9 * 4096 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+}
+
+// sum the per-workgroup partials and scatter into the canonical [co][ci][kh][kw] gradient
+__global__ void wgrad3_reduce_kernel(const float* __restrict__ part, long long part_ns, int G,
+                                     float* __restrict__ dW, float* __restrict__ db, long long grad_ns) {
+  const int net = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= PART3) return;
+  const float* p = part + (long long)net * part_ns + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = 0;
+  for (; g + 3 < G; g += 4) {
+    s0 += p[(size_t)g * PART3];
+    s1 += p[(size_t)(g + 1) * PART3];
+    s2 += p[(size_t)(g + 2) * PART3];
+    s3 += p[(size_t)(g + 3) * PART3];
+  }
+  for (; g < G; ++g) s0 += p[(size_t)g * PART3];
+  const float sum = (s0 + s1) + (s2 + s3);
+  if (e < 9 * 4096) {
+    const int s = e >> 12, ci = (e >> 6) & 63, co = e & 63;
+    dW[(long long)net * grad_ns + co * 576 + ci * 9 + s] = sum;
+  } else {
+    db[(long long)net * grad_ns + (e - 9 * 4096)] = sum;
+  }
+}
+
+static size_t wgrad3_lds(int RU, int U, int W) {
+  const int PW = W + 2, CO = 2 * (W / 2);
+  const size_t D = (size_t)U * RU * CO;
+  return ((size_t)U * (RU + 2) * PW * 64 + (D + 1) * 64 + ((D + 2 + 3) & ~(size_t)3) + 256) * 4;
+}
+
+bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
+  const int RO = 2 * (H / 2);
+  if (RO <= 0) return false;
+  // rows per unit: the largest even divisor-friendly RU that fits with U = 1
+  int RU = 0;
+  for (int cand = RO; cand >= 2; cand -= 2) {
+    if (wgrad3_lds(cand, 1, W) > LDS_MAX) continue;
+    if (RU == 0) RU = cand;                       // largest that fits
+    if (RO % cand == 0) { RU = cand; break; }     // prefer an exact split
+  }
+  if (RU == 0) return false;
+  int U = 1;
+  while (U < 8 && wgrad3_lds(RU, U + 1, W) <= LDS_MAX) ++U;
+  const int UPS = (RO + RU - 1) / RU;
+  const long long NU = (long long)n * UPS;
+  // one pass per workgroup when that still fills the chip; never more workgroups than passes
+  long long G = (NU + U - 1) / U;
+  if (G > 256) G = 256;                            // per net; 2 nets -> 512 WGs
+  // keep the unit count per workgroup a multiple of U where possible
+  p->RU = RU; p->U = U; p->G = (int)G; p->lds = wgrad3_lds(RU, U, W);
+  return true;
+}
+
+hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
+                         float* part, float* dW, float* db, long long grad_ns, hipStream_t st) {
+  Wgrad3Plan pl;
+  if (!plan_wgrad3(n, H, W, &pl)) return hipErrorInvalidValue;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LDS_MAX);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  Wgrad3Args a;
+  a.in = in; a.dpool = dpool; a.mask = mask; a.part = part;
+  a.in_ns = (long long)n * H * W * 64;
+  a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
+  a.part_ns = (long long)pl.G * PART3;
+  a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G;
+  hipLaunchKernelGGL(wgrad3_kernel, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((PART3 + 255) / 256, nets), dim3(256), 0, st,
+                     (const float*)part, a.part_ns, pl.G, dW, db, grad_ns);
+  return hipGetLastError();
+}
+
+}  // namespace cmlpl

@@ -1,0 +1,86 @@
+// Host-side launcher declarations (one per kernel family).  All launchers are
+// asynchronous on `st` and return hipError_t (hipSuccess = 0).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace cmlpl {
+
+constexpr int PACK_CONV = 9 * 64 * 64;       // one packed 3x3 weight set
+constexpr int PACK_PER_NET = 4 * PACK_CONV;  // conv1 fwd, conv1 dgrad, conv2 fwd, conv2 dgrad
+constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci][co] + db[co]
+constexpr size_t LDS_MAX = 160 * 1024;
+
+// ---- augment.hip
+hipError_t launch_augment(int nets, long long nl_xp, long long nu_xp, long long nl_x, long long nu_x,
+                          const float* xpl, const float* xl, const float* xpu, const float* xu,
+                          const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
+                          float* xn, float* sn, hipStream_t st);
+
+// ---- conv3x3.hip
+hipError_t launch_pack_weights(int nets, const float* params, long long pstride, long long off_w1,
+                               long long off_w2, float* packed, hipStream_t st);
+struct Conv3Plan { int S, MTW; size_t lds; };
+bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p);
+// mode 0: out = avgpool2(relu(conv(in)+bias+in)), mask_out = relu bits; in [nets][n][H*W][64]
+// mode 1: in = dpool [nets][n][(H/2)*(W/2)][64] + mask_in; out = dgrad(dz) + dz, [nets][n][H*W][64]
+hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in, const uint8_t* mask_in,
+                        const float* wpk, long long wpk_nstride, const float* bias, long long bias_nstride,
+                        float* out, uint8_t* mask_out, hipStream_t st);
+struct Wgrad3Plan { int RU, U, G; size_t lds; };
+bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p);
+hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
+                         float* part, float* dW, float* db, long long grad_nstride, hipStream_t st);
+
+// ---- conv0.hip
+hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w, const float* b,
+                            long long pstride, float* a0, hipStream_t st);
+int plan_conv0_wgrad_G(int n, int C, int HW);
+hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
+                              float* dW, float* db, long long grad_nstride, hipStream_t st);
+
+// ---- dense.hip
+hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const float* w, const float* b,
+                          long long pstride, float* y, hipStream_t st);
+// C[b][i][j] = scale * sum_r A[b][r][i] * B[b][r][j]  (+ optional colsum of A into bias[b][i])
+struct GemmTN {
+  const float* A; const float* B; float* C; float* bias;
+  long long a_bstride, b_bstride, c_bstride, bias_bstride;
+  int lda, ldb, ldc, M, N, R, batches;
+  float scale;
+};
+hipError_t launch_gemm_tn(const GemmTN& g, hipStream_t st);
+
+// ---- head.hip
+hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, const float* y, const float* dropmask,
+                           float* dropgen, float dropout_p, int train, uint64_t seed, uint64_t step,
+                           const float* wc, const float* bc, long long pstride,
+                           float* catd, float* ynorm, float* logits, float* feat, hipStream_t st);
+hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits, const float* dfeat,
+                           const float* dropmask, const float* wc, long long pstride,
+                           const float* y, const float* ynorm,
+                           float* dy, float* dp2, hipStream_t st);
+
+// ---- loss.hip
+struct LossArgs {
+  const float* logits; const float* feat; const int64_t* labels;   // [2][n][K], [2][n][1024]
+  const float* bank_f[2]; const float* bank_p[2];
+  float* bank_fw[2]; float* bank_pw[2];
+  int Q, ptr0, ptr1;
+  int bt, btu, K, smooth;
+  float adap_mask, T, alpha, w_contrast, w_mutual, pos_thr, neg_thr;
+  float* scalars; float* dlogits; float* dfeat; float* probs_out;
+  // workspace
+  float* rs_part; float* ep_part; float* Smat; float* G; float* GT; float* probs; float* masks; float* rowloss;
+};
+size_t loss_ws_floats(int bt, int btu, int K, int Q);
+void loss_ws_carve(LossArgs& a, float* ws);
+hipError_t launch_loss(const LossArgs& a, hipStream_t st);
+
+// ---- optim.hip
+hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
+                       float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
+                       hipStream_t st);
+
+}  // namespace cmlpl

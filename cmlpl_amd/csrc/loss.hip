@@ -1,0 +1,356 @@
+// The loss block of the CMLPL step (train.py:191-266), forward + analytic backward, and the
+// memory-bank write (train.py:223-237).  Five launches:
+//   pair_exp_kernel   : exp(f_a . f_b^T / T) tiles on the fp32 MFMA for the three products
+//                       fU_w x bank0 (train.py:213), fU_s x bank1 (:217), fU_s x fU_w (:246,257);
+//                       bank tiles are reduced on the fly to row sums and E.bank_probs partials
+//                       (the [btu,Q] similarity matrix is never materialised)
+//   loss_rows_kernel  : one wavefront per sample, lanes = classes: CE (:191-194), softmax (:203,209),
+//                       smoothing (:214-219), threshold masks (:220-228), mutual soft-CE (:239-242)
+//                       and d/dlogits of all of it
+//   graph_loss_kernel : one wavefront per unlabelled row: similarity softmax denominator by
+//                       wavefront shuffles (:247), pseudo-label graph Q/Qn (:249-256), contrastive
+//                       loss (:260-265) and dL/d(sim logits) -> G, G^T
+//   finalize_kernel   : bank write (modulo Q) + the logged scalars (:266,270,274-278)
+//   gemm_tn           : dfeat = G^T.f_w / G.f_s  (autograd of :246 / :257)
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace cmlpl {
+
+enum { RL_CLS_S = 0, RL_CLS_W, RL_ACC, RL_CON_S, RL_CON_W, RL_CTR, RL_NPOS, RL_NNEG, RL_COUNT };
+
+size_t loss_ws_floats(int bt, int btu, int K, int Q) {
+  const size_t CT = (Q + 31) / 32, RL = (size_t)(bt > btu ? bt : btu);
+  size_t f = 0;
+  f += 2 * CT * btu;              // rs_part
+  f += 2 * CT * btu * K;          // ep_part
+  f += 3 * (size_t)btu * btu;     // Smat, GT, G
+  f += 4 * (size_t)btu * K;       // probs
+  f += 2 * (size_t)btu;           // masks
+  f += RL_COUNT * RL;             // rowloss
+  return (f + 63) & ~(size_t)63;
+}
+
+void loss_ws_carve(LossArgs& a, float* ws) {
+  const size_t CT = (a.Q + 31) / 32, RL = (size_t)(a.bt > a.btu ? a.bt : a.btu);
+  const size_t btu = a.btu;
+  a.rs_part = ws; ws += 2 * CT * btu;
+  a.ep_part = ws; ws += 2 * CT * btu * a.K;
+  a.Smat = ws; ws += btu * btu;
+  a.GT = ws; ws += btu * btu;
+  a.G = ws; ws += btu * btu;
+  a.probs = ws; ws += 4 * btu * a.K;
+  a.masks = ws; ws += 2 * btu;
+  a.rowloss = ws; ws += RL_COUNT * RL;
+}
+
+constexpr int PS = 68;  // LDS row stride of the 64-deep k-chunk (64 + 4)
+
+__global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[32 * PS];
+  __shared__ __attribute__((aligned(16))) float Bs[128 * PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int prob = blockIdx.z;
+  if (prob < 2 && !a.smooth) return;
+  const int n = a.bt + a.btu, btu = a.btu, K = a.K;
+  const float* fU_s = a.feat + (long long)a.bt * FD;
+  const float* fU_w = a.feat + ((long long)n + a.bt) * FD;
+  const float* A = (prob == 0) ? fU_w : fU_s;
+  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : fU_w;
+  const int NB = (prob < 2) ? a.Q : btu;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 128;
+  if (c0 >= NB || r0 >= btu) return;
+  f32x16 acc = zero16();
+  for (int d0 = 0; d0 < FD; d0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = tid + 256 * q, row = idx >> 4, c4 = idx & 15;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < btu) v = *(const float4*)(A + (long long)(r0 + row) * FD + d0 + c4 * 4);
+      *(float4*)(As + row * PS + c4 * 4) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = tid + 256 * q, row = idx >> 4, c4 = idx & 15;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + row < NB) v = *(const float4*)(B + (long long)(c0 + row) * FD + d0 + c4 * 4);
+      *(float4*)(Bs + row * PS + c4 * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 av = *(const float4*)(As + l31 * PS + q * 8 + hh * 4);
+      const float4 bv = *(const float4*)(Bs + (wave * 32 + l31) * PS + q * 8 + hh * 4);
+      acc = mfma32(av.x, bv.x, acc);
+      acc = mfma32(av.y, bv.y, acc);
+      acc = mfma32(av.z, bv.z, acc);
+      acc = mfma32(av.w, bv.w, acc);
+    }
+  }
+  const int j = c0 + wave * 32 + l31;
+  const bool jv = j < NB;
+  if (c0 + wave * 32 >= NB) return;  // whole wave tile out of range (no further block sync)
+  float e[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e[r] = jv ? expf(acc[r] / a.T) : 0.f;
+  if (prob == 2) {
+    if (jv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = r0 + acc_row(r, lane);
+        if (i < btu) a.Smat[(long long)i * btu + j] = e[r];
+      }
+    }
+    return;
+  }
+  const int CT = (a.Q + 31) >> 5, ctile = (c0 >> 5) + wave;
+  float* rs = a.rs_part + ((long long)prob * CT + ctile) * btu;
+  float* ep = a.ep_part + ((long long)prob * CT + ctile) * btu * K;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float s = half_sum(e[r]);
+    const int i = r0 + acc_row(r, lane);
+    if (l31 == 0 && i < btu) rs[i] = s;
+  }
+  const float* bp = a.bank_p[prob] + (long long)(jv ? j : 0) * K;
+  for (int k = 0; k < K; ++k) {
+    const float pv = jv ? bp[k] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float s = half_sum(e[r] * pv);
+      const int i = r0 + acc_row(r, lane);
+      if (l31 == 0 && i < btu) ep[(long long)i * K + k] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int idx = blockIdx.x * 4 + wave;
+  const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K;
+  if (idx >= n) return;
+  const int RL = bt > btu ? bt : btu;
+  const bool kv = lane < K;
+  const float NEG = -3.0e38f;
+  if (idx < bt) {
+    const int i = idx;
+    const int yl = (int)a.labels[i];
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+      const float z = kv ? a.logits[((long long)net * n + i) * K + lane] : NEG;
+      const float mx = wave_max(z);
+      const float ez = kv ? expf(z - mx) : 0.f;
+      const float se = wave_sum(ez);
+      const float lse = mx + logf(se);
+      const float zy = __shfl(z, yl, 64);
+      if (kv) a.dlogits[((long long)net * n + i) * K + lane] = (ez / se - (lane == yl ? 1.f : 0.f)) / (float)bt;
+      if (lane == 0) a.rowloss[(net == 0 ? RL_CLS_S : RL_CLS_W) * RL + i] = lse - zy;
+      if (net == 1) {  // torch.max(labeled_output1, 1): first index of the maximum (train.py:194)
+        const unsigned long long bal = __ballot(kv && z == mx);
+        const int amax = __ffsll((long long)bal) - 1;
+        if (lane == 0) a.rowloss[RL_ACC * RL + i] = (amax == yl) ? 1.f : 0.f;
+      }
+    }
+    return;
+  }
+  const int i = idx - bt;
+  const float zs = kv ? a.logits[((long long)bt + i) * K + lane] : NEG;
+  const float zw = kv ? a.logits[((long long)n + bt + i) * K + lane] : NEG;
+  const float mxs = wave_max(zs), mxw = wave_max(zw);
+  const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
+  const float ses = wave_sum(es), sew = wave_sum(ew);
+  const float sms = es / ses, smw = ew / sew;            // softmax
+  const float lsms = zs - mxs - logf(ses), lsmw = zw - mxw - logf(sew);  // log_softmax
+  float pw = smw, ps = sms;                              // "probs" (Base1) / "probs1" (Base)
+  if (a.smooth) {
+    const int CT = (a.Q + 31) >> 5;
+    float rsw = 0.f, rss = 0.f;
+    for (int ct = lane; ct < CT; ct += 64) {
+      rsw += a.rs_part[((long long)0 * CT + ct) * btu + i];
+      rss += a.rs_part[((long long)1 * CT + ct) * btu + i];
+    }
+    rsw = wave_sum(rsw); rss = wave_sum(rss);
+    float epw = 0.f, eps_ = 0.f;
+    if (kv) {
+      for (int ct = 0; ct < CT; ++ct) {
+        epw += a.ep_part[(((long long)0 * CT + ct) * btu + i) * K + lane];
+        eps_ += a.ep_part[(((long long)1 * CT + ct) * btu + i) * K + lane];
+      }
+    }
+    pw = a.alpha * smw + (1.f - a.alpha) * (epw / rsw);
+    ps = a.alpha * sms + (1.f - a.alpha) * (eps_ / rss);
+  }
+  const float mw = (wave_max(kv ? pw : NEG) >= a.adap_mask) ? 1.f : 0.f;   // "mask"  (train.py:222)
+  const float ms = (wave_max(kv ? ps : NEG) >= a.adap_mask) ? 1.f : 0.f;   // "masks" (train.py:228)
+  const float spw = wave_sum(kv ? pw : 0.f), sps = wave_sum(kv ? ps : 0.f);
+  const float cs = -wave_sum(kv ? lsms * pw : 0.f) * mw;   // train.py:239
+  const float cw = -wave_sum(kv ? lsmw * ps : 0.f) * ms;   // train.py:240
+  if (kv) {
+    const float scale = a.w_mutual / (float)btu;
+    a.dlogits[((long long)bt + i) * K + lane] = scale * mw * (sms * spw - pw);
+    a.dlogits[((long long)n + bt + i) * K + lane] = scale * ms * (smw * sps - ps);
+    a.probs[((long long)0 * btu + i) * K + lane] = pw;
+    a.probs[((long long)1 * btu + i) * K + lane] = ps;
+    a.probs[((long long)2 * btu + i) * K + lane] = smw;
+    a.probs[((long long)3 * btu + i) * K + lane] = sms;
+    if (a.probs_out != nullptr) {
+      a.probs_out[((long long)0 * btu + i) * K + lane] = pw;
+      a.probs_out[((long long)1 * btu + i) * K + lane] = ps;
+      a.probs_out[((long long)2 * btu + i) * K + lane] = smw;
+      a.probs_out[((long long)3 * btu + i) * K + lane] = sms;
+    }
+  }
+  if (lane == 0) {
+    a.masks[i] = mw;
+    a.masks[btu + i] = ms;
+    a.rowloss[RL_CON_S * RL + i] = cs;
+    a.rowloss[RL_CON_W * RL + i] = cw;
+  }
+}
+
+__global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // per wave: gq[btu], pp[btu]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int btu = a.btu, K = a.K, i = blockIdx.x * 4 + wave;
+  if (i >= btu) return;
+  const int RL = a.bt > btu ? a.bt : btu;
+  float* gq = smem + (size_t)wave * 2 * btu;
+  float* pp = gq + btu;
+  const float* pw = a.probs;                              // smoothed p_w  ("probs")
+  const float* psi = a.probs + ((long long)btu + i) * K;  // smoothed p_s  ("probs1"), row i
+  const float* Srow = a.Smat + (long long)i * btu;
+  float sQ = 0.f, sN = 0.f, R = 0.f, npos = 0.f, nneg = 0.f;
+  for (int j = lane; j < btu; j += 64) {
+    float q0 = 0.f;
+    for (int k = 0; k < K; ++k) q0 = fmaf(psi[k], pw[(long long)j * K + k], q0);   // train.py:249
+    if (j == i) q0 = 1.f;                                                           // :250
+    const bool isp = q0 >= a.pos_thr, isn = q0 <= a.neg_thr;                        // :251,254
+    const float pos = isp ? q0 : 0.f, neg = isn ? (1.f - q0) : 0.f;
+    sQ += pos; sN += neg; R += Srow[j];
+    npos += isp ? 1.f : 0.f; nneg += isn ? 1.f : 0.f;
+    gq[j] = pos; pp[j] = neg;
+  }
+  sQ = wave_sum(sQ); sN = wave_sum(sN); R = wave_sum(R);
+  npos = wave_sum(npos); nneg = wave_sum(nneg);
+  __builtin_amdgcn_wave_barrier();
+  float lp = 0.f, ln = 0.f, gp = 0.f;
+  const float inv_btu = 1.f / (float)btu;
+  for (int j = lane; j < btu; j += 64) {
+    const float P = Srow[j] / R;                    // sim_probs (:247)
+    const float Qv = gq[j] / sQ;                    // :253
+    const float Qn = pp[j] / (sN + 1e-8f);          // :256
+    lp -= logf(P) * Qv;                             // :260
+    ln += logf(P + 1.f) * Qn;                       // :261
+    const float g = (-Qv / P + Qn / (1.f + P)) * inv_btu;   // dL/dP_ij
+    gp = fmaf(g, P, gp);
+    gq[j] = g; pp[j] = P;
+  }
+  lp = wave_sum(lp); ln = wave_sum(ln); gp = wave_sum(gp);
+  __builtin_amdgcn_wave_barrier();
+  const float scale = a.w_contrast / a.T;
+  for (int j = lane; j < btu; j += 64) {
+    const float Gij = pp[j] * (gq[j] - gp) * scale;   // softmax backward, then d(sim)/d(f.f/T)
+    a.G[(long long)i * btu + j] = Gij;
+    a.GT[(long long)j * btu + i] = Gij;
+  }
+  if (lane == 0) {
+    a.rowloss[RL_CTR * RL + i] = lp + ln;
+    a.rowloss[RL_NPOS * RL + i] = npos;
+    a.rowloss[RL_NNEG * RL + i] = nneg;
+  }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(LossArgs a) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K, Q = a.Q;
+  const int r = blockIdx.x;
+  if (r < n) {
+    // bank0 <- [fU_w ; fL_s], [p_w0 ; onehot]   bank1 <- [fU_s ; fL_w], [p_s0 ; onehot]   (train.py:223-236)
+    const int d0 = (a.ptr0 + r) % Q, d1 = (a.ptr1 + r) % Q;
+    const float *s0, *s1;
+    if (r < btu) { s0 = a.feat + ((long long)n + bt + r) * FD; s1 = a.feat + ((long long)bt + r) * FD; }
+    else         { s0 = a.feat + (long long)(r - btu) * FD;    s1 = a.feat + ((long long)n + r - btu) * FD; }
+    const float4 v0 = ((const float4*)s0)[tid], v1 = ((const float4*)s1)[tid];
+    ((float4*)(a.bank_fw[0] + (long long)d0 * FD))[tid] = v0;
+    ((float4*)(a.bank_fw[1] + (long long)d1 * FD))[tid] = v1;
+    if (tid < K) {
+      float q0, q1;
+      if (r < btu) { q0 = a.probs[((long long)2 * btu + r) * K + tid]; q1 = a.probs[((long long)3 * btu + r) * K + tid]; }
+      else { const int yl = (int)a.labels[r - btu]; q0 = q1 = (tid == yl) ? 1.f : 0.f; }
+      a.bank_pw[0][(long long)d0 * K + tid] = q0;
+      a.bank_pw[1][(long long)d1 * K + tid] = q1;
+    }
+    return;
+  }
+  const int RL = bt > btu ? bt : btu;
+  float v[RL_COUNT];
+#pragma unroll
+  for (int q = 0; q < RL_COUNT; ++q) {
+    const int cnt = (q <= RL_ACC) ? bt : btu;
+    float s = 0.f;
+    for (int i = tid; i < cnt; i += 256) s += a.rowloss[q * RL + i];
+    v[q] = block_sum(s, red, tid);
+  }
+  float mws = 0.f, mss = 0.f;
+  for (int i = tid; i < btu; i += 256) { mws += a.masks[i]; mss += a.masks[btu + i]; }
+  mws = block_sum(mws, red, tid);
+  mss = block_sum(mss, red, tid);
+  if (tid == 0) {
+    const float cls_s = v[RL_CLS_S] / bt, cls_w = v[RL_CLS_W] / bt, acc = v[RL_ACC] / bt;
+    const float con_s = v[RL_CON_S] / btu, con_w = v[RL_CON_W] / btu, ctr = v[RL_CTR] / btu;
+    float* o = a.scalars;
+    o[0] = ctr;                                              // loss_contrast  (train.py:274)
+    o[1] = cls_s + a.w_contrast * ctr + a.w_mutual * con_s;  // total_loss     (:266,275)
+    o[2] = cls_s;                                            // (:276)
+    o[3] = con_s;                                            // (:277)
+    o[4] = acc;                                              // (:278)
+    o[5] = cls_w + a.w_contrast * ctr + a.w_mutual * con_w;  // total_loss1    (:270)
+    o[6] = cls_w; o[7] = con_w; o[8] = ctr;                  // loss_contrast1 == loss_contrast numerically
+    o[9] = mws; o[10] = mss; o[11] = v[RL_NPOS]; o[12] = v[RL_NNEG];
+    o[13] = 0.f; o[14] = 0.f; o[15] = 0.f;
+  }
+}
+
+hipError_t launch_loss(const LossArgs& a, hipStream_t st) {
+  const int bt = a.bt, btu = a.btu, n = bt + btu;
+  hipError_t e;
+  // labelled rows carry no feature gradient (they only enter the banks)
+  if (bt > 0) {
+    e = hipMemsetAsync(a.dfeat, 0, (size_t)bt * FD * 4, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.dfeat + (long long)n * FD, 0, (size_t)bt * FD * 4, st);
+    if (e != hipSuccess) return e;
+  }
+  const int maxc = (a.smooth && a.Q > btu) ? a.Q : btu;
+  dim3 g1((maxc + 127) / 128, (btu + 31) / 32, 3);
+  hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(loss_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  const size_t lds = (size_t)4 * 2 * btu * 4;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(graph_loss_kernel, dim3((btu + 3) / 4), dim3(256), lds, st, a);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(finalize_kernel, dim3(n + 1), dim3(256), 0, st, a);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  // dfeat[0][bt:] = G . fU_w ;  dfeat[1][bt:] = G^T . fU_s   (batch 0 uses A = G^T, batch 1 A = G)
+  GemmTN g;
+  g.A = a.GT; g.a_bstride = (long long)btu * btu;
+  g.B = a.feat + ((long long)n + bt) * FD; g.b_bstride = -(long long)n * FD;
+  g.C = a.dfeat + (long long)bt * FD; g.c_bstride = (long long)n * FD;
+  g.bias = nullptr; g.bias_bstride = 0;
+  g.lda = btu; g.ldb = FD; g.ldc = FD; g.M = btu; g.N = FD; g.R = btu; g.batches = 2; g.scale = 1.f;
+  return launch_gemm_tn(g, st);
+}
+
+}  // namespace cmlpl

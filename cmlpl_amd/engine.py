@@ -1,0 +1,215 @@
+"""TrainEngine: the CMLPL training step (reference train.py:150-278) on one MI355X.
+
+Host logic only -- state ownership (flat parameter / Adam / bank buffers as torch
+tensors), the bank-pointer bookkeeping of train.py:234,237, the schedule scalars of
+train.py:147-148,212 -- and ONE ctypes call per step into ``cmlpl_train_step``
+(libcmlpl_hip.so).  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .config import FEAT_DIM, HyperParams, NetShape
+
+SCALAR_NAMES = ("ctr_s", "total_s", "cls_s", "con_s", "acc", "total_w", "cls_w", "con_w", "ctr_w",
+                "n_mask_w", "n_mask_s", "n_pos", "n_neg")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_f32(t: torch.Tensor, shape, name):
+    if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != tuple(shape) or not t.is_cuda:
+        raise ValueError(f"{name}: need contiguous float32 cuda tensor of shape {tuple(shape)}, "
+                         f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+
+
+class TrainEngine:
+    """Both networks (Base = net 0 / "s", Base1 = net 1 / "w"), their Adam state and
+    the two memory banks, resident in HBM for the whole run.
+
+    ``labeled_batch_size`` sizes the banks exactly like train.py:138
+    (``queue_size = 5 * labeled_batch_size * 2``).  Bank writes wrap modulo the bank
+    size where the reference's slice-assign would raise; the pointer advance is the
+    reference literal 256 (``hp.bank_step``) -- see DESIGN.md "memory bank".
+    """
+
+    def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
+                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("cmlpl_amd.TrainEngine needs a GPU (no CPU fallback)")
+        self.shape, self.hp = shape, hp or HyperParams()
+        self.device = torch.device(device)
+        self.bt_max, self.btu_max = int(labeled_batch_size), int(unlabeled_batch_size)
+        self.n_max = self.bt_max + self.btu_max
+        self.cshape = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+        self.layout = _lib.layout(self.cshape)
+        L = self.layout
+        self.P = int(L.param_total)
+        self.Q = self.hp.bank_mult * self.bt_max * 2                       # train.py:138
+        if self.Q < self.n_max:
+            raise ValueError("bank smaller than one batch (needs 10*bt >= bt+btu)")
+        dev = self.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.params, self.m, self.v, self.grads = z(2, self.P), z(2, self.P), z(2, self.P), z(2, self.P)
+        self.packed = z(2, int(L.packed_total))
+        self.bank_feats, self.bank_probs = z(2, self.Q, FEAT_DIM), z(2, self.Q, shape.K)   # train.py:139-144
+        self.ptr = [0, 0]                                                   # train.py:141,145
+        self.scalars = z(16)
+        self.logits, self.feat = z(2, self.n_max, shape.K), z(2, self.n_max, FEAT_DIM)
+        ws = self.lib.cmlpl_workspace_bytes(C.byref(self.cshape), 2, self.n_max, self.Q)
+        if ws == 0:
+            raise _lib.CmlplError("cmlpl_workspace_bytes", -2)
+        self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self.adam_t = 0
+        self.step_count = 0
+        self.seed = int(seed)
+        self._chp = self._make_hp()
+        self._packed_dirty = True
+
+    # ------------------------------------------------------------------ parameters
+    def _make_hp(self) -> _lib.HParams:
+        h = self.hp
+        return _lib.HParams(h.lr, h.beta1, h.beta2, h.eps, h.temperature, h.alpha, h.noise, h.dropout,
+                            h.w_contrast, h.w_mutual, h.pos_thr, h.neg_thr)
+
+    def tensor_shapes(self) -> "OrderedDict[str, tuple]":
+        s = self.shape
+        return OrderedDict([
+            ("conv0.weight", (64, s.C, 1, 1)), ("conv0.bias", (64,)),
+            ("conv1.weight", (64, 64, 3, 3)), ("conv1.bias", (64,)),
+            ("conv2.weight", (64, 64, 3, 3)), ("conv2.bias", (64,)),
+            ("feat_spe.weight", (FEAT_DIM, s.bands)), ("feat_spe.bias", (FEAT_DIM,)),
+            ("classifier.weight", (s.K, s.cls_in)), ("classifier.bias", (s.K,)),
+            ("feat_ss.weight", (256, FEAT_DIM)), ("feat_ss.bias", (256,)),
+            ("feat_ss2.weight", (64, FEAT_DIM)), ("feat_ss2.bias", (64,)),
+            ("feat_ss3.weight", (64, 256)), ("feat_ss3.bias", (64,)),
+        ])
+
+    def view(self, buf: torch.Tensor, net: int, key: str) -> torch.Tensor:
+        i = _lib.TENSOR_KEYS.index(key)
+        off, numel = int(self.layout.param_off[i]), int(self.layout.param_numel[i])
+        return buf[net, off:off + numel].view(self.tensor_shapes()[key])
+
+    def load_state_dict(self, net: int, sd: Dict[str, torch.Tensor]) -> None:
+        for key in _lib.TENSOR_KEYS:
+            if key in sd:
+                self.view(self.params, net, key).copy_(sd[key].to(self.device, torch.float32))
+        self._packed_dirty = True
+
+    def state_dict(self, net: int) -> "OrderedDict[str, torch.Tensor]":
+        order = ["conv0", "conv1", "conv2", "feat_spe", "feat_ss", "feat_ss2", "feat_ss3", "classifier"]
+        out = OrderedDict()
+        for mod in order:                      # registration order of tools/models.py:102-127
+            for leaf in ("weight", "bias"):
+                out[f"{mod}.{leaf}"] = self.view(self.params, net, f"{mod}.{leaf}").detach().clone()
+        return out
+
+    def grad(self, net: int, key: str) -> torch.Tensor:
+        return self.view(self.grads, net, key)
+
+    def init_params_default(self, seed: int = 1088) -> None:
+        """torch default init of nn.Conv2d / nn.Linear (kaiming-uniform a=sqrt(5)):
+        U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        shapes = self.tensor_shapes()
+        for net in range(2):
+            for key, shp in shapes.items():
+                fan_in = 1
+                for d in shapes[key.split(".")[0] + ".weight"][1:]:
+                    fan_in *= d
+                b = 1.0 / (fan_in ** 0.5)
+                self.view(self.params, net, key).copy_((torch.rand(shp, generator=g) * 2 - 1) * b)
+        self._packed_dirty = True
+
+    def _ensure_packed(self, stream) -> None:
+        if self._packed_dirty:
+            _lib.check("cmlpl_pack_weights",
+                       self.lib.cmlpl_pack_weights(C.byref(self.cshape), 2, _ptr(self.params), self.P,
+                                                   _ptr(self.packed), stream))
+            self._packed_dirty = False
+
+    # ------------------------------------------------------------------ the step
+    def step(self, XPl: torch.Tensor, Xl: torch.Tensor, Y: torch.Tensor, XPu: torch.Tensor, Xu: torch.Tensor,
+             epoch: int, batch_index: int, noise: Optional[Sequence[torch.Tensor]] = None,
+             dropmask: Optional[torch.Tensor] = None, apply_update: bool = True) -> None:
+        """One training step; asynchronous.  Results land in ``self.scalars`` (device),
+        ``self.logits`` / ``self.feat`` ([2][n][..]) and ``self.grads``.
+
+        noise    : None -> in-kernel Philox; or the 8 draws in reference order (parity mode)
+        dropmask : None -> Philox (or no dropout when hp.dropout == 0); or [2][n][cls_in] multipliers
+        """
+        s = self.shape
+        bt, btu = XPl.shape[0], XPu.shape[0]
+        n = bt + btu
+        if bt < 1 or btu < 1 or bt > self.bt_max or n > self.n_max:
+            raise ValueError(f"batch {bt}+{btu} outside the engine's capacity {self.bt_max}+{self.btu_max}")
+        _chk_f32(XPl, (bt, s.C, s.H, s.W), "XPl"); _chk_f32(Xl, (bt, s.bands), "Xl")
+        _chk_f32(XPu, (btu, s.C, s.H, s.W), "XPu"); _chk_f32(Xu, (btu, s.bands), "Xu")
+        if Y.dtype != torch.int64 or tuple(Y.shape) != (bt,) or not Y.is_cuda:
+            raise ValueError("Y: need int64 cuda tensor [bt]")
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._ensure_packed(stream)
+        io = _lib.StepIO()
+        io.d_xpl, io.d_xl, io.d_labels = XPl.data_ptr(), Xl.data_ptr(), Y.data_ptr()
+        io.d_xpu, io.d_xu = XPu.data_ptr(), Xu.data_ptr()
+        keep = None
+        if noise is not None:
+            shp = [XPl.shape, Xl.shape, XPl.shape, Xl.shape, XPu.shape, Xu.shape, XPu.shape, Xu.shape]
+            for t, sh in zip(noise, shp):
+                _chk_f32(t, sh, "noise")
+            keep = (C.c_void_p * 8)(*[t.data_ptr() for t in noise])
+            io.noise8 = C.cast(keep, C.POINTER(C.c_void_p))
+        if dropmask is not None:
+            _chk_f32(dropmask, (2, n, s.cls_in), "dropmask")
+            io.d_dropmask = dropmask.data_ptr()
+        io.d_params, io.d_m, io.d_v = self.params.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
+        io.d_grads, io.d_packed = self.grads.data_ptr(), self.packed.data_ptr()
+        for i in range(2):
+            io.banks.d_feats[i] = self.bank_feats[i].data_ptr()
+            io.banks.d_probs[i] = self.bank_probs[i].data_ptr()
+            io.banks.ptr[i] = self.ptr[i]
+        io.banks.Q = self.Q
+        io.d_scalars = self.scalars.data_ptr()
+        # outputs are laid out [2][n][..] for THIS n (views of the max-size buffers)
+        io.d_logits, io.d_feat = self.logits.data_ptr(), self.feat.data_ptr()
+        io.d_workspace, io.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
+        io.bt, io.btu = bt, btu
+        io.smooth = 1 if self.hp.smooth_gate(epoch, batch_index) else 0
+        io.adap_mask = float(self.hp.thr * self.hp.adap_thr(epoch))        # train.py:221
+        io.adam_t = self.adam_t + 1
+        io.seed, io.step = self.seed, self.step_count
+        io.apply_update = 1 if apply_update else 0
+        _lib.check("cmlpl_train_step",
+                   self.lib.cmlpl_train_step(C.byref(self.cshape), C.byref(self._chp), C.byref(io), stream))
+        # bank pointers, train.py:234,237 (ptr1 follows ptr0 -- reference quirk kept)
+        p0 = (self.ptr[0] + self.hp.bank_step) % self.Q
+        self.ptr = [p0, (p0 + self.hp.bank_step) % self.Q]
+        if apply_update:
+            self.adam_t += 1
+        self.step_count += 1
+        self._last_n = n
+
+    def outputs(self):
+        """(logits [2][n][K], feat [2][n][1024]) of the last step."""
+        n = self._last_n
+        K = self.shape.K
+        lo = self.logits.view(-1)[: 2 * n * K].view(2, n, K)
+        fe = self.feat.view(-1)[: 2 * n * FEAT_DIM].view(2, n, FEAT_DIM)
+        return lo, fe
+
+    def read_scalars(self) -> Dict[str, float]:
+        """Synchronising read of the logged row (train.py:274-278) and friends."""
+        vals = self.scalars.tolist()
+        return dict(zip(SCALAR_NAMES, vals))
+
+    def loss_row(self):
+        """[loss_contrast, total_loss, cls_loss, con_loss, acc] -- loss_hist row, train.py:274-278."""
+        return self.scalars[:5].tolist()

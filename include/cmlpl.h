@@ -1,0 +1,176 @@
+/* cmlpl.h -- C ABI of the MI355X-native CMLPL training hot path (libcmlpl_hip.so).
+ *
+ * The reference (liuli33/CMLPL) has no FFI/plugin interface: its hot path is inline
+ * PyTorch in train.py:150-279 and tools/models.py:97-152.  This header is therefore
+ * the boundary the reference's Python would bind via ctypes; each
+ * entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every pointer named d_* is DEVICE memory
+ *     owned by the caller (no ownership transfer, no hidden allocation);
+ *   - every call takes a hipStream_t as `void* stream`, is asynchronous and re-entrant
+ *     across streams (no implicit synchronisation, graph-capturable);
+ *   - return 0 = ok, negative = argument error (CMLPL_E_*), positive = hipError_t;
+ *   - all arithmetic is fp32; labels are int64 (torch.long).
+ *   - `nets` is 1 or 2: kernels are batched over the two networks Base/Base1
+ *     (train.py:118-125) through a grid dimension; per-network buffers are
+ *     laid out [net][...] with the strides returned by cmlpl_layout().
+ */
+#ifndef CMLPL_H
+#define CMLPL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMLPL_ABI_VERSION 1
+#define CMLPL_FEAT_DIM 1024 /* tools/models.py:119 */
+#define CMLPL_CONV_CH 64    /* tools/models.py:102-107 */
+
+enum {
+  CMLPL_E_ARG = -1,      /* null pointer / bad size */
+  CMLPL_E_SHAPE = -2,    /* unsupported shape (e.g. K > 64, window too large for LDS) */
+  CMLPL_E_WORKSPACE = -3 /* workspace too small */
+};
+
+/* Shape of one BaseNet2 (tools/models.py:98-128, generalised per SURVEY.md section 0). */
+typedef struct cmlpl_shape {
+  int32_t C;     /* conv0 input channels (reference literal 60, models.py:102) */
+  int32_t H, W;  /* window size (reference: 20x20)                            */
+  int32_t bands; /* num_features (models.py:121)                              */
+  int32_t K;     /* num_classes  (models.py:127), 1..64                       */
+} cmlpl_shape;
+
+/* Hyper-parameters consumed inside the step (train.py:356-379 flags + literals). */
+typedef struct cmlpl_hparams {
+  float lr, beta1, beta2, eps;      /* torch.optim.Adam defaults, train.py:131-132        */
+  float temperature, alpha;         /* train.py:374,371                                    */
+  float noise_sigma, dropout_p;     /* train.py:378,377                                    */
+  float w_contrast, w_mutual;       /* literals 0.5 / 4, train.py:266,270                  */
+  float pos_thr, neg_thr;           /* literals 0.8 / 0.3, train.py:251,254                */
+} cmlpl_hparams;
+
+/* Flat parameter buffer of ONE network: the 16 state_dict tensors of BaseNet2 in
+ * canonical PyTorch layouts, LIVE tensors first:
+ *   0 conv0.weight[64,C,1,1] 1 conv0.bias 2 conv1.weight[64,64,3,3] 3 conv1.bias
+ *   4 conv2.weight 5 conv2.bias 6 feat_spe.weight[1024,bands] 7 feat_spe.bias
+ *   8 classifier.weight[K,cls_in] 9 classifier.bias | 10..15 feat_ss*, dead (models.py:122-126)
+ * Each tensor's offset is a multiple of 4 floats. */
+#define CMLPL_NUM_TENSORS 16
+#define CMLPL_NUM_LIVE 10
+typedef struct cmlpl_layout_t {
+  int64_t param_off[CMLPL_NUM_TENSORS];   /* element offsets in the per-net flat buffer  */
+  int64_t param_numel[CMLPL_NUM_TENSORS];
+  int64_t param_total;                    /* floats per net (all 16 tensors)             */
+  int64_t param_live;                     /* floats per net covered by Adam (tensors 0-9) */
+  int64_t packed_total;                   /* floats per net of kernel-side packed conv weights */
+  int32_t cls_in;                         /* 64*(H/2/2)*(W/2/2) + 1024                    */
+  int32_t reserved;
+} cmlpl_layout_t;
+
+int cmlpl_abi_version(void);
+int cmlpl_layout(const cmlpl_shape* shape, cmlpl_layout_t* out);
+
+/* Bytes of device workspace needed by the calls below for up to `n` rows per network
+ * (n = labelled + unlabelled), `nets` networks and a bank of `bank_rows` rows. */
+size_t cmlpl_workspace_bytes(const cmlpl_shape* shape, int nets, int n, int bank_rows);
+
+/* Re-pack conv1/conv2 weights of `nets` networks into the kernel-side layouts
+ * (must be called after parameters change; cmlpl_adam_step does it itself). */
+int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params, int64_t param_stride,
+                       float* d_packed, void* stream);
+
+/* Input augmentation + batch concat: train.py:157-158,163-164,170-171,173-174,181-184.
+ *   xn[net] = cat(XPl, XPu) + sigma * N(0,1),  sn[net] = cat(Xl, Xu) + sigma * N(0,1)
+ * d_noise: NULL (in-kernel Philox, keyed by seed/step) or 8 device pointers in the
+ * reference's draw order [XPl/0, Xl/0, XPl/1, Xl/1, XPu/0, Xu/0, XPu/1, Xu/1].
+ * With bt == 0 or sigma == 0 it is a plain (concatenating) copy. */
+int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu,
+                  const float* d_xpl, const float* d_xl, const float* d_xpu, const float* d_xu,
+                  const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
+                  float* d_xn, float* d_sn, void* stream);
+
+/* BaseNet2.forward (tools/models.py:130-152) for `nets` networks on rows [n].
+ *   d_xn [nets][n][C][H*W], d_sn [nets][n][bands]  (already augmented)
+ *   d_dropmask: [nets][n][cls_in] multiplier (0 or 1/(1-p)); NULL with dropout_p == 0 or
+ *               train == 0 -> no dropout; NULL with train != 0 and p > 0 -> Philox mask
+ *   outputs: d_logits [nets][n][K], d_feat [nets][n][1024]; activations needed by
+ *   cmlpl_basenet2_bwd are kept in d_workspace. */
+int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n,
+                       const float* d_params, int64_t param_stride, const float* d_packed,
+                       const float* d_xn, const float* d_sn, const float* d_dropmask,
+                       float dropout_p, int train, uint64_t seed, uint64_t step,
+                       float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* Backward of the above w.r.t. the 10 live tensors (autograd of train.py:267,271).
+ *   d_dlogits [nets][n][K], d_dfeat [nets][n][1024] (may be NULL = zero)
+ *   d_grads   [nets][grad_stride] flat, same offsets as the parameters (tensors 0-9 written). */
+int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n,
+                       const float* d_params, int64_t param_stride, const float* d_packed,
+                       const float* d_xn, const float* d_sn,
+                       const float* d_dropmask, float dropout_p, int train, /* as given to _fwd */
+                       const float* d_dlogits, const float* d_dfeat,
+                       float* d_grads, int64_t grad_stride,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* State of the two memory banks (train.py:138-145). */
+typedef struct cmlpl_banks {
+  float* d_feats[2];  /* [Q][1024] queue_feats, queue_feats1 */
+  float* d_probs[2];  /* [Q][K]    queue_probs, queue_probs1 */
+  int32_t Q;          /* rows, 5*labeled_batch_size*2 (train.py:138) */
+  int32_t ptr[2];     /* write pointers BEFORE this step (host keeps train.py:234,237) */
+} cmlpl_banks;
+
+/* The loss block, train.py:191-266, forward + analytic backward, plus the bank write
+ * (train.py:223-237; rows are written modulo Q).
+ *   d_logits [2][n][K], d_feat [2][n][1024]: net 0 = Base ("s"), net 1 = Base1 ("w");
+ *   rows [0,bt) labelled, [bt,n) unlabelled; d_labels int64 [bt]
+ *   smooth    : train.py:212 gate (epoch > 0 or batch_index > queue_batch)
+ *   adap_mask : thr * exp(-0.5*(epoch/num_epochs)^2), train.py:147-148,221
+ *   outputs   : d_scalars[16] = {ctr_s,total_s,cls_s,con_s,acc, total_w,cls_w,con_w,ctr_w,
+ *                                n_mask_w,n_mask_s,n_pos,n_neg,0,0,0}   (train.py:274-278)
+ *               d_dlogits [2][n][K], d_dfeat [2][n][1024]
+ *               d_probs_out (optional) [4][btu][K] = {p_w, p_s smoothed, p_w0, p_s0}. */
+int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu,
+                       const float* d_logits, const float* d_feat, const int64_t* d_labels,
+                       const cmlpl_banks* banks, int smooth, float adap_mask,
+                       const cmlpl_hparams* hp,
+                       float* d_scalars, float* d_dlogits, float* d_dfeat, float* d_probs_out,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam.step for `nets` flat buffers (train.py:268,272); `t` is the 1-based
+ * step count.  Also refreshes the packed conv weights when d_packed != NULL. */
+int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t param_stride,
+                    const float* d_grads, int64_t grad_stride, float* d_m, float* d_v,
+                    int64_t t, const cmlpl_hparams* hp, float* d_packed, void* stream);
+
+/* One whole training step, train.py:150-278: augment -> 2x forward -> loss block ->
+ * bank write -> 2x backward -> 2x Adam.  d_state buffers persist across steps. */
+typedef struct cmlpl_step_io {
+  const float* d_xpl; const float* d_xl; const int64_t* d_labels;  /* labelled batch  */
+  const float* d_xpu; const float* d_xu;                           /* unlabelled batch */
+  const float* const* noise8;   /* NULL = Philox                                        */
+  const float* d_dropmask;      /* NULL = Philox; else [2][n][cls_in]                   */
+  float* d_params; float* d_m; float* d_v; float* d_grads; float* d_packed;  /* [2][param_total] (packed: [2][packed_total]) */
+  cmlpl_banks banks;
+  float* d_scalars;             /* [16] as in cmlpl_loss_fwd_bwd                        */
+  float* d_logits; float* d_feat; /* [2][n][K], [2][n][1024] (outputs)                  */
+  void* d_workspace; size_t workspace_bytes;
+  int32_t bt, btu;
+  int32_t smooth; float adap_mask;
+  int64_t adam_t;               /* 1-based                                               */
+  uint64_t seed, step;          /* Philox key / counter                                  */
+  int32_t apply_update;         /* 0 = stop after the gradients                          */
+  int32_t reserved;
+} cmlpl_step_io;
+
+int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMLPL_H */

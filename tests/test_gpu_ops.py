@@ -1,0 +1,193 @@
+"""GPU parity, op by op, through the C ABI: BaseNet2 forward/backward, the loss block and Adam
+against the CPU oracle on the same seeded inputs.  fp32; tolerances stated per check."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cmlpl_oracle as O
+from tests.gpu_util import DEV, report, to_shape
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "P": O.NetShape(60, 20, 20, 103, 9),        # reference-exact
+    "B2": O.NetShape(103, 11, 11, 103, 9),      # BASELINE configs[1]
+    "B4": O.NetShape(200, 11, 11, 200, 16),
+    "B5": O.NetShape(48, 15, 15, 48, 20),
+}
+
+
+def _module(shape, params, dropout):
+    from cmlpl_amd.models import BaseNet2
+    net = BaseNet2(num_features=shape.bands, dropout=dropout, num_classes=shape.K,
+                   in_channels=shape.C, window=shape.H).to(DEV)
+    net.load_state_dict(params)
+    return net
+
+
+@pytest.mark.parametrize("name,n", [("P", 5), ("P", 64), ("B2", 37), ("B2", 256), ("B4", 16), ("B5", 23)])
+def test_basenet2_forward_backward(name, n):
+    shape = SHAPES[name]
+    params = O.closed_form_params(shape, 7)
+    g = torch.Generator().manual_seed(100 + n)
+    x = torch.randn(n, shape.C, shape.H, shape.W, generator=g)
+    y = torch.randn(n, shape.bands, generator=g)
+    keep = 0.2
+    dm = (torch.rand(n, shape.cls_in, generator=g) < keep).float() / keep
+    dlog = torch.randn(n, shape.K, generator=g)
+    dfe = torch.randn(n, 1024, generator=g) * 0.1
+    # oracle
+    pr = {k: v.clone().requires_grad_(k in O.LIVE_KEYS) for k, v in params.items()}
+    lo_ref, fe_ref = O.basenet2_forward(pr, x, y, dm)
+    (lo_ref * dlog).sum().add((fe_ref * dfe).sum()).backward()
+    # HIP
+    net = _module(shape, params, dropout=0.8)
+    net.train()
+    lo, fe = net(x.to(DEV), y.to(DEV), dropmask=dm.to(DEV))
+    torch.cuda.synchronize()
+    report("logits", lo, lo_ref, 1e-4, 2e-5)
+    report("feat", fe, fe_ref, 1e-5, 1e-6)
+    ((lo * dlog.to(DEV)).sum() + (fe * dfe.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    hip = dict(net.named_parameters())
+    for k in O.LIVE_KEYS:
+        scale = float(pr[k].grad.abs().max())
+        report("grad " + k, hip[k].grad, pr[k].grad, 2e-4, 2e-5 * max(scale, 1e-3))
+    for k in ("feat_ss.weight", "feat_ss2.bias", "feat_ss3.weight"):
+        assert hip[k].grad is None          # dead parameters, like the reference
+
+
+def test_basenet2_eval_matches_oracle_and_state_dict_keys():
+    shape = SHAPES["P"]
+    params = O.closed_form_params(shape, 3)
+    net = _module(shape, params, dropout=0.8)
+    assert list(net.state_dict().keys()) == list(O.param_shapes(shape).keys())
+    for k, shp in O.param_shapes(shape).items():
+        assert tuple(net.state_dict()[k].shape) == tuple(shp)
+    net.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(33, 60, 20, 20, generator=g)
+    y = torch.randn(33, 103, generator=g)
+    with torch.no_grad():
+        lo, fe = net(x.to(DEV), y.to(DEV))
+    lo_ref, fe_ref = O.basenet2_forward(params, x, y, None)
+    report("logits", lo, lo_ref, 1e-4, 2e-5)
+    report("feat", fe, fe_ref, 1e-5, 1e-6)
+    assert torch.equal(lo.argmax(1).cpu(), lo_ref.argmax(1))
+
+
+def test_dropout_philox_statistics():
+    shape = SHAPES["B2"]
+    net = _module(shape, O.closed_form_params(shape, 3), dropout=0.8)
+    net.train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(64, 103, 11, 11, generator=g).to(DEV)
+    y = torch.randn(64, 103, generator=g).to(DEV)
+    lo1, _ = net(x, y)
+    lo2, _ = net(x, y)
+    net.eval()
+    lo3, _ = net(x, y)
+    assert torch.isfinite(lo1).all()
+    assert not torch.allclose(lo1, lo2)          # fresh mask per call
+    assert not torch.allclose(lo1, lo3)
+
+
+def _loss_inputs(shape, bt, btu, Q, seed, peaky):
+    g = torch.Generator().manual_seed(seed)
+    n = bt + btu
+    sc = 6.0 if peaky else 1.0
+    z = [torch.randn(n, shape.K, generator=g) * sc for _ in range(2)]
+    if peaky:   # make the two nets agree on many rows so Q0 crosses 0.8
+        z[1] = z[0] + 0.3 * torch.randn(n, shape.K, generator=g)
+    f = [O.l2norm(torch.relu(torch.randn(n, 1024, generator=g))) for _ in range(2)]
+    Y = torch.randint(0, shape.K, (bt,), generator=g)
+    bf = [O.l2norm(torch.relu(torch.randn(Q, 1024, generator=g))) for _ in range(2)]
+    bp = [torch.softmax(torch.randn(Q, shape.K, generator=g) * 3, 1) for _ in range(2)]
+    return z, f, Y, bf, bp
+
+
+@pytest.mark.parametrize("bt,btu,smooth,peaky,K", [(32, 32, True, False, 9), (128, 128, True, True, 9),
+                                                   (16, 48, False, True, 9), (24, 40, True, True, 20),
+                                                   (128, 128, False, False, 16)])
+def test_loss_block(bt, btu, smooth, peaky, K):
+    from cmlpl_amd import _lib
+    lib = _lib.load()
+    shape = O.NetShape(60, 20, 20, 103, K)
+    hp = O.HyperParams()
+    Q = 10 * bt if 10 * bt >= bt + btu else 4 * (bt + btu)
+    n = bt + btu
+    z, f, Y, bf, bp = _loss_inputs(shape, bt, btu, Q, 1000 + bt + btu, peaky)
+    adap = 0.9 if peaky else 1.0
+    zr = [t.clone().requires_grad_(True) for t in z]
+    fr = [t.clone().requires_grad_(True) for t in f]
+    lb = O.loss_block(zr[0], fr[0], zr[1], fr[1], Y, bt, bf, bp, smooth, adap, hp)
+    gs = torch.autograd.grad(lb["total_s"], [zr[0], fr[0]], allow_unused=True)
+    gw = torch.autograd.grad(lb["total_w"], [zr[1], fr[1]], allow_unused=True)
+    # HIP
+    cs = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+    d = lambda t: t.to(DEV).contiguous()
+    logits, feat, labels = d(torch.stack(z)), d(torch.stack(f)), d(Y)
+    bank_f, bank_p = [d(t.clone()) for t in bf], [d(t.clone()) for t in bp]
+    banks = _lib.Banks()
+    ptr = [Q - 5, 3]          # bank0 write wraps around the end
+    for i in range(2):
+        banks.d_feats[i] = bank_f[i].data_ptr(); banks.d_probs[i] = bank_p[i].data_ptr(); banks.ptr[i] = ptr[i]
+    banks.Q = Q
+    chp = _lib.HParams(hp.lr, hp.beta1, hp.beta2, hp.eps, hp.temperature, hp.alpha, hp.noise, hp.dropout,
+                       hp.w_contrast, hp.w_mutual, hp.pos_thr, hp.neg_thr)
+    scal = torch.zeros(16, device=DEV)
+    dlog, dfe = torch.full((2, n, K), 7.0, device=DEV), torch.full((2, n, 1024), 7.0, device=DEV)
+    probs = torch.zeros(4, btu, K, device=DEV)
+    wsb = lib.cmlpl_workspace_bytes(C.byref(cs), 2, n, Q)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = lib.cmlpl_loss_fwd_bwd(C.byref(cs), bt, btu, logits.data_ptr(), feat.data_ptr(), labels.data_ptr(),
+                                C.byref(banks), int(smooth), adap, C.byref(chp), scal.data_ptr(), dlog.data_ptr(),
+                                dfe.data_ptr(), probs.data_ptr(), ws.data_ptr(), ws.numel(),
+                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    s = scal.cpu().numpy()
+    want = [lb[k].item() for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc", "total_w", "cls_w", "con_w", "ctr_w")]
+    report("scalars", s[:9], np.array(want), 1e-4, 1e-6)        # loss parity: 1e-4 relative (north_star)
+    cnt = [lb["mask_w"].sum().item(), lb["mask_s"].sum().item(), (lb["Q"] > 0).sum().item()]
+    assert list(s[9:12]) == cnt, (s[9:13], cnt)
+    report("probs", probs, torch.stack([lb["p_w"], lb["p_s"], lb["p_w0"], lb["p_s0"]]), 1e-4, 1e-6)
+    report("dlogits_s", dlog[0], gs[0], 2e-4, 1e-7)
+    report("dlogits_w", dlog[1], gw[0], 2e-4, 1e-7)
+    zero = torch.zeros(n, 1024)
+    report("dfeat_s", dfe[0], gs[1] if gs[1] is not None else zero, 5e-4, 2e-7)
+    report("dfeat_w", dfe[1], gw[1] if gw[1] is not None else zero, 5e-4, 2e-7)
+    # bank write (train.py:232-236), modulo Q
+    for i, rows in enumerate((lb["bank0_rows"], lb["bank1_rows"])):
+        ef, ep = bf[i].clone(), bp[i].clone()
+        O.bank_write(ef, ptr[i], rows[0]); O.bank_write(ep, ptr[i], rows[1])
+        report(f"bank{i}_feats", bank_f[i], ef, 0, 0)            # pure copy: bit-exact
+        report(f"bank{i}_probs", bank_p[i], ep, 1e-5, 1e-7)
+
+
+def test_adam_step_matches_torch_formula():
+    from cmlpl_amd import _lib
+    lib = _lib.load()
+    shape = SHAPES["B2"]
+    cs = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+    L = _lib.layout(cs)
+    P, live = int(L.param_total), int(L.param_live)
+    hp = O.HyperParams()
+    chp = _lib.HParams(hp.lr, hp.beta1, hp.beta2, hp.eps, hp.temperature, hp.alpha, hp.noise, hp.dropout,
+                       hp.w_contrast, hp.w_mutual, hp.pos_thr, hp.neg_thr)
+    g = torch.Generator().manual_seed(4)
+    p = torch.randn(2, P, generator=g) * 0.05
+    pc, m, v = p.clone(), torch.zeros(2, P), torch.zeros(2, P)
+    dp, dm, dv = p.to(DEV), torch.zeros(2, P, device=DEV), torch.zeros(2, P, device=DEV)
+    for t in range(1, 5):
+        gr = torch.randn(2, P, generator=g) * (10.0 ** (t - 3))
+        rc = lib.cmlpl_adam_step(C.byref(cs), 2, dp.data_ptr(), P, gr.to(DEV).data_ptr(), P, dm.data_ptr(),
+                                 dv.data_ptr(), t, C.byref(chp), None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        for net in range(2):
+            O.adam_update(pc[net, :live], gr[net, :live], m[net, :live], v[net, :live], t, hp)
+        torch.cuda.synchronize()
+        report(f"adam t={t} params", dp[:, :live], pc[:, :live], 1e-6, 1e-7)
+        assert torch.equal(dp[:, live:].cpu(), p[:, live:])          # dead tensors untouched

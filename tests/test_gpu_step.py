@@ -1,0 +1,139 @@
+"""GPU parity of the whole training step (cmlpl_train_step) against
+  (a) the committed golden fixtures produced by the reference itself, and
+  (b) the CPU oracle run side by side on the same seeded inputs (explicit noise / dropout masks),
+plus size-independent properties at BASELINE.json's full batch."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cmlpl_oracle as O
+from tests.golden_util import GoldenCase, golden_cases, rel_err
+from tests.gpu_util import DEV, cuda_batch, report, to_hp, to_shape
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4          # north_star: loss parity within 1e-4 relative
+
+
+def _engine(g):
+    from cmlpl_amd import TrainEngine
+    eng = TrainEngine(to_shape(g.shape), g.bt, g.btu, to_hp(g.hp), device=DEV)
+    p0, p1 = g.params()
+    eng.load_state_dict(0, p0)
+    eng.load_state_dict(1, p1)
+    return eng, p0, p1
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_step_matches_golden_and_oracle(name):
+    g = GoldenCase(name)
+    eng, p0, p1 = _engine(g)
+    st = O.StepState.create(g.shape, p0, p1, g.bt, g.hp)
+    z = g.z
+    steps = min(g.steps, 8) if name != "p_traj_32" else g.steps
+    for s in range(steps):
+        b = g.batch(s)
+        epoch, bi = g.epoch_bi(s)
+        ref = O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"],
+                           epoch, bi, g.hp)
+        cb = cuda_batch(b)
+        eng.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], epoch, bi, noise=cb["noise"],
+                 dropmask=cb["dropmask"])
+        sc = eng.read_scalars()
+        row = [sc[k] for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc")]
+        extra = [sc[k] for k in ("total_w", "cls_w", "con_w", "ctr_w")]
+        print(f"[{name}] step {s}: hip={row} golden={list(z['hist'][s])}")
+        # (a) golden fixture (reference outputs)
+        assert rel_err(row, z["hist"][s], 1e-7) < LOSS_RTOL, (s, row, z["hist"][s])
+        assert rel_err(extra, z["extra"][s], 1e-7) < LOSS_RTOL, (s, extra, z["extra"][s])
+        assert eng.ptr == [int(v) for v in z["ptr"][s]]
+        assert [sc["n_mask_w"], sc["n_mask_s"], sc["n_pos"]] == list(z["counts"][s][:3])
+        # (b) oracle, tensor by tensor
+        lo, fe = eng.outputs()
+        report("logits", lo, torch.stack(ref["logits"]), 2e-4, 5e-5)
+        report("feat", fe, torch.stack(ref["feats"]), 1e-5, 1e-6)
+        for net in range(2):
+            for k in O.LIVE_KEYS:
+                gr = ref["grads"][net][k]
+                report(f"grad[{net}] {k}", eng.grad(net, k), gr, 5e-4, 5e-5 * max(float(gr.abs().max()), 1e-4))
+            gn = [float(eng.grad(net, k).double().norm()) for k in O.LIVE_KEYS]
+            assert rel_err(gn, z["grad_norms"][s][net], 1e-9) < 5e-4, (s, net)
+        if s in g.full_steps:
+            report("golden logits", lo, z[f"s{s}_logits"], 2e-4, 5e-5)
+    # parameters and banks after the trajectory
+    for net in range(2):
+        sd = eng.state_dict(net)
+        for k in O.LIVE_KEYS:
+            report(f"param[{net}] {k}", sd[k], st.params[net][k], 1e-4, 2e-6)
+        for k in ("feat_ss.weight", "feat_ss2.weight", "feat_ss3.bias"):
+            assert torch.equal(sd[k].cpu(), st.params[net][k])         # dead tensors never move
+    for i in range(2):
+        report(f"bank{i} feats", eng.bank_feats[i], st.bank_feats[i], 1e-5, 1e-6)
+        report(f"bank{i} probs", eng.bank_probs[i], st.bank_probs[i], 1e-4, 1e-6)
+
+
+def test_full_batch_properties_b2():
+    """BASELINE configs[1] size (11x11x103, 128+128), Philox noise/dropout: size-independent checks."""
+    from cmlpl_amd import TrainEngine
+    shape = O.NetShape(103, 11, 11, 103, 9)
+    hp = O.HyperParams()
+    b = cuda_batch(O.synthetic_batch(shape, 128, 128, 77, with_noise=False))
+
+    def run(seed, steps):
+        eng = TrainEngine(to_shape(shape), 128, 128, to_hp(hp), device=DEV, seed=seed)
+        eng.load_state_dict(0, O.closed_form_params(shape, 1))
+        eng.load_state_dict(1, O.closed_form_params(shape, 2))
+        rows = []
+        for s in range(steps):
+            eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, s)
+            rows.append(eng.read_scalars())
+        return eng, rows
+
+    e1, r1 = run(5, 6)
+    e2, r2 = run(5, 6)
+    e3, r3 = run(6, 6)
+    for a, c in zip(r1, r2):          # same seed -> bit-identical trajectory (deterministic kernels)
+        assert a == c
+    assert r1[0]["total_s"] != r3[0]["total_s"]                       # different Philox stream
+    assert all(np.isfinite(list(r.values())).all() for r in r1)
+    assert r1[-1]["cls_s"] < r1[0]["cls_s"]                            # same batch re-fit: CE falls
+    assert e1.ptr == [(6 * 256) % 1280, (6 * 256 + 256) % 1280]       # train.py:234,237
+    lo, fe = e1.outputs()
+    nrm = fe.norm(dim=2)
+    assert torch.allclose(nrm, torch.ones_like(nrm), atol=1e-5)       # Normalize: unit rows
+    # bank rows written this step are exactly the features of this step (copy, bit-exact)
+    p0 = (5 * 256) % 1280
+    assert torch.equal(e1.bank_feats[0][p0:p0 + 128], fe[1][128:])     # fU_w
+    assert torch.equal(e1.bank_feats[0][p0 + 128:p0 + 256], fe[0][:128])  # fL_s
+    onehot = torch.zeros(128, 9, device=DEV).scatter(1, b["Y"].view(-1, 1), 1)
+    assert torch.equal(e1.bank_probs[1][(p0 + 256) % 1280 + 128:(p0 + 256) % 1280 + 256], onehot)
+
+
+def test_philox_noise_statistics():
+    """augment kernel in Philox mode: N(0, sigma^2) per element, independent per network."""
+    import ctypes as C
+    from cmlpl_amd import _lib
+    lib = _lib.load()
+    shape = O.NetShape(103, 11, 11, 103, 9)
+    cs = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+    bt = btu = 64
+    xpl = torch.zeros(bt, 103, 11, 11, device=DEV); xpu = torch.ones(btu, 103, 11, 11, device=DEV)
+    xl = torch.zeros(bt, 103, device=DEV); xu = torch.ones(btu, 103, device=DEV)
+    xn = torch.empty(2, bt + btu, 103 * 121, device=DEV); sn = torch.empty(2, bt + btu, 103, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.cmlpl_augment(C.byref(cs), 2, bt, btu, xpl.data_ptr(), xl.data_ptr(), xpu.data_ptr(), xu.data_ptr(),
+                             None, 0.5, 123, 7, xn.data_ptr(), sn.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    lab, unl = xn[:, :bt], xn[:, bt:] - 1.0
+    for t in (lab, unl):
+        assert abs(float(t.mean())) < 2e-3 and abs(float(t.std()) - 0.5) < 2e-3
+    z = torch.cat([lab.flatten(), unl.flatten()]) / 0.5
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.05                    # Gaussian kurtosis
+    c = torch.corrcoef(torch.stack([xn[0, :bt].flatten(), xn[1, :bt].flatten()]))[0, 1]
+    assert abs(float(c)) < 5e-3                                         # nets draw independent noise
+    assert abs(float(sn[:, :bt].std()) - 0.5) < 1e-2
+    xn2 = torch.empty_like(xn)
+    assert lib.cmlpl_augment(C.byref(cs), 2, bt, btu, xpl.data_ptr(), xl.data_ptr(), xpu.data_ptr(), xu.data_ptr(),
+                             None, 0.5, 123, 7, xn2.data_ptr(), sn.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(xn, xn2)                                          # counter-based: reproducible

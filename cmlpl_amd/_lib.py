@@ -25,6 +25,7 @@ TENSOR_KEYS = (
 EXPORTS = (
     "cmlpl_abi_version", "cmlpl_layout", "cmlpl_workspace_bytes", "cmlpl_pack_weights", "cmlpl_augment",
     "cmlpl_basenet2_fwd", "cmlpl_basenet2_bwd", "cmlpl_loss_fwd_bwd", "cmlpl_adam_step", "cmlpl_train_step",
+    "cmlpl_debug_region",
 )
 
 
@@ -110,6 +111,7 @@ def load(path: str = LIB_PATH):
                                        vp, sz, vp]
     lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
+    lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]
     for s in EXPORTS[1:]:
         if s != "cmlpl_workspace_bytes":
             getattr(lib, s).restype = i32

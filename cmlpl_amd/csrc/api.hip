@@ -294,4 +294,24 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
   return 0;
 }
 
+int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* name, size_t* byte_offset,
+                       size_t* bytes) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  if (nets < 1 || nets > 2 || n < 1 || !name || !byte_offset || !bytes) return CMLPL_E_ARG;
+  NetWs w;
+  char* base = (char*)(uintptr_t)4096;   // fake base: only offsets are used
+  if (!carve_net(d, nets, n, base, &w)) return CMLPL_E_SHAPE;
+  const size_t N = (size_t)nets * n;
+  struct { const char* nm; const void* p; size_t b; } tab[] = {
+      {"a0", w.a0, N * d.HW * 256}, {"p1", w.p1, N * d.P2 * 256}, {"m1", w.m1, N * d.P2 * 64},
+      {"p2", w.p2, N * d.P4 * 256}, {"m2", w.m2, N * d.P4 * 64}, {"y", w.y, N * 4096},
+      {"ynorm", w.ynorm, N * 4}, {"catd", w.catd, N * d.F * 4}, {"dropgen", w.dropgen, N * d.F * 4},
+      {"dy", w.dy, N * 4096}, {"dp2", w.dp2, N * d.P4 * 256}, {"dp1", w.dp1, N * d.P2 * 256},
+      {"da0", w.da0, N * d.HW * 256}};
+  for (auto& t : tab)
+    if (!strcmp(t.nm, name)) { *byte_offset = (size_t)((const char*)t.p - base); *bytes = t.b; return 0; }
+  return CMLPL_E_ARG;
+}
+
 }  // extern "C"

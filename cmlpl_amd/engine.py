@@ -205,6 +205,14 @@ class TrainEngine:
         fe = self.feat.view(-1)[: 2 * n * FEAT_DIM].view(2, n, FEAT_DIM)
         return lo, fe
 
+    def debug_region(self, name: str, dtype=torch.float32) -> torch.Tensor:
+        """View of a saved activation of the last step inside the workspace (inspection / tests);
+        see cmlpl_debug_region in include/cmlpl.h."""
+        off, nbytes = C.c_size_t(), C.c_size_t()
+        _lib.check("cmlpl_debug_region", self.lib.cmlpl_debug_region(
+            C.byref(self.cshape), 2, self._last_n, name.encode(), C.byref(off), C.byref(nbytes)))
+        return self.workspace[off.value: off.value + nbytes.value].view(dtype)
+
     def read_scalars(self) -> Dict[str, float]:
         """Synchronising read of the logged row (train.py:274-278) and friends."""
         vals = self.scalars.tolist()

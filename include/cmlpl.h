@@ -170,6 +170,15 @@ typedef struct cmlpl_step_io {
 int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io,
                      void* stream);
 
+/* Inspection aid (tests, debugging): byte offset and size inside d_workspace of a saved
+ * activation of cmlpl_basenet2_fwd/_bwd for (nets, n).  Names: "a0" conv0 output
+ * [nets][n][H*W][64] f32; "p1"/"p2" pooled stage outputs [nets][n][P][64] f32; "m1"/"m2" ReLU
+ * masks [nets][n][P][64] u8 (bit (h&1)*2+(w&1) = relu(z) > 0 at that pixel of the 2x2 pool
+ * window); "y" spectral ReLU output [nets][n][1024] f32; "catd","dropgen" [nets][n][cls_in];
+ * "dy","dp2","dp1","da0" backward intermediates.  Returns CMLPL_E_ARG for an unknown name. */
+int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* name,
+                       size_t* byte_offset, size_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

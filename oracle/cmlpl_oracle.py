@@ -146,21 +146,25 @@ def l2norm(x: torch.Tensor) -> torch.Tensor:
 
 
 def basenet2_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor,
-                     dropmask: Optional[torch.Tensor] = None):
+                     dropmask: Optional[torch.Tensor] = None, taps: Optional[dict] = None):
     """x: [n,C,H,W], y: [n,bands].  ``dropmask`` is the explicit dropout
     multiplier ([n, cls_in], values 0 or 1/(1-p)); None = eval / p==0.
     Returns (logits [n,K], feat [n,1024])."""
     x = F.conv2d(x, p["conv0.weight"], p["conv0.bias"])                    # :132
     x_res = x
     x = F.conv2d(x, p["conv1.weight"], p["conv1.bias"], padding=1)         # :134
+    if taps is not None: taps["z1"] = (x + x_res).detach()                 # pre-ReLU, for mask audits
     x = F.relu(x + x_res)                                                   # :135
     x = F.avg_pool2d(x, 2, 2)                                               # :136
     x_res = x
     x = F.conv2d(x, p["conv2.weight"], p["conv2.bias"], padding=1)         # :138
+    if taps is not None: taps["z2"] = (x + x_res).detach()
     x = F.relu(x + x_res)                                                   # :139
     x = F.avg_pool2d(x, 2, 2)                                               # :140
     x = x.reshape(x.size(0), -1)                                            # :141
-    y = F.relu(F.linear(y, p["feat_spe.weight"], p["feat_spe.bias"]))      # :142-143
+    y = F.linear(y, p["feat_spe.weight"], p["feat_spe.bias"])              # :142
+    if taps is not None: taps["zy"] = y.detach()
+    y = F.relu(y)                                                           # :143
     cat = torch.cat([x, y], 1)                                              # :144
     feat = l2norm(y)                                                        # :145-146
     if dropmask is not None:
@@ -316,8 +320,9 @@ def train_step(state: StepState, XPl, Xl, Y, XPu, Xu, noise: Sequence[torch.Tens
     for net in range(2):
         ps.append({k: (v.detach().clone().requires_grad_(True) if k in LIVE_KEYS else v)
                    for k, v in state.params[net].items()})
-    z_s, f_s = basenet2_forward(ps[0], XP_b_all, X_b_all, dropmask[0])      # :175
-    z_w, f_w = basenet2_forward(ps[1], XP_e_all, X_e_all, dropmask[1])      # :185
+    taps = [{}, {}]
+    z_s, f_s = basenet2_forward(ps[0], XP_b_all, X_b_all, dropmask[0], taps[0])   # :175
+    z_w, f_w = basenet2_forward(ps[1], XP_e_all, X_e_all, dropmask[1], taps[1])   # :185
 
     smooth = (epoch > 0) or (batch_index > hp.queue_batch)                  # :212
     adap_mask = hp.thr * hp.adap_thr(epoch)                                 # :221
@@ -346,7 +351,7 @@ def train_step(state: StepState, XPl, Xl, Y, XPu, Xu, noise: Sequence[torch.Tens
 
     out = dict(lb)
     out.update(logits=[z_s.detach(), z_w.detach()], feats=[f_s.detach(), f_w.detach()],
-               grads=grads, smooth=smooth, adap_mask=adap_mask, n=n,
+               grads=grads, smooth=smooth, adap_mask=adap_mask, n=n, taps=taps,
                # loss_hist row, train.py:274-278
                hist=[float(lb[k].detach()) for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc")])
     return out

@@ -41,3 +41,47 @@ def cuda_batch(b):
         dm = b["dropmask"]
         out["dropmask"] = None if dm[0] is None else torch.stack(dm).to(DEV).contiguous()
     return out
+
+
+def relu_mask_audit(eng, taps, shape, n, ztol=2e-5):
+    """Compare the ReLU masks the HIP forward saved (workspace regions m1, m2, y) with the signs of
+    the oracle's pre-activations.  fp32 summation order differs between the two, so an element whose
+    pre-activation is ~1 ulp from zero may legitimately land on the other side; every mismatch must
+    therefore sit at |z_oracle| < ztol -- anything else is a kernel bug.  Returns flips[net][layer]."""
+    H2, W2 = shape.H // 2, shape.W // 2
+    H4, W4 = H2 // 2, W2 // 2
+    out = []
+    for net in range(2):
+        res = {}
+        for name, zkey, hh, ww in (("m1", "z1", H2, W2), ("m2", "z2", H4, W4)):
+            m = eng.debug_region(name, torch.uint8).view(2, n, hh * ww, 64)[net].cpu()
+            z = taps[net][zkey]                                  # [n, 64, Hfull, Wfull]
+            cnt, worst = 0, 0.0
+            for dh in range(2):
+                for dw in range(2):
+                    zz = z[:, :, dh:2 * hh:2, dw:2 * ww:2].permute(0, 2, 3, 1).reshape(n, hh * ww, 64)
+                    bit = ((m >> (dh * 2 + dw)) & 1).bool()
+                    diff = bit != (zz > 0)
+                    if diff.any():
+                        cnt += int(diff.sum())
+                        worst = max(worst, float(zz[diff].abs().max()))
+            assert worst < ztol, f"net {net} {name}: ReLU mask differs at |z|={worst:.3e} (not a rounding flip)"
+            res[zkey] = cnt
+        y = eng.debug_region("y").view(2, n, 1024)[net].cpu()
+        zy = taps[net]["zy"]
+        diff = (y > 0) != (zy > 0)
+        worst = float(zy[diff].abs().max()) if diff.any() else 0.0
+        assert worst < ztol, f"net {net} y: ReLU mask differs at |z|={worst:.3e}"
+        res["zy"] = int(diff.sum())
+        out.append(res)
+    return out
+
+
+def sync_engine_from_oracle(eng, st):
+    """Put the engine on the oracle's trajectory again (used after a legitimate ReLU-boundary flip)."""
+    for net in range(2):
+        for k in O.LIVE_KEYS:
+            eng.view(eng.params, net, k).copy_(st.params[net][k])
+            eng.view(eng.m, net, k).copy_(st.adam[net].m[k])
+            eng.view(eng.v, net, k).copy_(st.adam[net].v[k])
+    eng._packed_dirty = True

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- CMLPL training-step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload B2|P|B4|B5]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (reference train.py:150-278: noise augmentation, two BaseNet2
+forwards, loss block, bank write, two backwards, two Adam steps) over one synthetic batch that is
+already resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {   # name: (C, H, W, bands, K)   -- SURVEY.md section 8d
+    "B2": (103, 11, 11, 103, 9),    # BASELINE.json configs[1]: PaviaU 11x11x103, batch 256
+    "P": (60, 20, 20, 103, 9),      # the reference's own (PCA-60, 20x20) shape
+    "B4": (200, 11, 11, 200, 16),   # Indian-Pines-shaped
+    "B5": (48, 15, 15, 48, 20),     # Houston2018-shaped
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def synth(shape, bt, btu, seed, device):
+    """XP, X ~ N(0,1), Y ~ U{0..K-1} from torch.Generator(seed) (reference seed 1088, train.py:50)."""
+    C, H, W, bands, K = shape
+    g = torch.Generator().manual_seed(seed)
+    d = dict(XPl=torch.randn(bt, C, H, W, generator=g), Xl=torch.randn(bt, bands, generator=g),
+             Y=torch.randint(0, K, (bt,), generator=g),
+             XPu=torch.randn(btu, C, H, W, generator=g), Xu=torch.randn(btu, bands, generator=g))
+    return {k: v.to(device) for k, v in d.items()}
+
+
+def conv1_flops(shape, n, nets=2):
+    """Algorithmic FLOPs of ONE 3x3 64->64 convolution pass (fwd, dgrad or wgrad) over n patches per net,
+    dense-conv count as in SURVEY.md 8d: 2 * H*W * 64 * 576 per patch."""
+    C, H, W, bands, K = shape
+    return 2.0 * nets * n * H * W * 64 * 576
+
+
+def cpu_baseline(shape, bt, btu, budget_s=20.0):
+    """The oracle (CPU restatement of the reference step, verified against the reference's own outputs)
+    timed on this host's cores on the same workload; bounded sample."""
+    from oracle import cmlpl_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    s = O.NetShape(*shape)
+    hp = O.HyperParams()
+    st = O.StepState.create(s, O.closed_form_params(s, 1), O.closed_form_params(s, 2), bt, hp)
+    batches = [O.synthetic_batch(s, bt, btu, 1088 + i) for i in range(2)]
+    times = []
+    t_start = time.perf_counter()
+    i = 0
+    while True:
+        b = batches[i % 2]
+        t0 = time.perf_counter()
+        # the reference draws noise and the dropout mask inside the step (train.py:157-182, models.py:148)
+        noise = [torch.randn_like(t) for t in b["noise"]]
+        keep = 1.0 - hp.dropout
+        dm = [(torch.rand(bt + btu, s.cls_in) < keep).float() / keep for _ in range(2)]
+        O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], noise, dm, 1, i, hp)
+        times.append(time.perf_counter() - t0)
+        i += 1
+        if i >= 3 and (time.perf_counter() - t_start > budget_s or i >= 200):
+            break
+    times = times[2:] if len(times) > 4 else times
+    med = sorted(times)[len(times) // 2]
+    return {"value": (bt + btu) / med, "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} steps of the same {bt}+{btu} workload after 2 warm-up steps, median "
+                      f"{med * 1e3:.1f} ms/step, PyTorch-CPU {torch.__version__}, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="B2", choices=sorted(WORKLOADS))
+    ap.add_argument("--bt", type=int, default=128, help="labelled rows per GPU")
+    ap.add_argument("--btu", type=int, default=128, help="unlabelled rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    from cmlpl_amd import HyperParams, NetShape, TrainEngine, _lib
+    shape = WORKLOADS[args.workload]
+    hp = HyperParams()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        from cmlpl_amd.distributed import DistTrainEngine
+        eng = DistTrainEngine(NetShape(*shape), args.bt, args.btu, hp, device=device, seed=1088)
+    else:
+        eng = TrainEngine(NetShape(*shape), args.bt, args.btu, hp, device=device, seed=1088)
+    eng.init_params_default(1088)
+    batches = [synth(shape, args.bt, args.btu, 1088 + 7919 * rank + i, device) for i in range(4)]
+    lib = _lib.load()
+
+    def run(k, first_index):
+        for i in range(k):
+            b = batches[(first_index + i) % len(batches)]
+            eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], epoch=1, batch_index=first_index + i)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    run(args.warmup, 0)
+    barrier()
+    # the dominant kernel is bracketed by hipEvent pairs on the launch stream inside the timed region
+    import ctypes as C
+    dom_id = _lib.KERNEL_NAMES.index("conv1_wgrad")
+    _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(1 << dom_id, args.steps + 8))
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms = (C.c_double * len(_lib.KERNEL_NAMES))()
+    cnt = (C.c_int64 * len(_lib.KERNEL_NAMES))()
+    _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    scal = eng.read_scalars()
+    assert all(v == v for v in scal.values()), f"non-finite loss: {scal}"
+
+    n_local = args.bt + args.btu
+    patches = n_local * world * args.steps
+    dom_ms = ms[dom_id] / max(cnt[dom_id], 1)
+    flops = conv1_flops(shape, n_local)
+    achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    out = {
+        "metric": "HSI patches/sec per training step", "value": patches / dt, "unit": "patches/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: synthetic PaviaU-shaped patches {shape[1]}x{shape[2]}x{shape[0]}, "
+                               f"spectrum {shape[3]}, {shape[4]} classes, {args.bt} labelled + {args.btu} unlabelled "
+                               f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
+                               f"bank + Adam, epoch 1 (memory-bank smoothing active), Philox noise/dropout",
+                   "global_batch": n_local * world, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "wgrad3_kernel (conv1 weight gradient, both networks)",
+                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "flops_per_launch": flops, "ms_per_launch": dom_ms, "launches_timed": int(cnt[dom_id])},
+        "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
+    }
+
+    if args.breakdown and rank == 0:
+        _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(0xFFFFFFFF, 40 * 24))
+        run(40, args.warmup + args.steps)
+        barrier()
+        _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
+        tot = sum(ms[i] for i in range(len(_lib.KERNEL_NAMES)))
+        print(f"per-kernel device time over 40 steps (hipEvent pairs; sum {tot / 40 * 1e3:.1f} us/step):", file=sys.stderr)
+        for i, nm in enumerate(_lib.KERNEL_NAMES):
+            if cnt[i]:
+                print(f"  {nm:12s} {ms[i] / cnt[i] * 1e3:9.1f} us/launch  x{cnt[i] // 40}/step  "
+                      f"{100 * ms[i] / tot:5.1f} %", file=sys.stderr)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(shape, args.bt, args.btu)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,8 +25,12 @@ TENSOR_KEYS = (
 EXPORTS = (
     "cmlpl_abi_version", "cmlpl_layout", "cmlpl_workspace_bytes", "cmlpl_pack_weights", "cmlpl_augment",
     "cmlpl_basenet2_fwd", "cmlpl_basenet2_bwd", "cmlpl_loss_fwd_bwd", "cmlpl_adam_step", "cmlpl_train_step",
-    "cmlpl_debug_region",
+    "cmlpl_debug_region", "cmlpl_timing_begin", "cmlpl_timing_end",
 )
+
+KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
+                "cls_wgrad", "spe_wgrad", "conv2_dgrad", "conv2_wgrad", "conv2_wred", "conv1_dgrad", "conv1_wgrad",
+                "conv1_wred", "conv0_wgrad", "adam", "pack")
 
 
 class CmlplLibraryError(RuntimeError):
@@ -112,6 +116,8 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]
+    lib.cmlpl_timing_begin.argtypes = [C.c_uint32, i32]
+    lib.cmlpl_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(i64)]
     for s in EXPORTS[1:]:
         if s != "cmlpl_workspace_bytes":
             getattr(lib, s).restype = i32

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/cmlpl.h"
 #include "kernels.hpp"
 
@@ -84,6 +86,31 @@ void carve_step(const Dims& d, int n, int bank_rows, char* base, StepWs* w) {
 
 int chk(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
+// ---- optional per-kernel timing (cmlpl_timing_begin/_end): hipEvent pairs recorded on the launch stream
+// around the selected launches.  Off by default; the only process-global state of the library.
+struct Timing {
+  bool on = false;
+  uint32_t mask = 0;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ids;
+  size_t used = 0;
+} g_timing;
+
+template <class F>
+int timed(int id, hipStream_t st, F f) {
+  Timing& t = g_timing;
+  if (t.on && ((t.mask >> id) & 1u) && t.used + 2 <= t.ev.size()) {
+    hipEventRecord(t.ev[t.used], st);
+    const int rc = f();
+    hipEventRecord(t.ev[t.used + 1], st);
+    t.ids.push_back(id);
+    t.used += 2;
+    return rc;
+  }
+  return f();
+}
+#define TIMED(id, expr) timed((id), st, [&]() -> int { return (expr); })
+
 }  // namespace
 
 extern "C" {
@@ -139,8 +166,10 @@ int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const flo
   if (nets < 1 || nets > 2 || bt < 0 || btu < 0 || bt + btu < 1 || !d_xn || !d_sn) return CMLPL_E_ARG;
   if ((bt > 0 && (!d_xpl || !d_xl)) || (btu > 0 && (!d_xpu || !d_xu))) return CMLPL_E_ARG;
   const long long e = (long long)d.C * d.HW;
-  return chk(launch_augment(nets, bt * e, btu * e, (long long)bt * d.bands, (long long)btu * d.bands, d_xpl, d_xl,
-                            d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn, (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  return TIMED(CMLPL_K_AUGMENT, chk(launch_augment(nets, bt * e, btu * e, (long long)bt * d.bands,
+                            (long long)btu * d.bands, d_xpl, d_xl, d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn,
+                            st)));
 }
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
@@ -159,17 +188,17 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
   if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if ((rc = chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_params + L.param_off[0], d_params + L.param_off[1],
-                                 param_stride, w.a0, st)))) return rc;
-  if ((rc = chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV, PACK_PER_NET,
-                             d_params + L.param_off[3], param_stride, w.p1, w.m1, st)))) return rc;
-  if ((rc = chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + 2 * PACK_CONV, PACK_PER_NET,
-                             d_params + L.param_off[5], param_stride, w.p2, w.m2, st)))) return rc;
-  if ((rc = chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6], d_params + L.param_off[7],
-                               param_stride, w.y, st)))) return rc;
-  return chk(launch_head_fwd(nets, n, d.P4, d.K, w.p2, w.y, d_dropmask, w.dropgen, dropout_p, train, seed, step,
-                             d_params + L.param_off[8], d_params + L.param_off[9], param_stride, w.catd, w.ynorm,
-                             d_logits, d_feat, st));
+  if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_params + L.param_off[0],
+                                 d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV,
+                             PACK_PER_NET, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + 2 * PACK_CONV,
+                             PACK_PER_NET, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
+                               d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
+  return TIMED(CMLPL_K_HEAD_FWD, chk(launch_head_fwd(nets, n, d.P4, d.K, w.p2, w.y, d_dropmask, w.dropgen, dropout_p,
+                             train, seed, step, d_params + L.param_off[8], d_params + L.param_off[9], param_stride,
+                             w.catd, w.ynorm, d_logits, d_feat, st)));
 }
 
 int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
@@ -189,8 +218,8 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
   // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
-  if ((rc = chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask, d_params + L.param_off[8],
-                                param_stride, w.y, w.ynorm, w.dy, w.dp2, st)))) return rc;
+  if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,
+                                d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
   GemmTN g;
   // dW_cls[k][f] = sum_n dlogits[n][k] * catd[n][f] ; db_cls[k] = sum_n dlogits[n][k]
   g.A = d_dlogits; g.a_bstride = (long long)n * d.K; g.lda = d.K; g.M = d.K;
@@ -198,24 +227,26 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   g.C = d_grads + L.param_off[8]; g.c_bstride = grad_stride; g.ldc = d.F;
   g.bias = d_grads + L.param_off[9]; g.bias_bstride = grad_stride;
   g.R = n; g.batches = nets; g.scale = 1.f;
-  if ((rc = chk(launch_gemm_tn(g, st)))) return rc;
+  if ((rc = TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
   // dW_spe[o][b] = sum_n dy[n][o] * sn[n][b] ; db_spe[o] = sum_n dy[n][o]
   g.A = w.dy; g.a_bstride = (long long)n * 1024; g.lda = 1024; g.M = 1024;
   g.B = d_sn; g.b_bstride = (long long)n * d.bands; g.ldb = d.bands; g.N = d.bands;
   g.C = d_grads + L.param_off[6]; g.ldc = d.bands;
   g.bias = d_grads + L.param_off[7];
-  if ((rc = chk(launch_gemm_tn(g, st)))) return rc;
+  if ((rc = TIMED(CMLPL_K_SPE_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
   // spatial branch
-  if ((rc = chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + 3 * PACK_CONV, PACK_PER_NET, nullptr, 0,
-                             w.dp1, nullptr, st)))) return rc;
-  if ((rc = chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, d_grads + L.param_off[4],
-                              d_grads + L.param_off[5], grad_stride, st)))) return rc;
-  if ((rc = chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV, PACK_PER_NET, nullptr, 0,
-                             w.da0, nullptr, st)))) return rc;
-  if ((rc = chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, d_grads + L.param_off[2],
-                              d_grads + L.param_off[3], grad_stride, st)))) return rc;
-  return chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, d_grads + L.param_off[0],
-                                d_grads + L.param_off[1], grad_stride, st));
+  if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + 3 * PACK_CONV,
+                             PACK_PER_NET, nullptr, 0, w.dp1, nullptr, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_CONV2_WRED, chk(launch_wgrad3_reduce(nets, n, d.H2, d.W2, w.part2, d_grads + L.param_off[4],
+                              d_grads + L.param_off[5], grad_stride, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
+                             PACK_PER_NET, nullptr, 0, w.da0, nullptr, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_CONV1_WRED, chk(launch_wgrad3_reduce(nets, n, d.H, d.W, w.part1, d_grads + L.param_off[2],
+                              d_grads + L.param_off[3], grad_stride, st))))) return rc;
+  return TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0,
+                                d_grads + L.param_off[0], d_grads + L.param_off[1], grad_stride, st)));
 }
 
 int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
@@ -243,7 +274,8 @@ int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d
   a.w_contrast = hp->w_contrast; a.w_mutual = hp->w_mutual; a.pos_thr = hp->pos_thr; a.neg_thr = hp->neg_thr;
   a.scalars = d_scalars; a.dlogits = d_dlogits; a.dfeat = d_dfeat; a.probs_out = d_probs_out;
   loss_ws_carve(a, (float*)d_workspace);
-  return chk(launch_loss(a, (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  return TIMED(CMLPL_K_LOSS, chk(launch_loss(a, st)));
 }
 
 int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t param_stride,
@@ -254,10 +286,11 @@ int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t
   if (rc) return rc;
   if (nets < 1 || nets > 2 || !d_params || !d_grads || !d_m || !d_v || !hp || t < 1) return CMLPL_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if ((rc = chk(launch_adam(nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v, L.param_live, t, hp->lr,
-                            hp->beta1, hp->beta2, hp->eps, st)))) return rc;
+  if ((rc = TIMED(CMLPL_K_ADAM, chk(launch_adam(nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v,
+                            L.param_live, t, hp->lr, hp->beta1, hp->beta2, hp->eps, st))))) return rc;
   if (d_packed)
-    return chk(launch_pack_weights(nets, d_params, param_stride, L.param_off[2], L.param_off[4], d_packed, st));
+    return TIMED(CMLPL_K_PACK, chk(launch_pack_weights(nets, d_params, param_stride, L.param_off[2], L.param_off[4],
+                                                      d_packed, st)));
   return 0;
 }
 
@@ -292,6 +325,36 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
     return cmlpl_adam_step(shape, 2, io->d_params, L.param_total, io->d_grads, L.param_total, io->d_m, io->d_v,
                            io->adam_t, hp, io->d_packed, stream);
   return 0;
+}
+
+int cmlpl_timing_begin(uint32_t kernel_mask, int max_launches) {
+  Timing& t = g_timing;
+  if (t.on || max_launches < 1) return CMLPL_E_ARG;
+  t.ev.resize((size_t)max_launches * 2);
+  for (auto& e : t.ev) {
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return (int)rc;
+  }
+  t.ids.clear(); t.used = 0; t.mask = kernel_mask; t.on = true;
+  return 0;
+}
+
+int cmlpl_timing_end(double* ms_sum, int64_t* launches) {
+  Timing& t = g_timing;
+  if (!t.on || !ms_sum || !launches) return CMLPL_E_ARG;
+  t.on = false;
+  for (int i = 0; i < CMLPL_K_COUNT; ++i) { ms_sum[i] = 0.0; launches[i] = 0; }
+  int rc = 0;
+  for (size_t i = 0; i < t.ids.size(); ++i) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(t.ev[2 * i + 1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    ms_sum[t.ids[i]] += ms; launches[t.ids[i]] += 1;
+  }
+  for (auto& e : t.ev) hipEventDestroy(e);
+  t.ev.clear(); t.ids.clear(); t.used = 0;
+  return rc;
 }
 
 int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* name, size_t* byte_offset,

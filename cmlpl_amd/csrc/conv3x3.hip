@@ -463,7 +463,7 @@ bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
 }
 
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
-                         float* part, float* dW, float* db, long long grad_ns, hipStream_t st) {
+                         float* part, hipStream_t st) {
   Wgrad3Plan pl;
   if (!plan_wgrad3(n, H, W, &pl)) return hipErrorInvalidValue;
   static bool attr_done = false;
@@ -480,10 +480,15 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G;
   hipLaunchKernelGGL(wgrad3_kernel, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((PART3 + 255) / 256, nets), dim3(256), 0, st,
-                     (const float*)part, a.part_ns, pl.G, dW, db, grad_ns);
+  return hipGetLastError();
+}
+
+hipError_t launch_wgrad3_reduce(int nets, int n, int H, int W, const float* part, float* dW, float* db,
+                                long long grad_ns, hipStream_t st) {
+  Wgrad3Plan pl;
+  if (!plan_wgrad3(n, H, W, &pl)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((PART3 + 255) / 256, nets), dim3(256), 0, st, part,
+                     (long long)pl.G * PART3, pl.G, dW, db, grad_ns);
   return hipGetLastError();
 }
 

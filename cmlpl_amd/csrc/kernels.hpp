@@ -31,7 +31,9 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
 struct Wgrad3Plan { int RU, U, G; size_t lds; };
 bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
-                         float* part, float* dW, float* db, long long grad_nstride, hipStream_t st);
+                         float* part, hipStream_t st);
+hipError_t launch_wgrad3_reduce(int nets, int n, int H, int W, const float* part, float* dW, float* db,
+                                long long grad_nstride, hipStream_t st);
 
 // ---- conv0.hip
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w, const float* b,

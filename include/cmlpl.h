@@ -170,6 +170,19 @@ typedef struct cmlpl_step_io {
 int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io,
                      void* stream);
 
+/* Optional per-launch timing, measured with hipEvent pairs recorded on the launch stream around the
+ * selected kernels (bit i of kernel_mask selects CMLPL_K_i).  cmlpl_timing_end synchronises the
+ * recorded events and returns, per kernel id, the summed milliseconds and the number of launches.
+ * This is the only process-global state in the library; it is off unless _begin was called. */
+enum {
+  CMLPL_K_AUGMENT = 0, CMLPL_K_CONV0_FWD, CMLPL_K_CONV1_FWD, CMLPL_K_CONV2_FWD, CMLPL_K_SPE_FWD,
+  CMLPL_K_HEAD_FWD, CMLPL_K_LOSS, CMLPL_K_HEAD_BWD, CMLPL_K_CLS_WGRAD, CMLPL_K_SPE_WGRAD,
+  CMLPL_K_CONV2_DGRAD, CMLPL_K_CONV2_WGRAD, CMLPL_K_CONV2_WRED, CMLPL_K_CONV1_DGRAD, CMLPL_K_CONV1_WGRAD,
+  CMLPL_K_CONV1_WRED, CMLPL_K_CONV0_WGRAD, CMLPL_K_ADAM, CMLPL_K_PACK, CMLPL_K_COUNT
+};
+int cmlpl_timing_begin(uint32_t kernel_mask, int max_launches);
+int cmlpl_timing_end(double* ms_sum /*[CMLPL_K_COUNT]*/, int64_t* launches /*[CMLPL_K_COUNT]*/);
+
 /* Inspection aid (tests, debugging): byte offset and size inside d_workspace of a saved
  * activation of cmlpl_basenet2_fwd/_bwd for (nets, n).  Names: "a0" conv0 output
  * [nets][n][H*W][64] f32; "p1"/"p2" pooled stage outputs [nets][n][P][64] f32; "m1"/"m2" ReLU

@@ -53,6 +53,13 @@ def cpu_baseline(shape, bt, btu, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:  # container CPU share (cgroup v2 quota), if any: oversubscribing it makes the baseline meaningless
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    cores = min(cores, int(os.environ.get("CMLPL_CPU_THREADS", "32")))   # torch intra-op scaling flattens beyond this
     torch.set_num_threads(cores)
     s = O.NetShape(*shape)
     hp = O.HyperParams()

@@ -23,13 +23,10 @@ __global__ void augment_kernel(AugArgs a) {
   const long long N = a.nl[t] + a.nu[t];
   const long long e0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (e0 >= N) return;
-  float nz[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool need_noise = a.sigma != 0.f;
-  if (need_noise && !a.explicit_noise) {
-    const float4 g = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
-                                    (uint64_t)(e0 >> 2));
-    nz[0] = g.x; nz[1] = g.y; nz[2] = g.z; nz[3] = g.w;
-  }
+  if (need_noise && !a.explicit_noise)
+    nz = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net, (uint64_t)(e0 >> 2));
   const float* nl_ptr = a.noise[2 * net + t];         // XPl/net: 0,2 ; Xl/net: 1,3
   const float* nu_ptr = a.noise[4 + 2 * net + t];     // XPu/net: 4,6 ; Xu/net: 5,7
   float* dst = a.dst[t] + (long long)net * N;
@@ -39,7 +36,7 @@ __global__ void augment_kernel(AugArgs a) {
     if (e < N) {
       const bool lab = e < a.nl[t];
       const float x = lab ? a.srcl[t][e] : a.srcu[t][e - a.nl[t]];
-      float z = nz[q];
+      float z = (q == 0) ? nz.x : (q == 1) ? nz.y : (q == 2) ? nz.z : nz.w;
       if (need_noise && a.explicit_noise) z = lab ? nl_ptr[e] : nu_ptr[e - a.nl[t]];
       dst[e] = need_noise ? x + z * a.sigma : x;
     }

@@ -57,10 +57,54 @@ struct Conv3Args {
   int n, H, W, S;
 };
 
+// The 9-tap main loop.  NTA = number of this wave's M tiles that carry real pixels (wave-uniform, so
+// the loop body is branch-free and the compiler can hoist the ds_read_b128 of step kk+1 above the
+// MFMAs of step kk).  Tap weights go global -> registers (prefetched one tap ahead) -> LDS.
+template <int MTW, int NTA>
+__device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float* __restrict__ wbuf,
+                                           const float4* __restrict__ wg, float4 w0, float4 w1, float4 w2,
+                                           float4 w3, const int (&abase)[MTW], f32x16 (&acc)[MTW][2], int PW,
+                                           int tid, int l31, int hh) {
+  float4* wl = (float4*)wbuf;
+  const float* bbase = wbuf + (hh * 64 + l31) * 4;
+#pragma unroll 1
+  for (int s = 0; s < 9; ++s) {
+    __syncthreads();  // everyone done with wbuf of tap s-1 (and, for s == 0, the staged image is complete)
+    wl[tid] = w0; wl[tid + 256] = w1; wl[tid + 512] = w2; wl[tid + 768] = w3;
+    __syncthreads();
+    if (s + 1 < 9) {
+      const float4* wn = wg + (s + 1) * 1024 + tid;
+      w0 = wn[0]; w1 = wn[256]; w2 = wn[512]; w3 = wn[768];
+    }
+    if (NTA > 0) {
+      const int kh = s / 3, kw = s - kh * 3;
+      const float* ib = img + ((kh - 1) * PW + (kw - 1)) * CS;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const float4 b0 = *(const float4*)(bbase + kk * 512);
+        const float4 b1 = *(const float4*)(bbase + kk * 512 + 128);
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) {
+          const float4 av = *(const float4*)(ib + abase[t] + kk * 8);
+          acc[t][0] = mfma32(av.x, b0.x, acc[t][0]);
+          acc[t][1] = mfma32(av.x, b1.x, acc[t][1]);
+          acc[t][0] = mfma32(av.y, b0.y, acc[t][0]);
+          acc[t][1] = mfma32(av.y, b1.y, acc[t][1]);
+          acc[t][0] = mfma32(av.z, b0.z, acc[t][0]);
+          acc[t][1] = mfma32(av.z, b1.z, acc[t][1]);
+          acc[t][0] = mfma32(av.w, b0.w, acc[t][0]);
+          acc[t][1] = mfma32(av.w, b1.w, acc[t][1]);
+        }
+      }
+    }
+  }
+}
+
 template <int MODE, int MTW>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, s0 = blockIdx.x * a.S;
   const int H = a.H, W = a.W, HW = H * W, PW = W + 2, IMG = (H + 2) * PW;
   const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
@@ -82,9 +126,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     lut[m] = s * IMG + (r + 1) * PW + (c + 1);
   }
   const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
-  float4 wr[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) wr[r] = wg[tid + 256 * r];
+  // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
+  const float4 wp0 = wg[tid], wp1 = wg[tid + 256], wp2 = wg[tid + 512], wp3 = wg[tid + 768];
   __syncthreads();
 
   if (MODE == 0) {
@@ -132,37 +175,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     acc[t][1] = zero16();
   }
 
-  for (int s = 0; s < 9; ++s) {
-    __syncthreads();  // everyone done with wbuf of tap s-1 (and, for s==0, the image is complete)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ((float4*)wbuf)[tid + 256 * r] = wr[r];
-    __syncthreads();
-    if (s + 1 < 9) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r] = wg[(s + 1) * 1024 + tid + 256 * r];
-    }
-    const int kh = s / 3, kw = s - kh * 3;
-    const int shoff = ((kh - 1) * PW + (kw - 1)) * CS;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const float4 b0 = *(const float4*)(wbuf + ((2 * kk + hh) * 64 + l31) * 4);
-      const float4 b1 = *(const float4*)(wbuf + ((2 * kk + hh) * 64 + 32 + l31) * 4);
-#pragma unroll
-      for (int t = 0; t < MTW; ++t) {
-        if (wave + 4 * t < MT) {  // wave-uniform
-          const float4 av = *(const float4*)(img + abase[t] + shoff + kk * 8);
-          acc[t][0] = mfma32(av.x, b0.x, acc[t][0]);
-          acc[t][1] = mfma32(av.x, b1.x, acc[t][1]);
-          acc[t][0] = mfma32(av.y, b0.y, acc[t][0]);
-          acc[t][1] = mfma32(av.y, b1.y, acc[t][1]);
-          acc[t][0] = mfma32(av.z, b0.z, acc[t][0]);
-          acc[t][1] = mfma32(av.z, b1.z, acc[t][1]);
-          acc[t][0] = mfma32(av.w, b0.w, acc[t][0]);
-          acc[t][1] = mfma32(av.w, b1.w, acc[t][1]);
-        }
-      }
-    }
-  }
+  // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
+  if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
+  else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
 
   if (MODE == 0) {
@@ -294,7 +309,8 @@ struct Wgrad3Args {
 
 __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, g = blockIdx.x;
   const int H = a.H, W = a.W, HW = H * W, PW = W + 2;
   const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2, RO = 2 * H2, CO = 2 * W2;
@@ -308,17 +324,9 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
 
   float* img = smem;                        // [U][IMGU][64]
-  float* dz = img + (size_t)U * IMGU * 64;  // [D+1][64]
-  int* lut = (int*)(dz + (size_t)(D + 1) * 64);  // [D+2]
-  float* red = (float*)(lut + ((D + 2 + 3) & ~3));  // [256]
+  float* dz = img + (size_t)U * IMGU * 64;  // [D][64]
 
   for (int i = tid; i < U * IMGU * 64; i += 256) img[i] = 0.f;
-  for (int i = tid; i < 64; i += 256) dz[(size_t)D * 64 + i] = 0.f;
-  for (int d = tid; d < D + 2; d += 256) {
-    const int dd = (d < D) ? d : 0;
-    const int u = dd / DU, rem = dd - u * DU, r = rem / CO, c = rem - r * CO;
-    lut[d] = u * IMGU + (r + 1) * PW + (c + 1);
-  }
   const float* src = a.in + (long long)net * a.in_ns;
   const float* dp = a.dpool + (long long)net * a.dpool_ns;
   const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
@@ -376,20 +384,36 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
       }
     }
     __syncthreads();
-    {  // bias gradient: column sums of dz
-      const int co = tid & 63;
-      for (int d = tid >> 6; d < D; d += 4) dbacc += dz[(size_t)d * 64 + co];
-    }
-    const int pairs = (D + 1) >> 1;
-    const float* arow = img + it * 32 + l31;
-    const float* brow = dz + ct * 32 + l31;
-#pragma unroll 2
-    for (int t = 0; t < pairs; ++t) {
-      const int d = 2 * t + hh;
-      const int pos = lut[d] * 64;
-      const float b = brow[(size_t)d * 64];
+    // main loop over pixel pairs (c, c+1) of each staged output row; CO is even, so a pair never
+    // straddles a row and every address is affine in (row, c): no lookup, operands of pair t+1 are
+    // fetched while the 9 MFMAs of pair t run.  lane half hh takes pixel c+hh of the pair.
+    const int rows = U * RU, cpr = CO >> 1;
+    const float* arow0 = img + it * 32 + l31 + (PW + 1 + hh) * 64;   // (r+1)*PW + (c+1) with r = c = 0
+    const float* brow0 = dz + ct * 32 + l31 + hh * 64;
+    float an[9], bn;
+    {
 #pragma unroll
-      for (int s = 0; s < 9; ++s) acc[s] = mfma32(arow[pos + shoff[s]], b, acc[s]);
+      for (int s = 0; s < 9; ++s) an[s] = arow0[shoff[s]];
+      bn = brow0[0];
+    }
+    int u = 0, r = 0, cp = 0;
+    const int pairs = rows * cpr;
+    for (int t = 0; t < pairs; ++t) {
+      float ac[9];
+#pragma unroll
+      for (int s = 0; s < 9; ++s) ac[s] = an[s];
+      const float bc = bn;
+      // advance (u, r, cp) and fetch the next pair (the last fetch re-reads pair 0: harmless)
+      if (++cp == cpr) { cp = 0; if (++r == RU) { r = 0; ++u; } }
+      const int un = (t + 1 < pairs) ? u : 0, rn = (t + 1 < pairs) ? r : 0, cn = (t + 1 < pairs) ? cp : 0;
+      const float* ap = arow0 + (un * IMGU + rn * PW + 2 * cn) * 64;
+      const float* bp = brow0 + ((un * RU + rn) * CO + 2 * cn) * 64;
+#pragma unroll
+      for (int s = 0; s < 9; ++s) an[s] = ap[shoff[s]];
+      bn = bp[0];
+      dbacc += bc;
+#pragma unroll
+      for (int s = 0; s < 9; ++s) acc[s] = mfma32(ac[s], bc, acc[s]);
     }
   }
 
@@ -402,10 +426,11 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
       part[s * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r];
     }
   }
-  __syncthreads();
-  red[tid] = dbacc;
-  __syncthreads();
-  if (tid < 64) part[9 * 4096 + tid] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+  // bias gradient: waves with it == 0 (waves 0, 1) summed their B operand; fold the two pixel parities
+  if (it == 0) {
+    const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
+    if (hh == 0) part[9 * 4096 + ct * 32 + l31] = tot;
+  }
 }
 
 // sum the per-workgroup partials and scatter into the canonical [co][ci][kh][kw] gradient
@@ -436,7 +461,7 @@ __global__ void wgrad3_reduce_kernel(const float* __restrict__ part, long long p
 static size_t wgrad3_lds(int RU, int U, int W) {
   const int PW = W + 2, CO = 2 * (W / 2);
   const size_t D = (size_t)U * RU * CO;
-  return ((size_t)U * (RU + 2) * PW * 64 + (D + 1) * 64 + ((D + 2 + 3) & ~(size_t)3) + 256) * 4;
+  return ((size_t)U * (RU + 2) * PW * 64 + D * 64) * 4;
 }
 
 bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {

@@ -100,9 +100,9 @@ template <class F>
 int timed(int id, hipStream_t st, F f) {
   Timing& t = g_timing;
   if (t.on && ((t.mask >> id) & 1u) && t.used + 2 <= t.ev.size()) {
-    hipEventRecord(t.ev[t.used], st);
+    (void)hipEventRecord(t.ev[t.used], st);
     const int rc = f();
-    hipEventRecord(t.ev[t.used + 1], st);
+    (void)hipEventRecord(t.ev[t.used + 1], st);
     t.ids.push_back(id);
     t.used += 2;
     return rc;
@@ -352,7 +352,7 @@ int cmlpl_timing_end(double* ms_sum, int64_t* launches) {
     if (e != hipSuccess) { rc = (int)e; break; }
     ms_sum[t.ids[i]] += ms; launches[t.ids[i]] += 1;
   }
-  for (auto& e : t.ev) hipEventDestroy(e);
+  for (auto& e : t.ev) (void)hipEventDestroy(e);
   t.ev.clear(); t.ids.clear(); t.used = 0;
   return rc;
 }

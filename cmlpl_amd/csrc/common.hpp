@@ -43,6 +43,27 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
+// Staging copy with instruction-level parallelism: each thread first issues UNR independent loads, then
+// performs the UNR stores.  At this problem size the chip is far from full, so a staging loop that does
+// load -> wait -> store one element at a time is bound by memory latency, not bandwidth.
+//   load(idx)  must be safe for every idx in [0, tot) ; store(idx, v) is only called for idx < tot.
+template <int UNR, typename T, int NTHREADS = 256, class L, class S>
+__device__ __forceinline__ void staged_copy(int tot, int tid, L load, S store) {
+  for (int base = 0; base < tot; base += NTHREADS * UNR) {
+    T v[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      const int idx = base + q * NTHREADS + tid;
+      v[q] = load(idx < tot ? idx : tot - 1);
+    }
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      const int idx = base + q * NTHREADS + tid;
+      if (idx < tot) store(idx, v[q]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct Philox {
   static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

@@ -3,44 +3,64 @@
 //   conv0_fwd_kernel  : a0[pix][co] = sum_c xn[c][pix] * W[co][c] + b[co]
 //                       A operand straight from HBM: for a fixed band c, 32 consecutive pixels of the
 //                       NCHW tensor are one coalesced 128-B segment = the MFMA A fragment, so the input
-//                       is read exactly once and never staged.  Output is written pixel-major
-//                       (channel-last), the layout the 3x3 kernels consume.
-//   conv0_wgrad_kernel: dW[c][co] = sum_pix xn[c][pix] * da0[pix][co]  (split over samples, partials reduced)
+//                       is read exactly once and never staged.  Each lane keeps 16 band loads in flight
+//                       (double-buffered chunks).  Output is written pixel-major (channel-last), the
+//                       layout the 3x3 kernels consume.
+//   conv0_wgrad_kernel: dW[c][co] = sum_pix xn[c][pix] * da0[pix][co]  (one sample slab per workgroup
+//                       pass, partials reduced deterministically by partial_reduce_kernel)
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace cmlpl {
 
+constexpr int C0_CHUNK = 16;   // k-steps (2 bands each) fetched per batch
+
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ w,
                                                         const float* __restrict__ b, long long pstride,
                                                         float* __restrict__ a0, int n, int C, int HW) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // wT[Cp][65]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // wT[Cp+1][65]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y;
   const int Cp = (C + 1) & ~1;
   const float* W = w + (long long)net * pstride;
-  for (int i = tid; i < C * 64; i += 256) {
-    const int co = i / C, c = i - co * C;
-    smem[c * 65 + co] = W[i];
-  }
-  if (Cp != C) for (int i = tid; i < 64; i += 256) smem[C * 65 + i] = 0.f;
-  __syncthreads();
 
   const long long M = (long long)n * HW;
   const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + l31;
-  const bool valid = m < M;
-  const long long mm = valid ? m : 0;
+  const long long mm = (m < M) ? m : 0;
   const int sample = (int)(mm / HW), pix = (int)(mm - (long long)sample * HW);
   const float* ap = xn + ((long long)net * n + sample) * C * HW + pix;
-  f32x16 acc0 = zero16(), acc1 = zero16();
   const int KK = Cp >> 1;
-#pragma unroll 8
-  for (int kk = 0; kk < KK; ++kk) {
-    const int c = 2 * kk + hh;
-    const float a = (c < C) ? ap[(long long)c * HW] : 0.f;
-    const float b0 = smem[c * 65 + l31], b1 = smem[c * 65 + 32 + l31];
-    acc0 = mfma32(a, b0, acc0);
-    acc1 = mfma32(a, b1, acc1);
+  float cur[C0_CHUNK], nxt[C0_CHUNK];
+  auto fetch = [&](float (&buf)[C0_CHUNK], int k0) {
+#pragma unroll
+    for (int q = 0; q < C0_CHUNK; ++q) {
+      const int c = 2 * (k0 + q) + hh;
+      const bool ok = c < C;
+      const float v = ap[(long long)(ok ? c : 0) * HW];
+      buf[q] = ok ? v : 0.f;
+    }
+  };
+  fetch(cur, 0);   // in flight while the weights are staged
+
+  staged_copy<8, float>(C * 64, tid, [&](int i) { return W[i]; },
+                        [&](int i, float v) { const int co = i / C, c = i - co * C; smem[c * 65 + co] = v; });
+  if (Cp != C && tid < 64) smem[C * 65 + tid] = 0.f;
+  __syncthreads();
+
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  for (int k0 = 0; k0 < KK; k0 += C0_CHUNK) {
+    if (k0 + C0_CHUNK < KK) fetch(nxt, k0 + C0_CHUNK);
+#pragma unroll
+    for (int q = 0; q < C0_CHUNK; ++q) {
+      if (k0 + q < KK) {   // uniform
+        const int c = 2 * (k0 + q) + hh;
+        acc0 = mfma32(cur[q], smem[c * 65 + l31], acc0);
+        acc1 = mfma32(cur[q], smem[c * 65 + 32 + l31], acc1);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < C0_CHUNK; ++q) cur[q] = nxt[q];
   }
   const float* bias = b + (long long)net * pstride;
   const float bv0 = bias[l31], bv1 = bias[32 + l31];
@@ -66,16 +86,19 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
 }
 
 // ------------------------------------------------------------------------------------------
-// weight gradient.  One workgroup walks `SPG` samples; per sample the [C][HW] slab of xn is staged
-// in LDS (row stride odd => conflict-free column reads), da0 rows come straight from HBM/L2.
-// wave w: co tile = w&1, band tiles (w>>1), (w>>1)+2, ...   (MAXT tiles of 32 bands per wave)
+// weight gradient.  One workgroup walks its samples; per sample the [C][HW] slab of xn is staged
+// in LDS (row stride odd => conflict-free column reads), da0 rows come straight from HBM/L2 in
+// double-buffered batches of 8 pixel pairs.
+// wave w: co tile = w&1, band tiles (w>>1), (w>>1)+2, ...   (C0_MAXT tiles of 32 bands per wave)
 // ------------------------------------------------------------------------------------------
-constexpr int C0_MAXT = 4;   // up to 8 band tiles = 256 input channels
+constexpr int C0_MAXT = 4;    // up to 8 band tiles = 256 input channels
+constexpr int C0_PB = 8;      // pixel pairs per batch
 
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ xn, const float* __restrict__ da0,
                                                           float* __restrict__ part, int n, int C, int HW, int G) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // xs[Ct][HWp]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, g = blockIdx.x;
   const int NT = (C + 31) >> 5, Ct = NT * 32;
   const int HWp = (HW + 2) | 1;             // odd, >= HW+1 (one zero pad column for odd HW)
@@ -88,37 +111,52 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   float dbacc = 0.f;
   // rows >= C and columns >= HW stay zero for the whole kernel
   for (int i = tid; i < Ct * HWp; i += 256) smem[i] = 0.f;
+  const int pairs = (HW + 1) >> 1;
 
   for (int s = sbeg; s < send; ++s) {
+    const float* brow = da0 + ((long long)net * n + s) * HW * 64 + ct * 32 + l31;
+    float bc[C0_PB], bn[C0_PB];
+    auto fetch = [&](float (&buf)[C0_PB], int t0) {
+#pragma unroll
+      for (int q = 0; q < C0_PB; ++q) {
+        const int p = 2 * (t0 + q) + hh;
+        const bool ok = p < HW;
+        const float v = brow[(long long)(ok ? p : 0) * 64];
+        buf[q] = ok ? v : 0.f;
+      }
+    };
+    fetch(bc, 0);   // in flight while the slab is staged
     __syncthreads();
     const float* xs = xn + ((long long)net * n + s) * C * HW;
-    for (int i = tid; i < C * HW; i += 256) {
-      const int c = i / HW, p = i - c * HW;
-      smem[c * HWp + p] = xs[i];
-    }
+    staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
+                           [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
     __syncthreads();
-    const float* brow = da0 + ((long long)net * n + s) * HW * 64 + ct * 32 + l31;
-    const int pairs = (HW + 1) >> 1;
-#pragma unroll 4
-    for (int t = 0; t < pairs; ++t) {
-      const int p = 2 * t + hh;
-      const float b = (p < HW) ? brow[(long long)p * 64] : 0.f;
-      dbacc += b;
+    for (int t0 = 0; t0 < pairs; t0 += C0_PB) {
+      if (t0 + C0_PB < pairs) fetch(bn, t0 + C0_PB);
 #pragma unroll
-      for (int q = 0; q < C0_MAXT; ++q) {
-        const int tile = it0 + 2 * q;
-        if (tile < NT) acc[q] = mfma32(smem[(tile * 32 + l31) * HWp + p], b, acc[q]);
+      for (int q = 0; q < C0_PB; ++q) {
+        if (t0 + q < pairs) {   // uniform
+          const int p = 2 * (t0 + q) + hh;
+          dbacc += bc[q];
+#pragma unroll
+          for (int k = 0; k < C0_MAXT; ++k) {
+            const int tile = it0 + 2 * k;
+            if (tile < NT) acc[k] = mfma32(smem[(tile * 32 + l31) * HWp + p], bc[q], acc[k]);
+          }
+        }
       }
+#pragma unroll
+      for (int q = 0; q < C0_PB; ++q) bc[q] = bn[q];
     }
   }
   // partial layout [c][co] (+ 64 db)
   float* pp = part + ((long long)net * G + g) * ((long long)Ct * 64 + 64);
 #pragma unroll
-  for (int q = 0; q < C0_MAXT; ++q) {
-    const int tile = it0 + 2 * q;
+  for (int k = 0; k < C0_MAXT; ++k) {
+    const int tile = it0 + 2 * k;
     if (tile < NT) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pp[(tile * 32 + acc_row(r, lane)) * 64 + ct * 32 + l31] = acc[q][r];
+      for (int r = 0; r < 16; ++r) pp[(tile * 32 + acc_row(r, lane)) * 64 + ct * 32 + l31] = acc[k][r];
     }
   }
   if (it0 == 0) {
@@ -127,29 +165,58 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   }
 }
 
-__global__ void conv0_wgrad_reduce_kernel(const float* __restrict__ part, int G, int C, int Ct,
-                                          float* __restrict__ dW, float* __restrict__ db, long long grad_ns) {
+// out[map(e)] = sum_g part[g][e]: 64 elements x 4 slices of g per block, 8 loads in flight per thread,
+// fixed summation order (bit-reproducible, unlike float atomics).
+// mode 0: conv0  e = c*64+co -> dW[co*C + c] (c < C), tail 64 -> db
+// mode 1: conv3x3 e = s*4096 + ci*64 + co -> dW[co*576 + ci*9 + s], tail 64 -> db
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int G, int PS, int mode,
+                                                             int C, float* __restrict__ dW, float* __restrict__ db,
+                                                             long long grad_ns) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
   const int net = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int PS = Ct * 64 + 64;
-  if (e >= PS) return;
-  const float* p = part + (long long)net * G * PS + e;
+  const int e = blockIdx.x * 64 + el;
+  const bool ev = e < PS;
+  const float* p = part + (long long)net * G * PS + (ev ? e : 0);
   float s0 = 0.f, s1 = 0.f;
-  int g = 0;
-  for (; g + 1 < G; g += 2) { s0 += p[(size_t)g * PS]; s1 += p[(size_t)(g + 1) * PS]; }
-  if (g < G) s0 += p[(size_t)g * PS];
-  const float sum = s0 + s1;
-  if (e < Ct * 64) {
-    const int c = e >> 6, co = e & 63;
-    if (c < C) dW[(long long)net * grad_ns + co * C + c] = sum;
-  } else {
-    db[(long long)net * grad_ns + (e - Ct * 64)] = sum;
+  for (int g0 = sl; g0 < G; g0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int g = g0 + 4 * q;
+      const float x = p[(size_t)(g < G ? g : 0) * PS];
+      v[q] = (g < G) ? x : 0.f;
+    }
+    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    s1 += (v[4] + v[5]) + (v[6] + v[7]);
   }
+  red[sl][el] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && ev) {
+    const float sum = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    const int body = PS - 64;
+    if (e >= body) {
+      db[(long long)net * grad_ns + (e - body)] = sum;
+    } else if (mode == 0) {
+      const int c = e >> 6, co = e & 63;
+      if (c < C) dW[(long long)net * grad_ns + co * C + c] = sum;
+    } else {
+      const int s = e >> 12, ci = (e >> 6) & 63, co = e & 63;
+      dW[(long long)net * grad_ns + co * 576 + ci * 9 + s] = sum;
+    }
+  }
+}
+
+hipError_t launch_partial_reduce(int nets, const float* part, int G, int PS, int mode, int C, float* dW, float* db,
+                                 long long grad_ns, hipStream_t st) {
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((PS + 63) / 64, nets), dim3(256), 0, st, part, G, PS, mode, C, dW,
+                     db, grad_ns);
+  return hipGetLastError();
 }
 
 int plan_conv0_wgrad_G(int n, int C, int HW) {
   (void)C; (void)HW;
-  int G = n < 128 ? n : 128;     // per net; 2 nets -> up to 256 workgroups
+  int G = n < 256 ? n : 256;     // per net: one sample per workgroup up to 2 x 256 workgroups
   return G < 1 ? 1 : G;
 }
 
@@ -171,10 +238,7 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
   hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const int PS = Ct * 64 + 64;
-  hipLaunchKernelGGL(conv0_wgrad_reduce_kernel, dim3((PS + 255) / 256, nets), dim3(256), 0, st,
-                     (const float*)part, G, C, Ct, dW, db, grad_ns);
-  return hipGetLastError();
+  return launch_partial_reduce(nets, part, G, Ct * 64 + 64, 0, C, dW, db, grad_ns, st);
 }
 
 }  // namespace cmlpl

@@ -132,37 +132,45 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
 
   if (MODE == 0) {
     const float* src = a.in + (long long)net * a.in_ns;
-    const int tot = S * HW * 16;
-    for (int idx = tid; idx < tot; idx += 256) {
-      const int c4 = idx & 15, p = idx >> 4;
-      const int s = p / HW, pix = p - s * HW, h = pix / W, w = pix - h * W;
-      const int sample = s0 + s;
-      if (sample < a.n) {
-        const float4 v = *(const float4*)(src + ((size_t)sample * HW + pix) * 64 + c4 * 4);
-        *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
-      }
-    }
+    staged_copy<8, float4>(S * HW * 16, tid,
+        [&](int idx) {
+          const int c4 = idx & 15, p = idx >> 4, s = p / HW, pix = p - s * HW, sample = s0 + s;
+          const bool ok = sample < a.n;
+          const float4 v = *(const float4*)(src + ((size_t)(ok ? sample : s0) * HW + pix) * 64 + c4 * 4);
+          return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        },
+        [&](int idx, float4 v) {
+          const int c4 = idx & 15, p = idx >> 4, s = p / HW, pix = p - s * HW, h = pix / W, w = pix - h * W;
+          *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+        });
   } else {
     const float* dp = a.in + (long long)net * a.in_ns;
     const uint8_t* mk = a.mask_in + (long long)net * a.mask_in_ns;
-    const int tot = S * P2 * 64;
-    for (int idx = tid; idx < tot; idx += 256) {
-      const int c4 = idx & 15, sub = (idx >> 4) & 3, pp = idx >> 6;
-      const int s = pp / P2, q = pp - s * P2, ph = q / W2, pw = q - ph * W2;
-      const int sample = s0 + s;
-      if (sample < a.n) {
-        const size_t g = ((size_t)sample * P2 + q) * 64 + c4 * 4;
-        const float4 d = *(const float4*)(dp + g);
-        const uint32_t m4 = *(const uint32_t*)(mk + g);
-        float4 v;
-        v.x = ((m4 >> sub) & 1u) ? d.x * 0.25f : 0.f;
-        v.y = ((m4 >> (8 + sub)) & 1u) ? d.y * 0.25f : 0.f;
-        v.z = ((m4 >> (16 + sub)) & 1u) ? d.z * 0.25f : 0.f;
-        v.w = ((m4 >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
-        const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
-        *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
-      }
-    }
+    struct DM { float4 d; uint32_t m; };
+    // one (pooled pixel, 4 channels) item feeds the 4 full-resolution positions of its 2x2 window
+    staged_copy<8, DM>(S * P2 * 16, tid,
+        [&](int idx) {
+          const int c4 = idx & 15, pp = idx >> 4, s = pp / P2, q = pp - s * P2, sample = s0 + s;
+          const bool ok = sample < a.n;
+          const size_t g = ((size_t)(ok ? sample : s0) * P2 + q) * 64 + c4 * 4;
+          DM r;
+          r.d = *(const float4*)(dp + g);
+          r.m = ok ? *(const uint32_t*)(mk + g) : 0u;
+          return r;
+        },
+        [&](int idx, DM r) {
+          const int c4 = idx & 15, pp = idx >> 4, s = pp / P2, q = pp - s * P2, ph = q / W2, pw = q - ph * W2;
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            float4 v;
+            v.x = ((r.m >> sub) & 1u) ? r.d.x * 0.25f : 0.f;
+            v.y = ((r.m >> (8 + sub)) & 1u) ? r.d.y * 0.25f : 0.f;
+            v.z = ((r.m >> (16 + sub)) & 1u) ? r.d.z * 0.25f : 0.f;
+            v.w = ((r.m >> (24 + sub)) & 1u) ? r.d.w * 0.25f : 0.f;
+            const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
+            *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+          }
+        });
   }
 
   const int MT = (npx + 31) >> 5;
@@ -343,45 +351,54 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   for (int ub = ubeg; ub < uend; ub += U) {
     __syncthreads();  // previous pass finished reading img/dz
     // stage the input rows (row0-1 .. row0+RU) of each unit; rows outside the image are zero
+    staged_copy<8, float4>(U * (RU + 2) * W * 16, tid,
+        [&](int idx) {
+          const int c4 = idx & 15, p = idx >> 4;
+          const int u = p / ((RU + 2) * W), rem = p - u * (RU + 2) * W, ir = rem / W, w = rem - ir * W;
+          const int uid = ub + u;
+          const int uc = (uid < uend) ? uid : ubeg;
+          const int sample = uc / UPS, j = uc - sample * UPS, row = j * RU - 1 + ir;
+          const bool ok = (uid < uend) && row >= 0 && row < H;
+          const float4 v = *(const float4*)(src + ((size_t)sample * HW + (ok ? row : 0) * W + w) * 64 + c4 * 4);
+          return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        },
+        [&](int idx, float4 v) {
+          const int c4 = idx & 15, p = idx >> 4;
+          const int u = p / ((RU + 2) * W), rem = p - u * (RU + 2) * W, ir = rem / W, w = rem - ir * W;
+          *(float4*)(img + (size_t)(u * IMGU + ir * PW + w + 1) * 64 + c4 * 4) = v;
+        });
+    // stage dz = mask * dpool / 4 for the unit's output rows (one pooled item -> its 2x2 window)
     {
-      const int tot = U * (RU + 2) * W * 16;
-      for (int idx = tid; idx < tot; idx += 256) {
-        const int c4 = idx & 15, p = idx >> 4;
-        const int u = p / ((RU + 2) * W), rem = p - u * (RU + 2) * W, ir = rem / W, w = rem - ir * W;
-        const int uid = ub + u;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (uid < uend) {
-          const int sample = uid / UPS, j = uid - sample * UPS;
-          const int row = j * RU - 1 + ir;
-          if (row >= 0 && row < H) v = *(const float4*)(src + ((size_t)sample * HW + row * W + w) * 64 + c4 * 4);
-        }
-        *(float4*)(img + (size_t)(u * IMGU + ir * PW + w + 1) * 64 + c4 * 4) = v;
-      }
-    }
-    // stage dz = mask * dpool / 4 for the unit's output rows
-    {
-      const int tot = D * 16;
-      for (int idx = tid; idx < tot; idx += 256) {
-        const int c4 = idx & 15, d = idx >> 4;
-        const int u = d / DU, rem = d - u * DU, r = rem / CO, c = rem - r * CO;
-        const int uid = ub + u;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (uid < uend) {
-          const int sample = uid / UPS, j = uid - sample * UPS;
-          const int row = j * RU + r;
-          if (row < RO) {
-            const size_t gi = ((size_t)sample * P2 + (row >> 1) * W2 + (c >> 1)) * 64 + c4 * 4;
-            const float4 dv = *(const float4*)(dp + gi);
-            const uint32_t m4 = *(const uint32_t*)(mk + gi);
-            const int sub = (row & 1) * 2 + (c & 1);
-            v.x = ((m4 >> sub) & 1u) ? dv.x * 0.25f : 0.f;
-            v.y = ((m4 >> (8 + sub)) & 1u) ? dv.y * 0.25f : 0.f;
-            v.z = ((m4 >> (16 + sub)) & 1u) ? dv.z * 0.25f : 0.f;
-            v.w = ((m4 >> (24 + sub)) & 1u) ? dv.w * 0.25f : 0.f;
-          }
-        }
-        *(float4*)(dz + (size_t)d * 64 + c4 * 4) = v;
-      }
+      struct DM { float4 d; uint32_t m; };
+      const int RUh = RU >> 1;
+      staged_copy<8, DM>(U * RUh * W2 * 16, tid,
+          [&](int idx) {
+            const int c4 = idx & 15, p = idx >> 4;
+            const int u = p / (RUh * W2), rem = p - u * RUh * W2, rh = rem / W2, pw = rem - rh * W2;
+            const int uid = ub + u;
+            const int uc = (uid < uend) ? uid : ubeg;
+            const int sample = uc / UPS, j = uc - sample * UPS, prow = j * RUh + rh;   // pooled row
+            const bool ok = (uid < uend) && prow < H2;
+            const size_t gi = ((size_t)sample * P2 + (ok ? prow : 0) * W2 + pw) * 64 + c4 * 4;
+            DM r;
+            r.d = *(const float4*)(dp + gi);
+            r.m = ok ? *(const uint32_t*)(mk + gi) : 0u;
+            return r;
+          },
+          [&](int idx, DM r) {
+            const int c4 = idx & 15, p = idx >> 4;
+            const int u = p / (RUh * W2), rem = p - u * RUh * W2, rh = rem / W2, pw = rem - rh * W2;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+              float4 v;
+              v.x = ((r.m >> sub) & 1u) ? r.d.x * 0.25f : 0.f;
+              v.y = ((r.m >> (8 + sub)) & 1u) ? r.d.y * 0.25f : 0.f;
+              v.z = ((r.m >> (16 + sub)) & 1u) ? r.d.z * 0.25f : 0.f;
+              v.w = ((r.m >> (24 + sub)) & 1u) ? r.d.w * 0.25f : 0.f;
+              const int d = u * DU + (2 * rh + (sub >> 1)) * CO + 2 * pw + (sub & 1);
+              *(float4*)(dz + (size_t)d * 64 + c4 * 4) = v;
+            }
+          });
     }
     __syncthreads();
     // main loop over pixel pairs (c, c+1) of each staged output row; CO is even, so a pair never
@@ -430,31 +447,6 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   if (it == 0) {
     const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
     if (hh == 0) part[9 * 4096 + ct * 32 + l31] = tot;
-  }
-}
-
-// sum the per-workgroup partials and scatter into the canonical [co][ci][kh][kw] gradient
-__global__ void wgrad3_reduce_kernel(const float* __restrict__ part, long long part_ns, int G,
-                                     float* __restrict__ dW, float* __restrict__ db, long long grad_ns) {
-  const int net = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= PART3) return;
-  const float* p = part + (long long)net * part_ns + e;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int g = 0;
-  for (; g + 3 < G; g += 4) {
-    s0 += p[(size_t)g * PART3];
-    s1 += p[(size_t)(g + 1) * PART3];
-    s2 += p[(size_t)(g + 2) * PART3];
-    s3 += p[(size_t)(g + 3) * PART3];
-  }
-  for (; g < G; ++g) s0 += p[(size_t)g * PART3];
-  const float sum = (s0 + s1) + (s2 + s3);
-  if (e < 9 * 4096) {
-    const int s = e >> 12, ci = (e >> 6) & 63, co = e & 63;
-    dW[(long long)net * grad_ns + co * 576 + ci * 9 + s] = sum;
-  } else {
-    db[(long long)net * grad_ns + (e - 9 * 4096)] = sum;
   }
 }
 
@@ -512,9 +504,7 @@ hipError_t launch_wgrad3_reduce(int nets, int n, int H, int W, const float* part
                                 long long grad_ns, hipStream_t st) {
   Wgrad3Plan pl;
   if (!plan_wgrad3(n, H, W, &pl)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((PART3 + 255) / 256, nets), dim3(256), 0, st, part,
-                     (long long)pl.G * PART3, pl.G, dW, db, grad_ns);
-  return hipGetLastError();
+  return launch_partial_reduce(nets, part, pl.G, PART3, 1, 64, dW, db, grad_ns, st);
 }
 
 }  // namespace cmlpl

@@ -23,14 +23,14 @@ __global__ __launch_bounds__(256) void spe_fwd_kernel(const float* __restrict__ 
   float* Bs = smem + 32 * BP;                       // [128][BP]
   const float* S = sn + (long long)net * n * bands;
   const float* W = w + (long long)net * pstride;
-  for (int i = tid; i < 32 * BP; i += 256) {
-    const int r = i / BP, k = i - r * BP;
-    As[i] = (k < bands && r0 + r < n) ? S[(long long)(r0 + r) * bands + k] : 0.f;
-  }
-  for (int i = tid; i < 128 * BP; i += 256) {
-    const int o = i / BP, k = i - o * BP;
-    Bs[i] = (k < bands) ? W[(long long)(o0 + o) * bands + k] : 0.f;
-  }
+  staged_copy<8, float>(32 * BP, tid,
+      [&](int i) { const int r = i / BP, k = i - r * BP; const bool ok = (k < bands) && (r0 + r < n);
+                   const float v = S[ok ? (long long)(r0 + r) * bands + k : 0]; return ok ? v : 0.f; },
+      [&](int i, float v) { As[i] = v; });
+  staged_copy<16, float>(128 * BP, tid,
+      [&](int i) { const int o = i / BP, k = i - o * BP; const bool ok = k < bands;
+                   const float v = W[(long long)(o0 + o) * bands + (ok ? k : 0)]; return ok ? v : 0.f; },
+      [&](int i, float v) { Bs[i] = v; });
   __syncthreads();
   f32x16 acc = zero16();
   const float* ar = As + l31 * BP + hh;
@@ -65,48 +65,74 @@ hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const flo
   return hipGetLastError();
 }
 
-// one wave per 32x32 output tile; 4 waves of a workgroup share the M tile (consecutive N tiles)
+// One workgroup per 32x32 output tile; the reduction index r is split over the 4 waves (each takes a
+// contiguous quarter), every wave keeps 16 operand pairs (32 loads) in flight, and the four partial
+// accumulators are folded through LDS.  These GEMMs are tiny (R = batch rows): what matters is the
+// number of dependent memory round trips per wave, which this shape cuts to R/128.
+constexpr int GT_DEPTH = 16;
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int bz = blockIdx.z;
-  const int mt = blockIdx.y, nt = blockIdx.x * 4 + wave;
-  const int NT = (g.N + 31) >> 5;
-  if (nt >= NT) return;
+  __shared__ float red[3][16][64];
+  __shared__ float ared[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bz = blockIdx.z, mt = blockIdx.y, nt = blockIdx.x;
   const float* A = g.A + (long long)bz * g.a_bstride;
   const float* B = g.B + (long long)bz * g.b_bstride;
   const int i = mt * 32 + l31, j = nt * 32 + l31;
   const bool iv = i < g.M, jv = j < g.N;
   const float* ap = A + (iv ? i : 0);
   const float* bp = B + (jv ? j : 0);
+  const int R = g.R;
+  const int pairs = (R + 1) >> 1;
+  const int ppw = (pairs + 3) >> 2;                    // pairs per wave
+  const int t0 = wave * ppw, t1 = (t0 + ppw < pairs) ? t0 + ppw : pairs;
   f32x16 acc = zero16();
   float asum = 0.f;
-  const int R = g.R, pairs = (R + 1) >> 1;
-#pragma unroll 8
-  for (int t = 0; t < pairs; ++t) {
-    const int r = 2 * t + hh;
-    const bool rv = r < R;
-    const float a = (rv && iv) ? ap[(long long)r * g.lda] : 0.f;
-    const float b = (rv && jv) ? bp[(long long)r * g.ldb] : 0.f;
-    asum += a;
-    acc = mfma32(a, b, acc);
-  }
-  float* C = g.C + (long long)bz * g.c_bstride;
-  if (jv) {
+  for (int tb = t0; tb < t1; tb += GT_DEPTH) {
+    float av[GT_DEPTH], bv[GT_DEPTH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + acc_row(r, lane);
-      if (row < g.M) C[(long long)row * g.ldc + j] = acc[r] * g.scale;
+    for (int q = 0; q < GT_DEPTH; ++q) {
+      const int r = 2 * (tb + q) + hh;
+      const bool rv = (tb + q < t1) && (r < R);
+      const int rc = rv ? r : 0;
+      const float a = ap[(long long)rc * g.lda], b = bp[(long long)rc * g.ldb];
+      av[q] = (rv && iv) ? a : 0.f;
+      bv[q] = (rv && jv) ? b : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < GT_DEPTH; ++q) {
+      asum += av[q];
+      acc = mfma32(av[q], bv[q], acc);
     }
   }
-  if (g.bias != nullptr && nt == 0) {
-    const float tot = asum + __shfl_xor(asum, 32, 64);
-    if (hh == 0 && iv) g.bias[(long long)bz * g.bias_bstride + i] = tot * g.scale;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  ared[wave][lane] = asum;
+  __syncthreads();
+  if (wave == 0) {
+    float* C = g.C + (long long)bz * g.c_bstride;
+    if (jv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + acc_row(r, lane);
+        const float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        if (row < g.M) C[(long long)row * g.ldc + j] = v * g.scale;
+      }
+    }
+    if (g.bias != nullptr && nt == 0) {
+      float tot = (ared[0][lane] + ared[1][lane]) + (ared[2][lane] + ared[3][lane]);
+      tot += __shfl_xor(tot, 32, 64);
+      if (hh == 0 && iv) g.bias[(long long)bz * g.bias_bstride + i] = tot * g.scale;
+    }
   }
 }
 
 hipError_t launch_gemm_tn(const GemmTN& g, hipStream_t st) {
   const int MT = (g.M + 31) / 32, NT = (g.N + 31) / 32;
-  dim3 grid((NT + 3) / 4, MT, g.batches);
+  dim3 grid(NT, MT, g.batches);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, g);
   return hipGetLastError();
 }

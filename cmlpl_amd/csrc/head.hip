@@ -1,7 +1,8 @@
 // Classifier head of BaseNet2 (tools/models.py:141,144-150): flatten + concat + dropout + Linear,
 // and the L2 normalisation of the spectral feature (Normalize, models.py:87-90, no epsilon).
-// One wavefront per sample: the 64*H4*W4 + 1024 wide row lives in that wave's LDS slice and the
-// K class dot products are reduced with wavefront shuffles.
+// One 256-thread workgroup per sample: the 64*H4*W4 + 1024 wide row is built once in LDS with all
+// loads of a thread in flight together; each wavefront then owns a subset of the K classes and reduces
+// its dot products with wavefront shuffles (no block-level reduction on the logits path).
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -15,13 +16,16 @@ struct HeadFwdArgs {
   int n, HW4, K;
 };
 
+constexpr int HEAD_MAXQ = 12;   // ceil(F / 256) <= 12  (F <= 3072)
+
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int net = blockIdx.y, sample = blockIdx.x * 4 + wave;
-  if (sample >= a.n) return;  // whole wave; no block-level sync below
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // row[F] + red[4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int net = blockIdx.y, sample = blockIdx.x;
   const int SF = a.HW4 * 64, F = SF + FD, K = a.K;
-  float* row = smem + (size_t)wave * F;
+  float* row = smem;
+  float* red = smem + F;
   const long long rs = (long long)net * a.n + sample;
   const float* p2 = a.p2 + rs * SF;
   const float* y = a.y + rs * FD;
@@ -31,57 +35,72 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   const float* dm = (dmode == 1) ? a.dropmask + rs * F : nullptr;
   float* dg = (dmode == 2) ? a.dropgen + rs * F : nullptr;
   const float keep_scale = 1.0f / (1.0f - a.dropout_p);
+  const int NQ = (F + 255) >> 8;
+
+  float v[HEAD_MAXQ], mlt[HEAD_MAXQ];
+#pragma unroll
+  for (int q = 0; q < HEAD_MAXQ; ++q) {
+    const int f = tid + 256 * q;
+    v[q] = 0.f; mlt[q] = 1.f;
+    if (q < NQ && f < F) {
+      if (f < SF) {
+        const int c = f / a.HW4, hw = f - c * a.HW4;   // canonical NCHW flatten order (x.view, models.py:141)
+        v[q] = p2[hw * 64 + c];
+      } else {
+        v[q] = y[f - SF];
+      }
+      if (dmode == 1) mlt[q] = dm[f];
+    }
+  }
   float ss = 0.f;
-  for (int f = lane; f < F; f += 64) {
-    float v;
-    if (f < SF) {
-      const int c = f / a.HW4, hw = f - c * a.HW4;   // canonical NCHW flatten order (x.view, models.py:141)
-      v = p2[hw * 64 + c];
-    } else {
-      v = y[f - SF];
-      ss += v * v;
+#pragma unroll
+  for (int q = 0; q < HEAD_MAXQ; ++q) {
+    const int f = tid + 256 * q;
+    if (q < NQ && f < F) {
+      float x = v[q];
+      if (f >= SF) ss = fmaf(x, x, ss);
+      if (dmode == 2) {
+        const unsigned long long e = (unsigned long long)sample * F + f;
+        const float4 u = philox_uniform4(a.seed, a.step, STREAM_DROPOUT + net, e >> 2);
+        const float uu = ((e & 3) == 0) ? u.x : ((e & 3) == 1) ? u.y : ((e & 3) == 2) ? u.z : u.w;
+        mlt[q] = (uu >= a.dropout_p) ? keep_scale : 0.f;
+        dg[f] = mlt[q];
+      }
+      if (dmode != 0) x *= mlt[q];
+      row[f] = x;
+      catd[f] = x;
     }
-    if (dmode == 1) v *= dm[f];
-    else if (dmode == 2) {
-      const unsigned long long e = (unsigned long long)sample * F + f;
-      const float4 u = philox_uniform4(a.seed, a.step, STREAM_DROPOUT + net, e >> 2);
-      const float uu = ((e & 3) == 0) ? u.x : ((e & 3) == 1) ? u.y : ((e & 3) == 2) ? u.z : u.w;
-      const float mlt = (uu >= a.dropout_p) ? keep_scale : 0.f;
-      dg[f] = mlt;
-      v *= mlt;
-    }
-    row[f] = v;
-    catd[f] = v;
   }
   ss = wave_sum(ss);
-  const float norm = sqrtf(ss);
-  if (lane == 0) a.ynorm[rs] = norm;
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  if (tid == 0) a.ynorm[rs] = norm;
   float* feat = a.feat + rs * FD;
-  for (int j = lane; j < FD; j += 64) feat[j] = y[j] / norm;
-
+  {  // the y part of this thread's row slice is still in v[] (pre-dropout): f = SF + j  <=>  j = f - SF
+#pragma unroll
+    for (int q = 0; q < HEAD_MAXQ; ++q) {
+      const int f = tid + 256 * q;
+      if (q < NQ && f >= SF && f < F) feat[f - SF] = v[q] / norm;
+    }
+  }
+  // logits: wave w owns classes w, w+4, ...
   const float* wc = a.wc + (long long)net * a.pstride;
   const float* bc = a.bc + (long long)net * a.pstride;
-  for (int kc = 0; kc < K; kc += 4) {
+  for (int k = wave; k < K; k += 4) {
+    const float* wk = wc + (long long)k * F;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    const float* w0 = wc + (long long)(kc) * F;
-    const float* w1 = wc + (long long)((kc + 1 < K) ? kc + 1 : K - 1) * F;
-    const float* w2 = wc + (long long)((kc + 2 < K) ? kc + 2 : K - 1) * F;
-    const float* w3 = wc + (long long)((kc + 3 < K) ? kc + 3 : K - 1) * F;
-    for (int f = lane; f < F; f += 64) {
-      const float c = row[f];
-      acc0 = fmaf(c, w0[f], acc0);
-      acc1 = fmaf(c, w1[f], acc1);
-      acc2 = fmaf(c, w2[f], acc2);
-      acc3 = fmaf(c, w3[f], acc3);
+    int f = lane;
+    for (; f + 192 < F; f += 256) {
+      const float w0 = wk[f], w1 = wk[f + 64], w2 = wk[f + 128], w3 = wk[f + 192];
+      acc0 = fmaf(row[f], w0, acc0);
+      acc1 = fmaf(row[f + 64], w1, acc1);
+      acc2 = fmaf(row[f + 128], w2, acc2);
+      acc3 = fmaf(row[f + 192], w3, acc3);
     }
-    acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2); acc3 = wave_sum(acc3);
-    if (lane == 0) {
-      float* lo = a.logits + rs * K;
-      lo[kc] = acc0 + bc[kc];
-      if (kc + 1 < K) lo[kc + 1] = acc1 + bc[kc + 1];
-      if (kc + 2 < K) lo[kc + 2] = acc2 + bc[kc + 2];
-      if (kc + 3 < K) lo[kc + 3] = acc3 + bc[kc + 3];
-    }
+    for (; f < F; f += 64) acc0 = fmaf(row[f], wk[f], acc0);
+    const float tot = wave_sum((acc0 + acc1) + (acc2 + acc3));
+    if (lane == 0) a.logits[rs * K + k] = tot + bc[k];
   }
 }
 
@@ -93,16 +112,10 @@ hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, con
   a.p2 = p2; a.y = y; a.dropmask = dropmask; a.dropgen = dropgen; a.wc = wc; a.bc = bc; a.pstride = pstride;
   a.catd = catd; a.ynorm = ynorm; a.logits = logits; a.feat = feat;
   a.dropout_p = dropout_p; a.train = train; a.seed = seed; a.step = step; a.n = n; a.HW4 = HW4; a.K = K;
-  const size_t lds = (size_t)4 * (HW4 * 64 + FD) * 4;
-  if (lds > LDS_MAX) return hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_MAX);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((n + 3) / 4, nets), dim3(256), lds, st, a);
+  const int F = HW4 * 64 + FD;
+  if (F > 256 * HEAD_MAXQ) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(F + 4) * 4;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(n, nets), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -119,38 +132,57 @@ struct HeadBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
-  __shared__ float dls[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int net = blockIdx.y, sample = blockIdx.x * 4 + wave;
-  if (sample >= a.n) return;
+  __shared__ float dls[64];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int net = blockIdx.y, sample = blockIdx.x;
   const int SF = a.HW4 * 64, F = SF + FD, K = a.K;
   const long long rs = (long long)net * a.n + sample;
-  dls[wave][lane] = (lane < K) ? a.dlogits[rs * K + lane] : 0.f;
+  if (tid < 64) dls[tid] = (tid < K) ? a.dlogits[rs * K + tid] : 0.f;
   const float* y = a.y + rs * FD;
   const float* df = (a.dfeat != nullptr) ? a.dfeat + rs * FD : nullptr;
   const float norm = a.ynorm[rs];
-  float dot = 0.f;   // <feat, dfeat> with feat = y / ||y|| (same division as the forward pass)
-  if (df != nullptr) {
-    for (int j = lane; j < FD; j += 64) dot = fmaf(y[j] / norm, df[j], dot);
-    dot = wave_sum(dot);
+  // this thread's 4 spectral elements j = tid + 256*q
+  float yv[4], dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    yv[q] = y[tid + 256 * q];
+    dv[q] = (df != nullptr) ? df[tid + 256 * q] : 0.f;
   }
+  float dot = 0.f;   // <feat, dfeat> with feat = y / ||y|| (same division as the forward pass)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dot = fmaf(yv[q] / norm, dv[q], dot);
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = (red[0] + red[1]) + (red[2] + red[3]);
   const float* wc = a.wc + (long long)net * a.pstride;
   const float* dm = (a.dropmask != nullptr) ? a.dropmask + rs * F : nullptr;
   float* dp2 = a.dp2 + rs * SF;
   float* dy = a.dy + rs * FD;
-  __builtin_amdgcn_wave_barrier();
-  for (int f = lane; f < F; f += 64) {
-    float dc = 0.f;
-    for (int k = 0; k < K; ++k) dc = fmaf(dls[wave][k], wc[(long long)k * F + f], dc);
+  for (int f = tid; f < F; f += 256) {
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    const float* wf = wc + f;
+    int k = 0;
+    for (; k + 3 < K; k += 4) {
+      const float w0 = wf[(long long)k * F], w1 = wf[(long long)(k + 1) * F];
+      const float w2 = wf[(long long)(k + 2) * F], w3 = wf[(long long)(k + 3) * F];
+      d0 = fmaf(dls[k], w0, d0); d1 = fmaf(dls[k + 1], w1, d1);
+      d2 = fmaf(dls[k + 2], w2, d2); d3 = fmaf(dls[k + 3], w3, d3);
+    }
+    for (; k < K; ++k) d0 = fmaf(dls[k], wf[(long long)k * F], d0);
+    float dc = (d0 + d1) + (d2 + d3);
     if (dm != nullptr) dc *= dm[f];
     if (f < SF) {
       const int c = f / a.HW4, hw = f - c * a.HW4;
       dp2[hw * 64 + c] = dc;
     } else {
       const int j = f - SF;
+      const float yj = y[j];
       float g = dc;
-      if (df != nullptr) g += (df[j] - (y[j] / norm) * dot) / norm;
-      dy[j] = (y[j] > 0.f) ? g : 0.f;
+      if (df != nullptr) g += (df[j] - (yj / norm) * dot) / norm;
+      dy[j] = (yj > 0.f) ? g : 0.f;
     }
   }
 }
@@ -162,7 +194,7 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
   HeadBwdArgs a;
   a.dlogits = dlogits; a.dfeat = dfeat; a.dropmask = dropmask; a.wc = wc; a.pstride = pstride;
   a.y = y; a.ynorm = ynorm; a.dy = dy; a.dp2 = dp2; a.n = n; a.HW4 = HW4; a.K = K;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((n + 3) / 4, nets), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(n, nets), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -39,6 +39,8 @@ hipError_t launch_wgrad3_reduce(int nets, int n, int H, int W, const float* part
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w, const float* b,
                             long long pstride, float* a0, hipStream_t st);
 int plan_conv0_wgrad_G(int n, int C, int HW);
+hipError_t launch_partial_reduce(int nets, const float* part, int G, int PS, int mode, int C, float* dW, float* db,
+                                 long long grad_ns, hipStream_t st);
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
                               float* dW, float* db, long long grad_nstride, hipStream_t st);
 

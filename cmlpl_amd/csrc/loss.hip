@@ -44,12 +44,15 @@ void loss_ws_carve(LossArgs& a, float* ws) {
   a.rowloss = ws; ws += RL_COUNT * RL;
 }
 
-constexpr int PS = 68;  // LDS row stride of the 64-deep k-chunk (64 + 4)
-
+// One workgroup per 32x32 tile of one product.  The 1024-long contraction is split over the 4 waves
+// (256 each); every lane loads its operand fragments straight from L2 as 16-byte pieces (8 A + 8 B
+// loads in flight per batch), so there is no LDS staging and no barrier in the main loop.  The four
+// partial tiles meet in LDS; each wave then finishes 4 of the 16 accumulator rows (exp, row sums and
+// the E.bank_probs partials by half-wave shuffles).
 __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[32 * PS];
-  __shared__ __attribute__((aligned(16))) float Bs[128 * PS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
   if (prob < 2 && !a.smooth) return;
   const int n = a.bt + a.btu, btu = a.btu, K = a.K;
@@ -58,69 +61,65 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const float* A = (prob == 0) ? fU_w : fU_s;
   const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : fU_w;
   const int NB = (prob < 2) ? a.Q : btu;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 128;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   if (c0 >= NB || r0 >= btu) return;
+  const int ia = r0 + l31, jb = c0 + l31;
+  const float* ap = A + (long long)(ia < btu ? ia : 0) * FD + wave * 256 + hh * 4;
+  const float* bp = B + (long long)(jb < NB ? jb : 0) * FD + wave * 256 + hh * 4;
   f32x16 acc = zero16();
-  for (int d0 = 0; d0 < FD; d0 += 64) {
-    __syncthreads();
+#pragma unroll 1
+  for (int qb = 0; qb < 32; qb += 8) {
+    float4 av[8], bv[8];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int idx = tid + 256 * q, row = idx >> 4, c4 = idx & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < btu) v = *(const float4*)(A + (long long)(r0 + row) * FD + d0 + c4 * 4);
-      *(float4*)(As + row * PS + c4 * 4) = v;
+    for (int q = 0; q < 8; ++q) {
+      av[q] = *(const float4*)(ap + (qb + q) * 8);
+      bv[q] = *(const float4*)(bp + (qb + q) * 8);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int idx = tid + 256 * q, row = idx >> 4, c4 = idx & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + row < NB) v = *(const float4*)(B + (long long)(c0 + row) * FD + d0 + c4 * 4);
-      *(float4*)(Bs + row * PS + c4 * 4) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 av = *(const float4*)(As + l31 * PS + q * 8 + hh * 4);
-      const float4 bv = *(const float4*)(Bs + (wave * 32 + l31) * PS + q * 8 + hh * 4);
-      acc = mfma32(av.x, bv.x, acc);
-      acc = mfma32(av.y, bv.y, acc);
-      acc = mfma32(av.z, bv.z, acc);
-      acc = mfma32(av.w, bv.w, acc);
+      acc = mfma32(av[q].x, bv[q].x, acc);
+      acc = mfma32(av[q].y, bv[q].y, acc);
+      acc = mfma32(av[q].z, bv[q].z, acc);
+      acc = mfma32(av[q].w, bv[q].w, acc);
     }
   }
-  const int j = c0 + wave * 32 + l31;
-  const bool jv = j < NB;
-  if (c0 + wave * 32 >= NB) return;  // whole wave tile out of range (no further block sync)
-  float e[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) e[r] = jv ? expf(acc[r] / a.T) : 0.f;
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // wave w finishes accumulator rows 4w .. 4w+3
+  const bool jv = jb < NB;
+  float e[4];
+  int irow[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = wave * 4 + q;
+    const float u = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    e[q] = jv ? expf(u / a.T) : 0.f;
+    irow[q] = r0 + acc_row(r, lane);
+  }
   if (prob == 2) {
     if (jv) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = r0 + acc_row(r, lane);
-        if (i < btu) a.Smat[(long long)i * btu + j] = e[r];
-      }
+      for (int q = 0; q < 4; ++q)
+        if (irow[q] < btu) a.Smat[(long long)irow[q] * btu + jb] = e[q];
     }
     return;
   }
-  const int CT = (a.Q + 31) >> 5, ctile = (c0 >> 5) + wave;
+  const int CT = (a.Q + 31) >> 5, ctile = c0 >> 5;
   float* rs = a.rs_part + ((long long)prob * CT + ctile) * btu;
   float* ep = a.ep_part + ((long long)prob * CT + ctile) * btu * K;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float s = half_sum(e[r]);
-    const int i = r0 + acc_row(r, lane);
-    if (l31 == 0 && i < btu) rs[i] = s;
+  for (int q = 0; q < 4; ++q) {
+    const float sum = half_sum(e[q]);
+    if (l31 == 0 && irow[q] < btu) rs[irow[q]] = sum;
   }
-  const float* bp = a.bank_p[prob] + (long long)(jv ? j : 0) * K;
+  const float* bpr = a.bank_p[prob] + (long long)(jv ? jb : 0) * K;
   for (int k = 0; k < K; ++k) {
-    const float pv = jv ? bp[k] : 0.f;
+    const float pv = jv ? bpr[k] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float s = half_sum(e[r] * pv);
-      const int i = r0 + acc_row(r, lane);
-      if (l31 == 0 && i < btu) ep[(long long)i * K + k] = s;
+    for (int q = 0; q < 4; ++q) {
+      const float sum = half_sum(e[q] * pv);
+      if (l31 == 0 && irow[q] < btu) ep[(long long)irow[q] * K + k] = sum;
     }
   }
 }
@@ -164,6 +163,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const float lsms = zs - mxs - logf(ses), lsmw = zw - mxw - logf(sew);  // log_softmax
   float pw = smw, ps = sms;                              // "probs" (Base1) / "probs1" (Base)
   if (a.smooth) {
+    // sum the per-column-tile partials of pair_exp_kernel.  Lanes are split into 64/KP groups of KP >= K
+    // lanes; group gq takes tiles ct = gq, gq+G, ... for class (lane % KP), 8 loads in flight at a time.
     const int CT = (a.Q + 31) >> 5;
     float rsw = 0.f, rss = 0.f;
     for (int ct = lane; ct < CT; ct += 64) {
@@ -171,13 +172,28 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
       rss += a.rs_part[((long long)1 * CT + ct) * btu + i];
     }
     rsw = wave_sum(rsw); rss = wave_sum(rss);
+    int KP = 1;
+    while (KP < K) KP <<= 1;
+    const int G = 64 / KP, gq = lane / KP, kq = lane - gq * KP;
+    const bool kqv = kq < K;
     float epw = 0.f, eps_ = 0.f;
-    if (kv) {
-      for (int ct = 0; ct < CT; ++ct) {
-        epw += a.ep_part[(((long long)0 * CT + ct) * btu + i) * K + lane];
-        eps_ += a.ep_part[(((long long)1 * CT + ct) * btu + i) * K + lane];
+    const float* e0 = a.ep_part + ((long long)0 * CT * btu + i) * K + (kqv ? kq : 0);
+    const float* e1 = a.ep_part + ((long long)1 * CT * btu + i) * K + (kqv ? kq : 0);
+    const long long cstride = (long long)btu * K;
+    for (int cb = gq; cb < CT; cb += 8 * G) {
+      float t0[8], t1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int ct = cb + q * G;
+        const bool ok = ct < CT;
+        const float x0 = e0[(long long)(ok ? ct : 0) * cstride], x1 = e1[(long long)(ok ? ct : 0) * cstride];
+        t0[q] = ok ? x0 : 0.f; t1[q] = ok ? x1 : 0.f;
       }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { epw += t0[q]; eps_ += t1[q]; }
     }
+    for (int o = KP; o < 64; o <<= 1) { epw += __shfl_xor(epw, o, 64); eps_ += __shfl_xor(eps_, o, 64); }
+    // lanes 0..K-1 (group 0) now hold the full sums for class = lane
     pw = a.alpha * smw + (1.f - a.alpha) * (epw / rsw);
     ps = a.alpha * sms + (1.f - a.alpha) * (eps_ / rss);
   }
@@ -332,7 +348,7 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   const int maxc = (a.smooth && a.Q > btu) ? a.Q : btu;
-  dim3 g1((maxc + 127) / 128, (btu + 31) / 32, 3);
+  dim3 g1((maxc + 31) / 32, (btu + 31) / 32, 3);
   hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(loss_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);

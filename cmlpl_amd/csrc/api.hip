@@ -69,7 +69,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
 
 // extra regions used only by cmlpl_train_step / cmlpl_loss_fwd_bwd
 struct StepWs {
-  float *xn, *sn, *dlogits, *dfeat, *loss;
+  float *xn, *sn, *dlogits, *dfeat, *probs, *loss;
   size_t bytes;
 };
 
@@ -80,7 +80,8 @@ void carve_step(const Dims& d, int n, int bank_rows, char* base, StepWs* w) {
   w->sn = (float*)take((size_t)2 * n * d.bands * 4);
   w->dlogits = (float*)take((size_t)2 * n * d.K * 4);
   w->dfeat = (float*)take((size_t)2 * n * 1024 * 4);
-  w->loss = (float*)take(loss_ws_floats(n, n, d.K, bank_rows > n ? bank_rows : n) * 4);
+  w->probs = (float*)take((size_t)4 * n * d.K * 4);
+  w->loss = (float*)take(loss_ws_floats(n, n, n, d.K, bank_rows > n ? bank_rows : n) * 4);
   w->bytes = off;
 }
 
@@ -160,22 +161,22 @@ int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params
 
 int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const float* d_xpl, const float* d_xl,
                   const float* d_xpu, const float* d_xu, const float* const* noise8, float sigma, uint64_t seed,
-                  uint64_t step, float* d_xn, float* d_sn, void* stream) {
+                  uint64_t step, const cmlpl_shard* shard, float* d_xn, float* d_sn, void* stream) {
   Dims d;
   if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
   if (nets < 1 || nets > 2 || bt < 0 || btu < 0 || bt + btu < 1 || !d_xn || !d_sn) return CMLPL_E_ARG;
   if ((bt > 0 && (!d_xpl || !d_xl)) || (btu > 0 && (!d_xpu || !d_xu))) return CMLPL_E_ARG;
-  const long long e = (long long)d.C * d.HW;
+  if (shard && (shard->nlab != bt || shard->nunl != btu)) return CMLPL_E_ARG;
+  const int lab0 = shard ? shard->lab0 : 0, unl_base = shard ? shard->bt_g + shard->unl0 : bt;
   hipStream_t st = (hipStream_t)stream;
-  return TIMED(CMLPL_K_AUGMENT, chk(launch_augment(nets, bt * e, btu * e, (long long)bt * d.bands,
-                            (long long)btu * d.bands, d_xpl, d_xl, d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn,
-                            st)));
+  return TIMED(CMLPL_K_AUGMENT, chk(launch_augment(nets, bt, btu, d.C * d.HW, d.bands, lab0, unl_base, d_xpl, d_xl,
+                            d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn, st)));
 }
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
                        const float* d_packed, const float* d_xn, const float* d_sn, const float* d_dropmask,
-                       float dropout_p, int train, uint64_t seed, uint64_t step, float* d_logits, float* d_feat,
-                       void* d_workspace, size_t workspace_bytes, void* stream) {
+                       float dropout_p, int train, uint64_t seed, uint64_t step, const cmlpl_shard* shard,
+                       float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes, void* stream) {
   Dims d;
   cmlpl_layout_t L;
   if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
@@ -196,9 +197,12 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
                              PACK_PER_NET, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
   if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
                                d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
+  if (shard && shard->nlab + shard->nunl != n) return CMLPL_E_ARG;
+  const int nlab = shard ? shard->nlab : n, lab0 = shard ? shard->lab0 : 0;
+  const int unl_base = shard ? shard->bt_g + shard->unl0 : n;
   return TIMED(CMLPL_K_HEAD_FWD, chk(launch_head_fwd(nets, n, d.P4, d.K, w.p2, w.y, d_dropmask, w.dropgen, dropout_p,
-                             train, seed, step, d_params + L.param_off[8], d_params + L.param_off[9], param_stride,
-                             w.catd, w.ynorm, d_logits, d_feat, st)));
+                             train, seed, step, nlab, lab0, unl_base, d_params + L.param_off[8],
+                             d_params + L.param_off[9], param_stride, w.catd, w.ynorm, d_logits, d_feat, st)));
 }
 
 int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
@@ -249,18 +253,18 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
                                 d_grads + L.param_off[0], d_grads + L.param_off[1], grad_stride, st)));
 }
 
-int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
-                       const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
-                       const cmlpl_hparams* hp, float* d_scalars, float* d_dlogits, float* d_dfeat,
-                       float* d_probs_out, void* d_workspace, size_t workspace_bytes, void* stream) {
-  Dims d;
-  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
-  if (bt < 1 || btu < 1 || btu > 2048 || !d_logits || !d_feat || !d_labels || !banks || !hp || !d_scalars ||
-      !d_dlogits || !d_dfeat || !d_workspace)
+namespace {
+int fill_loss_args(const Dims& d, const cmlpl_shard* sh, const float* d_logits, const float* d_feat,
+                   const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
+                   const cmlpl_hparams* hp, void* ws, size_t ws_bytes, LossArgs* out) {
+  if (!sh || !d_logits || !d_feat || !d_labels || !banks || !hp || !ws) return CMLPL_E_ARG;
+  if (sh->bt_g < 1 || sh->btu_g < 1 || sh->btu_g > 2048 || sh->nlab < 0 || sh->nunl < 1 || sh->lab0 < 0 ||
+      sh->unl0 < 0 || sh->lab0 + sh->nlab > sh->bt_g || sh->unl0 + sh->nunl > sh->btu_g)
     return CMLPL_E_ARG;
-  if (banks->Q < bt + btu || !banks->d_feats[0] || !banks->d_feats[1] || !banks->d_probs[0] || !banks->d_probs[1])
+  if (banks->Q < sh->bt_g + sh->btu_g || !banks->d_feats[0] || !banks->d_feats[1] || !banks->d_probs[0] ||
+      !banks->d_probs[1])
     return CMLPL_E_ARG;
-  if (loss_ws_floats(bt, btu, d.K, banks->Q) * 4 > workspace_bytes) return CMLPL_E_WORKSPACE;
+  if (loss_ws_floats(sh->nlab, sh->nunl, sh->btu_g, d.K, banks->Q) * 4 > ws_bytes) return CMLPL_E_WORKSPACE;
   LossArgs a;
   memset(&a, 0, sizeof(a));
   a.logits = d_logits; a.feat = d_feat; a.labels = d_labels;
@@ -269,13 +273,81 @@ int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d
     a.bank_fw[i] = banks->d_feats[i]; a.bank_pw[i] = banks->d_probs[i];
   }
   a.Q = banks->Q; a.ptr0 = ((banks->ptr[0] % a.Q) + a.Q) % a.Q; a.ptr1 = ((banks->ptr[1] % a.Q) + a.Q) % a.Q;
-  a.bt = bt; a.btu = btu; a.K = d.K; a.smooth = smooth;
+  a.bt = sh->bt_g; a.btu = sh->btu_g; a.K = d.K; a.smooth = smooth;
+  a.lab0 = sh->lab0; a.nlab = sh->nlab; a.unl0 = sh->unl0; a.nunl = sh->nunl;
   a.adap_mask = adap_mask; a.T = hp->temperature; a.alpha = hp->alpha;
   a.w_contrast = hp->w_contrast; a.w_mutual = hp->w_mutual; a.pos_thr = hp->pos_thr; a.neg_thr = hp->neg_thr;
-  a.scalars = d_scalars; a.dlogits = d_dlogits; a.dfeat = d_dfeat; a.probs_out = d_probs_out;
-  loss_ws_carve(a, (float*)d_workspace);
+  loss_ws_carve(a, (float*)ws);
+  *out = a;
+  return 0;
+}
+}  // namespace
+
+size_t cmlpl_loss_workspace_bytes(const cmlpl_shape* shape, const cmlpl_shard* shard, int bank_rows) {
+  Dims d;
+  if (!make_dims(shape, &d) || !shard || shard->nunl < 1 || shard->btu_g < 1 || bank_rows < 1) return 0;
+  return loss_ws_floats(shard->nlab, shard->nunl, shard->btu_g, d.K, bank_rows) * 4;
+}
+
+int cmlpl_loss_phase1(const cmlpl_shape* shape, const cmlpl_shard* shard, const float* d_logits, const float* d_feat,
+                      const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
+                      const cmlpl_hparams* hp, float* d_dlogits, float* d_probs_local, void* d_workspace,
+                      size_t workspace_bytes, void* stream) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  LossArgs a;
+  int rc = fill_loss_args(d, shard, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_workspace,
+                          workspace_bytes, &a);
+  if (rc) return rc;
+  if (!d_dlogits || !d_probs_local) return CMLPL_E_ARG;
+  a.dlogits = d_dlogits; a.probs_l = d_probs_local;
   hipStream_t st = (hipStream_t)stream;
-  return TIMED(CMLPL_K_LOSS, chk(launch_loss(a, st)));
+  return TIMED(CMLPL_K_LOSS, chk(launch_loss_phase1(a, st)));
+}
+
+int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard, const float* d_logits, const float* d_feat,
+                      const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
+                      const cmlpl_hparams* hp, const float* d_probs_global, int probs_shard_rows, float* d_scalars,
+                      float* d_dfeat, float* d_dfeat_w_partial, void* d_workspace, size_t workspace_bytes,
+                      void* stream) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  LossArgs a;
+  int rc = fill_loss_args(d, shard, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_workspace,
+                          workspace_bytes, &a);
+  if (rc) return rc;
+  if (!d_probs_global || !d_scalars || !d_dfeat || !d_dfeat_w_partial || probs_shard_rows < 1 ||
+      shard->btu_g % probs_shard_rows != 0)
+    return CMLPL_E_ARG;
+  a.probs_g = d_probs_global; a.pshard = probs_shard_rows; a.scalars = d_scalars; a.dfeat = d_dfeat;
+  a.dfw_part = d_dfeat_w_partial;
+  hipStream_t st = (hipStream_t)stream;
+  return TIMED(CMLPL_K_LOSS2, chk(launch_loss_phase2(a, st)));
+}
+
+int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
+                       const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
+                       const cmlpl_hparams* hp, float* d_scalars, float* d_dlogits, float* d_dfeat,
+                       float* d_probs, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!d_probs || !d_dfeat) return CMLPL_E_ARG;
+  cmlpl_shard sh = {bt, btu, 0, bt, 0, btu};
+  int rc = cmlpl_loss_phase1(shape, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_dlogits, d_probs,
+                             d_workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  // one GPU: the probabilities are already global, and the column-side gradient goes straight to dfeat[1]
+  return cmlpl_loss_phase2(shape, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_probs, btu,
+                           d_scalars, d_dfeat, d_dfeat + ((size_t)(bt + btu) + bt) * 1024, d_workspace,
+                           workspace_bytes, stream);
+}
+
+int cmlpl_dist_unpack(const cmlpl_shape* shape, int world, int bt_local, int btu_local, const float* d_gathered,
+                      float* d_logits_g, float* d_feat_g, int64_t* d_labels_g, void* stream) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  if (world < 1 || bt_local < 1 || btu_local < 1 || !d_gathered || !d_logits_g || !d_feat_g || !d_labels_g)
+    return CMLPL_E_ARG;
+  return chk(launch_dist_unpack(d_gathered, world, bt_local, btu_local, d.K, d_logits_g, d_feat_g,
+                                (long long*)d_labels_g, (hipStream_t)stream));
 }
 
 int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t param_stride,
@@ -310,14 +382,16 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
   if (nw.bytes + sw.bytes > io->workspace_bytes) return CMLPL_E_WORKSPACE;
   const int train = 1;
   int rc;
+  const cmlpl_shard sh = {io->bt, io->btu, 0, io->bt, 0, io->btu};
   if ((rc = cmlpl_augment(shape, 2, io->bt, io->btu, io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->noise8,
-                          hp->noise_sigma, io->seed, io->step, sw.xn, sw.sn, stream))) return rc;
+                          hp->noise_sigma, io->seed, io->step, &sh, sw.xn, sw.sn, stream))) return rc;
   if ((rc = cmlpl_basenet2_fwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn,
-                               io->d_dropmask, hp->dropout_p, train, io->seed, io->step, io->d_logits, io->d_feat,
-                               io->d_workspace, nw.bytes, stream))) return rc;
+                               io->d_dropmask, hp->dropout_p, train, io->seed, io->step, &sh, io->d_logits,
+                               io->d_feat, io->d_workspace, nw.bytes, stream))) return rc;
   if ((rc = cmlpl_loss_fwd_bwd(shape, io->bt, io->btu, io->d_logits, io->d_feat, io->d_labels, &io->banks,
-                               io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, nullptr, sw.loss,
-                               loss_ws_floats(n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream))) return rc;
+                               io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, sw.probs, sw.loss,
+                               loss_ws_floats(n, n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream)))
+    return rc;
   if ((rc = cmlpl_basenet2_bwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn, io->d_dropmask,
                                hp->dropout_p, train, sw.dlogits, sw.dfeat, io->d_grads, L.param_total,
                                io->d_workspace, nw.bytes, stream))) return rc;

@@ -1,8 +1,13 @@
 // Input augmentation + batch concat (train.py:157-158,163-164,170-174,181-184):
 //   xn[net] = cat(XPl, XPu) + sigma*N(0,1)      sn[net] = cat(Xl, Xu) + sigma*N(0,1)
 // The reference draws the noise on the CPU generator and copies it over PCIe every step; here it is
-// Philox4x32-10 + Box-Muller in registers (or explicit noise tensors in parity mode).
+// Philox4x32-10 + Box-Muller in registers (or explicit noise tensors in parity mode).  The Philox
+// counter is (4-element group within the sample, GLOBAL sample index, stream, step): a sample gets
+// the same noise no matter how the batch is sharded over GPUs.
 // HBM-bound elementwise kernel: reads each source once, writes one noisy copy per network.
+//
+// dist_unpack_kernel: re-orders the all-gathered per-rank [logits | feat | labels] blocks into the
+// global row order [labelled of all ranks ; unlabelled of all ranks] the loss kernels expect.
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -12,38 +17,44 @@ struct AugArgs {
   const float* srcl[2]; const float* srcu[2];     // [0] = XP, [1] = X
   const float* noise[8];                          // reference draw order, or all null
   float* dst[2];                                  // xn, sn
-  long long nl[2], nu[2];                         // labelled / unlabelled element counts
+  int per[2];                                     // elements per sample: C*H*W, bands
+  int bt, btu, lab0, unl_base;                    // local rows and their global sample indices
   float sigma; int nets; int explicit_noise; uint64_t seed, step;
 };
 
 __global__ void augment_kernel(AugArgs a) {
-  const int seg = blockIdx.y;                 // 0: XP net0, 1: XP net1, 2: X net0, 3: X net1
+  const int seg = blockIdx.z;                 // 0: XP net0, 1: XP net1, 2: X net0, 3: X net1
   const int t = seg >> 1, net = seg & 1;
   if (net >= a.nets) return;
-  const long long N = a.nl[t] + a.nu[t];
-  const long long e0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (e0 >= N) return;
-  float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int per = a.per[t], s = blockIdx.y;   // local sample
+  const int e0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (e0 >= per) return;
+  const bool lab = s < a.bt;
+  const int sl = lab ? s : s - a.bt;
+  const float* src = (lab ? a.srcl[t] : a.srcu[t]) + (long long)sl * per;
+  float* dst = a.dst[t] + ((long long)net * (a.bt + a.btu) + s) * per;
   const bool need_noise = a.sigma != 0.f;
-  if (need_noise && !a.explicit_noise)
-    nz = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net, (uint64_t)(e0 >> 2));
-  const float* nl_ptr = a.noise[2 * net + t];         // XPl/net: 0,2 ; Xl/net: 1,3
-  const float* nu_ptr = a.noise[4 + 2 * net + t];     // XPu/net: 4,6 ; Xu/net: 5,7
-  float* dst = a.dst[t] + (long long)net * N;
+  float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (need_noise && !a.explicit_noise) {
+    const uint64_t gs = (uint64_t)(lab ? a.lab0 + sl : a.unl_base + sl);
+    nz = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
+                        (gs << 24) | (uint64_t)(e0 >> 2));
+  }
+  const float* nptr = nullptr;
+  if (need_noise && a.explicit_noise) nptr = (lab ? a.noise[2 * net + t] : a.noise[4 + 2 * net + t]) + (long long)sl * per;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const long long e = e0 + q;
-    if (e < N) {
-      const bool lab = e < a.nl[t];
-      const float x = lab ? a.srcl[t][e] : a.srcu[t][e - a.nl[t]];
+    const int e = e0 + q;
+    if (e < per) {
       float z = (q == 0) ? nz.x : (q == 1) ? nz.y : (q == 2) ? nz.z : nz.w;
-      if (need_noise && a.explicit_noise) z = lab ? nl_ptr[e] : nu_ptr[e - a.nl[t]];
+      if (nptr != nullptr) z = nptr[e];
+      const float x = src[e];
       dst[e] = need_noise ? x + z * a.sigma : x;
     }
   }
 }
 
-hipError_t launch_augment(int nets, long long nl_xp, long long nu_xp, long long nl_x, long long nu_x,
+hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
                           float* xn, float* sn, hipStream_t st) {
@@ -51,11 +62,51 @@ hipError_t launch_augment(int nets, long long nl_xp, long long nu_xp, long long 
   a.srcl[0] = xpl; a.srcl[1] = xl; a.srcu[0] = xpu; a.srcu[1] = xu;
   for (int i = 0; i < 8; ++i) a.noise[i] = noise8 ? noise8[i] : nullptr;
   a.dst[0] = xn; a.dst[1] = sn;
-  a.nl[0] = nl_xp; a.nu[0] = nu_xp; a.nl[1] = nl_x; a.nu[1] = nu_x;
+  a.per[0] = per_xp; a.per[1] = per_x; a.bt = bt; a.btu = btu; a.lab0 = lab0; a.unl_base = unl_base;
   a.sigma = sigma; a.nets = nets; a.explicit_noise = noise8 != nullptr; a.seed = seed; a.step = step;
-  const long long N = nl_xp + nu_xp;
-  dim3 grid((unsigned)(((N + 3) / 4 + 255) / 256), 4);
+  const int mx = per_xp > per_x ? per_xp : per_x;
+  dim3 grid(((mx + 3) / 4 + 255) / 256, bt + btu, 4);
   hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// recv: [W][ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels-as-float ], n_l = bt_l + btu_l
+__global__ void dist_unpack_kernel(const float* __restrict__ recv, int W, int bt_l, int btu_l, int K,
+                                   float* __restrict__ logits_g, float* __restrict__ feat_g,
+                                   long long* __restrict__ labels_g) {
+  const int n_l = bt_l + btu_l, bt_g = W * bt_l, n_g = W * n_l;
+  const long long pack = 2LL * n_l * K + 2LL * n_l * FD + bt_l;
+  const long long nfeat4 = 2LL * n_g * (FD / 4), nlog = 2LL * n_g * K;
+  const long long total = nfeat4 + nlog + bt_g;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (i < nfeat4) {
+      const int c4 = (int)(i % (FD / 4));
+      const long long row = i / (FD / 4);
+      const int net = (int)(row / n_g), g = (int)(row - (long long)net * n_g);
+      const int rank = (g < bt_g) ? g / bt_l : (g - bt_g) / btu_l;
+      const int loc = (g < bt_g) ? g - rank * bt_l : bt_l + (g - bt_g) - rank * btu_l;
+      const float* src = recv + rank * pack + 2LL * n_l * K + ((long long)net * n_l + loc) * FD;
+      ((float4*)feat_g)[i] = ((const float4*)src)[c4];
+    } else if (i < nfeat4 + nlog) {
+      const long long j = i - nfeat4;
+      const int k = (int)(j % K);
+      const long long row = j / K;
+      const int net = (int)(row / n_g), g = (int)(row - (long long)net * n_g);
+      const int rank = (g < bt_g) ? g / bt_l : (g - bt_g) / btu_l;
+      const int loc = (g < bt_g) ? g - rank * bt_l : bt_l + (g - bt_g) - rank * btu_l;
+      logits_g[j] = recv[rank * pack + ((long long)net * n_l + loc) * K + k];
+    } else {
+      const int g = (int)(i - nfeat4 - nlog);
+      const int rank = g / bt_l, loc = g - rank * bt_l;
+      labels_g[g] = (long long)(recv[rank * pack + 2LL * n_l * K + 2LL * n_l * FD + loc] + 0.5f);
+    }
+  }
+}
+
+hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
+                              long long* labels_g, hipStream_t st) {
+  hipLaunchKernelGGL(dist_unpack_kernel, dim3(512), dim3(256), 0, st, recv, W, bt_l, btu_l, K, logits_g, feat_g,
+                     labels_g);
   return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@ struct HeadFwdArgs {
   float* catd; float* ynorm; float* logits; float* feat;
   float dropout_p; int train; uint64_t seed, step;
   int n, HW4, K;
+  int nlab, lab0, unl_base;   // local row -> GLOBAL sample index (Philox key independent of sharding)
 };
 
 constexpr int HEAD_MAXQ = 12;   // ceil(F / 256) <= 12  (F <= 3072)
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
       float x = v[q];
       if (f >= SF) ss = fmaf(x, x, ss);
       if (dmode == 2) {
-        const unsigned long long e = (unsigned long long)sample * F + f;
+        const unsigned long long gs = (sample < a.nlab) ? a.lab0 + sample : a.unl_base + (sample - a.nlab);
+        const unsigned long long e = gs * F + f;
         const float4 u = philox_uniform4(a.seed, a.step, STREAM_DROPOUT + net, e >> 2);
         const float uu = ((e & 3) == 0) ? u.x : ((e & 3) == 1) ? u.y : ((e & 3) == 2) ? u.z : u.w;
         mlt[q] = (uu >= a.dropout_p) ? keep_scale : 0.f;
@@ -106,12 +108,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
 
 hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, const float* y, const float* dropmask,
                            float* dropgen, float dropout_p, int train, uint64_t seed, uint64_t step,
+                           int nlab, int lab0, int unl_base,
                            const float* wc, const float* bc, long long pstride,
                            float* catd, float* ynorm, float* logits, float* feat, hipStream_t st) {
   HeadFwdArgs a;
   a.p2 = p2; a.y = y; a.dropmask = dropmask; a.dropgen = dropgen; a.wc = wc; a.bc = bc; a.pstride = pstride;
   a.catd = catd; a.ynorm = ynorm; a.logits = logits; a.feat = feat;
   a.dropout_p = dropout_p; a.train = train; a.seed = seed; a.step = step; a.n = n; a.HW4 = HW4; a.K = K;
+  a.nlab = nlab; a.lab0 = lab0; a.unl_base = unl_base;
   const int F = HW4 * 64 + FD;
   if (F > 256 * HEAD_MAXQ) return hipErrorInvalidValue;
   const size_t lds = (size_t)(F + 4) * 4;

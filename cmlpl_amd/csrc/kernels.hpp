@@ -13,10 +13,12 @@ constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci]
 constexpr size_t LDS_MAX = 160 * 1024;
 
 // ---- augment.hip
-hipError_t launch_augment(int nets, long long nl_xp, long long nu_xp, long long nl_x, long long nu_x,
+hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
                           float* xn, float* sn, hipStream_t st);
+hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
+                              long long* labels_g, hipStream_t st);
 
 // ---- conv3x3.hip
 hipError_t launch_pack_weights(int nets, const float* params, long long pstride, long long off_w1,
@@ -59,6 +61,7 @@ hipError_t launch_gemm_tn(const GemmTN& g, hipStream_t st);
 // ---- head.hip
 hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, const float* y, const float* dropmask,
                            float* dropgen, float dropout_p, int train, uint64_t seed, uint64_t step,
+                           int nlab, int lab0, int unl_base,
                            const float* wc, const float* bc, long long pstride,
                            float* catd, float* ynorm, float* logits, float* feat, hipStream_t st);
 hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits, const float* dfeat,
@@ -66,21 +69,27 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
                            const float* y, const float* ynorm,
                            float* dy, float* dp2, hipStream_t st);
 
-// ---- loss.hip
+// ---- loss.hip   (row-sharded: see the header of loss.hip)
 struct LossArgs {
-  const float* logits; const float* feat; const int64_t* labels;   // [2][n][K], [2][n][1024]
+  const float* logits; const float* feat; const int64_t* labels;   // GLOBAL [2][n][K], [2][n][1024], [bt]
   const float* bank_f[2]; const float* bank_p[2];
   float* bank_fw[2]; float* bank_pw[2];
   int Q, ptr0, ptr1;
-  int bt, btu, K, smooth;
+  int bt, btu, K, smooth;                 // global labelled / unlabelled rows
+  int lab0, nlab, unl0, nunl;             // this shard's rows
+  int pshard;                             // rows per shard in probs_g (= btu on one GPU)
   float adap_mask, T, alpha, w_contrast, w_mutual, pos_thr, neg_thr;
-  float* scalars; float* dlogits; float* dfeat; float* probs_out;
+  float* scalars; float* dlogits; float* dfeat;   // local layouts: [2][nlab+nunl][K], [2][nlab+nunl][1024]
+  float* probs_l;                         // [4][nunl][K] written by phase 1
+  const float* probs_g;                   // shard-major [btu/pshard][4][pshard][K] read by phase 2
+  float* dfw_part;                        // [btu][1024] partial of dfeat_w over this shard's rows
   // workspace
-  float* rs_part; float* ep_part; float* Smat; float* G; float* GT; float* probs; float* masks; float* rowloss;
+  float* rs_part; float* ep_part; float* Smat; float* G; float* GT; float* masks; float* rowloss;
 };
-size_t loss_ws_floats(int bt, int btu, int K, int Q);
+size_t loss_ws_floats(int nlab, int nunl, int btu_g, int K, int Q);
 void loss_ws_carve(LossArgs& a, float* ws);
-hipError_t launch_loss(const LossArgs& a, hipStream_t st);
+hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st);
+hipError_t launch_loss_phase2(const LossArgs& a, hipStream_t st);
 
 // ---- optim.hip
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,

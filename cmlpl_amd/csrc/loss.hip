@@ -1,17 +1,26 @@
 // The loss block of the CMLPL step (train.py:191-266), forward + analytic backward, and the
-// memory-bank write (train.py:223-237).  Five launches:
-//   pair_exp_kernel   : exp(f_a . f_b^T / T) tiles on the fp32 MFMA for the three products
-//                       fU_w x bank0 (train.py:213), fU_s x bank1 (:217), fU_s x fU_w (:246,257);
-//                       bank tiles are reduced on the fly to row sums and E.bank_probs partials
-//                       (the [btu,Q] similarity matrix is never materialised)
-//   loss_rows_kernel  : one wavefront per sample, lanes = classes: CE (:191-194), softmax (:203,209),
-//                       smoothing (:214-219), threshold masks (:220-228), mutual soft-CE (:239-242)
-//                       and d/dlogits of all of it
-//   graph_loss_kernel : one wavefront per unlabelled row: similarity softmax denominator by
-//                       wavefront shuffles (:247), pseudo-label graph Q/Qn (:249-256), contrastive
-//                       loss (:260-265) and dL/d(sim logits) -> G, G^T
-//   finalize_kernel   : bank write (modulo Q) + the logged scalars (:266,270,274-278)
-//   gemm_tn           : dfeat = G^T.f_w / G.f_s  (autograd of :246 / :257)
+// memory-bank write (train.py:223-237).
+//
+// Every kernel works on a ROW SHARD: inputs (logits, feats, labels, probabilities) are the GLOBAL
+// batch, outputs are produced for the local labelled rows [lab0, lab0+nlab) and local unlabelled rows
+// [unl0, unl0+nunl) only.  One GPU = the full range; under data parallelism each rank owns a slice and
+// the host code in cmlpl_amd/distributed.py exchanges what crosses ranks.
+//
+//   phase 1
+//     pair_exp_kernel   : exp(f_a . f_b^T / T) tiles on the fp32 MFMA for the three products
+//                         fU_w x bank0 (train.py:213), fU_s x bank1 (:217), fU_s x fU_w (:246,257),
+//                         local rows x all columns; bank tiles are reduced on the fly to row sums and
+//                         E.bank_probs partials (the [btu,Q] similarity matrix is never materialised)
+//     loss_rows_kernel  : one wavefront per local sample, lanes = classes: CE (:191-194), softmax
+//                         (:203,209), smoothing (:214-219), threshold masks (:220-228), mutual soft-CE
+//                         (:239-242) and d/dlogits of all of it
+//   phase 2  (needs the smoothed probabilities of ALL unlabelled rows)
+//     graph_loss_kernel : one wavefront per local unlabelled row: similarity softmax denominator by
+//                         wavefront shuffles (:247), pseudo-label graph Q/Qn (:249-256), contrastive
+//                         loss (:260-265) and dL/d(sim logits) -> G, G^T
+//     finalize_kernel   : bank write of the GLOBAL batch (modulo Q) + this shard's share of the logged
+//                         scalars (:266,270,274-278); shares are additive across shards
+//     gemm_tn           : dfeat_s(local rows) = G . fU_w ; dfeat_w(all rows, partial) = G^T . fU_s(local)
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -19,29 +28,35 @@ namespace cmlpl {
 
 enum { RL_CLS_S = 0, RL_CLS_W, RL_ACC, RL_CON_S, RL_CON_W, RL_CTR, RL_NPOS, RL_NNEG, RL_COUNT };
 
-size_t loss_ws_floats(int bt, int btu, int K, int Q) {
-  const size_t CT = (Q + 31) / 32, RL = (size_t)(bt > btu ? bt : btu);
+size_t loss_ws_floats(int nlab, int nunl, int btu_g, int K, int Q) {
+  const size_t CT = (Q + 31) / 32, RL = (size_t)(nlab > nunl ? nlab : nunl);
   size_t f = 0;
-  f += 2 * CT * btu;              // rs_part
-  f += 2 * CT * btu * K;          // ep_part
-  f += 3 * (size_t)btu * btu;     // Smat, GT, G
-  f += 4 * (size_t)btu * K;       // probs
-  f += 2 * (size_t)btu;           // masks
-  f += RL_COUNT * RL;             // rowloss
+  f += 2 * CT * nunl;                 // rs_part
+  f += 2 * CT * nunl * K;             // ep_part
+  f += 3 * (size_t)nunl * btu_g;      // Smat, GT, G
+  f += 2 * (size_t)nunl;              // masks
+  f += RL_COUNT * RL;                 // rowloss
   return (f + 63) & ~(size_t)63;
 }
 
 void loss_ws_carve(LossArgs& a, float* ws) {
-  const size_t CT = (a.Q + 31) / 32, RL = (size_t)(a.bt > a.btu ? a.bt : a.btu);
-  const size_t btu = a.btu;
-  a.rs_part = ws; ws += 2 * CT * btu;
-  a.ep_part = ws; ws += 2 * CT * btu * a.K;
-  a.Smat = ws; ws += btu * btu;
-  a.GT = ws; ws += btu * btu;
-  a.G = ws; ws += btu * btu;
-  a.probs = ws; ws += 4 * btu * a.K;
-  a.masks = ws; ws += 2 * btu;
+  const size_t CT = (a.Q + 31) / 32, RL = (size_t)(a.nlab > a.nunl ? a.nlab : a.nunl);
+  const size_t nunl = a.nunl, btu = a.btu;
+  a.rs_part = ws; ws += 2 * CT * nunl;
+  a.ep_part = ws; ws += 2 * CT * nunl * a.K;
+  a.Smat = ws; ws += nunl * btu;
+  a.GT = ws; ws += nunl * btu;
+  a.G = ws; ws += nunl * btu;
+  a.masks = ws; ws += 2 * nunl;
   a.rowloss = ws; ws += RL_COUNT * RL;
+}
+
+// probabilities of global unlabelled row g: which = 0 p_w, 1 p_s (smoothed), 2 p_w0, 3 p_s0.
+// Layout is shard-major [btu / pshard][4][pshard][K] -- exactly what an all-gather of per-rank
+// [4][nunl][K] blocks produces (one GPU: pshard = btu, i.e. plain [4][btu][K]).
+__device__ __forceinline__ const float* prob_row(const LossArgs& a, int which, int g) {
+  const int sh = g / a.pshard, l = g - sh * a.pshard;
+  return a.probs_g + (((long long)sh * 4 + which) * a.pshard + l) * a.K;
 }
 
 // One workgroup per 32x32 tile of one product.  The 1024-long contraction is split over the 4 waves
@@ -55,16 +70,16 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
   if (prob < 2 && !a.smooth) return;
-  const int n = a.bt + a.btu, btu = a.btu, K = a.K;
-  const float* fU_s = a.feat + (long long)a.bt * FD;
-  const float* fU_w = a.feat + ((long long)n + a.bt) * FD;
-  const float* A = (prob == 0) ? fU_w : fU_s;
+  const int n = a.bt + a.btu, btu = a.btu, nunl = a.nunl, K = a.K;
+  const float* fU_s = a.feat + (long long)a.bt * FD;             // all unlabelled rows, Base
+  const float* fU_w = a.feat + ((long long)n + a.bt) * FD;       // all unlabelled rows, Base1
+  const float* A = ((prob == 0) ? fU_w : fU_s) + (long long)a.unl0 * FD;   // local rows
   const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : fU_w;
   const int NB = (prob < 2) ? a.Q : btu;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  if (c0 >= NB || r0 >= btu) return;
+  if (c0 >= NB || r0 >= nunl) return;
   const int ia = r0 + l31, jb = c0 + l31;
-  const float* ap = A + (long long)(ia < btu ? ia : 0) * FD + wave * 256 + hh * 4;
+  const float* ap = A + (long long)(ia < nunl ? ia : 0) * FD + wave * 256 + hh * 4;
   const float* bp = B + (long long)(jb < NB ? jb : 0) * FD + wave * 256 + hh * 4;
   f32x16 acc = zero16();
 #pragma unroll 1
@@ -101,17 +116,17 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
     if (jv) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (irow[q] < btu) a.Smat[(long long)irow[q] * btu + jb] = e[q];
+        if (irow[q] < nunl) a.Smat[(long long)irow[q] * btu + jb] = e[q];
     }
     return;
   }
   const int CT = (a.Q + 31) >> 5, ctile = c0 >> 5;
-  float* rs = a.rs_part + ((long long)prob * CT + ctile) * btu;
-  float* ep = a.ep_part + ((long long)prob * CT + ctile) * btu * K;
+  float* rs = a.rs_part + ((long long)prob * CT + ctile) * nunl;
+  float* ep = a.ep_part + ((long long)prob * CT + ctile) * nunl * K;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float sum = half_sum(e[q]);
-    if (l31 == 0 && irow[q] < btu) rs[irow[q]] = sum;
+    if (l31 == 0 && irow[q] < nunl) rs[irow[q]] = sum;
   }
   const float* bpr = a.bank_p[prob] + (long long)(jv ? jb : 0) * K;
   for (int k = 0; k < K; ++k) {
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float sum = half_sum(e[q] * pv);
-      if (l31 == 0 && irow[q] < btu) ep[(long long)irow[q] * K + k] = sum;
+      if (l31 == 0 && irow[q] < nunl) ep[(long long)irow[q] * K + k] = sum;
     }
   }
 }
@@ -128,34 +143,35 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int idx = blockIdx.x * 4 + wave;
   const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K;
-  if (idx >= n) return;
-  const int RL = bt > btu ? bt : btu;
+  const int nlab = a.nlab, nunl = a.nunl, nl = nlab + nunl;
+  if (idx >= nl) return;
+  const int RL = nlab > nunl ? nlab : nunl;
   const bool kv = lane < K;
   const float NEG = -3.0e38f;
-  if (idx < bt) {
-    const int i = idx;
-    const int yl = (int)a.labels[i];
+  if (idx < nlab) {
+    const int il = idx, ig = a.lab0 + il;                 // local / global labelled row
+    const int yl = (int)a.labels[ig];
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
-      const float z = kv ? a.logits[((long long)net * n + i) * K + lane] : NEG;
+      const float z = kv ? a.logits[((long long)net * n + ig) * K + lane] : NEG;
       const float mx = wave_max(z);
       const float ez = kv ? expf(z - mx) : 0.f;
       const float se = wave_sum(ez);
       const float lse = mx + logf(se);
       const float zy = __shfl(z, yl, 64);
-      if (kv) a.dlogits[((long long)net * n + i) * K + lane] = (ez / se - (lane == yl ? 1.f : 0.f)) / (float)bt;
-      if (lane == 0) a.rowloss[(net == 0 ? RL_CLS_S : RL_CLS_W) * RL + i] = lse - zy;
+      if (kv) a.dlogits[((long long)net * nl + il) * K + lane] = (ez / se - (lane == yl ? 1.f : 0.f)) / (float)bt;
+      if (lane == 0) a.rowloss[(net == 0 ? RL_CLS_S : RL_CLS_W) * RL + il] = lse - zy;
       if (net == 1) {  // torch.max(labeled_output1, 1): first index of the maximum (train.py:194)
         const unsigned long long bal = __ballot(kv && z == mx);
         const int amax = __ffsll((long long)bal) - 1;
-        if (lane == 0) a.rowloss[RL_ACC * RL + i] = (amax == yl) ? 1.f : 0.f;
+        if (lane == 0) a.rowloss[RL_ACC * RL + il] = (amax == yl) ? 1.f : 0.f;
       }
     }
     return;
   }
-  const int i = idx - bt;
-  const float zs = kv ? a.logits[((long long)bt + i) * K + lane] : NEG;
-  const float zw = kv ? a.logits[((long long)n + bt + i) * K + lane] : NEG;
+  const int i = idx - nlab, ig = a.unl0 + i;               // local / global unlabelled row
+  const float zs = kv ? a.logits[((long long)bt + ig) * K + lane] : NEG;
+  const float zw = kv ? a.logits[((long long)n + bt + ig) * K + lane] : NEG;
   const float mxs = wave_max(zs), mxw = wave_max(zw);
   const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
   const float ses = wave_sum(es), sew = wave_sum(ew);
@@ -168,8 +184,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     const int CT = (a.Q + 31) >> 5;
     float rsw = 0.f, rss = 0.f;
     for (int ct = lane; ct < CT; ct += 64) {
-      rsw += a.rs_part[((long long)0 * CT + ct) * btu + i];
-      rss += a.rs_part[((long long)1 * CT + ct) * btu + i];
+      rsw += a.rs_part[((long long)0 * CT + ct) * nunl + i];
+      rss += a.rs_part[((long long)1 * CT + ct) * nunl + i];
     }
     rsw = wave_sum(rsw); rss = wave_sum(rss);
     int KP = 1;
@@ -177,9 +193,9 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     const int G = 64 / KP, gq = lane / KP, kq = lane - gq * KP;
     const bool kqv = kq < K;
     float epw = 0.f, eps_ = 0.f;
-    const float* e0 = a.ep_part + ((long long)0 * CT * btu + i) * K + (kqv ? kq : 0);
-    const float* e1 = a.ep_part + ((long long)1 * CT * btu + i) * K + (kqv ? kq : 0);
-    const long long cstride = (long long)btu * K;
+    const float* e0 = a.ep_part + ((long long)0 * CT * nunl + i) * K + (kqv ? kq : 0);
+    const float* e1 = a.ep_part + ((long long)1 * CT * nunl + i) * K + (kqv ? kq : 0);
+    const long long cstride = (long long)nunl * K;
     for (int cb = gq; cb < CT; cb += 8 * G) {
       float t0[8], t1[8];
 #pragma unroll
@@ -204,22 +220,16 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const float cw = -wave_sum(kv ? lsmw * ps : 0.f) * ms;   // train.py:240
   if (kv) {
     const float scale = a.w_mutual / (float)btu;
-    a.dlogits[((long long)bt + i) * K + lane] = scale * mw * (sms * spw - pw);
-    a.dlogits[((long long)n + bt + i) * K + lane] = scale * ms * (smw * sps - ps);
-    a.probs[((long long)0 * btu + i) * K + lane] = pw;
-    a.probs[((long long)1 * btu + i) * K + lane] = ps;
-    a.probs[((long long)2 * btu + i) * K + lane] = smw;
-    a.probs[((long long)3 * btu + i) * K + lane] = sms;
-    if (a.probs_out != nullptr) {
-      a.probs_out[((long long)0 * btu + i) * K + lane] = pw;
-      a.probs_out[((long long)1 * btu + i) * K + lane] = ps;
-      a.probs_out[((long long)2 * btu + i) * K + lane] = smw;
-      a.probs_out[((long long)3 * btu + i) * K + lane] = sms;
-    }
+    a.dlogits[((long long)nlab + i) * K + lane] = scale * mw * (sms * spw - pw);
+    a.dlogits[((long long)nl + nlab + i) * K + lane] = scale * ms * (smw * sps - ps);
+    a.probs_l[((long long)0 * nunl + i) * K + lane] = pw;
+    a.probs_l[((long long)1 * nunl + i) * K + lane] = ps;
+    a.probs_l[((long long)2 * nunl + i) * K + lane] = smw;
+    a.probs_l[((long long)3 * nunl + i) * K + lane] = sms;
   }
   if (lane == 0) {
     a.masks[i] = mw;
-    a.masks[btu + i] = ms;
+    a.masks[nunl + i] = ms;
     a.rowloss[RL_CON_S * RL + i] = cs;
     a.rowloss[RL_CON_W * RL + i] = cw;
   }
@@ -228,19 +238,20 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
 __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // per wave: gq[btu], pp[btu]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int btu = a.btu, K = a.K, i = blockIdx.x * 4 + wave;
-  if (i >= btu) return;
-  const int RL = a.bt > btu ? a.bt : btu;
+  const int btu = a.btu, K = a.K, i = blockIdx.x * 4 + wave;    // local row
+  if (i >= a.nunl) return;
+  const int ig = a.unl0 + i;                                    // global row (diagonal position)
+  const int RL = a.nlab > a.nunl ? a.nlab : a.nunl;
   float* gq = smem + (size_t)wave * 2 * btu;
   float* pp = gq + btu;
-  const float* pw = a.probs;                              // smoothed p_w  ("probs")
-  const float* psi = a.probs + ((long long)btu + i) * K;  // smoothed p_s  ("probs1"), row i
+  const float* psi = prob_row(a, 1, ig);                        // smoothed p_s ("probs1"), row i
   const float* Srow = a.Smat + (long long)i * btu;
   float sQ = 0.f, sN = 0.f, R = 0.f, npos = 0.f, nneg = 0.f;
   for (int j = lane; j < btu; j += 64) {
+    const float* pwj = prob_row(a, 0, j);                       // smoothed p_w ("probs"), row j
     float q0 = 0.f;
-    for (int k = 0; k < K; ++k) q0 = fmaf(psi[k], pw[(long long)j * K + k], q0);   // train.py:249
-    if (j == i) q0 = 1.f;                                                           // :250
+    for (int k = 0; k < K; ++k) q0 = fmaf(psi[k], pwj[k], q0);                      // train.py:249
+    if (j == ig) q0 = 1.f;                                                           // :250
     const bool isp = q0 >= a.pos_thr, isn = q0 <= a.neg_thr;                        // :251,254
     const float pos = isp ? q0 : 0.f, neg = isn ? (1.f - q0) : 0.f;
     sQ += pos; sN += neg; R += Srow[j];
@@ -267,8 +278,8 @@ __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
   const float scale = a.w_contrast / a.T;
   for (int j = lane; j < btu; j += 64) {
     const float Gij = pp[j] * (gq[j] - gp) * scale;   // softmax backward, then d(sim)/d(f.f/T)
-    a.G[(long long)i * btu + j] = Gij;
-    a.GT[(long long)j * btu + i] = Gij;
+    a.G[(long long)i * btu + j] = Gij;                // [nunl][btu]
+    a.GT[(long long)j * a.nunl + i] = Gij;            // [btu][nunl]
   }
   if (lane == 0) {
     a.rowloss[RL_CTR * RL + i] = lp + ln;
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(LossArgs a) {
   const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K, Q = a.Q;
   const int r = blockIdx.x;
   if (r < n) {
-    // bank0 <- [fU_w ; fL_s], [p_w0 ; onehot]   bank1 <- [fU_s ; fL_w], [p_s0 ; onehot]   (train.py:223-236)
+    // GLOBAL batch: bank0 <- [fU_w ; fL_s], [p_w0 ; onehot]   bank1 <- [fU_s ; fL_w], [p_s0 ; onehot]
+    // (train.py:223-236); identical on every shard
     const int d0 = (a.ptr0 + r) % Q, d1 = (a.ptr1 + r) % Q;
     const float *s0, *s1;
     if (r < btu) { s0 = a.feat + ((long long)n + bt + r) * FD; s1 = a.feat + ((long long)bt + r) * FD; }
@@ -301,24 +313,25 @@ __global__ __launch_bounds__(256) void finalize_kernel(LossArgs a) {
     ((float4*)(a.bank_fw[1] + (long long)d1 * FD))[tid] = v1;
     if (tid < K) {
       float q0, q1;
-      if (r < btu) { q0 = a.probs[((long long)2 * btu + r) * K + tid]; q1 = a.probs[((long long)3 * btu + r) * K + tid]; }
+      if (r < btu) { q0 = prob_row(a, 2, r)[tid]; q1 = prob_row(a, 3, r)[tid]; }
       else { const int yl = (int)a.labels[r - btu]; q0 = q1 = (tid == yl) ? 1.f : 0.f; }
       a.bank_pw[0][(long long)d0 * K + tid] = q0;
       a.bank_pw[1][(long long)d1 * K + tid] = q1;
     }
     return;
   }
-  const int RL = bt > btu ? bt : btu;
+  // this shard's share of the scalars: local sums over GLOBAL counts (additive across shards)
+  const int RL = a.nlab > a.nunl ? a.nlab : a.nunl;
   float v[RL_COUNT];
 #pragma unroll
   for (int q = 0; q < RL_COUNT; ++q) {
-    const int cnt = (q <= RL_ACC) ? bt : btu;
+    const int cnt = (q <= RL_ACC) ? a.nlab : a.nunl;
     float s = 0.f;
     for (int i = tid; i < cnt; i += 256) s += a.rowloss[q * RL + i];
     v[q] = block_sum(s, red, tid);
   }
   float mws = 0.f, mss = 0.f;
-  for (int i = tid; i < btu; i += 256) { mws += a.masks[i]; mss += a.masks[btu + i]; }
+  for (int i = tid; i < a.nunl; i += 256) { mws += a.masks[i]; mss += a.masks[a.nunl + i]; }
   mws = block_sum(mws, red, tid);
   mss = block_sum(mss, red, tid);
   if (tid == 0) {
@@ -337,35 +350,44 @@ __global__ __launch_bounds__(256) void finalize_kernel(LossArgs a) {
   }
 }
 
-hipError_t launch_loss(const LossArgs& a, hipStream_t st) {
-  const int bt = a.bt, btu = a.btu, n = bt + btu;
+hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
   hipError_t e;
-  // labelled rows carry no feature gradient (they only enter the banks)
-  if (bt > 0) {
-    e = hipMemsetAsync(a.dfeat, 0, (size_t)bt * FD * 4, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.dfeat + (long long)n * FD, 0, (size_t)bt * FD * 4, st);
-    if (e != hipSuccess) return e;
-  }
-  const int maxc = (a.smooth && a.Q > btu) ? a.Q : btu;
-  dim3 g1((maxc + 31) / 32, (btu + 31) / 32, 3);
+  const int nl = a.nlab + a.nunl;
+  const int maxc = (a.smooth && a.Q > a.btu) ? a.Q : a.btu;
+  dim3 g1((maxc + 31) / 32, (a.nunl + 31) / 32, 3);
   hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(loss_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(loss_rows_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_loss_phase2(const LossArgs& a, hipStream_t st) {
+  hipError_t e;
+  const int bt = a.bt, btu = a.btu, n = bt + btu, nl = a.nlab + a.nunl;
+  // labelled rows carry no feature gradient (they only enter the banks)
+  if (a.nlab > 0) {
+    e = hipMemsetAsync(a.dfeat, 0, (size_t)a.nlab * FD * 4, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.dfeat + (long long)nl * FD, 0, (size_t)a.nlab * FD * 4, st);
+    if (e != hipSuccess) return e;
+  }
   const size_t lds = (size_t)4 * 2 * btu * 4;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(graph_loss_kernel, dim3((btu + 3) / 4), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(graph_loss_kernel, dim3((a.nunl + 3) / 4), dim3(256), lds, st, a);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(finalize_kernel, dim3(n + 1), dim3(256), 0, st, a);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  // dfeat[0][bt:] = G . fU_w ;  dfeat[1][bt:] = G^T . fU_s   (batch 0 uses A = G^T, batch 1 A = G)
+  // dfeat_s[local rows] = G . fU_w            : C[i][d] = sum_l GT[l][i] * fU_w[l][d]   (R = btu, M = nunl)
   GemmTN g;
-  g.A = a.GT; g.a_bstride = (long long)btu * btu;
-  g.B = a.feat + ((long long)n + bt) * FD; g.b_bstride = -(long long)n * FD;
-  g.C = a.dfeat + (long long)bt * FD; g.c_bstride = (long long)n * FD;
-  g.bias = nullptr; g.bias_bstride = 0;
-  g.lda = btu; g.ldb = FD; g.ldc = FD; g.M = btu; g.N = FD; g.R = btu; g.batches = 2; g.scale = 1.f;
+  g.A = a.GT; g.lda = a.nunl; g.M = a.nunl; g.R = btu;
+  g.B = a.feat + ((long long)n + bt) * FD; g.ldb = FD; g.N = FD;
+  g.C = a.dfeat + (long long)a.nlab * FD; g.ldc = FD;
+  g.a_bstride = g.b_bstride = g.c_bstride = 0; g.bias = nullptr; g.bias_bstride = 0; g.batches = 1; g.scale = 1.f;
+  if ((e = launch_gemm_tn(g, st)) != hipSuccess) return e;
+  // dfeat_w[all rows] (this shard's partial) = G^T . fU_s[local] : C[l][d] = sum_i G[i][l] * fU_s[unl0+i][d]
+  g.A = a.G; g.lda = btu; g.M = btu; g.R = a.nunl;
+  g.B = a.feat + ((long long)bt + a.unl0) * FD;
+  g.C = a.dfw_part;
   return launch_gemm_tn(g, st);
 }
 

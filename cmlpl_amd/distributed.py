@@ -1,0 +1,231 @@
+"""Sample-sharded data parallelism for the CMLPL step, one process per GPU.
+
+The reference is single-process; this layer is the build's own design for one xGMI node:
+both networks and both memory banks are replicated, every rank takes bt/W labelled + btu/W unlabelled
+rows, and a step exchanges exactly what crosses samples:
+
+  1. local augment + 2x BaseNet2 forward                          (no communication)
+  2. ALL-GATHER  one packed buffer [logits | feat | labels] per rank  -> global logits/feats/labels
+  3. loss phase 1 on the local rows (bank smoothing, CE, masks, mutual loss)
+  4. ALL-GATHER  the smoothed probabilities [4][btu/W][K]         (the pseudo-label graph Q0 = p_s.p_w^T
+                                                                   needs every key's probabilities)
+  5. loss phase 2: local rows x global keys contrastive loss, identical bank write on every rank
+  6. REDUCE-SCATTER the column-side gradient d fU_w [btu][1024]   (backward of gathering the keys)
+  7. local 2x backward
+  8. ALL-REDUCE(sum) one flat gradient bucket (both networks, 2 x 207,881 floats for PaviaU);
+     losses are normalised by GLOBAL counts inside the kernels, so the sum IS the global gradient
+  9. Adam on every rank (replicated, deterministic)
+
+Four collectives per step, all NCCL(=RCCL)-over-xGMI through torch.distributed; message sizes are
+1-4 MB, i.e. latency-bound on 7 x 153 GB/s links, hence one packed bucket per exchange rather than
+one collective per tensor.  W-rank results equal the 1-rank results on the same global batch up to
+fp32 summation order (tests/test_distributed_*.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from .config import FEAT_DIM, HyperParams, NetShape
+from .engine import SCALAR_NAMES, TrainEngine, _chk_f32
+
+
+class TorchDistComm:
+    """torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor):
+        self.dist.reduce_scatter_tensor(out, inp, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_reduce(self, t: torch.Tensor):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class SingleComm:
+    """world size 1: every collective is a copy."""
+    world, rank = 1, 0
+
+    def all_gather(self, out, inp): out.view(-1).copy_(inp.view(-1))
+    def reduce_scatter(self, out, inp): out.view(-1).copy_(inp.view(-1))
+    def all_reduce(self, t): pass
+
+
+class DistTrainEngine(TrainEngine):
+    """TrainEngine whose step is sharded by sample over ``comm.world`` ranks.  Batch sizes given to
+    the constructor are PER RANK; banks are sized from the global labelled batch (train.py:138)."""
+
+    STAGES = ("forward", "phase1", "phase2", "backward", "update")
+
+    def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
+                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, comm=None):
+        if comm is None:
+            import torch.distributed as dist
+            comm = TorchDistComm() if (dist.is_available() and dist.is_initialized()) else SingleComm()
+        self.comm = comm
+        W = self.world = comm.world
+        self.rank = comm.rank
+        super().__init__(shape, labeled_batch_size, unlabeled_batch_size, hp, device, seed,
+                         bank_labeled=labeled_batch_size * W)
+        bt_l, btu_l, K = self.bt_max, self.btu_max, shape.K
+        n_l = bt_l + btu_l
+        self.bt_g, self.btu_g, self.n_g = bt_l * W, btu_l * W, n_l * W
+        dev = self.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.pack_len = 2 * n_l * K + 2 * n_l * FEAT_DIM + bt_l
+        self.pack, self.recv = z(self.pack_len), z(W * self.pack_len)
+        self.logits_l = self.pack[:2 * n_l * K].view(2, n_l, K)
+        self.feat_l = self.pack[2 * n_l * K: 2 * n_l * K + 2 * n_l * FEAT_DIM].view(2, n_l, FEAT_DIM)
+        self.labels_f = self.pack[2 * n_l * K + 2 * n_l * FEAT_DIM:]
+        self.logits_g, self.feat_g = z(2, self.n_g, K), z(2, self.n_g, FEAT_DIM)
+        self.labels_g = torch.zeros(self.bt_g, dtype=torch.int64, device=dev)
+        self.probs_l, self.probs_g = z(4, btu_l, K), z(W, 4, btu_l, K)
+        self.dlogits_l, self.dfeat_l = z(2, n_l, K), z(2, n_l, FEAT_DIM)
+        self.dfw_part = z(self.btu_g, FEAT_DIM)
+        self.xn, self.sn = z(2, n_l, shape.C * shape.H * shape.W), z(2, n_l, shape.bands)
+        self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
+        lw = self.lib.cmlpl_loss_workspace_bytes(C.byref(self.cshape), C.byref(self.cshard), self.Q)
+        if lw == 0:
+            raise _lib.CmlplError("cmlpl_loss_workspace_bytes", -2)
+        self.loss_ws = torch.empty(lw, dtype=torch.uint8, device=dev)
+        self._ctx = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _banks(self) -> _lib.Banks:
+        b = _lib.Banks()
+        for i in range(2):
+            b.d_feats[i] = self.bank_feats[i].data_ptr()
+            b.d_probs[i] = self.bank_probs[i].data_ptr()
+            b.ptr[i] = self.ptr[i]
+        b.Q = self.Q
+        return b
+
+    # ------------------------------------------------------------------ stages (no communication inside)
+    def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True):
+        s, lib = self.shape, self.lib
+        bt_l, btu_l = self.bt_max, self.btu_max
+        n_l = bt_l + btu_l
+        _chk_f32(XPl, (bt_l, s.C, s.H, s.W), "XPl"); _chk_f32(Xl, (bt_l, s.bands), "Xl")
+        _chk_f32(XPu, (btu_l, s.C, s.H, s.W), "XPu"); _chk_f32(Xu, (btu_l, s.bands), "Xu")
+        st = self._stream()
+        self._ensure_packed(st)
+        keep = None
+        noise8 = None
+        if noise is not None:
+            keep = (C.c_void_p * 8)(*[t.data_ptr() for t in noise])
+            noise8 = C.cast(keep, C.POINTER(C.c_void_p))
+        if dropmask is not None:
+            _chk_f32(dropmask, (2, n_l, s.cls_in), "dropmask")
+        self._ctx = dict(epoch=epoch, batch_index=batch_index, apply_update=apply_update, dropmask=dropmask,
+                         smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
+                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)), keep=keep)
+        _lib.check("cmlpl_augment", lib.cmlpl_augment(
+            C.byref(self.cshape), 2, bt_l, btu_l, XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(),
+            noise8, self.hp.noise, self.seed, self.step_count, C.byref(self.cshard), self.xn.data_ptr(),
+            self.sn.data_ptr(), st))
+        _lib.check("cmlpl_basenet2_fwd", lib.cmlpl_basenet2_fwd(
+            C.byref(self.cshape), 2, n_l, self.params.data_ptr(), self.P, self.packed.data_ptr(), self.xn.data_ptr(),
+            self.sn.data_ptr(), None if dropmask is None else dropmask.data_ptr(), self.hp.dropout, 1, self.seed,
+            self.step_count, C.byref(self.cshard), self.logits_l.data_ptr(), self.feat_l.data_ptr(),
+            self.workspace.data_ptr(), self.workspace.numel(), st))
+        self.labels_f.copy_(Y)
+
+    def stage_phase1(self):
+        c, st = self._ctx, self._stream()
+        _lib.check("cmlpl_dist_unpack", self.lib.cmlpl_dist_unpack(
+            C.byref(self.cshape), self.world, self.bt_max, self.btu_max, self.recv.data_ptr(),
+            self.logits_g.data_ptr(), self.feat_g.data_ptr(), self.labels_g.data_ptr(), st))
+        banks = self._banks()
+        _lib.check("cmlpl_loss_phase1", self.lib.cmlpl_loss_phase1(
+            C.byref(self.cshape), C.byref(self.cshard), self.logits_g.data_ptr(), self.feat_g.data_ptr(),
+            self.labels_g.data_ptr(), C.byref(banks), c["smooth"], c["adap"], C.byref(self._chp),
+            self.dlogits_l.data_ptr(), self.probs_l.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
+
+    def stage_phase2(self):
+        c, st = self._ctx, self._stream()
+        banks = self._banks()
+        _lib.check("cmlpl_loss_phase2", self.lib.cmlpl_loss_phase2(
+            C.byref(self.cshape), C.byref(self.cshard), self.logits_g.data_ptr(), self.feat_g.data_ptr(),
+            self.labels_g.data_ptr(), C.byref(banks), c["smooth"], c["adap"], C.byref(self._chp),
+            self.probs_g.data_ptr(), self.btu_max, self.scalars.data_ptr(), self.dfeat_l.data_ptr(),
+            self.dfw_part.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
+
+    def stage_backward(self):
+        c, st = self._ctx, self._stream()
+        n_l = self.bt_max + self.btu_max
+        dm = c["dropmask"]
+        _lib.check("cmlpl_basenet2_bwd", self.lib.cmlpl_basenet2_bwd(
+            C.byref(self.cshape), 2, n_l, self.params.data_ptr(), self.P, self.packed.data_ptr(), self.xn.data_ptr(),
+            self.sn.data_ptr(), None if dm is None else dm.data_ptr(), self.hp.dropout, 1,
+            self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.grads.data_ptr(), self.P,
+            self.workspace.data_ptr(), self.workspace.numel(), st))
+
+    def stage_update(self):
+        c, st = self._ctx, self._stream()
+        if c["apply_update"]:
+            _lib.check("cmlpl_adam_step", self.lib.cmlpl_adam_step(
+                C.byref(self.cshape), 2, self.params.data_ptr(), self.P, self.grads.data_ptr(), self.P,
+                self.m.data_ptr(), self.v.data_ptr(), self.adam_t + 1, C.byref(self._chp), self.packed.data_ptr(), st))
+            self.adam_t += 1
+        p0 = (self.ptr[0] + self.hp.bank_step) % self.Q                 # train.py:234,237
+        self.ptr = [p0, (p0 + self.hp.bank_step) % self.Q]
+        self.step_count += 1
+        self._last_n = self.bt_max + self.btu_max
+        self._ctx = None
+
+    # the collective that follows each stage: (output, input, kind)
+    def exchange_after(self, stage: str):
+        n_l = self.bt_max + self.btu_max
+        live = int(self.layout.param_live)
+        if stage == "forward":
+            return [("all_gather", self.recv, self.pack)]
+        if stage == "phase1":
+            return [("all_gather", self.probs_g, self.probs_l)]
+        if stage == "phase2":   # backward of "gather the keys": sum the partials, keep this rank's rows
+            return [("reduce_scatter", self.dfeat_l[1, self.bt_max:], self.dfw_part)]
+        if stage == "backward":  # one flat bucket per network's live tensors
+            return [("all_reduce", self.grads[0, :live], None), ("all_reduce", self.grads[1, :live], None)]
+        return []
+
+    # ------------------------------------------------------------------ the step
+    def step(self, XPl, Xl, Y, XPu, Xu, epoch: int, batch_index: int, noise: Optional[Sequence[torch.Tensor]] = None,
+             dropmask: Optional[torch.Tensor] = None, apply_update: bool = True) -> None:
+        """Per-rank inputs: this rank's bt/W labelled and btu/W unlabelled rows (noise / dropmask, when given,
+        are this rank's slices too)."""
+        self.stage_forward(XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update)
+        for stage in self.STAGES:
+            if stage != "forward":
+                getattr(self, "stage_" + stage)()
+            for kind, out, inp in self.exchange_after(stage):
+                if kind == "all_gather":
+                    self.comm.all_gather(out, inp)
+                elif kind == "reduce_scatter":
+                    self.comm.reduce_scatter(out, inp)
+                else:
+                    self.comm.all_reduce(out)
+
+    def outputs(self):
+        """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..]."""
+        return self.logits_g, self.feat_g
+
+    def read_scalars(self):
+        t = self.scalars.clone()
+        self.comm.all_reduce(t)             # shares are additive (finalize_kernel)
+        return dict(zip(SCALAR_NAMES, t.tolist()))
+
+    def loss_row(self):
+        t = self.scalars.clone()
+        self.comm.all_reduce(t)
+        return t[:5].tolist()

@@ -41,7 +41,7 @@ class TrainEngine:
     """
 
     def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
-                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088):
+                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, bank_labeled: int = 0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("cmlpl_amd.TrainEngine needs a GPU (no CPU fallback)")
@@ -53,7 +53,8 @@ class TrainEngine:
         self.layout = _lib.layout(self.cshape)
         L = self.layout
         self.P = int(L.param_total)
-        self.Q = self.hp.bank_mult * self.bt_max * 2                       # train.py:138
+        # train.py:138 (bank_labeled: the GLOBAL labelled batch under data parallelism)
+        self.Q = self.hp.bank_mult * (bank_labeled or self.bt_max) * 2
         if self.Q < self.n_max:
             raise ValueError("bank smaller than one batch (needs 10*bt >= bt+btu)")
         dev = self.device

@@ -44,7 +44,7 @@ class _BaseNet2Fn(torch.autograd.Function):
         _lib.check("cmlpl_basenet2_fwd", lib.cmlpl_basenet2_fwd(
             C.byref(mod._cshape), 1, n, flat.data_ptr(), mod._P, packed.data_ptr(), x.data_ptr(), y.data_ptr(),
             None if dropmask is None else dropmask.data_ptr(), float(mod.dropout), train,
-            int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, mod._calls,
+            int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, mod._calls, None,
             logits.data_ptr(), feat.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         ctx.mod, ctx.n, ctx.train = mod, n, train
         ctx.save_for_backward(x, y, dropmask if dropmask is not None else torch.empty(0), flat, packed, ws)

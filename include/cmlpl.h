@@ -82,6 +82,16 @@ size_t cmlpl_workspace_bytes(const cmlpl_shape* shape, int nets, int n, int bank
 int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params, int64_t param_stride,
                        float* d_packed, void* stream);
 
+/* Row shard of a data-parallel step: the global batch has bt_g labelled and
+ * btu_g unlabelled rows; this rank owns labelled rows [lab0, lab0+nlab) and unlabelled rows
+ * [unl0, unl0+nunl).  One GPU: {bt, btu, 0, bt, 0, btu} (or NULL where allowed).  In-kernel Philox
+ * streams are keyed by the GLOBAL sample index, so noise/dropout do not depend on the sharding. */
+typedef struct cmlpl_shard {
+  int32_t bt_g, btu_g;
+  int32_t lab0, nlab;
+  int32_t unl0, nunl;
+} cmlpl_shard;
+
 /* Input augmentation + batch concat: train.py:157-158,163-164,170-171,173-174,181-184.
  *   xn[net] = cat(XPl, XPu) + sigma * N(0,1),  sn[net] = cat(Xl, Xu) + sigma * N(0,1)
  * d_noise: NULL (in-kernel Philox, keyed by seed/step) or 8 device pointers in the
@@ -90,7 +100,7 @@ int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params
 int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu,
                   const float* d_xpl, const float* d_xl, const float* d_xpu, const float* d_xu,
                   const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
-                  float* d_xn, float* d_sn, void* stream);
+                  const cmlpl_shard* shard /* NULL = one GPU */, float* d_xn, float* d_sn, void* stream);
 
 /* BaseNet2.forward (tools/models.py:130-152) for `nets` networks on rows [n].
  *   d_xn [nets][n][C][H*W], d_sn [nets][n][bands]  (already augmented)
@@ -102,6 +112,7 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n,
                        const float* d_params, int64_t param_stride, const float* d_packed,
                        const float* d_xn, const float* d_sn, const float* d_dropmask,
                        float dropout_p, int train, uint64_t seed, uint64_t step,
+                       const cmlpl_shard* shard /* NULL = rows are global samples 0..n-1 */,
                        float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes,
                        void* stream);
 
@@ -133,13 +144,42 @@ typedef struct cmlpl_banks {
  *   outputs   : d_scalars[16] = {ctr_s,total_s,cls_s,con_s,acc, total_w,cls_w,con_w,ctr_w,
  *                                n_mask_w,n_mask_s,n_pos,n_neg,0,0,0}   (train.py:274-278)
  *               d_dlogits [2][n][K], d_dfeat [2][n][1024]
- *               d_probs_out (optional) [4][btu][K] = {p_w, p_s smoothed, p_w0, p_s0}. */
+ *               d_probs [4][btu][K] = {p_w, p_s smoothed, p_w0, p_s0}  (required scratch/output). */
 int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu,
                        const float* d_logits, const float* d_feat, const int64_t* d_labels,
                        const cmlpl_banks* banks, int smooth, float adap_mask,
                        const cmlpl_hparams* hp,
-                       float* d_scalars, float* d_dlogits, float* d_dfeat, float* d_probs_out,
+                       float* d_scalars, float* d_dlogits, float* d_dfeat, float* d_probs,
                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The same loss block split at the one point where a data-parallel step must exchange data.
+ * Inputs are the GLOBAL logits/feats/labels (rows ordered [labelled of all ranks ; unlabelled of all
+ * ranks]); outputs cover this rank's rows only.
+ *   phase 1: similarity tiles (local rows x banks / all keys), per-row softmax, CE, smoothing, masks,
+ *            mutual loss; writes d_dlogits [2][nlab+nunl][K] and d_probs_local [4][nunl][K]
+ *   -- caller all-gathers d_probs_local into d_probs_global (rank-major [W][4][nunl][K]) --
+ *   phase 2: pseudo-label graph + contrastive loss for the local rows, bank write of the global batch,
+ *            this rank's additive share of d_scalars[16], d_dfeat [2][nlab+nunl][1024] (net-0 rows final;
+ *            net-1 rows are to be overwritten by the caller with its reduce-scattered slice of)
+ *            d_dfeat_w_partial [btu_g][1024] = this rank's partial of the column-side gradient. */
+size_t cmlpl_loss_workspace_bytes(const cmlpl_shape* shape, const cmlpl_shard* shard, int bank_rows);
+int cmlpl_loss_phase1(const cmlpl_shape* shape, const cmlpl_shard* shard,
+                      const float* d_logits, const float* d_feat, const int64_t* d_labels,
+                      const cmlpl_banks* banks, int smooth, float adap_mask, const cmlpl_hparams* hp,
+                      float* d_dlogits, float* d_probs_local,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
+int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard,
+                      const float* d_logits, const float* d_feat, const int64_t* d_labels,
+                      const cmlpl_banks* banks, int smooth, float adap_mask, const cmlpl_hparams* hp,
+                      const float* d_probs_global, int probs_shard_rows,
+                      float* d_scalars, float* d_dfeat, float* d_dfeat_w_partial,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Re-order an all-gathered buffer [world][ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels as float ]
+ * (n_l = bt_local + btu_local, per-rank rows [labelled ; unlabelled]) into the global row order. */
+int cmlpl_dist_unpack(const cmlpl_shape* shape, int world, int bt_local, int btu_local,
+                      const float* d_gathered, float* d_logits_g, float* d_feat_g, int64_t* d_labels_g,
+                      void* stream);
 
 /* torch.optim.Adam.step for `nets` flat buffers (train.py:268,272); `t` is the 1-based
  * step count.  Also refreshes the packed conv weights when d_packed != NULL. */
@@ -178,7 +218,7 @@ enum {
   CMLPL_K_AUGMENT = 0, CMLPL_K_CONV0_FWD, CMLPL_K_CONV1_FWD, CMLPL_K_CONV2_FWD, CMLPL_K_SPE_FWD,
   CMLPL_K_HEAD_FWD, CMLPL_K_LOSS, CMLPL_K_HEAD_BWD, CMLPL_K_CLS_WGRAD, CMLPL_K_SPE_WGRAD,
   CMLPL_K_CONV2_DGRAD, CMLPL_K_CONV2_WGRAD, CMLPL_K_CONV2_WRED, CMLPL_K_CONV1_DGRAD, CMLPL_K_CONV1_WGRAD,
-  CMLPL_K_CONV1_WRED, CMLPL_K_CONV0_WGRAD, CMLPL_K_ADAM, CMLPL_K_PACK, CMLPL_K_COUNT
+  CMLPL_K_CONV1_WRED, CMLPL_K_CONV0_WGRAD, CMLPL_K_ADAM, CMLPL_K_PACK, CMLPL_K_LOSS2, CMLPL_K_COUNT
 };
 int cmlpl_timing_begin(uint32_t kernel_mask, int max_launches);
 int cmlpl_timing_end(double* ms_sum /*[CMLPL_K_COUNT]*/, int64_t* launches /*[CMLPL_K_COUNT]*/);

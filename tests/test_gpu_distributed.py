@@ -1,0 +1,116 @@
+"""GPU: the sample-sharded data-parallel step (cmlpl_amd.distributed) against the single-GPU step on
+the same GLOBAL batch.  W ranks are emulated in one process on one GPU: every stage runs for all ranks,
+then the collective that follows it is performed on the ranks' buffers (the real multi-process wiring of
+the same stages is covered on CPU/gloo in test_distributed_gloo.py)."""
+import pytest
+import torch
+
+from oracle import cmlpl_oracle as O
+from tests.gpu_util import DEV, cuda_batch, report, to_hp, to_shape
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeComm:
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+
+
+def lockstep_step(engines, per_rank_inputs, epoch, batch_index, **kw):
+    W = len(engines)
+    for e, inp in zip(engines, per_rank_inputs):
+        e.stage_forward(*inp["args"], epoch, batch_index, noise=inp.get("noise"), dropmask=inp.get("dropmask"), **kw)
+    for stage in engines[0].STAGES:
+        if stage != "forward":
+            for e in engines:
+                getattr(e, "stage_" + stage)()
+        specs = [e.exchange_after(stage) for e in engines]
+        for k in range(len(specs[0])):
+            kind = specs[0][k][0]
+            if kind == "all_gather":
+                full = torch.cat([specs[r][k][2].reshape(-1) for r in range(W)])
+                for r in range(W):
+                    specs[r][k][1].view(-1).copy_(full)
+            elif kind == "reduce_scatter":
+                tot = sum(specs[r][k][2] for r in range(W))
+                for r, chunk in enumerate(tot.chunk(W, dim=0)):
+                    specs[r][k][1].copy_(chunk)
+            else:
+                tot = sum(specs[r][k][1] for r in range(W))
+                for r in range(W):
+                    specs[r][k][1].copy_(tot)
+
+
+def shard_inputs(cb, W, bt, btu, cls_in, with_noise):
+    out = []
+    bl, bul = bt // W, btu // W
+    for r in range(W):
+        ls, us = slice(r * bl, (r + 1) * bl), slice(r * bul, (r + 1) * bul)
+        d = dict(args=(cb["XPl"][ls].contiguous(), cb["Xl"][ls].contiguous(), cb["Y"][ls].contiguous(),
+                       cb["XPu"][us].contiguous(), cb["Xu"][us].contiguous()))
+        if with_noise:
+            nz = cb["noise"]
+            d["noise"] = [nz[0][ls].contiguous(), nz[1][ls].contiguous(), nz[2][ls].contiguous(), nz[3][ls].contiguous(),
+                          nz[4][us].contiguous(), nz[5][us].contiguous(), nz[6][us].contiguous(), nz[7][us].contiguous()]
+            dm = cb["dropmask"]      # [2][n][F], rows [labelled ; unlabelled]
+            d["dropmask"] = torch.cat([dm[:, ls], dm[:, bt:][:, us]], dim=1).contiguous()
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("W,shape_name,bt,btu,explicit", [(2, "B2", 32, 32, True), (4, "B2", 64, 64, True),
+                                                          (2, "P", 16, 16, True), (2, "B2", 64, 64, False),
+                                                          (8, "B2", 64, 128, False)])
+def test_sharded_step_equals_single_gpu_step(W, shape_name, bt, btu, explicit):
+    from cmlpl_amd import TrainEngine
+    from cmlpl_amd.distributed import DistTrainEngine
+    shape = {"B2": O.NetShape(103, 11, 11, 103, 9), "P": O.NetShape(60, 20, 20, 103, 9)}[shape_name]
+    hp = O.HyperParams()
+    p0, p1 = O.closed_form_params(shape, 31), O.closed_form_params(shape, 32)
+    ref = TrainEngine(to_shape(shape), bt, btu, to_hp(hp), device=DEV, seed=99)
+    engines = [DistTrainEngine(to_shape(shape), bt // W, btu // W, to_hp(hp), device=DEV, seed=99, comm=FakeComm(W, r))
+               for r in range(W)]
+    for e in [ref] + engines:
+        e.load_state_dict(0, p0); e.load_state_dict(1, p1)
+    assert engines[0].Q == ref.Q
+    for s in range(4):
+        b = O.synthetic_batch(shape, bt, btu, 900 + s, separable=1.0 if s >= 2 else 0.0)
+        cb = cuda_batch(b)
+        epoch = 1          # smoothing active from the first step
+        if explicit:
+            ref.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], epoch, s, noise=cb["noise"], dropmask=cb["dropmask"])
+        else:
+            ref.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], epoch, s)
+        lockstep_step(engines, shard_inputs(cb, W, bt, btu, shape.cls_in, explicit), epoch, s)
+        torch.cuda.synchronize()
+        want = ref.read_scalars()
+        got_t = sum(e.scalars for e in engines)                      # shares are additive
+        got = dict(zip(want.keys(), got_t.tolist()))
+        print(f"step {s}: W={W} got={ {k: round(v, 6) for k, v in got.items()} }")
+        for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc", "total_w", "cls_w", "con_w"):
+            assert abs(got[k] - want[k]) <= 1e-5 * abs(want[k]) + 1e-6, (s, k, got[k], want[k])
+        assert [got[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")] == \
+               [want[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")]
+        lo, fe = ref.outputs()
+        report("logits_g", engines[0].logits_g, lo, 0, 0)           # same kernels, same inputs: bit-identical
+        report("feat_g", engines[-1].feat_g, fe, 0, 0)
+        for net in range(2):
+            for k in O.LIVE_KEYS:
+                gr = ref.grad(net, k)
+                mx = max(float(gr.abs().max()), 1e-6)
+                for e in (engines[0], engines[-1]):
+                    report(f"grad[{net}] {k}", e.grad(net, k), gr, 2e-4, 2e-5 * mx)
+        for i in range(2):
+            for e in (engines[0], engines[-1]):
+                report(f"bank{i} feats", e.bank_feats[i], ref.bank_feats[i], 0, 0)
+                report(f"bank{i} probs", e.bank_probs[i], ref.bank_probs[i], 1e-6, 1e-7)
+        assert engines[0].ptr == ref.ptr
+    for net in range(2):
+        sd_ref = ref.state_dict(net)
+        for e in engines:
+            sd = e.state_dict(net)
+            for k in O.LIVE_KEYS:
+                report(f"param[{net}] {k}", sd[k], sd_ref[k], 1e-4, 3e-5)
+    # every replica holds the same parameters bit for bit (same all-reduced gradient, same Adam)
+    for e in engines[1:]:
+        assert torch.equal(e.params, engines[0].params)

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""CMLPL training driver on MI355X -- same command line as the reference's ``train.py``
+(flags of train.py:356-379, printed line of train.py:282-289), with the per-step hot path
+(train.py:150-278) executed by ``cmlpl_amd.TrainEngine`` (hand-written gfx950 kernels).
+
+Differences from the reference that are deliberate, MI355X-first choices:
+  * the labelled / unlabelled splits live in HBM for the whole run and batches are gathered there by
+    index (the reference copies every batch over PCIe and draws noise on the CPU);
+  * noise and dropout come from in-kernel Philox streams seeded with the reference's seed 1088;
+  * the five logged scalars are read back once per ``print_per_batches`` steps, not five times a step.
+``--synthetic SHAPE`` (B2 | P | B4 | B5) runs without the datasets, which are not shipped.
+Multi-GPU: ``python -m torch.distributed.run --nproc-per-node N train.py ...`` shards every batch by
+sample over the ranks (cmlpl_amd.distributed)."""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from cmlpl_amd import HyperParams, NetShape
+from hsi_loader import HSIDataSet, SyntheticHSIDataSet
+from tools.hyper_tools import CalAccuracy, test_whole
+from tools.models import BaseNet2
+
+DATASETS = {1: (9, 103), 2: (16, 204), 3: (15, 144), 4: (16, 200)}     # num_classes, num_features (train.py:75-90)
+SYNTH = {"B2": (103, 11, 11, 103, 9), "P": (60, 20, 20, 103, 9), "B4": (200, 11, 11, 200, 16),
+         "B5": (48, 15, 15, 48, 20)}
+
+
+class DeviceLoader:
+    """shuffle=True DataLoader semantics (one random permutation per epoch, last short batch kept)
+    over arrays that already sit in HBM."""
+
+    def __init__(self, arrays, batch_size, generator):
+        self.XP, self.X, self.Y = arrays
+        self.bs, self.g = batch_size, generator
+
+    def __len__(self):
+        return (len(self.X) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        perm = torch.randperm(len(self.X), generator=self.g).to(self.X.device)
+        for i in range(0, len(perm), self.bs):
+            idx = perm[i:i + self.bs]
+            yield self.XP[idx], self.X[idx], self.Y[idx]
+
+
+def main(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    torch.manual_seed(1088)                                         # seed_torch(), train.py:50-58
+    if args.synthetic:
+        shape = SYNTH[args.synthetic]
+        num_classes, num_features = shape[4], shape[3]
+        labeled = SyntheticHSIDataSet(shape, args.num_unlabel, 'label', seed=1)
+        unlabeled = SyntheticHSIDataSet(shape, args.num_unlabel, 'unlabel', seed=2)
+        whole = SyntheticHSIDataSet(shape, 4096, 'wholeset', seed=3)
+        Y_test, test_array = whole.Y.numpy(), np.arange(len(whole))
+    else:
+        num_classes, num_features = DATASETS[int(args.dataID)]
+        labeled = HSIDataSet(int(args.dataID), 'label', max_iters=args.num_unlabel)
+        unlabeled = HSIDataSet(int(args.dataID), 'unlabel', max_iters=args.num_unlabel, num_unlabel=args.num_unlabel)
+        whole = HSIDataSet(int(args.dataID), 'wholeset')
+        test_array = np.load(labeled.root + 'test_array.npy')
+        Y_test = (np.load(labeled.root + 'Y.npy') - 1)[test_array]
+        shape = (labeled.XP.shape[1], labeled.XP.shape[2], labeled.XP.shape[3], num_features, num_classes)
+
+    hp = HyperParams(lr=args.lr, num_epochs=args.num_epochs, thr=args.thr, alpha=args.alpha,
+                     queue_batch=args.queue_batch, temperature=args.temperature, dropout=args.dropout,
+                     noise=args.noise)
+    bt, btu = args.labeled_batch_size, args.unlabeled_batch_size
+    if world > 1:
+        import torch.distributed as dist
+        from cmlpl_amd.distributed import DistTrainEngine
+        dist.init_process_group("nccl", device_id=device)
+        eng = DistTrainEngine(NetShape(*shape), bt // world, btu // world, hp, device=device, seed=1088)
+    else:
+        from cmlpl_amd import TrainEngine
+        eng = TrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088)
+    eng.init_params_default(1088)
+
+    gen = torch.Generator().manual_seed(1088)
+    lab_loader = DeviceLoader(labeled.device_arrays(device), bt, gen)
+    unl_loader = DeviceLoader(unlabeled.device_arrays(device), btu, gen)
+    num_batches = min(len(lab_loader), len(unl_loader))              # train.py:134
+    ppb = args.print_per_batches
+    hist = []
+    t_start = time.time()
+    for epoch in range(args.num_epochs):                             # train.py:146
+        for batch_index, (lab, unl) in enumerate(zip(lab_loader, unl_loader)):
+            XPl, Xl, Yl = lab
+            XPu, Xu, _ = unl
+            if world > 1:                                            # shard by sample
+                XPl, Xl, Yl = (t.chunk(world)[rank].contiguous() for t in (XPl, Xl, Yl))
+                XPu, Xu = (t.chunk(world)[rank].contiguous() for t in (XPu, Xu))
+            if XPl.shape[0] < 1 or XPu.shape[0] < 1 or XPl.shape[0] + XPu.shape[0] > eng.n_max:
+                continue
+            eng.step(XPl.contiguous(), Xl.contiguous(), Yl, XPu.contiguous(), Xu.contiguous(), epoch, batch_index)
+            if (batch_index + 1) % ppb == 0:                         # train.py:281-289 (row of the last step)
+                row = eng.loss_row()
+                hist.append(row)
+                if rank == 0:
+                    print('Epoch %d/%d:  %d/%d loss_contrast= %.2f total_loss = %.4f cls_loss = %.4f con_loss = %.4f '
+                          'acc = %.2f\n' % (epoch + 1, args.num_epochs, batch_index + 1, num_batches,
+                                            row[0], row[1], row[2], row[3], row[4] * 100))
+    torch.cuda.synchronize()
+    if rank == 0:
+        steps = eng.step_count
+        print('training: %d steps in %.2f s' % (steps, time.time() - t_start))
+        # whole-image inference + accuracy (train.py:291-306)
+        for net in range(2):
+            model = BaseNet2(num_features=num_features, dropout=args.dropout, num_classes=num_classes,
+                             in_channels=shape[0], window=shape[1]).to(device)
+            model.load_state_dict(eng.state_dict(net))
+            loader = torch.utils.data.DataLoader(whole, batch_size=args.val_batch_size, shuffle=False)
+            t1 = time.time()
+            pred = test_whole(model, loader, print_per_batches=10 ** 9)
+            OA, Kappa, producerA = CalAccuracy(pred[test_array], Y_test)
+            tag = '' if net == 0 else '1'
+            print('inference time == %.3f s' % (time.time() - t1))
+            print('Result:\n OA%s=%.2f,Kappa=%.2f' % (tag, OA * 100, Kappa * 100))
+            print('producerA%s:' % tag, producerA * 100)
+            print('AA%s=%.2f' % (tag, np.mean(producerA) * 100))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--dataID', type=int, default=1)
+    parser.add_argument('--num_label', type=int, default=5)
+    parser.add_argument('--save_path_prefix', type=str, default='./')
+    # train
+    parser.add_argument('--labeled_batch_size', type=int, default=128)
+    parser.add_argument('--unlabeled_batch_size', type=int, default=128)
+    parser.add_argument('--val_batch_size', type=int, default=512)
+    parser.add_argument('--num_workers', type=int, default=1)
+    parser.add_argument('--lr', type=float, default=5e-4)
+    parser.add_argument('--num_epochs', type=int, default=20)
+    parser.add_argument('--print_per_batches', type=int, default=10)
+    parser.add_argument('--num_unlabel', type=int, default=10000)
+    parser.add_argument('--thr', type=float, default=1, help='pseudo label threshold')
+    parser.add_argument('--alpha', type=float, default=0.95)
+    parser.add_argument('--queue-batch', type=float, default=17, help='number of batches stored in memory bank')
+    parser.add_argument('--temperature', default=0.3, type=float, help='softmax temperature')
+    # network
+    parser.add_argument('--teacher_alpha', type=float, default=0.95)
+    parser.add_argument('--dropout', type=float, default=0.8)
+    parser.add_argument('--noise', type=float, default=0.5)
+    parser.add_argument('--m', type=int, default=5, help='number of stochastic augmentations')
+    # this build
+    parser.add_argument('--synthetic', choices=sorted(SYNTH), default=None,
+                        help='run on seeded synthetic patches of this shape (datasets are not shipped)')
+    main(parser.parse_args())

@@ -42,10 +42,10 @@ class TorchDistComm:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
-        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+        self.dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
 
     def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor):
-        self.dist.reduce_scatter_tensor(out, inp, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.dist.reduce_scatter_tensor(out.view(-1), inp.view(-1), op=self.dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce(self, t: torch.Tensor):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -58,6 +58,25 @@ class SingleComm:
     def all_gather(self, out, inp): out.view(-1).copy_(inp.view(-1))
     def reduce_scatter(self, out, inp): out.view(-1).copy_(inp.view(-1))
     def all_reduce(self, t): pass
+
+
+def drive_step(engine, comm, *fwd_args, **fwd_kw) -> None:
+    """Run the stages of one sharded step with the collective that follows each of them.  ``engine``
+    provides STAGES, stage_<name>() and exchange_after(name) -> [(kind, out, inp)] (DistTrainEngine, or the
+    CPU stand-in used by the gloo tests)."""
+    engine.stage_forward(*fwd_args, **fwd_kw)
+    for stage in engine.STAGES:
+        if stage != "forward":
+            getattr(engine, "stage_" + stage)()
+        for kind, out, inp in engine.exchange_after(stage):
+            if kind == "all_gather":
+                comm.all_gather(out, inp)
+            elif kind == "reduce_scatter":
+                comm.reduce_scatter(out, inp)
+            elif kind == "all_reduce":
+                comm.all_reduce(out)
+            else:
+                raise ValueError(kind)
 
 
 class DistTrainEngine(TrainEngine):
@@ -204,17 +223,7 @@ class DistTrainEngine(TrainEngine):
              dropmask: Optional[torch.Tensor] = None, apply_update: bool = True) -> None:
         """Per-rank inputs: this rank's bt/W labelled and btu/W unlabelled rows (noise / dropmask, when given,
         are this rank's slices too)."""
-        self.stage_forward(XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update)
-        for stage in self.STAGES:
-            if stage != "forward":
-                getattr(self, "stage_" + stage)()
-            for kind, out, inp in self.exchange_after(stage):
-                if kind == "all_gather":
-                    self.comm.all_gather(out, inp)
-                elif kind == "reduce_scatter":
-                    self.comm.reduce_scatter(out, inp)
-                else:
-                    self.comm.all_reduce(out)
+        drive_step(self, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update)
 
     def outputs(self):
         """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..]."""

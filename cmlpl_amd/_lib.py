@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcmlpl_hip.so")
+LIB_PATH = os.environ.get("CMLPL_LIB") or os.path.join(HERE, "libcmlpl_hip.so")
 ABI_VERSION = 1
 NUM_TENSORS = 16
 NUM_LIVE = 10
@@ -31,7 +31,7 @@ EXPORTS = (
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
                 "cls_wgrad", "spe_wgrad", "conv2_dgrad", "conv2_wgrad", "conv2_wred", "conv1_dgrad", "conv1_wgrad",
-                "conv1_wred", "conv0_wgrad", "adam", "pack", "loss2")
+                "conv1_wred", "conv0_wgrad", "adam", "pack", "loss_graph", "loss_fin", "loss_dfeat")
 
 
 class CmlplLibraryError(RuntimeError):
@@ -120,7 +120,7 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_basenet2_bwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, vp, vp, vp, i64, vp, sz, vp]
     lib.cmlpl_loss_fwd_bwd.argtypes = [SP, i32, i32, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp,
                                        vp, sz, vp]
-    lib.cmlpl_loss_phase1.argtypes = [SP, SH, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, sz, vp]
+    lib.cmlpl_loss_phase1.argtypes = [SP, SH, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp, sz, vp]
     lib.cmlpl_loss_phase2.argtypes = [SP, SH, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, i32, vp, vp, vp, vp, sz,
                                       vp]
     lib.cmlpl_loss_workspace_bytes.argtypes = [SP, SH, i32]

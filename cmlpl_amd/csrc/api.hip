@@ -1,6 +1,7 @@
 // C-ABI entry points (include/cmlpl.h): argument checking, workspace carving and the launch
 // sequence of one training step.  No allocation, no synchronisation, graph-capturable.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -97,6 +98,43 @@ struct Timing {
   size_t used = 0;
 } g_timing;
 
+// ---- fork/join helpers.  Independent branches of the step DAG (spectral vs spatial forward, weight
+// gradients vs data gradients, bank write vs dfeat GEMMs) run on two auxiliary streams forked from /
+// joined to the caller's stream with events: at 256 patches no single kernel fills the chip for its
+// whole duration (staging, drain and tail phases), so overlapping kernels recovers that idle time.
+// The pool is process-global and created on first use; fork/join is graph-capturable.
+struct AuxStreams {
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t ev[8];
+  bool ok = false, enabled = true;
+  AuxStreams() {
+    const char* e = getenv("CMLPL_SINGLE_STREAM");
+    enabled = !(e && e[0] == '1');
+    if (!enabled) return;
+    for (int i = 0; i < 2; ++i)
+      if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return;
+    for (int i = 0; i < 8; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
+    ok = true;
+  }
+};
+AuxStreams& aux() { static AuxStreams a; return a; }
+// aux stream i continues after everything enqueued on `from` so far
+inline hipStream_t fork_to(hipStream_t from, int i, int evi) {
+  AuxStreams& a = aux();
+  if (!a.ok) return from;
+  (void)hipEventRecord(a.ev[evi], from);
+  (void)hipStreamWaitEvent(a.s[i], a.ev[evi], 0);
+  return a.s[i];
+}
+// `to` waits for everything enqueued on aux stream i so far
+inline void join_from(hipStream_t to, int i, int evi) {
+  AuxStreams& a = aux();
+  if (!a.ok) return;
+  (void)hipEventRecord(a.ev[evi], a.s[i]);
+  (void)hipStreamWaitEvent(to, a.ev[evi], 0);
+}
+
 template <class F>
 int timed(int id, hipStream_t st, F f) {
   Timing& t = g_timing;
@@ -189,14 +227,19 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
   if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  hipStream_t main_st = st;
+  {  // spectral branch (feat_spe + ReLU) runs beside the spatial conv stack
+    hipStream_t st = fork_to(main_st, 0, 0);
+    if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
+                                 d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
+  }
   if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_params + L.param_off[0],
                                  d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
   if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV,
                              PACK_PER_NET, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
   if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + 2 * PACK_CONV,
                              PACK_PER_NET, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
-  if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
-                               d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
+  join_from(main_st, 0, 1);
   if (shard && shard->nlab + shard->nunl != n) return CMLPL_E_ARG;
   const int nlab = shard ? shard->nlab : n, lab0 = shard ? shard->lab0 : 0;
   const int unl_base = shard ? shard->bt_g + shard->unl0 : n;
@@ -224,33 +267,46 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
   if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,
                                 d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
-  GemmTN g;
-  // dW_cls[k][f] = sum_n dlogits[n][k] * catd[n][f] ; db_cls[k] = sum_n dlogits[n][k]
-  g.A = d_dlogits; g.a_bstride = (long long)n * d.K; g.lda = d.K; g.M = d.K;
-  g.B = w.catd; g.b_bstride = (long long)n * d.F; g.ldb = d.F; g.N = d.F;
-  g.C = d_grads + L.param_off[8]; g.c_bstride = grad_stride; g.ldc = d.F;
-  g.bias = d_grads + L.param_off[9]; g.bias_bstride = grad_stride;
-  g.R = n; g.batches = nets; g.scale = 1.f;
-  if ((rc = TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
-  // dW_spe[o][b] = sum_n dy[n][o] * sn[n][b] ; db_spe[o] = sum_n dy[n][o]
-  g.A = w.dy; g.a_bstride = (long long)n * 1024; g.lda = 1024; g.M = 1024;
-  g.B = d_sn; g.b_bstride = (long long)n * d.bands; g.ldb = d.bands; g.N = d.bands;
-  g.C = d_grads + L.param_off[6]; g.ldc = d.bands;
-  g.bias = d_grads + L.param_off[7];
-  if ((rc = TIMED(CMLPL_K_SPE_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
-  // spatial branch
+  hipStream_t main_st = st;
+  {  // classifier / spectral weight gradients: independent of the spatial backward chain
+    hipStream_t st = fork_to(main_st, 0, 2);
+    GemmTN g;
+    // dW_cls[k][f] = sum_n dlogits[n][k] * catd[n][f] ; db_cls[k] = sum_n dlogits[n][k]
+    g.A = d_dlogits; g.a_bstride = (long long)n * d.K; g.lda = d.K; g.M = d.K;
+    g.B = w.catd; g.b_bstride = (long long)n * d.F; g.ldb = d.F; g.N = d.F;
+    g.C = d_grads + L.param_off[8]; g.c_bstride = grad_stride; g.ldc = d.F;
+    g.bias = d_grads + L.param_off[9]; g.bias_bstride = grad_stride;
+    g.R = n; g.batches = nets; g.scale = 1.f;
+    if ((rc = TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
+    // dW_spe[o][b] = sum_n dy[n][o] * sn[n][b] ; db_spe[o] = sum_n dy[n][o]
+    g.A = w.dy; g.a_bstride = (long long)n * 1024; g.lda = 1024; g.M = 1024;
+    g.B = d_sn; g.b_bstride = (long long)n * d.bands; g.ldb = d.bands; g.N = d.bands;
+    g.C = d_grads + L.param_off[6]; g.ldc = d.bands;
+    g.bias = d_grads + L.param_off[7];
+    if ((rc = TIMED(CMLPL_K_SPE_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
+  }
+  // spatial branch: the data-gradient chain stays on the caller's stream, each weight gradient forks off
+  {  // conv2 weight gradient needs only dp2/m2/p1 (ready since head_bwd): forked before conv2_dgrad is enqueued
+    hipStream_t st = fork_to(main_st, 1, 3);
+    if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
+    if ((rc = TIMED(CMLPL_K_CONV2_WRED, chk(launch_wgrad3_reduce(nets, n, d.H2, d.W2, w.part2, d_grads + L.param_off[4],
+                                d_grads + L.param_off[5], grad_stride, st))))) return rc;
+  }
   if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + 3 * PACK_CONV,
                              PACK_PER_NET, nullptr, 0, w.dp1, nullptr, st))))) return rc;
-  if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
-  if ((rc = TIMED(CMLPL_K_CONV2_WRED, chk(launch_wgrad3_reduce(nets, n, d.H2, d.W2, w.part2, d_grads + L.param_off[4],
-                              d_grads + L.param_off[5], grad_stride, st))))) return rc;
+  {  // conv1 weight gradient needs dp1 (conv2_dgrad output): fork after it, runs beside conv1_dgrad
+    hipStream_t st = fork_to(main_st, 0, 4);
+    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
+    if ((rc = TIMED(CMLPL_K_CONV1_WRED, chk(launch_wgrad3_reduce(nets, n, d.H, d.W, w.part1, d_grads + L.param_off[2],
+                                d_grads + L.param_off[3], grad_stride, st))))) return rc;
+  }
   if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
                              PACK_PER_NET, nullptr, 0, w.da0, nullptr, st))))) return rc;
-  if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
-  if ((rc = TIMED(CMLPL_K_CONV1_WRED, chk(launch_wgrad3_reduce(nets, n, d.H, d.W, w.part1, d_grads + L.param_off[2],
-                              d_grads + L.param_off[3], grad_stride, st))))) return rc;
-  return TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0,
+  rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0,
                                 d_grads + L.param_off[0], d_grads + L.param_off[1], grad_stride, st)));
+  join_from(main_st, 0, 5);
+  join_from(main_st, 1, 6);
+  return rc;
 }
 
 namespace {
@@ -291,16 +347,16 @@ size_t cmlpl_loss_workspace_bytes(const cmlpl_shape* shape, const cmlpl_shard* s
 
 int cmlpl_loss_phase1(const cmlpl_shape* shape, const cmlpl_shard* shard, const float* d_logits, const float* d_feat,
                       const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
-                      const cmlpl_hparams* hp, float* d_dlogits, float* d_probs_local, void* d_workspace,
-                      size_t workspace_bytes, void* stream) {
+                      const cmlpl_hparams* hp, float* d_dlogits, float* d_dfeat, float* d_probs_local,
+                      void* d_workspace, size_t workspace_bytes, void* stream) {
   Dims d;
   if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
   LossArgs a;
   int rc = fill_loss_args(d, shard, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_workspace,
                           workspace_bytes, &a);
   if (rc) return rc;
-  if (!d_dlogits || !d_probs_local) return CMLPL_E_ARG;
-  a.dlogits = d_dlogits; a.probs_l = d_probs_local;
+  if (!d_dlogits || !d_dfeat || !d_probs_local) return CMLPL_E_ARG;
+  a.dlogits = d_dlogits; a.dfeat = d_dfeat; a.probs_l = d_probs_local;
   hipStream_t st = (hipStream_t)stream;
   return TIMED(CMLPL_K_LOSS, chk(launch_loss_phase1(a, st)));
 }
@@ -322,7 +378,16 @@ int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard, const 
   a.probs_g = d_probs_global; a.pshard = probs_shard_rows; a.scalars = d_scalars; a.dfeat = d_dfeat;
   a.dfw_part = d_dfeat_w_partial;
   hipStream_t st = (hipStream_t)stream;
-  return TIMED(CMLPL_K_LOSS2, chk(launch_loss_phase2(a, st)));
+  int rc2 = TIMED(CMLPL_K_LOSS2, chk(launch_loss_graph(a, st)));
+  if (rc2) return rc2;
+  hipStream_t main_st = st;
+  {  // bank write + scalars beside the two dfeat GEMMs
+    hipStream_t st = fork_to(main_st, 0, 7);
+    if ((rc2 = TIMED(CMLPL_K_LOSS_FIN, chk(launch_loss_finalize(a, st))))) return rc2;
+  }
+  rc2 = TIMED(CMLPL_K_LOSS_DFEAT, chk(launch_loss_dfeat(a, st)));
+  join_from(main_st, 0, 7);
+  return rc2;
 }
 
 int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
@@ -331,8 +396,8 @@ int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d
                        float* d_probs, void* d_workspace, size_t workspace_bytes, void* stream) {
   if (!d_probs || !d_dfeat) return CMLPL_E_ARG;
   cmlpl_shard sh = {bt, btu, 0, bt, 0, btu};
-  int rc = cmlpl_loss_phase1(shape, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_dlogits, d_probs,
-                             d_workspace, workspace_bytes, stream);
+  int rc = cmlpl_loss_phase1(shape, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_dlogits, d_dfeat,
+                             d_probs, d_workspace, workspace_bytes, stream);
   if (rc) return rc;
   // one GPU: the probabilities are already global, and the column-side gradient goes straight to dfeat[1]
   return cmlpl_loss_phase2(shape, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_probs, btu,

@@ -13,6 +13,10 @@
 // step (pack_weights_kernel) to [tap][ci/4][co][4] so that both MFMA operands are ds_read_b128.
 #include <stdlib.h>
 
+#ifndef CMLPL_ABL
+#define CMLPL_ABL 0
+#endif
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -377,6 +381,9 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
 
   for (int ub = ubeg; ub < uend; ub += U) {
     __syncthreads();  // previous pass finished reading img/dz
+#if CMLPL_ABL == 3
+    if (ub >= 0) goto staged;
+#endif
     // stage the input rows (row0-1 .. row0+RU) of each unit; rows outside the image are zero
     staged_copy<8, float4>(U * (RU + 2) * W * 16, tid,
         [&](int idx) {
@@ -427,6 +434,9 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
             }
           });
     }
+#if CMLPL_ABL == 3
+  staged:
+#endif
     __syncthreads();
     // main loop over pixel pairs (c, c+1) of each staged output row; CO is even, so a pair never
     // straddles a row and every address is affine in (row, c): no lookup, operands of pair t+1 are
@@ -452,13 +462,22 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
       const int un = (t + 1 < pairs) ? u : 0, rn = (t + 1 < pairs) ? r : 0, cn = (t + 1 < pairs) ? cp : 0;
       const float* ap = arow0 + (un * IMGU + rn * PW + 2 * cn) * 64;
       const float* bp = brow0 + ((un * RU + rn) * CO + 2 * cn) * 64;
+#if CMLPL_ABL != 2
 #pragma unroll
       for (int s = 0; s < 9; ++s) an[s] = ap[shoff[s]];
       bn = bp[0];
+#else
+      asm volatile("" :: "v"(ap), "v"(bp));
+#endif
       __builtin_amdgcn_sched_barrier(0);   // reads of pair t+1 stay above the MFMAs of pair t
       dbacc += bc;
+#if CMLPL_ABL != 1
 #pragma unroll
       for (int s = 0; s < 9; ++s) acc[s] = mfma32(ac[s], bc, acc[s]);
+#else
+#pragma unroll
+      for (int s = 0; s < 9; ++s) asm volatile("" :: "v"(ac[s]), "v"(bc));
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 9; ++s) ac[s] = an[s];

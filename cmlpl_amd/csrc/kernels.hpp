@@ -89,7 +89,9 @@ struct LossArgs {
 size_t loss_ws_floats(int nlab, int nunl, int btu_g, int K, int Q);
 void loss_ws_carve(LossArgs& a, float* ws);
 hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st);
-hipError_t launch_loss_phase2(const LossArgs& a, hipStream_t st);
+hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st);
+hipError_t launch_loss_finalize(const LossArgs& a, hipStream_t st);
+hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st);
 
 // ---- optim.hip
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,

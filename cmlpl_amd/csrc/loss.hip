@@ -160,6 +160,11 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
       const float lse = mx + logf(se);
       const float zy = __shfl(z, yl, 64);
       if (kv) a.dlogits[((long long)net * nl + il) * K + lane] = (ez / se - (lane == yl ? 1.f : 0.f)) / (float)bt;
+      {  // labelled rows carry no feature gradient (they only enter the banks)
+        float4* dz = (float4*)(a.dfeat + ((long long)net * nl + il) * FD);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dz[lane + 64 * q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (lane == 0) a.rowloss[(net == 0 ? RL_CLS_S : RL_CLS_W) * RL + il] = lse - zy;
       if (net == 1) {  // torch.max(labeled_output1, 1): first index of the maximum (train.py:194)
         const unsigned long long bal = __ballot(kv && z == mx);
@@ -361,22 +366,21 @@ hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_loss_phase2(const LossArgs& a, hipStream_t st) {
-  hipError_t e;
-  const int bt = a.bt, btu = a.btu, n = bt + btu, nl = a.nlab + a.nunl;
-  // labelled rows carry no feature gradient (they only enter the banks)
-  if (a.nlab > 0) {
-    e = hipMemsetAsync(a.dfeat, 0, (size_t)a.nlab * FD * 4, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.dfeat + (long long)nl * FD, 0, (size_t)a.nlab * FD * 4, st);
-    if (e != hipSuccess) return e;
-  }
-  const size_t lds = (size_t)4 * 2 * btu * 4;
+hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)4 * 2 * a.btu * 4;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(graph_loss_kernel, dim3((a.nunl + 3) / 4), dim3(256), lds, st, a);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(finalize_kernel, dim3(n + 1), dim3(256), 0, st, a);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return hipGetLastError();
+}
+
+hipError_t launch_loss_finalize(const LossArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(a.bt + a.btu + 1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
+  hipError_t e;
+  const int bt = a.bt, btu = a.btu, n = bt + btu;
   // dfeat_s[local rows] = G . fU_w            : C[i][d] = sum_l GT[l][i] * fU_w[l][d]   (R = btu, M = nunl)
   GemmTN g;
   g.A = a.GT; g.lda = a.nunl; g.M = a.nunl; g.R = btu;

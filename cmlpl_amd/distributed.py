@@ -170,7 +170,8 @@ class DistTrainEngine(TrainEngine):
         _lib.check("cmlpl_loss_phase1", self.lib.cmlpl_loss_phase1(
             C.byref(self.cshape), C.byref(self.cshard), self.logits_g.data_ptr(), self.feat_g.data_ptr(),
             self.labels_g.data_ptr(), C.byref(banks), c["smooth"], c["adap"], C.byref(self._chp),
-            self.dlogits_l.data_ptr(), self.probs_l.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
+            self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.probs_l.data_ptr(), self.loss_ws.data_ptr(),
+            self.loss_ws.numel(), st))
 
     def stage_phase2(self):
         c, st = self._ctx, self._stream()

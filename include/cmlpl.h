@@ -166,7 +166,7 @@ size_t cmlpl_loss_workspace_bytes(const cmlpl_shape* shape, const cmlpl_shard* s
 int cmlpl_loss_phase1(const cmlpl_shape* shape, const cmlpl_shard* shard,
                       const float* d_logits, const float* d_feat, const int64_t* d_labels,
                       const cmlpl_banks* banks, int smooth, float adap_mask, const cmlpl_hparams* hp,
-                      float* d_dlogits, float* d_probs_local,
+                      float* d_dlogits, float* d_dfeat /* labelled rows are zeroed here */, float* d_probs_local,
                       void* d_workspace, size_t workspace_bytes, void* stream);
 int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard,
                       const float* d_logits, const float* d_feat, const int64_t* d_labels,
@@ -218,7 +218,8 @@ enum {
   CMLPL_K_AUGMENT = 0, CMLPL_K_CONV0_FWD, CMLPL_K_CONV1_FWD, CMLPL_K_CONV2_FWD, CMLPL_K_SPE_FWD,
   CMLPL_K_HEAD_FWD, CMLPL_K_LOSS, CMLPL_K_HEAD_BWD, CMLPL_K_CLS_WGRAD, CMLPL_K_SPE_WGRAD,
   CMLPL_K_CONV2_DGRAD, CMLPL_K_CONV2_WGRAD, CMLPL_K_CONV2_WRED, CMLPL_K_CONV1_DGRAD, CMLPL_K_CONV1_WGRAD,
-  CMLPL_K_CONV1_WRED, CMLPL_K_CONV0_WGRAD, CMLPL_K_ADAM, CMLPL_K_PACK, CMLPL_K_LOSS2, CMLPL_K_COUNT
+  CMLPL_K_CONV1_WRED, CMLPL_K_CONV0_WGRAD, CMLPL_K_ADAM, CMLPL_K_PACK, CMLPL_K_LOSS2, CMLPL_K_LOSS_FIN,
+  CMLPL_K_LOSS_DFEAT, CMLPL_K_COUNT
 };
 int cmlpl_timing_begin(uint32_t kernel_mask, int max_launches);
 int cmlpl_timing_end(double* ms_sum /*[CMLPL_K_COUNT]*/, int64_t* launches /*[CMLPL_K_COUNT]*/);

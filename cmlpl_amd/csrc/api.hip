@@ -108,8 +108,11 @@ struct AuxStreams {
   hipEvent_t ev[8];
   bool ok = false, enabled = true;
   AuxStreams() {
-    const char* e = getenv("CMLPL_SINGLE_STREAM");
-    enabled = !(e && e[0] == '1');
+    // measured on MI355X at B2/256: forked branches do overlap, but LDS capacity admits one big workgroup
+    // per CU, so co-scheduled kernels time-slice the CUs and every fork/join adds a 6-12 us gap: net zero.
+    // Opt-in only (CMLPL_MULTI_STREAM=1).
+    const char* e = getenv("CMLPL_MULTI_STREAM");
+    enabled = (e && e[0] == '1');
     if (!enabled) return;
     for (int i = 0; i < 2; ++i)
       if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return;
@@ -277,36 +280,39 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
     g.C = d_grads + L.param_off[8]; g.c_bstride = grad_stride; g.ldc = d.F;
     g.bias = d_grads + L.param_off[9]; g.bias_bstride = grad_stride;
     g.R = n; g.batches = nets; g.scale = 1.f;
-    if ((rc = TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
-    // dW_spe[o][b] = sum_n dy[n][o] * sn[n][b] ; db_spe[o] = sum_n dy[n][o]
-    g.A = w.dy; g.a_bstride = (long long)n * 1024; g.lda = 1024; g.M = 1024;
-    g.B = d_sn; g.b_bstride = (long long)n * d.bands; g.ldb = d.bands; g.N = d.bands;
-    g.C = d_grads + L.param_off[6]; g.ldc = d.bands;
-    g.bias = d_grads + L.param_off[7];
-    if ((rc = TIMED(CMLPL_K_SPE_WGRAD, chk(launch_gemm_tn(g, st))))) return rc;
+    // dW_spe[o][b] = sum_n dy[n][o] * sn[n][b] ; db_spe[o] = sum_n dy[n][o]   (same launch)
+    GemmTN h = g;
+    h.A = w.dy; h.a_bstride = (long long)n * 1024; h.lda = 1024; h.M = 1024;
+    h.B = d_sn; h.b_bstride = (long long)n * d.bands; h.ldb = d.bands; h.N = d.bands;
+    h.C = d_grads + L.param_off[6]; h.ldc = d.bands;
+    h.bias = d_grads + L.param_off[7];
+    if ((rc = TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn2(g, h, st))))) return rc;
   }
   // spatial branch: the data-gradient chain stays on the caller's stream, each weight gradient forks off
   {  // conv2 weight gradient needs only dp2/m2/p1 (ready since head_bwd): forked before conv2_dgrad is enqueued
     hipStream_t st = fork_to(main_st, 1, 3);
     if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
-    if ((rc = TIMED(CMLPL_K_CONV2_WRED, chk(launch_wgrad3_reduce(nets, n, d.H2, d.W2, w.part2, d_grads + L.param_off[4],
-                                d_grads + L.param_off[5], grad_stride, st))))) return rc;
   }
   if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + 3 * PACK_CONV,
                              PACK_PER_NET, nullptr, 0, w.dp1, nullptr, st))))) return rc;
   {  // conv1 weight gradient needs dp1 (conv2_dgrad output): fork after it, runs beside conv1_dgrad
     hipStream_t st = fork_to(main_st, 0, 4);
     if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
-    if ((rc = TIMED(CMLPL_K_CONV1_WRED, chk(launch_wgrad3_reduce(nets, n, d.H, d.W, w.part1, d_grads + L.param_off[2],
-                                d_grads + L.param_off[3], grad_stride, st))))) return rc;
   }
   if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
                              PACK_PER_NET, nullptr, 0, w.da0, nullptr, st))))) return rc;
-  rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0,
-                                d_grads + L.param_off[0], d_grads + L.param_off[1], grad_stride, st)));
+  if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
+    return rc;
   join_from(main_st, 0, 5);
   join_from(main_st, 1, 6);
-  return rc;
+  // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
+  ReduceTable rt;
+  rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride;
+  reduce_table_add(rt, w.part1, wgrad3_G(n, d.H, d.W), PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
+  reduce_table_add(rt, w.part2, wgrad3_G(n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
+  reduce_table_add(rt, w.part0, plan_conv0_wgrad_G(n, d.C, d.HW), conv0_partial_size(d.C), 0, d.C,
+                   d_grads + L.param_off[0], d_grads + L.param_off[1]);
+  return TIMED(CMLPL_K_CONV1_WRED, chk(launch_partial_reduce(nets, rt, st)));
 }
 
 namespace {
@@ -423,12 +429,9 @@ int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t
   if (rc) return rc;
   if (nets < 1 || nets > 2 || !d_params || !d_grads || !d_m || !d_v || !hp || t < 1) return CMLPL_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if ((rc = TIMED(CMLPL_K_ADAM, chk(launch_adam(nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v,
-                            L.param_live, t, hp->lr, hp->beta1, hp->beta2, hp->eps, st))))) return rc;
-  if (d_packed)
-    return TIMED(CMLPL_K_PACK, chk(launch_pack_weights(nets, d_params, param_stride, L.param_off[2], L.param_off[4],
-                                                      d_packed, st)));
-  return 0;
+  return TIMED(CMLPL_K_ADAM, chk(launch_adam(nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v,
+                            L.param_live, t, hp->lr, hp->beta1, hp->beta2, hp->eps, d_packed, L.param_off[2],
+                            L.param_off[4], st)));
 }
 
 int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io, void* stream) {

@@ -166,18 +166,21 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 }
 
 // out[map(e)] = sum_g part[g][e]: 64 elements x 4 slices of g per block, 8 loads in flight per thread,
-// fixed summation order (bit-reproducible, unlike float atomics).
+// fixed summation order (bit-reproducible, unlike float atomics).  Up to 3 tensors per launch.
 // mode 0: conv0  e = c*64+co -> dW[co*C + c] (c < C), tail 64 -> db
 // mode 1: conv3x3 e = s*4096 + ci*64 + co -> dW[co*576 + ci*9 + s], tail 64 -> db
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int G, int PS, int mode,
-                                                             int C, float* __restrict__ dW, float* __restrict__ db,
-                                                             long long grad_ns) {
+__global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t) {
   __shared__ float red[4][64];
   const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
   const int net = blockIdx.y;
-  const int e = blockIdx.x * 64 + el;
+  int pi = 0;
+  if (t.count > 1 && (int)blockIdx.x >= t.p[1].blk0) pi = 1;
+  if (t.count > 2 && (int)blockIdx.x >= t.p[2].blk0) pi = 2;
+  const ReduceProb pr = t.p[pi];
+  const int G = pr.G, PS = pr.PS;
+  const int e = ((int)blockIdx.x - pr.blk0) * 64 + el;
   const bool ev = e < PS;
-  const float* p = part + (long long)net * G * PS + (ev ? e : 0);
+  const float* p = pr.part + (long long)net * G * PS + (ev ? e : 0);
   float s0 = 0.f, s1 = 0.f;
   for (int g0 = sl; g0 < G; g0 += 32) {
     float v[8];
@@ -196,23 +199,29 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
     const float sum = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
     const int body = PS - 64;
     if (e >= body) {
-      db[(long long)net * grad_ns + (e - body)] = sum;
-    } else if (mode == 0) {
+      pr.db[(long long)net * t.grad_ns + (e - body)] = sum;
+    } else if (pr.mode == 0) {
       const int c = e >> 6, co = e & 63;
-      if (c < C) dW[(long long)net * grad_ns + co * C + c] = sum;
+      if (c < pr.C) pr.dW[(long long)net * t.grad_ns + co * pr.C + c] = sum;
     } else {
       const int s = e >> 12, ci = (e >> 6) & 63, co = e & 63;
-      dW[(long long)net * grad_ns + co * 576 + ci * 9 + s] = sum;
+      pr.dW[(long long)net * t.grad_ns + co * 576 + ci * 9 + s] = sum;
     }
   }
 }
 
-hipError_t launch_partial_reduce(int nets, const float* part, int G, int PS, int mode, int C, float* dW, float* db,
-                                 long long grad_ns, hipStream_t st) {
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((PS + 63) / 64, nets), dim3(256), 0, st, part, G, PS, mode, C, dW,
-                     db, grad_ns);
+void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db) {
+  ReduceProb& p = t.p[t.count++];
+  p.part = part; p.dW = dW; p.db = db; p.G = G; p.PS = PS; p.mode = mode; p.C = C; p.blk0 = t.total_blocks;
+  t.total_blocks += (PS + 63) / 64;
+}
+
+hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st) {
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(t.total_blocks, nets), dim3(256), 0, st, t);
   return hipGetLastError();
 }
+
+int conv0_partial_size(int C) { return ((C + 31) / 32) * 32 * 64 + 64; }
 
 int plan_conv0_wgrad_G(int n, int C, int HW) {
   (void)C; (void)HW;
@@ -221,7 +230,7 @@ int plan_conv0_wgrad_G(int n, int C, int HW) {
 }
 
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
-                              float* dW, float* db, long long grad_ns, hipStream_t st) {
+                              hipStream_t st) {
   const int NT = (C + 31) / 32, Ct = NT * 32;
   if (NT > 2 * C0_MAXT) return hipErrorInvalidValue;
   const int HWp = (HW + 2) | 1;
@@ -236,9 +245,7 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
   }
   const int G = plan_conv0_wgrad_G(n, C, HW);
   hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  return launch_partial_reduce(nets, part, G, Ct * 64 + 64, 0, C, dW, db, grad_ns, st);
+  return hipGetLastError();
 }
 
 }  // namespace cmlpl

@@ -553,11 +553,9 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   return hipGetLastError();
 }
 
-hipError_t launch_wgrad3_reduce(int nets, int n, int H, int W, const float* part, float* dW, float* db,
-                                long long grad_ns, hipStream_t st) {
+int wgrad3_G(int n, int H, int W) {
   Wgrad3Plan pl;
-  if (!plan_wgrad3(n, H, W, &pl)) return hipErrorInvalidValue;
-  return launch_partial_reduce(nets, part, pl.G, PART3, 1, 64, dW, db, grad_ns, st);
+  return plan_wgrad3(n, H, W, &pl) ? pl.G : 0;
 }
 
 }  // namespace cmlpl

@@ -71,12 +71,21 @@ hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const flo
 // number of dependent memory round trips per wave, which this shape cuts to R/128.
 constexpr int GT_DEPTH = 16;
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
+struct GemmTN2 { GemmTN p[2]; int nblk0; };
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN2 t) {
   __shared__ float red[3][16][64];
   __shared__ float ared[4][64];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bz = blockIdx.z, mt = blockIdx.y, nt = blockIdx.x;
+  // linear block id -> (problem, nt, mt, batch)
+  const int pi = ((int)blockIdx.x >= t.nblk0) ? 1 : 0;
+  const GemmTN g = t.p[pi];
+  int b = (int)blockIdx.x - (pi ? t.nblk0 : 0);
+  const int NTg = (g.N + 31) >> 5, MTg = (g.M + 31) >> 5;
+  const int nt = b % NTg; b /= NTg;
+  const int mt = b % MTg;
+  const int bz = b / MTg;
   const float* A = g.A + (long long)bz * g.a_bstride;
   const float* B = g.B + (long long)bz * g.b_bstride;
   const int i = mt * 32 + l31, j = nt * 32 + l31;
@@ -130,10 +139,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
   }
 }
 
+static int gemm_blocks(const GemmTN& g) { return ((g.M + 31) / 32) * ((g.N + 31) / 32) * g.batches; }
+
 hipError_t launch_gemm_tn(const GemmTN& g, hipStream_t st) {
-  const int MT = (g.M + 31) / 32, NT = (g.N + 31) / 32;
-  dim3 grid(NT, MT, g.batches);
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, g);
+  GemmTN2 t;
+  t.p[0] = g; t.p[1] = g; t.nblk0 = gemm_blocks(g);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(t.nblk0), dim3(256), 0, st, t);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_tn2(const GemmTN& g0, const GemmTN& g1, hipStream_t st) {
+  GemmTN2 t;
+  t.p[0] = g0; t.p[1] = g1; t.nblk0 = gemm_blocks(g0);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(t.nblk0 + gemm_blocks(g1)), dim3(256), 0, st, t);
   return hipGetLastError();
 }
 

@@ -34,17 +34,20 @@ struct Wgrad3Plan { int RU, U, G; size_t lds; };
 bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st);
-hipError_t launch_wgrad3_reduce(int nets, int n, int H, int W, const float* part, float* dW, float* db,
-                                long long grad_nstride, hipStream_t st);
+int wgrad3_G(int n, int H, int W);
 
 // ---- conv0.hip
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w, const float* b,
                             long long pstride, float* a0, hipStream_t st);
 int plan_conv0_wgrad_G(int n, int C, int HW);
-hipError_t launch_partial_reduce(int nets, const float* part, int G, int PS, int mode, int C, float* dW, float* db,
-                                 long long grad_ns, hipStream_t st);
+// deterministic sum of per-workgroup weight-gradient partials, up to 3 tensors in one launch
+struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C, blk0; };
+struct ReduceTable { ReduceProb p[3]; int count, total_blocks; long long grad_ns; };
+void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db);
+hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st);
+int conv0_partial_size(int C);
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
-                              float* dW, float* db, long long grad_nstride, hipStream_t st);
+                              hipStream_t st);
 
 // ---- dense.hip
 hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const float* w, const float* b,
@@ -57,6 +60,7 @@ struct GemmTN {
   float scale;
 };
 hipError_t launch_gemm_tn(const GemmTN& g, hipStream_t st);
+hipError_t launch_gemm_tn2(const GemmTN& g0, const GemmTN& g1, hipStream_t st);   // two problems, one launch
 
 // ---- head.hip
 hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, const float* y, const float* dropmask,
@@ -96,6 +100,6 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st);
 // ---- optim.hip
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
-                       hipStream_t st);
+                       float* packed, long long off_w1, long long off_w2, hipStream_t st);
 
 }  // namespace cmlpl

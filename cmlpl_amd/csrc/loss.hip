@@ -387,12 +387,13 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   g.B = a.feat + ((long long)n + bt) * FD; g.ldb = FD; g.N = FD;
   g.C = a.dfeat + (long long)a.nlab * FD; g.ldc = FD;
   g.a_bstride = g.b_bstride = g.c_bstride = 0; g.bias = nullptr; g.bias_bstride = 0; g.batches = 1; g.scale = 1.f;
-  if ((e = launch_gemm_tn(g, st)) != hipSuccess) return e;
   // dfeat_w[all rows] (this shard's partial) = G^T . fU_s[local] : C[l][d] = sum_i G[i][l] * fU_s[unl0+i][d]
-  g.A = a.G; g.lda = btu; g.M = btu; g.R = a.nunl;
-  g.B = a.feat + ((long long)bt + a.unl0) * FD;
-  g.C = a.dfw_part;
-  return launch_gemm_tn(g, st);
+  GemmTN h = g;
+  h.A = a.G; h.lda = btu; h.M = btu; h.R = a.nunl;
+  h.B = a.feat + ((long long)bt + a.unl0) * FD;
+  h.C = a.dfw_part;
+  (void)e;
+  return launch_gemm_tn2(g, h, st);
 }
 
 }  // namespace cmlpl

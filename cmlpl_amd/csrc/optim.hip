@@ -8,7 +8,8 @@ namespace cmlpl {
 
 __global__ void adam_kernel(float* __restrict__ params, long long pstride, const float* __restrict__ grads,
                             long long gstride, float* __restrict__ m, float* __restrict__ v, long long live,
-                            float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps) {
+                            float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps,
+                            float* __restrict__ packed, long long off_w1, long long off_w2) {
   const int net = blockIdx.y;
   const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 >= live) return;
@@ -30,17 +31,33 @@ __global__ void adam_kernel(float* __restrict__ params, long long pstride, const
   *(float4*)mm = make_float4(ma[0], ma[1], ma[2], ma[3]);
   *(float4*)vv = make_float4(va[0], va[1], va[2], va[3]);
   *(float4*)p = make_float4(pa[0], pa[1], pa[2], pa[3]);
+  // the 3x3 kernels read re-packed weights ([tap][ci/4][co][4], forward and transposed+flipped): refresh
+  // them here instead of a separate launch (same mapping as pack_weights_kernel)
+  if (packed != nullptr) {
+    const int which = (i4 >= off_w1 && i4 < off_w1 + PACK_CONV) ? 0 : (i4 >= off_w2 && i4 < off_w2 + PACK_CONV) ? 2 : -1;
+    if (which >= 0) {
+      float* pk = packed + (long long)net * PACK_PER_NET + which * PACK_CONV;
+      const int e0 = (int)(i4 - (which == 0 ? off_w1 : off_w2));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q, kw = e % 3, kh = (e / 3) % 3, ci = (e / 9) & 63, co = e / 576;
+        pk[(((kh * 3 + kw) * 16 + (ci >> 2)) * 64 + co) * 4 + (ci & 3)] = pa[q];
+        pk[PACK_CONV + ((((2 - kh) * 3 + (2 - kw)) * 16 + (co >> 2)) * 64 + ci) * 4 + (co & 3)] = pa[q];
+      }
+    }
+  }
 }
 
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
-                       hipStream_t st) {
+                       float* packed, long long off_w1, long long off_w2, hipStream_t st) {
   const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
   const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   const long long n4 = (live + 3) / 4;
   dim3 grid((unsigned)((n4 + 255) / 256), nets);
   hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, st, params, pstride, grads, gstride, m, v, live,
-                     (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), step_size, bc2_sqrt, eps);
+                     (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), step_size, bc2_sqrt, eps, packed, off_w1,
+                     off_w2);
   return hipGetLastError();
 }
 

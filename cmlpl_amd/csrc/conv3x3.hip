@@ -124,9 +124,17 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
   }
 }
 
-template <int MODE, int MTW>
-__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// Everything a 3x3 workgroup does before its tap loop: zero-bordered LDS image of S samples (FWD: the
+// activation; DGRAD: dz = mask * upsample(dpool) / 4 formed on the fly), output-pixel LUT, and the tap-0
+// weights requested early so their latency overlaps the staging.
+struct Conv3Ctx {
+  int tid, lane, l31, hh, wave, net, s0, H, W, HW, PW, IMG, H2, W2, P2, RO, CO, PX, S, npx;
+  float* img; float* wbuf; int* lut; const float4* wg;
+  float4 wp0, wp1, wp2, wp3;
+};
+
+template <int MODE>
+__device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, s0 = blockIdx.x * a.S;
@@ -136,22 +144,21 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   const int PX = RO * CO, S = a.S, npx = S * PX;
   float* img = smem;                       // [S][IMG][CS]
   float* wbuf = img + (size_t)S * IMG * CS;  // [16][64][4]
-  int* lut = (int*)(wbuf + 4096);          // [MTW*128] padded-image position of output pixel m
-
+  int* lut = (int*)(wbuf + 4096);          // padded-image position of output pixel m
   {  // zero the padded images (border must be zero; interior overwritten below)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* p = (float4*)img;
     const int tot = S * IMG * (CS / 4);
     for (int i = tid; i < tot; i += 256) p[i] = z;
   }
-  for (int m = tid; m < MTW * 128; m += 256) {
+  for (int m = tid; m < lut_entries; m += 256) {
     const int mm = (m < npx) ? m : 0;
     const int s = mm / PX, rem = mm - s * PX, r = rem / CO, c = rem - r * CO;
     lut[m] = s * IMG + (r + 1) * PW + (c + 1);
   }
   const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
   // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
-  const float4 wp0 = wg[tid], wp1 = wg[tid + 256], wp2 = wg[tid + 512], wp3 = wg[tid + 768];
+  c.wp0 = wg[tid]; c.wp1 = wg[tid + 256]; c.wp2 = wg[tid + 512]; c.wp3 = wg[tid + 768];
   __syncthreads();
 
   if (MODE == 0) {
@@ -197,6 +204,40 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
         });
   }
 
+  c.tid = tid; c.lane = lane; c.l31 = l31; c.hh = hh; c.wave = wave; c.net = net; c.s0 = s0;
+  c.H = H; c.W = W; c.HW = HW; c.PW = PW; c.IMG = IMG; c.H2 = H2; c.W2 = W2; c.P2 = P2;
+  c.RO = RO; c.CO = CO; c.PX = PX; c.S = S; c.npx = npx;
+  c.img = img; c.wbuf = wbuf; c.lut = lut; c.wg = wg;
+}
+
+// avgpool2 + ReLU-mask epilogue shared by the forward kernels (img holds relu(z) at the pixel centres)
+__device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c) {
+  float* out = a.out + (long long)c.net * a.out_ns;
+  uint8_t* mo = a.mask_out + (long long)c.net * a.mask_out_ns;
+  const int tot = c.S * c.P2 * 64;
+  for (int idx = c.tid; idx < tot; idx += 256) {
+    const int co = idx & 63, pp = idx >> 6;
+    const int s = pp / c.P2, q = pp - s * c.P2, ph = q / c.W2, pw = q - ph * c.W2;
+    const int sample = c.s0 + s;
+    if (sample < a.n) {
+      const float* p = c.img + (size_t)(s * c.IMG + (2 * ph + 1) * c.PW + 2 * pw + 1) * CS + co;
+      const float v00 = p[0], v01 = p[CS], v10 = p[c.PW * CS], v11 = p[c.PW * CS + CS];
+      const size_t g = ((size_t)sample * c.P2 + q) * 64 + co;
+      out[g] = (v00 + v01 + v10 + v11) * 0.25f;
+      mo[g] = (uint8_t)((v00 > 0.f ? 1 : 0) | (v01 > 0.f ? 2 : 0) | (v10 > 0.f ? 4 : 0) | (v11 > 0.f ? 8 : 0));
+    }
+  }
+}
+
+template <int MODE, int MTW>
+__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Conv3Ctx c;
+  conv3_stage<MODE>(a, smem, MTW * 128, c);
+  const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
+  const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
+  float* img = c.img; float* wbuf = c.wbuf; int* lut = c.lut; const float4* wg = c.wg;
+  const float4 wp0 = c.wp0, wp1 = c.wp1, wp2 = c.wp2, wp3 = c.wp3;
   const int MT = (npx + 31) >> 5;
   int abase[MTW];
   f32x16 acc[MTW][2];
@@ -233,21 +274,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
       }
     }
     __syncthreads();
-    float* out = a.out + (long long)net * a.out_ns;
-    uint8_t* mo = a.mask_out + (long long)net * a.mask_out_ns;
-    const int tot = S * P2 * 64;
-    for (int idx = tid; idx < tot; idx += 256) {
-      const int co = idx & 63, pp = idx >> 6;
-      const int s = pp / P2, q = pp - s * P2, ph = q / W2, pw = q - ph * W2;
-      const int sample = s0 + s;
-      if (sample < a.n) {
-        const float* p = img + (size_t)(s * IMG + (2 * ph + 1) * PW + 2 * pw + 1) * CS + co;
-        const float v00 = p[0], v01 = p[CS], v10 = p[PW * CS], v11 = p[PW * CS + CS];
-        const size_t g = ((size_t)sample * P2 + q) * 64 + co;
-        out[g] = (v00 + v01 + v10 + v11) * 0.25f;
-        mo[g] = (uint8_t)((v00 > 0.f ? 1 : 0) | (v01 > 0.f ? 2 : 0) | (v10 > 0.f ? 4 : 0) | (v11 > 0.f ? 8 : 0));
-      }
-    }
+    conv3_pool_store(a, c);
   } else {
     float* out = a.out + (long long)net * a.out_ns;
     const int nvalid = (a.n - s0 < S ? a.n - s0 : S) * PX;  // rows that map to real samples
@@ -270,6 +297,90 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   }
 }
 
+
+// Small-map variant (all output pixels of the workgroup fit ONE 32-row tile, e.g. the 5x5 / 4x4 maps of
+// conv2 at 11x11 windows): instead of one busy wave and three idle ones, wave w takes output-channel half
+// (w & 1) and input-channel half (w >> 1); the two K halves are folded through LDS before the epilogue.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(Conv3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Conv3Ctx c;
+  conv3_stage<MODE>(a, smem, 128, c);
+  const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net;
+  const int nt = wave & 1, kh2 = wave >> 1;
+  float* img = c.img; float* wbuf = c.wbuf; const int* lut = c.lut;
+  const int abase = lut[l31] * CS + 4 * hh;
+  f32x16 acc = zero16();
+  {
+    float4 w0 = c.wp0, w1 = c.wp1, w2 = c.wp2, w3 = c.wp3;
+    float4* wl = (float4*)wbuf;
+    const float* bbase = wbuf + (hh * 64 + nt * 32 + l31) * 4;
+#pragma unroll 1
+    for (int s = 0; s < 9; ++s) {
+      __syncthreads();
+      wl[tid] = w0; wl[tid + 256] = w1; wl[tid + 512] = w2; wl[tid + 768] = w3;
+      __syncthreads();
+      if (s + 1 < 9) {
+        const float4* wn = c.wg + (s + 1) * 1024 + tid;
+        w0 = wn[0]; w1 = wn[256]; w2 = wn[512]; w3 = wn[768];
+      }
+      const int khh = s / 3, kww = s - khh * 3;
+      const float* ib = img + ((khh - 1) * c.PW + (kww - 1)) * CS + abase;
+      float4 av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = kh2 * 4 + q;
+        av[q] = *(const float4*)(ib + kk * 8);
+        bv[q] = *(const float4*)(bbase + kk * 512);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc = mfma32(av[q].x, bv[q].x, acc);
+        acc = mfma32(av[q].y, bv[q].y, acc);
+        acc = mfma32(av[q].z, bv[q].z, acc);
+        acc = mfma32(av[q].w, bv[q].w, acc);
+      }
+    }
+  }
+  __syncthreads();                       // tap loop done everywhere: wbuf becomes the K-half exchange
+  float* xch = wbuf + nt * 1024;         // [16][64] per output-channel half
+  if (kh2 == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (kh2 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += xch[r * 64 + lane];
+    if (MODE == 0) {
+      const float bv = (a.bias + (long long)net * a.bias_ns)[nt * 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = acc_row(r, lane);
+        if (m < c.npx) {
+          float* p = img + (size_t)lut[m] * CS + nt * 32 + l31;
+          *p = fmaxf(acc[r] + bv + *p, 0.f);
+        }
+      }
+    } else {
+      float* out = a.out + (long long)net * a.out_ns;
+      const int nvalid = (a.n - c.s0 < c.S ? a.n - c.s0 : c.S) * c.PX;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = acc_row(r, lane);
+        if (m < nvalid) {
+          const float* p = img + (size_t)lut[m] * CS + nt * 32 + l31;
+          out[((size_t)c.s0 * c.HW + m) * 64 + nt * 32 + l31] = acc[r] + *p;
+        }
+      }
+    }
+  }
+  if (MODE == 0) {
+    __syncthreads();
+    conv3_pool_store(a, c);
+  }
+}
+
 static size_t conv3_lds(int S, int H, int W, int MTW) {
   return ((size_t)S * (H + 2) * (W + 2) * CS + 4096 + (size_t)MTW * 128) * 4;
 }
@@ -286,16 +397,19 @@ bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
   for (int S = 1; S <= 16; ++S) {
     const int MT = (S * PX + 31) / 32, MTW = (MT + 3) / 4;
     if (MTW > 4) break;
+    const bool split = (MT == 1);          // one tile: the 4 waves split (co half, ci half) instead
     const size_t lds = conv3_lds(S, H, W, MTW);
     if (lds > LDS_MAX) break;
     const long long wgs = (rows + S - 1) / S;
     const int resident = (int)(LDS_MAX / lds) < 4 ? (int)(LDS_MAX / lds) : 4;    // workgroups per CU
     const long long per_cu = (wgs + 255) / 256;                                    // workgroups queued per CU
     const long long waves_deep = (per_cu + resident - 1) / resident;               // sequential rounds
-    const double mfma = (double)per_cu * MTW;                                      // tile-times on the busiest SIMD
+    const double mfma = (double)per_cu * (split ? 0.25 : MTW);                     // tile-times on the busiest SIMD
     const double overhead = 0.45 * (double)waves_deep + (resident > 1 ? 0.0 : 0.15 * MTW);
     const double cost = mfma + overhead;
-    if (force_s ? (S == force_s) : (cost < best - 1e-9)) { best = cost; p->S = S; p->MTW = MTW; p->lds = lds; ok = true; }
+    if (force_s ? (S == force_s) : (cost < best - 1e-9)) {
+      best = cost; p->S = S; p->MTW = split ? 0 : MTW; p->lds = lds; ok = true;
+    }
   }
   return ok;
 }
@@ -328,6 +442,17 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
+    case 0: {                                                                  \
+      static bool attr0 = false;                                               \
+      if (!attr0) {                                                            \
+        hipError_t e0 = hipFuncSetAttribute((const void*)conv3x3_small_kernel<M>,                          \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);      \
+        if (e0 != hipSuccess) return e0;                                       \
+        attr0 = true;                                                          \
+      }                                                                        \
+      hipLaunchKernelGGL((conv3x3_small_kernel<M>), grid, dim3(256), pl.lds, st, a);                        \
+      return hipGetLastError();                                                \
+    }                                                                          \
     case 1: return launch_conv3_t<M, 1>(a, grid, pl.lds, st);                  \
     case 2: return launch_conv3_t<M, 2>(a, grid, pl.lds, st);                  \
     case 3: return launch_conv3_t<M, 3>(a, grid, pl.lds, st);                  \

@@ -23,39 +23,44 @@ struct AugArgs {
 };
 
 __global__ void augment_kernel(AugArgs a) {
-  const int seg = blockIdx.z;                 // 0: XP net0, 1: XP net1, 2: X net0, 3: X net1
-  const int t = seg >> 1, net = seg & 1;
-  if (net >= a.nets) return;
+  const int t = blockIdx.z;                   // 0: XP, 1: X
   const int per = a.per[t], s = blockIdx.y;   // local sample
   // a block covers 1024 consecutive elements of one sample; thread t takes elements t, t+256, t+512, t+768
-  // of that span (fully coalesced 4-byte accesses) and feeds them from ONE Philox block
+  // of that span (fully coalesced 4-byte accesses); the source is read once and written once per network,
+  // each network with its own Philox block
   const int base = blockIdx.x * 1024;
   if (base >= per) return;
   const bool lab = s < a.bt;
   const int sl = lab ? s : s - a.bt;
   const float* src = (lab ? a.srcl[t] : a.srcu[t]) + (long long)sl * per;
-  float* dst = a.dst[t] + ((long long)net * (a.bt + a.btu) + s) * per;
   const bool need_noise = a.sigma != 0.f;
-  float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (need_noise && !a.explicit_noise) {
-    const uint64_t gs = (uint64_t)(lab ? a.lab0 + sl : a.unl_base + sl);
-    nz = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
-                        (gs << 24) | (uint64_t)(blockIdx.x * 256 + threadIdx.x));
-  }
-  const float* nptr = nullptr;
-  if (need_noise && a.explicit_noise) nptr = (lab ? a.noise[2 * net + t] : a.noise[4 + 2 * net + t]) + (long long)sl * per;
-  float x[4], z[4] = {nz.x, nz.y, nz.z, nz.w};
+  float x[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int e = base + q * 256 + threadIdx.x;
-    const int ec = e < per ? e : per - 1;
-    x[q] = src[ec];
-    if (nptr != nullptr) z[q] = nptr[ec];
+    x[q] = src[e < per ? e : per - 1];
   }
+  const uint64_t gs = (uint64_t)(lab ? a.lab0 + sl : a.unl_base + sl);
+  for (int net = 0; net < a.nets; ++net) {
+    float* dst = a.dst[t] + ((long long)net * (a.bt + a.btu) + s) * per;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (need_noise && !a.explicit_noise) {
+      const float4 nz = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
+                                       (gs << 24) | (uint64_t)(blockIdx.x * 256 + threadIdx.x));
+      z[0] = nz.x; z[1] = nz.y; z[2] = nz.z; z[3] = nz.w;
+    } else if (need_noise) {
+      const float* nptr = (lab ? a.noise[2 * net + t] : a.noise[4 + 2 * net + t]) + (long long)sl * per;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int e = base + q * 256 + threadIdx.x;
-    if (e < per) dst[e] = need_noise ? x[q] + z[q] * a.sigma : x[q];
+      for (int q = 0; q < 4; ++q) {
+        const int e = base + q * 256 + threadIdx.x;
+        z[q] = nptr[e < per ? e : per - 1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = base + q * 256 + threadIdx.x;
+      if (e < per) dst[e] = need_noise ? x[q] + z[q] * a.sigma : x[q];
+    }
   }
 }
 
@@ -70,7 +75,7 @@ hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int 
   a.per[0] = per_xp; a.per[1] = per_x; a.bt = bt; a.btu = btu; a.lab0 = lab0; a.unl_base = unl_base;
   a.sigma = sigma; a.nets = nets; a.explicit_noise = noise8 != nullptr; a.seed = seed; a.step = step;
   const int mx = per_xp > per_x ? per_xp : per_x;
-  dim3 grid((mx + 1023) / 1024, bt + btu, 4);
+  dim3 grid((mx + 1023) / 1024, bt + btu, 2);
   hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

@@ -86,24 +86,32 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
       if (q < NQ && f >= SF && f < F) feat[f - SF] = v[q] / norm;
     }
   }
-  // logits: wave w owns classes w, w+4, ...
+  // logits: wave w takes the quarter [w*F4, (w+1)*F4) of the row for ALL classes (8 accumulators at a time,
+  // every weight load independent), then the four partial dot products meet in LDS
   const float* wc = a.wc + (long long)net * a.pstride;
   const float* bc = a.bc + (long long)net * a.pstride;
-  for (int k = wave; k < K; k += 4) {
-    const float* wk = wc + (long long)k * F;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    int f = lane;
-    for (; f + 192 < F; f += 256) {
-      const float w0 = wk[f], w1 = wk[f + 64], w2 = wk[f + 128], w3 = wk[f + 192];
-      acc0 = fmaf(row[f], w0, acc0);
-      acc1 = fmaf(row[f + 64], w1, acc1);
-      acc2 = fmaf(row[f + 128], w2, acc2);
-      acc3 = fmaf(row[f + 192], w3, acc3);
+  float* part = red + 4;                       // [4 waves][64 classes]
+  const int F4 = (F + 3) >> 2, f0 = wave * F4, f1 = (f0 + F4 < F) ? f0 + F4 : F;
+  for (int kc = 0; kc < K; kc += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int f = f0 + lane; f < f1; f += 64) {
+      const float x = row[f];
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[j] = wc[(long long)((kc + j < K) ? kc + j : K - 1) * F + f];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(x, wv[j], acc[j]);
     }
-    for (; f < F; f += 64) acc0 = fmaf(row[f], wk[f], acc0);
-    const float tot = wave_sum((acc0 + acc1) + (acc2 + acc3));
-    if (lane == 0) a.logits[rs * K + k] = tot + bc[k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = wave_sum(acc[j]);
+      if (lane == 0 && kc + j < K) part[wave * 64 + kc + j] = t;
+    }
   }
+  __syncthreads();
+  if (tid < K) a.logits[rs * K + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bc[tid];
 }
 
 hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, const float* y, const float* dropmask,
@@ -118,7 +126,7 @@ hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, con
   a.nlab = nlab; a.lab0 = lab0; a.unl_base = unl_base;
   const int F = HW4 * 64 + FD;
   if (F > 256 * HEAD_MAXQ) return hipErrorInvalidValue;
-  const size_t lds = (size_t)(F + 4) * 4;
+  const size_t lds = (size_t)(F + 4 + 256) * 4;
   hipLaunchKernelGGL(head_fwd_kernel, dim3(n, nets), dim3(256), lds, st, a);
   return hipGetLastError();
 }

@@ -79,16 +79,19 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   if (c0 >= NB || r0 >= nunl) return;
   const int ia = r0 + l31, jb = c0 + l31;
-  const float* ap = A + (long long)(ia < nunl ? ia : 0) * FD + wave * 256 + hh * 4;
-  const float* bp = B + (long long)(jb < NB ? jb : 0) * FD + wave * 256 + hh * 4;
+  // k assignment: within each 32-float (128-B) line of a row, half-wave hh owns floats [16hh, 16hh+16) as four
+  // float4; A and B use the same assignment, so any bijection of k is valid.  A line is fetched once and
+  // fully consumed by the two half-waves (L1 hit for 3 of 4 loads) instead of 4 separate sector fetches.
+  const float* ap = A + (long long)(ia < nunl ? ia : 0) * FD + wave * 256 + hh * 16;
+  const float* bp = B + (long long)(jb < NB ? jb : 0) * FD + wave * 256 + hh * 16;
   f32x16 acc = zero16();
 #pragma unroll 1
-  for (int qb = 0; qb < 32; qb += 8) {
+  for (int lb = 0; lb < 8; lb += 2) {            // 8 lines per wave, 2 lines (16 loads) in flight
     float4 av[8], bv[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      av[q] = *(const float4*)(ap + (qb + q) * 8);
-      bv[q] = *(const float4*)(bp + (qb + q) * 8);
+      av[q] = *(const float4*)(ap + (lb + (q >> 2)) * 32 + (q & 3) * 4);
+      bv[q] = *(const float4*)(bp + (lb + (q >> 2)) * 32 + (q & 3) * 4);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {

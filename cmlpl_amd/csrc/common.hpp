@@ -70,8 +70,11 @@ struct Philox {
   __device__ static __forceinline__ uint4 gen(uint4 c, uint2 k) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-      uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+      // one 64-bit product (v_mad_u64_u32) gives hi and lo: 32-bit multiplies are quarter-rate on CDNA,
+      // and this generator is what bounds the augmentation kernel
+      const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
+      const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+      const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
       c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
       k.x += W0; k.y += W1;
     }

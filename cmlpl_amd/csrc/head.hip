@@ -17,7 +17,7 @@ struct HeadFwdArgs {
   int nlab, lab0, unl_base;   // local row -> GLOBAL sample index (Philox key independent of sharding)
 };
 
-constexpr int HEAD_MAXQ = 12;   // ceil(F / 256) <= 12  (F <= 3072)
+constexpr int HEAD_MAXQ4 = 3;   // ceil(F / 1024) <= 3  (F <= 3072)
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // row[F] + red[4]
@@ -36,41 +36,49 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   const float* dm = (dmode == 1) ? a.dropmask + rs * F : nullptr;
   float* dg = (dmode == 2) ? a.dropgen + rs * F : nullptr;
   const float keep_scale = 1.0f / (1.0f - a.dropout_p);
-  const int NQ = (F + 255) >> 8;
-
-  float v[HEAD_MAXQ], mlt[HEAD_MAXQ];
-#pragma unroll
-  for (int q = 0; q < HEAD_MAXQ; ++q) {
-    const int f = tid + 256 * q;
-    v[q] = 0.f; mlt[q] = 1.f;
-    if (q < NQ && f < F) {
-      if (f < SF) {
-        const int c = f / a.HW4, hw = f - c * a.HW4;   // canonical NCHW flatten order (x.view, models.py:141)
-        v[q] = p2[hw * 64 + c];
-      } else {
-        v[q] = y[f - SF];
-      }
-      if (dmode == 1) mlt[q] = dm[f];
-    }
-  }
+  // thread t owns the 4 consecutive row elements f = 1024*q + 4*t .. +3 (F is a multiple of 4): float4 traffic
+  // to catd / dropmask / LDS, and ONE Philox block per 4 dropout decisions
+  const int NQ = (F + 1023) >> 10;
+  float4 v[HEAD_MAXQ4];
   float ss = 0.f;
 #pragma unroll
-  for (int q = 0; q < HEAD_MAXQ; ++q) {
-    const int f = tid + 256 * q;
-    if (q < NQ && f < F) {
-      float x = v[q];
-      if (f >= SF) ss = fmaf(x, x, ss);
-      if (dmode == 2) {
-        const unsigned long long gs = (sample < a.nlab) ? a.lab0 + sample : a.unl_base + (sample - a.nlab);
-        const unsigned long long e = gs * F + f;
-        const float4 u = philox_uniform4(a.seed, a.step, STREAM_DROPOUT + net, e >> 2);
-        const float uu = ((e & 3) == 0) ? u.x : ((e & 3) == 1) ? u.y : ((e & 3) == 2) ? u.z : u.w;
-        mlt[q] = (uu >= a.dropout_p) ? keep_scale : 0.f;
-        dg[f] = mlt[q];
+  for (int q = 0; q < HEAD_MAXQ4; ++q) {
+    const int f0 = 1024 * q + 4 * tid;
+    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < NQ && f0 < F) {
+      if (f0 >= SF) {
+        v[q] = *(const float4*)(y + (f0 - SF));
+      } else {   // canonical NCHW flatten order (x.view, models.py:141): f = c*HW4 + hw
+        float t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int f = f0 + j, c = f / a.HW4, hw = f - c * a.HW4;
+          t4[j] = p2[hw * 64 + c];
+        }
+        v[q] = make_float4(t4[0], t4[1], t4[2], t4[3]);
       }
-      if (dmode != 0) x *= mlt[q];
-      row[f] = x;
-      catd[f] = x;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < HEAD_MAXQ4; ++q) {
+    const int f0 = 1024 * q + 4 * tid;
+    if (q < NQ && f0 < F) {
+      float4 x = v[q];
+      if (f0 >= SF) ss += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+      if (dmode == 1) {
+        const float4 m4 = *(const float4*)(dm + f0);
+        x.x *= m4.x; x.y *= m4.y; x.z *= m4.z; x.w *= m4.w;
+      } else if (dmode == 2) {
+        const unsigned long long gs = (sample < a.nlab) ? a.lab0 + sample : a.unl_base + (sample - a.nlab);
+        const float4 u = philox_uniform4(a.seed, a.step, STREAM_DROPOUT + net, (gs * F + f0) >> 2);
+        float4 m4;
+        m4.x = (u.x >= a.dropout_p) ? keep_scale : 0.f; m4.y = (u.y >= a.dropout_p) ? keep_scale : 0.f;
+        m4.z = (u.z >= a.dropout_p) ? keep_scale : 0.f; m4.w = (u.w >= a.dropout_p) ? keep_scale : 0.f;
+        *(float4*)(dg + f0) = m4;
+        x.x *= m4.x; x.y *= m4.y; x.z *= m4.z; x.w *= m4.w;
+      }
+      *(float4*)(row + f0) = x;
+      *(float4*)(catd + f0) = x;
     }
   }
   ss = wave_sum(ss);
@@ -79,11 +87,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
   if (tid == 0) a.ynorm[rs] = norm;
   float* feat = a.feat + rs * FD;
-  {  // the y part of this thread's row slice is still in v[] (pre-dropout): f = SF + j  <=>  j = f - SF
+  {  // the spectral part of this thread's slice is still in v[] (pre-dropout)
 #pragma unroll
-    for (int q = 0; q < HEAD_MAXQ; ++q) {
-      const int f = tid + 256 * q;
-      if (q < NQ && f >= SF && f < F) feat[f - SF] = v[q] / norm;
+    for (int q = 0; q < HEAD_MAXQ4; ++q) {
+      const int f0 = 1024 * q + 4 * tid;
+      if (q < NQ && f0 >= SF && f0 < F) {
+        float4 o = v[q];
+        o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
+        *(float4*)(feat + (f0 - SF)) = o;
+      }
     }
   }
   // logits: wave w takes the quarter [w*F4, (w+1)*F4) of the row for ALL classes (8 accumulators at a time,
@@ -125,7 +137,7 @@ hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, con
   a.dropout_p = dropout_p; a.train = train; a.seed = seed; a.step = step; a.n = n; a.HW4 = HW4; a.K = K;
   a.nlab = nlab; a.lab0 = lab0; a.unl_base = unl_base;
   const int F = HW4 * 64 + FD;
-  if (F > 256 * HEAD_MAXQ) return hipErrorInvalidValue;
+  if (F > 1024 * HEAD_MAXQ4 || (F & 3)) return hipErrorInvalidValue;
   const size_t lds = (size_t)(F + 4 + 256) * 4;
   hipLaunchKernelGGL(head_fwd_kernel, dim3(n, nets), dim3(256), lds, st, a);
   return hipGetLastError();

@@ -26,6 +26,11 @@ WORKLOADS = {   # name: (C, H, W, bands, K)   -- SURVEY.md section 8d
     "B5": (48, 15, 15, 48, 20),     # Houston2018-shaped
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# HBM bytes per launch of the dominant kernel (conv1 wgrad3_kernel, B2, 128+128 rows, both networks) from
+# rocprofv3 PMC, separate passes: FETCH_SIZE 9917.5 KB x 2 (gfx950 reports half of wide coalesced reads)
+# + WRITE_SIZE 36928 KB; profiles/r01_c_final_pmc_hbm_traffic.txt.  Algorithmic bytes: 20.0 MB in
+# (a0 + dpool + masks) + 37.8 MB of partials out = 57.8 MB, i.e. no wasted re-reads.
+DOMINANT_TRAFFIC_B2_256 = (2 * 9917.5 + 36928.0) * 1024
 
 
 def synth(shape, bt, btu, seed, device):
@@ -177,7 +182,9 @@ def main():
                    "global_batch": n_local * world, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": "wgrad3_kernel (conv1 weight gradient, both networks)",
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": DOMINANT_TRAFFIC_B2_256 if (args.workload == "B2" and n_local == 256) else None,
+                     "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                      "flops_per_launch": flops, "ms_per_launch": dom_ms, "launches_timed": int(cnt[dom_id])},
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
     }

@@ -59,13 +59,17 @@ __device__ __forceinline__ const float* prob_row(const LossArgs& a, int which, i
   return a.probs_g + (((long long)sh * 4 + which) * a.pshard + l) * a.K;
 }
 
-// One workgroup per 32x32 tile of one product.  The 1024-long contraction is split over the 4 waves
-// (256 each); every lane loads its operand fragments straight from L2 as 16-byte pieces (8 A + 8 B
-// loads in flight per batch), so there is no LDS staging and no barrier in the main loop.  The four
-// partial tiles meet in LDS; each wave then finishes 4 of the 16 accumulator rows (exp, row sums and
-// the E.bank_probs partials by half-wave shuffles).
+// One workgroup per 32x32 tile of one product; the 1024-long contraction is split over the 4 waves (256
+// each = 8 lines of 128 B per row).  Loading MFMA fragments straight from memory would touch 32 different
+// 128-B lines per instruction and use a quarter of each (measured: ~500 MB of L1<->L2 traffic per launch,
+// waves 66 % stalled).  Instead each instruction fetches WHOLE lines -- 8 rows x 128 B -- into a small
+// per-wave LDS tile ([32 rows][32+4 floats], no block barrier: only the owning wave touches it), from
+// which the fragments are read as ds_read_b128; the next step's loads are already in flight in registers.
+constexpr int PT = 36;              // per-wave tile row stride in floats (32 + 4)
+
 __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
-  __shared__ float red[4][16][64];
+  __shared__ __attribute__((aligned(16))) float lds[4 * 16 * 64];     // staging tiles, later the reduction buffer
+  float (*red)[16][64] = (float (*)[16][64])lds;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
@@ -78,29 +82,52 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const int NB = (prob < 2) ? a.Q : btu;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   if (c0 >= NB || r0 >= nunl) return;
-  const int ia = r0 + l31, jb = c0 + l31;
-  // k assignment: within each 32-float (128-B) line of a row, half-wave hh owns floats [16hh, 16hh+16) as four
-  // float4; A and B use the same assignment, so any bijection of k is valid.  A line is fetched once and
-  // fully consumed by the two half-waves (L1 hit for 3 of 4 loads) instead of 4 separate sector fetches.
-  const float* ap = A + (long long)(ia < nunl ? ia : 0) * FD + wave * 256 + hh * 16;
-  const float* bp = B + (long long)(jb < NB ? jb : 0) * FD + wave * 256 + hh * 16;
+  const int jb = c0 + l31;
+  float* tA = lds + wave * (2 * 32 * PT);        // 2 x 1152 floats per wave (fits the 4096-float quarter)
+  float* tB = tA + 32 * PT;
+  // loader role: lane -> (row group r8 = lane>>3, 16-byte chunk c8 = lane&7); load j covers rows 8j + r8
+  const int r8 = lane >> 3, c8 = lane & 7;
+  // (named registers, not arrays: loop-carried arrays end up in scratch)
+  const long long ko = wave * 256 + c8 * 4;
+#define CMLPL_ROWPTR(base, r, lim) ((base) + (long long)((r) < (lim) ? (r) : 0) * FD + ko)
+  const float* la0 = CMLPL_ROWPTR(A, r0 + r8, nunl);
+  const float* la1 = CMLPL_ROWPTR(A, r0 + 8 + r8, nunl);
+  const float* la2 = CMLPL_ROWPTR(A, r0 + 16 + r8, nunl);
+  const float* la3 = CMLPL_ROWPTR(A, r0 + 24 + r8, nunl);
+  const float* lb0 = CMLPL_ROWPTR(B, c0 + r8, NB);
+  const float* lb1 = CMLPL_ROWPTR(B, c0 + 8 + r8, NB);
+  const float* lb2 = CMLPL_ROWPTR(B, c0 + 16 + r8, NB);
+  const float* lb3 = CMLPL_ROWPTR(B, c0 + 24 + r8, NB);
+#undef CMLPL_ROWPTR
+  float4 a0 = *(const float4*)la0, a1 = *(const float4*)la1, a2 = *(const float4*)la2, a3 = *(const float4*)la3;
+  float4 b0 = *(const float4*)lb0, b1 = *(const float4*)lb1, b2 = *(const float4*)lb2, b3 = *(const float4*)lb3;
+  float* wA = tA + r8 * PT + c8 * 4;
+  float* wB = tB + r8 * PT + c8 * 4;
+  const float* rA = tA + l31 * PT + hh * 16;     // half-wave hh owns floats [16hh, 16hh+16) of the line
+  const float* rB = tB + l31 * PT + hh * 16;
   f32x16 acc = zero16();
 #pragma unroll 1
-  for (int lb = 0; lb < 8; lb += 2) {            // 8 lines per wave, 2 lines (16 loads) in flight
-    float4 av[8], bv[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      av[q] = *(const float4*)(ap + (lb + (q >> 2)) * 32 + (q & 3) * 4);
-      bv[q] = *(const float4*)(bp + (lb + (q >> 2)) * 32 + (q & 3) * 4);
+  for (int ln = 0; ln < 8; ++ln) {               // 8 lines of 32 floats
+    *(float4*)(wA) = a0; *(float4*)(wA + 8 * PT) = a1; *(float4*)(wA + 16 * PT) = a2; *(float4*)(wA + 24 * PT) = a3;
+    *(float4*)(wB) = b0; *(float4*)(wB + 8 * PT) = b1; *(float4*)(wB + 16 * PT) = b2; *(float4*)(wB + 24 * PT) = b3;
+    if (ln + 1 < 8) {
+      const int o = (ln + 1) * 32;
+      a0 = *(const float4*)(la0 + o); a1 = *(const float4*)(la1 + o);
+      a2 = *(const float4*)(la2 + o); a3 = *(const float4*)(la3 + o);
+      b0 = *(const float4*)(lb0 + o); b1 = *(const float4*)(lb1 + o);
+      b2 = *(const float4*)(lb2 + o); b3 = *(const float4*)(lb3 + o);
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      acc = mfma32(av[q].x, bv[q].x, acc);
-      acc = mfma32(av[q].y, bv[q].y, acc);
-      acc = mfma32(av[q].z, bv[q].z, acc);
-      acc = mfma32(av[q].w, bv[q].w, acc);
-    }
+    const float4 x0 = *(const float4*)(rA), x1 = *(const float4*)(rA + 4), x2 = *(const float4*)(rA + 8),
+                 x3 = *(const float4*)(rA + 12);
+    const float4 y0 = *(const float4*)(rB), y1 = *(const float4*)(rB + 4), y2 = *(const float4*)(rB + 8),
+                 y3 = *(const float4*)(rB + 12);
+#define CMLPL_M4(PA, PB)                                                            \
+    acc = mfma32(PA.x, PB.x, acc); acc = mfma32(PA.y, PB.y, acc);                   \
+    acc = mfma32(PA.z, PB.z, acc); acc = mfma32(PA.w, PB.w, acc);
+    CMLPL_M4(x0, y0) CMLPL_M4(x1, y1) CMLPL_M4(x2, y2) CMLPL_M4(x3, y3)
+#undef CMLPL_M4
   }
+  __syncthreads();                               // every wave is done with its staging tile: reuse as `red`
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();

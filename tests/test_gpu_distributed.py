@@ -92,8 +92,8 @@ def test_sharded_step_equals_single_gpu_step(W, shape_name, bt, btu, explicit):
         assert [got[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")] == \
                [want[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")]
         lo, fe = ref.outputs()
-        report("logits_g", engines[0].logits_g, lo, 1e-5, 2e-6)     # same kernels; only the tile grouping differs
-        report("feat_g", engines[-1].feat_g, fe, 1e-5, 1e-6)
+        report("logits_g", engines[0].logits_g, lo, 1e-5, 1e-5)     # same kernels; only the tile grouping differs
+        report("feat_g", engines[-1].feat_g, fe, 1e-5, 5e-6)     # after updates: fp32 reduction-order drift
         for net in range(2):
             for k in O.LIVE_KEYS:
                 gr = ref.grad(net, k)
@@ -102,8 +102,8 @@ def test_sharded_step_equals_single_gpu_step(W, shape_name, bt, btu, explicit):
                     report(f"grad[{net}] {k}", e.grad(net, k), gr, 2e-4, 2e-5 * mx)
         for i in range(2):
             for e in (engines[0], engines[-1]):
-                report(f"bank{i} feats", e.bank_feats[i], ref.bank_feats[i], 1e-5, 1e-6)
-                report(f"bank{i} probs", e.bank_probs[i], ref.bank_probs[i], 1e-5, 1e-6)
+                report(f"bank{i} feats", e.bank_feats[i], ref.bank_feats[i], 1e-5, 5e-6)
+                report(f"bank{i} probs", e.bank_probs[i], ref.bank_probs[i], 1e-5, 5e-6)
         assert engines[0].ptr == ref.ptr
     for net in range(2):
         sd_ref = ref.state_dict(net)

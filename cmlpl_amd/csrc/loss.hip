@@ -68,7 +68,7 @@ __device__ __forceinline__ const float* prob_row(const LossArgs& a, int which, i
 constexpr int PT = 36;              // per-wave tile row stride in floats (32 + 4)
 
 __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * 16 * 64];     // staging tiles, later the reduction buffer
+  __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * PT];  // 4 waves x (A,B) tiles; later reused as red[4][16][64]
   float (*red)[16][64] = (float (*)[16][64])lds;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   if (c0 >= NB || r0 >= nunl) return;
   const int jb = c0 + l31;
-  float* tA = lds + wave * (2 * 32 * PT);        // 2 x 1152 floats per wave (fits the 4096-float quarter)
+  float* tA = lds + wave * (2 * 32 * PT);        // 2 x 1152 floats per wave
   float* tB = tA + 32 * PT;
   // loader role: lane -> (row group r8 = lane>>3, 16-byte chunk c8 = lane&7); load j covers rows 8j + r8
   const int r8 = lane >> 3, c8 = lane & 7;

@@ -26,7 +26,7 @@ EXPORTS = (
     "cmlpl_abi_version", "cmlpl_layout", "cmlpl_workspace_bytes", "cmlpl_pack_weights", "cmlpl_augment",
     "cmlpl_basenet2_fwd", "cmlpl_basenet2_bwd", "cmlpl_loss_fwd_bwd", "cmlpl_adam_step", "cmlpl_train_step",
     "cmlpl_debug_region", "cmlpl_timing_begin", "cmlpl_timing_end", "cmlpl_loss_phase1", "cmlpl_loss_phase2",
-    "cmlpl_dist_unpack", "cmlpl_loss_workspace_bytes",
+    "cmlpl_dist_unpack", "cmlpl_loss_workspace_bytes", "cmlpl_extract_patches",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -126,6 +126,7 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_loss_workspace_bytes.argtypes = [SP, SH, i32]
     lib.cmlpl_loss_workspace_bytes.restype = sz
     lib.cmlpl_dist_unpack.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.cmlpl_extract_patches.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp]
     lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]

@@ -469,6 +469,14 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
   return 0;
 }
 
+int cmlpl_extract_patches(const float* d_cube, int rows, int cols, int C, int w, const int64_t* d_pixel_idx, int n,
+                          float* d_out, void* stream) {
+  if (!d_cube || !d_pixel_idx || !d_out || rows < 1 || cols < 1 || C < 1 || w < 1 || n < 1) return CMLPL_E_ARG;
+  if (w / 2 > rows || w / 2 > cols || (size_t)w * w * (C | 1) * 4 > LDS_MAX) return CMLPL_E_SHAPE;
+  return chk(launch_extract_patches(d_cube, rows, cols, C, w, (const long long*)d_pixel_idx, n, d_out,
+                                    (hipStream_t)stream));
+}
+
 int cmlpl_timing_begin(uint32_t kernel_mask, int max_launches) {
   Timing& t = g_timing;
   if (t.on || max_launches < 1) return CMLPL_E_ARG;

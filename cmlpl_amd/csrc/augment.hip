@@ -120,4 +120,48 @@ hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Patch extraction on device (reference tools/hyper_tools.py:35-55 MirrowCut + :226-243 ExtractPatches):
+// out[p][ch][i][j] = cube[mirror(r+i-hw)][mirror(c+j-hw)][ch] for pixel k = idx[p] = r*cols + c, hw = w/2,
+// symmetric (edge-repeating) mirror.  Pure gather, exact.  One workgroup per patch; the w*w x C tile goes
+// through LDS so that the cube is read along its contiguous channel axis and the band-major patch is
+// written along its contiguous pixel axis (odd LDS row stride: conflict-free transpose).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void extract_patches_kernel(const float* __restrict__ cube, int rows, int cols, int C,
+                                                              int w, const long long* __restrict__ idx, int n,
+                                                              float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const long long k = idx[p];
+  const int r = (int)(k / cols), c = (int)(k - (long long)r * cols), hw = w >> 1, ww = w * w, CP = C | 1;
+  for (int e = tid; e < ww * C; e += 256) {
+    const int pix = e / C, ch = e - pix * C, i = pix / w, j = pix - i * w;
+    int rr = r + i - hw, cc = c + j - hw;
+    rr = rr < 0 ? -rr - 1 : (rr >= rows ? 2 * rows - 1 - rr : rr);
+    cc = cc < 0 ? -cc - 1 : (cc >= cols ? 2 * cols - 1 - cc : cc);
+    tile[pix * CP + ch] = cube[((long long)rr * cols + cc) * C + ch];
+  }
+  __syncthreads();
+  float* o = out + (long long)p * C * ww;
+  for (int e = tid; e < C * ww; e += 256) {
+    const int ch = e / ww, pix = e - ch * ww;
+    o[e] = tile[pix * CP + ch];
+  }
+}
+
+hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, int w, const long long* idx, int n,
+                                  float* out, hipStream_t st) {
+  const size_t lds = (size_t)w * w * (C | 1) * 4;
+  if (lds > LDS_MAX) return hipErrorInvalidValue;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)extract_patches_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(extract_patches_kernel, dim3(n), dim3(256), lds, st, cube, rows, cols, C, w, idx, n, out);
+  return hipGetLastError();
+}
+
 }  // namespace cmlpl

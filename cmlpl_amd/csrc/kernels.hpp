@@ -20,6 +20,9 @@ hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int 
 hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
                               long long* labels_g, hipStream_t st);
 
+hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, int w, const long long* idx, int n,
+                                  float* out, hipStream_t st);
+
 // ---- conv3x3.hip
 hipError_t launch_pack_weights(int nets, const float* params, long long pstride, long long off_w1,
                                long long off_w2, float* packed, hipStream_t st);

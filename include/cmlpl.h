@@ -210,6 +210,14 @@ typedef struct cmlpl_step_io {
 int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io,
                      void* stream);
 
+/* Caller-side row N3: w x w patch windows gathered on device from the z-scored / PCA'd
+ * scene cube instead of materialising XP.npy (tools/hyper_tools.py:35-55 MirrowCut, :226-243
+ * ExtractPatches; for PaviaU that tensor is 19.9 GB).  d_cube [rows][cols][C] f32, d_pixel_idx int64 [n]
+ * row-major pixel indices, d_out [n][C][w][w].  Exact (pure gather).  Even w reproduces the reference;
+ * odd w (which the reference cannot run) is the centred generalisation. */
+int cmlpl_extract_patches(const float* d_cube, int rows, int cols, int C, int w,
+                          const int64_t* d_pixel_idx, int n, float* d_out, void* stream);
+
 /* Optional per-launch timing, measured with hipEvent pairs recorded on the launch stream around the
  * selected kernels (bit i of kernel_mask selects CMLPL_K_i).  cmlpl_timing_end synchronises the
  * recorded events and returns, per kernel id, the summed milliseconds and the number of launches.

@@ -390,3 +390,32 @@ def synthetic_batch(shape: NetShape, bt: int, btu: int, seed: int, with_noise: b
         else:
             out["dropmask"] = [None, None]
     return out
+
+
+# --------------------------------------------------------------------------- #
+# next row N3: patch extraction  (tools/hyper_tools.py:35-55 MirrowCut, :226-243 ExtractPatches)
+# --------------------------------------------------------------------------- #
+def mirror_index(t: np.ndarray, size: int) -> np.ndarray:
+    """Index into the original axis of the symmetric (edge-repeating) mirror extension built by
+    MirrowCut (hyper_tools.py:35-55): t < 0 -> -t-1 ; t >= size -> 2*size-1-t."""
+    t = np.asarray(t)
+    return np.where(t < 0, -t - 1, np.where(t >= size, 2 * size - 1 - t, t))
+
+
+def extract_patches(X: np.ndarray, w: int, pixel_idx: Optional[np.ndarray] = None) -> np.ndarray:
+    """X: [row, col, C] cube -> patches [n, C, w, w] for the given row-major pixel indices (all pixels
+    when None).  Restates ExtractPatches (hyper_tools.py:226-243): pixel (r, c) takes mirror-extended rows
+    r-hw .. r-hw+w-1 and columns c-hw .. c-hw+w-1 with hw = w // 2, then moveaxis(3, 1).  For even w this
+    is exactly the reference (its slice [index-hw : index+hw] has 2*hw = w rows); for odd w the reference
+    raises a broadcast error, and this is the centred generalisation."""
+    row, col, C = X.shape
+    hw = w // 2
+    if pixel_idx is None:
+        pixel_idx = np.arange(row * col)
+    pixel_idx = np.asarray(pixel_idx, dtype=np.int64)
+    r, c = pixel_idx // col, pixel_idx % col
+    off = np.arange(w) - hw
+    rr = mirror_index(r[:, None] + off[None, :], row)          # [n, w]
+    cc = mirror_index(c[:, None] + off[None, :], col)          # [n, w]
+    patches = X[rr[:, :, None], cc[:, None, :], :]             # [n, w, w, C]
+    return np.ascontiguousarray(np.moveaxis(patches, 3, 1)).astype(np.float32)

@@ -29,17 +29,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
-sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
-sys.path.insert(0, REF)
-
 import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
-from tools.models import BaseNet2 as RefBaseNet2  # noqa: E402  (the reference's)
+from tests.golden._refload import load_reference_module  # noqa: E402
 
-sys.path.remove(REF)
-for _m in [m for m in sys.modules if m == "tools" or m.startswith("tools.")]:
-    _ref_tools = sys.modules.pop(_m)          # do not shadow the repo's own `tools` package
+RefBaseNet2 = load_reference_module("tools/models.py", "ref_models").BaseNet2     # the reference's own class
 
 from oracle import cmlpl_oracle as O  # noqa: E402  (input generators only)
 

@@ -191,3 +191,24 @@ def test_adam_step_matches_torch_formula():
         torch.cuda.synchronize()
         report(f"adam t={t} params", dp[:, :live], pc[:, :live], 1e-6, 1e-7)
         assert torch.equal(dp[:, live:].cpu(), p[:, live:])          # dead tensors untouched
+
+
+def test_whole_image_inference_matches_oracle():
+    """tools.hyper_tools.test_whole (reference hyper_tools.py:416-437) over a 'wholeset'
+    loader with a ragged last batch: same argmax as the oracle's eval forward for every pixel."""
+    from torch.utils.data import DataLoader
+    from hsi_loader import SyntheticHSIDataSet
+    from tools.hyper_tools import CalAccuracy, test_whole
+    shape = SHAPES["B2"]
+    params = O.closed_form_params(shape, 9)
+    net = _module(shape, params, dropout=0.8)
+    ds = SyntheticHSIDataSet((shape.C, shape.H, shape.W, shape.bands, shape.K), 1100, "wholeset", seed=3)
+    pred = test_whole(net, DataLoader(ds, batch_size=512, shuffle=False), print_per_batches=10 ** 9)
+    lo_ref, _ = O.basenet2_forward(params, ds.XP, ds.X, None)
+    ref = lo_ref.argmax(1).numpy()
+    assert pred.shape == (1100,)
+    top2 = lo_ref.topk(2, 1)[0]
+    clear = ((top2[:, 0] - top2[:, 1]) > 1e-4).numpy()            # ignore fp32 near-ties
+    assert np.array_equal(pred[clear], ref[clear]) and clear.mean() > 0.99
+    OA, Kappa, pa = CalAccuracy(pred, ref)
+    assert OA > 0.99 and pa.shape == (shape.K,)

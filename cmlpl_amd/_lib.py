@@ -114,9 +114,9 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_workspace_bytes.restype = sz
     lib.cmlpl_pack_weights.argtypes = [SP, i32, vp, i64, vp, vp]
     SH = C.POINTER(Shard)
-    lib.cmlpl_augment.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp), f32, u64, u64, SH, vp, vp, vp]
-    lib.cmlpl_basenet2_fwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, u64, u64, SH, vp, vp, vp, sz,
-                                       vp]
+    lib.cmlpl_augment.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp), f32, u64, u64, SH, vp, vp, vp, vp]
+    lib.cmlpl_basenet2_fwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, vp, f32, i32, u64, u64, SH, vp, vp, vp,
+                                       sz, vp]
     lib.cmlpl_basenet2_bwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, vp, vp, vp, i64, vp, sz, vp]
     lib.cmlpl_loss_fwd_bwd.argtypes = [SP, i32, i32, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp,
                                        vp, sz, vp]

@@ -70,7 +70,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
 
 // extra regions used only by cmlpl_train_step / cmlpl_loss_fwd_bwd
 struct StepWs {
-  float *xn, *sn, *dlogits, *dfeat, *probs, *loss;
+  float *xn, *sn, *snT, *dlogits, *dfeat, *probs, *loss;
   size_t bytes;
 };
 
@@ -79,6 +79,7 @@ void carve_step(const Dims& d, int n, int bank_rows, char* base, StepWs* w) {
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up256(bytes); return p; };
   w->xn = (float*)take((size_t)2 * n * d.C * d.HW * 4);
   w->sn = (float*)take((size_t)2 * n * d.bands * 4);
+  w->snT = (float*)take((size_t)2 * n * d.bands * 4);
   w->dlogits = (float*)take((size_t)2 * n * d.K * 4);
   w->dfeat = (float*)take((size_t)2 * n * 1024 * 4);
   w->probs = (float*)take((size_t)4 * n * d.K * 4);
@@ -87,6 +88,13 @@ void carve_step(const Dims& d, int n, int bank_rows, char* base, StepWs* w) {
 }
 
 int chk(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+PackInfo make_pack_info(const Dims& d, const cmlpl_layout_t& L) {
+  PackInfo pi;
+  pi.stride = L.packed_total; pi.off_w0 = L.param_off[0]; pi.off_w1 = L.param_off[2]; pi.off_w2 = L.param_off[4];
+  pi.off_ws = L.param_off[6]; pi.C = d.C; pi.bands = d.bands;
+  return pi;
+}
 
 // ---- optional per-kernel timing (cmlpl_timing_begin/_end): hipEvent pairs recorded on the launch stream
 // around the selected launches.  Off by default; the only process-global state of the library.
@@ -174,7 +182,7 @@ int cmlpl_layout(const cmlpl_shape* shape, cmlpl_layout_t* out) {
     if (i == CMLPL_NUM_LIVE - 1) out->param_live = off;
   }
   out->param_total = off;
-  out->packed_total = PACK_PER_NET;
+  out->packed_total = pack_total(d.C, d.bands);
   out->cls_in = d.F;
   out->reserved = 0;
   return 0;
@@ -193,16 +201,17 @@ size_t cmlpl_workspace_bytes(const cmlpl_shape* shape, int nets, int n, int bank
 int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params, int64_t param_stride,
                        float* d_packed, void* stream) {
   cmlpl_layout_t L;
+  Dims d;
   int rc = cmlpl_layout(shape, &L);
   if (rc) return rc;
+  make_dims(shape, &d);
   if (!d_params || !d_packed || nets < 1 || nets > 2) return CMLPL_E_ARG;
-  return chk(launch_pack_weights(nets, d_params, param_stride, L.param_off[2], L.param_off[4], d_packed,
-                                 (hipStream_t)stream));
+  return chk(launch_pack_weights(nets, d_params, param_stride, make_pack_info(d, L), d_packed, (hipStream_t)stream));
 }
 
 int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const float* d_xpl, const float* d_xl,
                   const float* d_xpu, const float* d_xu, const float* const* noise8, float sigma, uint64_t seed,
-                  uint64_t step, const cmlpl_shard* shard, float* d_xn, float* d_sn, void* stream) {
+                  uint64_t step, const cmlpl_shard* shard, float* d_xn, float* d_sn, float* d_snT, void* stream) {
   Dims d;
   if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
   if (nets < 1 || nets > 2 || bt < 0 || btu < 0 || bt + btu < 1 || !d_xn || !d_sn) return CMLPL_E_ARG;
@@ -211,12 +220,13 @@ int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const flo
   const int lab0 = shard ? shard->lab0 : 0, unl_base = shard ? shard->bt_g + shard->unl0 : bt;
   hipStream_t st = (hipStream_t)stream;
   return TIMED(CMLPL_K_AUGMENT, chk(launch_augment(nets, bt, btu, d.C * d.HW, d.bands, lab0, unl_base, d_xpl, d_xl,
-                            d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn, st)));
+                            d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn, d_snT, st)));
 }
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
-                       const float* d_packed, const float* d_xn, const float* d_sn, const float* d_dropmask,
-                       float dropout_p, int train, uint64_t seed, uint64_t step, const cmlpl_shard* shard,
+                       const float* d_packed, const float* d_xn, const float* d_sn, const float* d_snT,
+                       const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
+                       const cmlpl_shard* shard,
                        float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes, void* stream) {
   Dims d;
   cmlpl_layout_t L;
@@ -231,17 +241,30 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
   hipStream_t st = (hipStream_t)stream;
   int rc;
   hipStream_t main_st = st;
-  {  // spectral branch (feat_spe + ReLU) runs beside the spatial conv stack
+  const long long pk_ns = L.packed_total;
+  {  // spectral branch (feat_spe + ReLU); with multi-stream enabled it runs beside the spatial conv stack
     hipStream_t st = fork_to(main_st, 0, 0);
-    if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
-                                 d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
+    if (d_snT != nullptr) {
+      // y[row][o] = relu( sum_band snT[band][row] * wsT[band][o] + b[o] ): both operands k-major, K split over waves
+      GemmTN g;
+      g.A = d_snT; g.a_bstride = (long long)n * d.bands; g.lda = n; g.M = n;
+      g.B = d_packed + pack_off_wst(d.C); g.b_bstride = pk_ns; g.ldb = 1024; g.N = 1024;
+      g.C = w.y; g.c_bstride = (long long)n * 1024; g.ldc = 1024;
+      g.bias = nullptr; g.bias_bstride = 0;
+      g.bias_in = d_params + L.param_off[7]; g.bias_in_bstride = param_stride; g.relu = 1;
+      g.R = d.bands; g.batches = nets; g.scale = 1.f;
+      if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_gemm_tn(g, st))))) return rc;
+    } else {
+      if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
+                                   d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
+    }
   }
-  if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_params + L.param_off[0],
+  if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
                                  d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
   if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV,
-                             PACK_PER_NET, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
+                             pk_ns, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
   if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + 2 * PACK_CONV,
-                             PACK_PER_NET, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
+                             pk_ns, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
   join_from(main_st, 0, 1);
   if (shard && shard->nlab + shard->nunl != n) return CMLPL_E_ARG;
   const int nlab = shard ? shard->nlab : n, lab0 = shard ? shard->lab0 : 0;
@@ -274,6 +297,7 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   {  // classifier / spectral weight gradients: independent of the spatial backward chain
     hipStream_t st = fork_to(main_st, 0, 2);
     GemmTN g;
+    g.bias_in = nullptr; g.bias_in_bstride = 0; g.relu = 0;
     // dW_cls[k][f] = sum_n dlogits[n][k] * catd[n][f] ; db_cls[k] = sum_n dlogits[n][k]
     g.A = d_dlogits; g.a_bstride = (long long)n * d.K; g.lda = d.K; g.M = d.K;
     g.B = w.catd; g.b_bstride = (long long)n * d.F; g.ldb = d.F; g.N = d.F;
@@ -294,13 +318,13 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
     if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
   }
   if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + 3 * PACK_CONV,
-                             PACK_PER_NET, nullptr, 0, w.dp1, nullptr, st))))) return rc;
+                             L.packed_total, nullptr, 0, w.dp1, nullptr, st))))) return rc;
   {  // conv1 weight gradient needs dp1 (conv2_dgrad output): fork after it, runs beside conv1_dgrad
     hipStream_t st = fork_to(main_st, 0, 4);
     if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
   }
   if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
-                             PACK_PER_NET, nullptr, 0, w.da0, nullptr, st))))) return rc;
+                             L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
   if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
     return rc;
   join_from(main_st, 0, 5);
@@ -425,13 +449,15 @@ int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t
                     const float* d_grads, int64_t grad_stride, float* d_m, float* d_v, int64_t t,
                     const cmlpl_hparams* hp, float* d_packed, void* stream) {
   cmlpl_layout_t L;
+  Dims d;
   int rc = cmlpl_layout(shape, &L);
   if (rc) return rc;
+  make_dims(shape, &d);
   if (nets < 1 || nets > 2 || !d_params || !d_grads || !d_m || !d_v || !hp || t < 1) return CMLPL_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   return TIMED(CMLPL_K_ADAM, chk(launch_adam(nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v,
-                            L.param_live, t, hp->lr, hp->beta1, hp->beta2, hp->eps, d_packed, L.param_off[2],
-                            L.param_off[4], st)));
+                            L.param_live, t, hp->lr, hp->beta1, hp->beta2, hp->eps, d_packed,
+                            make_pack_info(d, L), st)));
 }
 
 int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io, void* stream) {
@@ -452,8 +478,8 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
   int rc;
   const cmlpl_shard sh = {io->bt, io->btu, 0, io->bt, 0, io->btu};
   if ((rc = cmlpl_augment(shape, 2, io->bt, io->btu, io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->noise8,
-                          hp->noise_sigma, io->seed, io->step, &sh, sw.xn, sw.sn, stream))) return rc;
-  if ((rc = cmlpl_basenet2_fwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn,
+                          hp->noise_sigma, io->seed, io->step, &sh, sw.xn, sw.sn, sw.snT, stream))) return rc;
+  if ((rc = cmlpl_basenet2_fwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn, sw.snT,
                                io->d_dropmask, hp->dropout_p, train, io->seed, io->step, &sh, io->d_logits,
                                io->d_feat, io->d_workspace, nw.bytes, stream))) return rc;
   if ((rc = cmlpl_loss_fwd_bwd(shape, io->bt, io->btu, io->d_logits, io->d_feat, io->d_labels, &io->banks,

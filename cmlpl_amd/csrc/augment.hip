@@ -17,6 +17,7 @@ struct AugArgs {
   const float* srcl[2]; const float* srcu[2];     // [0] = XP, [1] = X
   const float* noise[8];                          // reference draw order, or all null
   float* dst[2];                                  // xn, sn
+  float* snT;                                     // optional [nets][bands][n] copy of sn (k-major for feat_spe)
   int per[2];                                     // elements per sample: C*H*W, bands
   int bt, btu, lab0, unl_base;                    // local rows and their global sample indices
   float sigma; int nets; int explicit_noise; uint64_t seed, step;
@@ -59,7 +60,11 @@ __global__ void augment_kernel(AugArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = base + q * 256 + threadIdx.x;
-      if (e < per) dst[e] = need_noise ? x[q] + z[q] * a.sigma : x[q];
+      if (e < per) {
+        const float v = need_noise ? x[q] + z[q] * a.sigma : x[q];
+        dst[e] = v;
+        if (t == 1 && a.snT != nullptr) a.snT[((long long)net * per + e) * (a.bt + a.btu) + s] = v;
+      }
     }
   }
 }
@@ -67,8 +72,9 @@ __global__ void augment_kernel(AugArgs a) {
 hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
-                          float* xn, float* sn, hipStream_t st) {
+                          float* xn, float* sn, float* snT, hipStream_t st) {
   AugArgs a;
+  a.snT = snT;
   a.srcl[0] = xpl; a.srcl[1] = xl; a.srcu[0] = xpu; a.srcu[1] = xu;
   for (int i = 0; i < 8; ++i) a.noise[i] = noise8 ? noise8[i] : nullptr;
   a.dst[0] = xn; a.dst[1] = sn;

@@ -15,52 +15,50 @@ namespace cmlpl {
 
 constexpr int C0_CHUNK = 16;   // k-steps (2 bands each) fetched per batch
 
-__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ w,
-                                                        const float* __restrict__ b, long long pstride,
-                                                        float* __restrict__ a0, int n, int C, int HW) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // wT[Cp+1][65]
+// Both operands come straight from memory as MFMA fragments: A[pixel][band] = 32 consecutive pixels of one
+// band of the NCHW input (128-B segment), B[band][co] = 32 consecutive output channels of the k-major weight
+// copy w0T (128-B segment, L2-resident).  No LDS, no barrier; 48 loads in flight per lane, double-buffered.
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ w0t,
+                                                        long long w0t_ns, const float* __restrict__ b,
+                                                        long long pstride, float* __restrict__ a0, int n, int C,
+                                                        int HW) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y;
   const int Cp = (C + 1) & ~1;
-  const float* W = w + (long long)net * pstride;
-
+  const float* WT = w0t + (long long)net * w0t_ns + l31;
   const long long M = (long long)n * HW;
   const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + l31;
   const long long mm = (m < M) ? m : 0;
   const int sample = (int)(mm / HW), pix = (int)(mm - (long long)sample * HW);
   const float* ap = xn + ((long long)net * n + sample) * C * HW + pix;
   const int KK = Cp >> 1;
-  float cur[C0_CHUNK], nxt[C0_CHUNK];
-  auto fetch = [&](float (&buf)[C0_CHUNK], int k0) {
+  float ca[C0_CHUNK], cb0[C0_CHUNK], cb1[C0_CHUNK], na[C0_CHUNK], nb0[C0_CHUNK], nb1[C0_CHUNK];
+  auto fetch = [&](float (&fa)[C0_CHUNK], float (&f0)[C0_CHUNK], float (&f1)[C0_CHUNK], int k0) {
 #pragma unroll
     for (int q = 0; q < C0_CHUNK; ++q) {
       const int c = 2 * (k0 + q) + hh;
-      const bool ok = c < C;
+      const bool ok = c < C;                       // c == C (odd C) hits the zero pad row of w0T
+      const int cw = (c < Cp) ? c : 0;
       const float v = ap[(long long)(ok ? c : 0) * HW];
-      buf[q] = ok ? v : 0.f;
+      fa[q] = ok ? v : 0.f;
+      f0[q] = WT[cw * 64];
+      f1[q] = WT[cw * 64 + 32];
     }
   };
-  fetch(cur, 0);   // in flight while the weights are staged
-
-  staged_copy<8, float>(C * 64, tid, [&](int i) { return W[i]; },
-                        [&](int i, float v) { const int co = i / C, c = i - co * C; smem[c * 65 + co] = v; });
-  if (Cp != C && tid < 64) smem[C * 65 + tid] = 0.f;
-  __syncthreads();
-
+  fetch(ca, cb0, cb1, 0);
   f32x16 acc0 = zero16(), acc1 = zero16();
   for (int k0 = 0; k0 < KK; k0 += C0_CHUNK) {
-    if (k0 + C0_CHUNK < KK) fetch(nxt, k0 + C0_CHUNK);
+    if (k0 + C0_CHUNK < KK) fetch(na, nb0, nb1, k0 + C0_CHUNK);
 #pragma unroll
     for (int q = 0; q < C0_CHUNK; ++q) {
       if (k0 + q < KK) {   // uniform
-        const int c = 2 * (k0 + q) + hh;
-        acc0 = mfma32(cur[q], smem[c * 65 + l31], acc0);
-        acc1 = mfma32(cur[q], smem[c * 65 + 32 + l31], acc1);
+        acc0 = mfma32(ca[q], cb0[q], acc0);
+        acc1 = mfma32(ca[q], cb1[q], acc1);
       }
     }
 #pragma unroll
-    for (int q = 0; q < C0_CHUNK; ++q) cur[q] = nxt[q];
+    for (int q = 0; q < C0_CHUNK; ++q) { ca[q] = na[q]; cb0[q] = nb0[q]; cb1[q] = nb1[q]; }
   }
   const float* bias = b + (long long)net * pstride;
   const float bv0 = bias[l31], bv1 = bias[32 + l31];
@@ -76,12 +74,11 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
   }
 }
 
-hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w, const float* b,
-                            long long pstride, float* a0, hipStream_t st) {
+hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w0t, long long w0t_ns,
+                            const float* b, long long pstride, float* a0, hipStream_t st) {
   const long long M = (long long)n * HW;
-  const size_t lds = (size_t)(((C + 1) & ~1) + 1) * 65 * 4;
   dim3 grid((unsigned)((M + 127) / 128), nets);
-  hipLaunchKernelGGL(conv0_fwd_kernel, grid, dim3(256), lds, st, xn, w, b, pstride, a0, n, C, HW);
+  hipLaunchKernelGGL(conv0_fwd_kernel, grid, dim3(256), 0, st, xn, w0t, w0t_ns, b, pstride, a0, n, C, HW);
   return hipGetLastError();
 }
 

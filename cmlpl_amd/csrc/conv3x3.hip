@@ -29,27 +29,37 @@ constexpr int CS = 68;  // LDS pixel stride in floats (64 + 4): conflict-free ds
 //   fwd  : wf[s][q][co][r] = W[co][4q+r][kh][kw]            s = kh*3+kw
 //   dgrad: wd[s][q][ci][r] = W[4q+r][ci][2-kh][2-kw]        (transposed + flipped)
 // ------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* __restrict__ params, long long pstride, long long off_w1,
-                                    long long off_w2, float* __restrict__ packed) {
+__global__ void pack_weights_kernel(const float* __restrict__ params, long long pstride, PackInfo pi,
+                                    float* __restrict__ packed) {
   const int net = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 4*PACK_CONV
-  if (e >= PACK_PER_NET) return;
-  const int which = e / PACK_CONV;          // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
-  const int i = e - which * PACK_CONV;
-  const int r = i & 3, oc = (i >> 2) & 63, q = (i >> 8) & 15, s = i >> 12;
-  const int kh = s / 3, kw = s - kh * 3;
-  const float* W = params + (long long)net * pstride + ((which < 2) ? off_w1 : off_w2);
-  const int k = 4 * q + r;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= pi.stride) return;
+  const float* P = params + (long long)net * pstride;
   float v;
-  if ((which & 1) == 0) v = W[((oc * 64 + k) * 3 + kh) * 3 + kw];                    // co=oc, ci=k
-  else                  v = W[((k * 64 + oc) * 3 + (2 - kh)) * 3 + (2 - kw)];        // co=k, ci=oc
-  packed[(long long)net * PACK_PER_NET + e] = v;
+  if (e < PACK_PER_NET) {
+    const int which = (int)(e / PACK_CONV);          // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
+    const int i = (int)(e - (long long)which * PACK_CONV);
+    const int r = i & 3, oc = (i >> 2) & 63, q = (i >> 8) & 15, s = i >> 12;
+    const int kh = s / 3, kw = s - kh * 3;
+    const float* W = P + ((which < 2) ? pi.off_w1 : pi.off_w2);
+    const int k = 4 * q + r;
+    if ((which & 1) == 0) v = W[((oc * 64 + k) * 3 + kh) * 3 + kw];                    // co=oc, ci=k
+    else                  v = W[((k * 64 + oc) * 3 + (2 - kh)) * 3 + (2 - kw)];        // co=k, ci=oc
+  } else if (e < pack_off_wst(pi.C)) {
+    const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
+    v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
+  } else {
+    const long long i = e - pack_off_wst(pi.C);
+    const int band = (int)(i >> 10), o = (int)(i & 1023);
+    v = P[pi.off_ws + (long long)o * pi.bands + band];
+  }
+  packed[(long long)net * pi.stride + e] = v;
 }
 
-hipError_t launch_pack_weights(int nets, const float* params, long long pstride, long long off_w1,
-                               long long off_w2, float* packed, hipStream_t st) {
-  dim3 grid((PACK_PER_NET + 255) / 256, nets);
-  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, params, pstride, off_w1, off_w2, packed);
+hipError_t launch_pack_weights(int nets, const float* params, long long pstride, const PackInfo& pi, float* packed,
+                               hipStream_t st) {
+  dim3 grid((unsigned)((pi.stride + 255) / 256), nets);
+  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, params, pstride, pi, packed);
   return hipGetLastError();
 }
 

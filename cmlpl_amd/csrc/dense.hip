@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN2 t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + acc_row(r, lane);
-        const float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
-        if (row < g.M) C[(long long)row * g.ldc + j] = v * g.scale;
+        float v = (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]) * g.scale;
+        if (g.bias_in != nullptr) v += g.bias_in[(long long)bz * g.bias_in_bstride + j];
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (row < g.M) C[(long long)row * g.ldc + j] = v;
       }
     }
     if (g.bias != nullptr && nt == 0) {

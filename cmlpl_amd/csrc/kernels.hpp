@@ -9,6 +9,14 @@ namespace cmlpl {
 
 constexpr int PACK_CONV = 9 * 64 * 64;       // one packed 3x3 weight set
 constexpr int PACK_PER_NET = 4 * PACK_CONV;  // conv1 fwd, conv1 dgrad, conv2 fwd, conv2 dgrad
+// after the four 3x3 packs, each net's packed buffer holds k-major copies of the two "thin" weights:
+//   w0T [Cp][64]      = conv0.weight^T  (Cp = C rounded up to even, pad row zero)
+//   wsT [bands][1024] = feat_spe.weight^T
+// so that their MFMA B fragments (fixed k, 32 consecutive outputs) are coalesced 128-B global reads.
+__host__ __device__ inline long long pack_off_w0t() { return PACK_PER_NET; }
+__host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET + (long long)((C + 1) & ~1) * 64; }
+__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_wst(C) + (long long)bands * 1024; }
+struct PackInfo { long long stride, off_w0, off_w1, off_w2, off_ws; int C, bands; };
 constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci][co] + db[co]
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -16,7 +24,7 @@ constexpr size_t LDS_MAX = 160 * 1024;
 hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
-                          float* xn, float* sn, hipStream_t st);
+                          float* xn, float* sn, float* snT, hipStream_t st);
 hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
                               long long* labels_g, hipStream_t st);
 
@@ -24,8 +32,8 @@ hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, 
                                   float* out, hipStream_t st);
 
 // ---- conv3x3.hip
-hipError_t launch_pack_weights(int nets, const float* params, long long pstride, long long off_w1,
-                               long long off_w2, float* packed, hipStream_t st);
+hipError_t launch_pack_weights(int nets, const float* params, long long pstride, const PackInfo& pi, float* packed,
+                               hipStream_t st);
 struct Conv3Plan { int S, MTW; size_t lds; };
 bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p);
 // mode 0: out = avgpool2(relu(conv(in)+bias+in)), mask_out = relu bits; in [nets][n][H*W][64]
@@ -40,8 +48,8 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
 int wgrad3_G(int n, int H, int W);
 
 // ---- conv0.hip
-hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w, const float* b,
-                            long long pstride, float* a0, hipStream_t st);
+hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w0t, long long w0t_ns,
+                            const float* b, long long pstride, float* a0, hipStream_t st);
 int plan_conv0_wgrad_G(int n, int C, int HW);
 // deterministic sum of per-workgroup weight-gradient partials, up to 3 tensors in one launch
 struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C, blk0; };
@@ -58,6 +66,7 @@ hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const flo
 // C[b][i][j] = scale * sum_r A[b][r][i] * B[b][r][j]  (+ optional colsum of A into bias[b][i])
 struct GemmTN {
   const float* A; const float* B; float* C; float* bias;
+  const float* bias_in; long long bias_in_bstride; int relu;   // epilogue: C = [relu](acc*scale + bias_in[j])
   long long a_bstride, b_bstride, c_bstride, bias_bstride;
   int lda, ldb, ldc, M, N, R, batches;
   float scale;
@@ -103,6 +112,6 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st);
 // ---- optim.hip
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
-                       float* packed, long long off_w1, long long off_w2, hipStream_t st);
+                       float* packed, const PackInfo& pi, hipStream_t st);
 
 }  // namespace cmlpl

@@ -417,6 +417,7 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   g.B = a.feat + ((long long)n + bt) * FD; g.ldb = FD; g.N = FD;
   g.C = a.dfeat + (long long)a.nlab * FD; g.ldc = FD;
   g.a_bstride = g.b_bstride = g.c_bstride = 0; g.bias = nullptr; g.bias_bstride = 0; g.batches = 1; g.scale = 1.f;
+  g.bias_in = nullptr; g.bias_in_bstride = 0; g.relu = 0;
   // dfeat_w[all rows] (this shard's partial) = G^T . fU_s[local] : C[l][d] = sum_i G[i][l] * fU_s[unl0+i][d]
   GemmTN h = g;
   h.A = a.G; h.lda = btu; h.M = btu; h.R = a.nunl;

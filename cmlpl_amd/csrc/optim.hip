@@ -9,7 +9,7 @@ namespace cmlpl {
 __global__ void adam_kernel(float* __restrict__ params, long long pstride, const float* __restrict__ grads,
                             long long gstride, float* __restrict__ m, float* __restrict__ v, long long live,
                             float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps,
-                            float* __restrict__ packed, long long off_w1, long long off_w2) {
+                            float* __restrict__ packed, PackInfo pi) {
   const int net = blockIdx.y;
   const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 >= live) return;
@@ -34,15 +34,28 @@ __global__ void adam_kernel(float* __restrict__ params, long long pstride, const
   // the 3x3 kernels read re-packed weights ([tap][ci/4][co][4], forward and transposed+flipped): refresh
   // them here instead of a separate launch (same mapping as pack_weights_kernel)
   if (packed != nullptr) {
-    const int which = (i4 >= off_w1 && i4 < off_w1 + PACK_CONV) ? 0 : (i4 >= off_w2 && i4 < off_w2 + PACK_CONV) ? 2 : -1;
+    float* pkn = packed + (long long)net * pi.stride;
+    const int which = (i4 >= pi.off_w1 && i4 < pi.off_w1 + PACK_CONV) ? 0 : (i4 >= pi.off_w2 && i4 < pi.off_w2 + PACK_CONV) ? 2 : -1;
     if (which >= 0) {
-      float* pk = packed + (long long)net * PACK_PER_NET + which * PACK_CONV;
-      const int e0 = (int)(i4 - (which == 0 ? off_w1 : off_w2));
+      float* pk = pkn + which * PACK_CONV;
+      const int e0 = (int)(i4 - (which == 0 ? pi.off_w1 : pi.off_w2));
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int e = e0 + q, kw = e % 3, kh = (e / 3) % 3, ci = (e / 9) & 63, co = e / 576;
         pk[(((kh * 3 + kw) * 16 + (ci >> 2)) * 64 + co) * 4 + (ci & 3)] = pa[q];
         pk[PACK_CONV + ((((2 - kh) * 3 + (2 - kw)) * 16 + (co >> 2)) * 64 + ci) * 4 + (co & 3)] = pa[q];
+      }
+    } else if (i4 >= pi.off_w0 && i4 < pi.off_w0 + 64LL * pi.C) {      // conv0.weight[co][c] -> w0T[c][co]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long e = i4 + q - pi.off_w0;
+        if (e < 64LL * pi.C) { const int co = (int)(e / pi.C), c = (int)(e - (long long)co * pi.C); pkn[pack_off_w0t() + c * 64 + co] = pa[q]; }
+      }
+    } else if (i4 >= pi.off_ws && i4 < pi.off_ws + 1024LL * pi.bands) { // feat_spe.weight[o][band] -> wsT[band][o]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long e = i4 + q - pi.off_ws;
+        if (e < 1024LL * pi.bands) { const int o = (int)(e / pi.bands), band = (int)(e - (long long)o * pi.bands); pkn[pack_off_wst(pi.C) + (long long)band * 1024 + o] = pa[q]; }
       }
     }
   }
@@ -50,14 +63,13 @@ __global__ void adam_kernel(float* __restrict__ params, long long pstride, const
 
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
-                       float* packed, long long off_w1, long long off_w2, hipStream_t st) {
+                       float* packed, const PackInfo& pi, hipStream_t st) {
   const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
   const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   const long long n4 = (live + 3) / 4;
   dim3 grid((unsigned)((n4 + 255) / 256), nets);
   hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, st, params, pstride, grads, gstride, m, v, live,
-                     (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), step_size, bc2_sqrt, eps, packed, off_w1,
-                     off_w2);
+                     (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), step_size, bc2_sqrt, eps, packed, pi);
   return hipGetLastError();
 }
 

@@ -111,6 +111,7 @@ class DistTrainEngine(TrainEngine):
         self.dlogits_l, self.dfeat_l = z(2, n_l, K), z(2, n_l, FEAT_DIM)
         self.dfw_part = z(self.btu_g, FEAT_DIM)
         self.xn, self.sn = z(2, n_l, shape.C * shape.H * shape.W), z(2, n_l, shape.bands)
+        self.snT = z(2, shape.bands, n_l)
         self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
         lw = self.lib.cmlpl_loss_workspace_bytes(C.byref(self.cshape), C.byref(self.cshard), self.Q)
         if lw == 0:
@@ -153,10 +154,11 @@ class DistTrainEngine(TrainEngine):
         _lib.check("cmlpl_augment", lib.cmlpl_augment(
             C.byref(self.cshape), 2, bt_l, btu_l, XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(),
             noise8, self.hp.noise, self.seed, self.step_count, C.byref(self.cshard), self.xn.data_ptr(),
-            self.sn.data_ptr(), st))
+            self.sn.data_ptr(), self.snT.data_ptr(), st))
         _lib.check("cmlpl_basenet2_fwd", lib.cmlpl_basenet2_fwd(
             C.byref(self.cshape), 2, n_l, self.params.data_ptr(), self.P, self.packed.data_ptr(), self.xn.data_ptr(),
-            self.sn.data_ptr(), None if dropmask is None else dropmask.data_ptr(), self.hp.dropout, 1, self.seed,
+            self.sn.data_ptr(), self.snT.data_ptr(), None if dropmask is None else dropmask.data_ptr(), self.hp.dropout, 1,
+            self.seed,
             self.step_count, C.byref(self.cshard), self.logits_l.data_ptr(), self.feat_l.data_ptr(),
             self.workspace.data_ptr(), self.workspace.numel(), st))
         self.labels_f.copy_(Y)

@@ -42,7 +42,7 @@ class _BaseNet2Fn(torch.autograd.Function):
         train = 1 if mod.training else 0
         mod._calls += 1
         _lib.check("cmlpl_basenet2_fwd", lib.cmlpl_basenet2_fwd(
-            C.byref(mod._cshape), 1, n, flat.data_ptr(), mod._P, packed.data_ptr(), x.data_ptr(), y.data_ptr(),
+            C.byref(mod._cshape), 1, n, flat.data_ptr(), mod._P, packed.data_ptr(), x.data_ptr(), y.data_ptr(), None,
             None if dropmask is None else dropmask.data_ptr(), float(mod.dropout), train,
             int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, mod._calls, None,
             logits.data_ptr(), feat.data_ptr(), ws.data_ptr(), ws.numel(), stream))

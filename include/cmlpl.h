@@ -65,7 +65,8 @@ typedef struct cmlpl_layout_t {
   int64_t param_numel[CMLPL_NUM_TENSORS];
   int64_t param_total;                    /* floats per net (all 16 tensors)             */
   int64_t param_live;                     /* floats per net covered by Adam (tensors 0-9) */
-  int64_t packed_total;                   /* floats per net of kernel-side packed conv weights */
+  int64_t packed_total;                   /* floats per net of kernel-side re-packed weights (3x3 taps, k-major
+                                             copies of conv0 / feat_spe); written by cmlpl_pack_weights and Adam */
   int32_t cls_in;                         /* 64*(H/2/2)*(W/2/2) + 1024                    */
   int32_t reserved;
 } cmlpl_layout_t;
@@ -100,7 +101,8 @@ typedef struct cmlpl_shard {
 int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu,
                   const float* d_xpl, const float* d_xl, const float* d_xpu, const float* d_xu,
                   const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
-                  const cmlpl_shard* shard /* NULL = one GPU */, float* d_xn, float* d_sn, void* stream);
+                  const cmlpl_shard* shard /* NULL = one GPU */, float* d_xn, float* d_sn,
+                  float* d_snT /* optional [nets][bands][n] copy of sn, k-major for feat_spe */, void* stream);
 
 /* BaseNet2.forward (tools/models.py:130-152) for `nets` networks on rows [n].
  *   d_xn [nets][n][C][H*W], d_sn [nets][n][bands]  (already augmented)
@@ -110,7 +112,9 @@ int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu,
  *   cmlpl_basenet2_bwd are kept in d_workspace. */
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n,
                        const float* d_params, int64_t param_stride, const float* d_packed,
-                       const float* d_xn, const float* d_sn, const float* d_dropmask,
+                       const float* d_xn, const float* d_sn,
+                       const float* d_snT /* optional: sn transposed [nets][bands][n] (from cmlpl_augment) */,
+                       const float* d_dropmask,
                        float dropout_p, int train, uint64_t seed, uint64_t step,
                        const cmlpl_shard* shard /* NULL = rows are global samples 0..n-1 */,
                        float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes,

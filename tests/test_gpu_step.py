@@ -144,7 +144,7 @@ def test_philox_noise_statistics():
     xn = torch.empty(2, bt + btu, 103 * 121, device=DEV); sn = torch.empty(2, bt + btu, 103, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     assert lib.cmlpl_augment(C.byref(cs), 2, bt, btu, xpl.data_ptr(), xl.data_ptr(), xpu.data_ptr(), xu.data_ptr(),
-                             None, 0.5, 123, 7, None, xn.data_ptr(), sn.data_ptr(), st) == 0
+                             None, 0.5, 123, 7, None, xn.data_ptr(), sn.data_ptr(), None, st) == 0
     torch.cuda.synchronize()
     lab, unl = xn[:, :bt], xn[:, bt:] - 1.0
     for t in (lab, unl):
@@ -156,6 +156,6 @@ def test_philox_noise_statistics():
     assert abs(float(sn[:, :bt].std()) - 0.5) < 1e-2
     xn2 = torch.empty_like(xn)
     assert lib.cmlpl_augment(C.byref(cs), 2, bt, btu, xpl.data_ptr(), xl.data_ptr(), xpu.data_ptr(), xu.data_ptr(),
-                             None, 0.5, 123, 7, None, xn2.data_ptr(), sn.data_ptr(), st) == 0
+                             None, 0.5, 123, 7, None, xn2.data_ptr(), sn.data_ptr(), None, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(xn, xn2)                                          # counter-based: reproducible

@@ -13,52 +13,46 @@
 
 namespace cmlpl {
 
-constexpr int C0_CHUNK = 16;   // k-steps (2 bands each) fetched per batch
+constexpr int C0_KMAX = 128;    // k-steps of 2 bands: up to 256 input channels
 
-// Both operands come straight from memory as MFMA fragments: A[pixel][band] = 32 consecutive pixels of one
-// band of the NCHW input (128-B segment), B[band][co] = 32 consecutive output channels of the k-major weight
-// copy w0T (128-B segment, L2-resident).  No LDS, no barrier; 48 loads in flight per lane, double-buffered.
+// A[pixel][band] fragments come straight from HBM (32 consecutive pixels of one band of the NCHW input = one
+// 128-B segment) and EVERY band load of a lane is issued before anything is consumed: at ~2 waves per SIMD
+// the kernel is bound by the number of sequential memory round trips, and this makes it one.  The k-major
+// weight copy w0T (L2-resident, maintained by Adam) is copied straight into LDS meanwhile.
+template <int KCAP>
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ w0t,
                                                         long long w0t_ns, const float* __restrict__ b,
                                                         long long pstride, float* __restrict__ a0, int n, int C,
                                                         int HW) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cp][64]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y;
-  const int Cp = (C + 1) & ~1;
-  const float* WT = w0t + (long long)net * w0t_ns + l31;
+  const int Cp = (C + 1) & ~1, KK = Cp >> 1;
   const long long M = (long long)n * HW;
   const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + l31;
   const long long mm = (m < M) ? m : 0;
   const int sample = (int)(mm / HW), pix = (int)(mm - (long long)sample * HW);
   const float* ap = xn + ((long long)net * n + sample) * C * HW + pix;
-  const int KK = Cp >> 1;
-  float ca[C0_CHUNK], cb0[C0_CHUNK], cb1[C0_CHUNK], na[C0_CHUNK], nb0[C0_CHUNK], nb1[C0_CHUNK];
-  auto fetch = [&](float (&fa)[C0_CHUNK], float (&f0)[C0_CHUNK], float (&f1)[C0_CHUNK], int k0) {
+  float av[KCAP];
 #pragma unroll
-    for (int q = 0; q < C0_CHUNK; ++q) {
-      const int c = 2 * (k0 + q) + hh;
-      const bool ok = c < C;                       // c == C (odd C) hits the zero pad row of w0T
-      const int cw = (c < Cp) ? c : 0;
-      const float v = ap[(long long)(ok ? c : 0) * HW];
-      fa[q] = ok ? v : 0.f;
-      f0[q] = WT[cw * 64];
-      f1[q] = WT[cw * 64 + 32];
-    }
-  };
-  fetch(ca, cb0, cb1, 0);
+  for (int q = 0; q < KCAP; ++q) {
+    const int c = 2 * q + hh;
+    const bool ok = (q < KK) && (c < C);
+    const float v = ap[(long long)(ok ? c : 0) * HW];
+    av[q] = ok ? v : 0.f;
+  }
+  const float4* wsrc = (const float4*)(w0t + (long long)net * w0t_ns);
+  staged_copy<8, float4>(Cp * 16, tid, [&](int i) { return wsrc[i]; }, [&](int i, float4 v) { ((float4*)wl)[i] = v; });
+  __syncthreads();
   f32x16 acc0 = zero16(), acc1 = zero16();
-  for (int k0 = 0; k0 < KK; k0 += C0_CHUNK) {
-    if (k0 + C0_CHUNK < KK) fetch(na, nb0, nb1, k0 + C0_CHUNK);
 #pragma unroll
-    for (int q = 0; q < C0_CHUNK; ++q) {
-      if (k0 + q < KK) {   // uniform
-        acc0 = mfma32(ca[q], cb0[q], acc0);
-        acc1 = mfma32(ca[q], cb1[q], acc1);
-      }
+  for (int q = 0; q < KCAP; ++q) {
+    if (q < KK) {   // uniform
+      const int c = 2 * q + hh;
+      acc0 = mfma32(av[q], wl[c * 64 + l31], acc0);
+      acc1 = mfma32(av[q], wl[c * 64 + 32 + l31], acc1);
     }
-#pragma unroll
-    for (int q = 0; q < C0_CHUNK; ++q) { ca[q] = na[q]; cb0[q] = nb0[q]; cb1[q] = nb1[q]; }
   }
   const float* bias = b + (long long)net * pstride;
   const float bv0 = bias[l31], bv1 = bias[32 + l31];
@@ -77,8 +71,13 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w0t, long long w0t_ns,
                             const float* b, long long pstride, float* a0, hipStream_t st) {
   const long long M = (long long)n * HW;
+  const int KK = ((C + 1) & ~1) / 2;
+  if (KK > C0_KMAX) return hipErrorInvalidValue;
+  const size_t lds = (size_t)2 * KK * 64 * 4;
   dim3 grid((unsigned)((M + 127) / 128), nets);
-  hipLaunchKernelGGL(conv0_fwd_kernel, grid, dim3(256), 0, st, xn, w0t, w0t_ns, b, pstride, a0, n, C, HW);
+  if (KK <= 32)      hipLaunchKernelGGL((conv0_fwd_kernel<32>), grid, dim3(256), lds, st, xn, w0t, w0t_ns, b, pstride, a0, n, C, HW);
+  else if (KK <= 64) hipLaunchKernelGGL((conv0_fwd_kernel<64>), grid, dim3(256), lds, st, xn, w0t, w0t_ns, b, pstride, a0, n, C, HW);
+  else               hipLaunchKernelGGL((conv0_fwd_kernel<128>), grid, dim3(256), lds, st, xn, w0t, w0t_ns, b, pstride, a0, n, C, HW);
   return hipGetLastError();
 }
 
@@ -89,7 +88,7 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
 // wave w: co tile = w&1, band tiles (w>>1), (w>>1)+2, ...   (C0_MAXT tiles of 32 bands per wave)
 // ------------------------------------------------------------------------------------------
 constexpr int C0_MAXT = 4;    // up to 8 band tiles = 256 input channels
-constexpr int C0_PB = 8;      // pixel pairs per batch
+constexpr int C0_PB = 32;     // pixel pairs fetched per batch (double-buffered): an 11x11 sample is two round trips
 
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ xn, const float* __restrict__ da0,
                                                           float* __restrict__ part, int n, int C, int HW, int G) {
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     fetch(bc, 0);   // in flight while the slab is staged
     __syncthreads();
     const float* xs = xn + ((long long)net * n + s) * C * HW;
-    staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
+    staged_copy<32, float>(C * HW, tid, [&](int i) { return xs[i]; },
                            [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
     __syncthreads();
     for (int t0 = 0; t0 < pairs; t0 += C0_PB) {

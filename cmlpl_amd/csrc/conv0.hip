@@ -88,7 +88,7 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
 // wave w: co tile = w&1, band tiles (w>>1), (w>>1)+2, ...   (C0_MAXT tiles of 32 bands per wave)
 // ------------------------------------------------------------------------------------------
 constexpr int C0_MAXT = 4;    // up to 8 band tiles = 256 input channels
-constexpr int C0_PB = 32;     // pixel pairs fetched per batch (double-buffered): an 11x11 sample is two round trips
+constexpr int C0_PB = 8;      // pixel pairs per batch (double-buffered); larger batches cost VGPRs -> occupancy (measured: 28 -> 54 us)
 
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ xn, const float* __restrict__ da0,
                                                           float* __restrict__ part, int n, int C, int HW, int G) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     fetch(bc, 0);   // in flight while the slab is staged
     __syncthreads();
     const float* xs = xn + ((long long)net * n + s) * C * HW;
-    staged_copy<32, float>(C * HW, tid, [&](int i) { return xs[i]; },
+    staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
                            [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
     __syncthreads();
     for (int t0 = 0; t0 < pairs; t0 += C0_PB) {

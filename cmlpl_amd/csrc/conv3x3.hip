@@ -481,7 +481,14 @@ struct Wgrad3Args {
   int n, H, W, RU, U, G;
 };
 
+// CSPL = 1: one workgroup produces all 64 output channels (wave = (co tile, ci tile), 9 taps each).
+// CSPL = 2: the output channels are split over two workgroups (blockIdx.z = co half); a workgroup then stages
+//           only its half of dz (LDS ~53 KB instead of 131 KB for 11x11 maps), so 2-3 workgroups share a CU and
+//           one's staging / partial write-out overlaps another's MFMAs; wave = (ci tile, tap parity), 5 or 4 taps.
+template <int CSPL>
 __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
+  constexpr int DC = 64 / CSPL;            // dz channels staged by this workgroup
+  constexpr int NS = (CSPL == 1) ? 9 : 5;  // tap slots per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -498,21 +505,27 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
 
   float* img = smem;                        // [U][IMGU][64]
-  float* dz = img + (size_t)U * IMGU * 64;  // [D][64]
+  float* dz = img + (size_t)U * IMGU * 64;  // [D][DC]
 
   for (int i = tid; i < U * IMGU * 64; i += 256) img[i] = 0.f;
   const float* src = a.in + (long long)net * a.in_ns;
   const float* dp = a.dpool + (long long)net * a.dpool_ns;
   const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
 
-  const int ct = wave & 1, it = wave >> 1;
-  f32x16 acc[9];
+  const int ct = (CSPL == 1) ? (wave & 1) : (int)blockIdx.z;
+  const int it = (CSPL == 1) ? (wave >> 1) : (wave & 1);
+  const int wh = (CSPL == 1) ? 0 : (wave >> 1);
+  f32x16 acc[NS];
 #pragma unroll
-  for (int s = 0; s < 9; ++s) acc[s] = zero16();
+  for (int s = 0; s < NS; ++s) acc[s] = zero16();
   float dbacc = 0.f;
-  int shoff[9];
+  int shoff[NS];
 #pragma unroll
-  for (int s = 0; s < 9; ++s) shoff[s] = ((s / 3 - 1) * PW + (s % 3 - 1)) * 64;
+  for (int s = 0; s < NS; ++s) {
+    const int tap = (CSPL == 1) ? s : (2 * s + wh < 9 ? 2 * s + wh : 0);   // inactive slot: any valid address
+    shoff[s] = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * 64;
+  }
+  const bool last_active = (CSPL == 1) || (wh == 0);      // slot NS-1 exists only for tap parity 0 (wave-uniform)
 
   for (int ub = ubeg; ub < uend; ub += U) {
     __syncthreads();  // previous pass finished reading img/dz
@@ -540,22 +553,23 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
     {
       struct DM { float4 d; uint32_t m; };
       const int RUh = RU >> 1;
-      staged_copy<8, DM>(U * RUh * W2 * 16, tid,
+      constexpr int C4N = 16 / CSPL;       // float4 chunks of this workgroup's channel range
+      staged_copy<8, DM>(U * RUh * W2 * C4N, tid,
           [&](int idx) {
-            const int c4 = idx & 15, p = idx >> 4;
+            const int c4 = idx % C4N, p = idx / C4N;
             const int u = p / (RUh * W2), rem = p - u * RUh * W2, rh = rem / W2, pw = rem - rh * W2;
             const int uid = ub + u;
             const int uc = (uid < uend) ? uid : ubeg;
             const int sample = uc / UPS, j = uc - sample * UPS, prow = j * RUh + rh;   // pooled row
             const bool ok = (uid < uend) && prow < H2;
-            const size_t gi = ((size_t)sample * P2 + (ok ? prow : 0) * W2 + pw) * 64 + c4 * 4;
+            const size_t gi = ((size_t)sample * P2 + (ok ? prow : 0) * W2 + pw) * 64 + (CSPL == 1 ? 0 : ct * 32) + c4 * 4;
             DM r;
             r.d = *(const float4*)(dp + gi);
             r.m = ok ? *(const uint32_t*)(mk + gi) : 0u;
             return r;
           },
           [&](int idx, DM r) {
-            const int c4 = idx & 15, p = idx >> 4;
+            const int c4 = idx % C4N, p = idx / C4N;
             const int u = p / (RUh * W2), rem = p - u * RUh * W2, rh = rem / W2, pw = rem - rh * W2;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
@@ -565,7 +579,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
               v.z = ((r.m >> (16 + sub)) & 1u) ? r.d.z * 0.25f : 0.f;
               v.w = ((r.m >> (24 + sub)) & 1u) ? r.d.w * 0.25f : 0.f;
               const int d = u * DU + (2 * rh + (sub >> 1)) * CO + 2 * pw + (sub & 1);
-              *(float4*)(dz + (size_t)d * 64 + c4 * 4) = v;
+              *(float4*)(dz + (size_t)d * DC + c4 * 4) = v;
             }
           });
     }
@@ -578,28 +592,28 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
     // fetched while the 9 MFMAs of pair t run.  lane half hh takes pixel c+hh of the pair.
     const int rows = U * RU, cpr = CO >> 1;
     const float* arow0 = img + it * 32 + l31 + (PW + 1 + hh) * 64;   // (r+1)*PW + (c+1) with r = c = 0
-    const float* brow0 = dz + ct * 32 + l31 + hh * 64;
-    float an[9], bn;
+    const float* brow0 = dz + (CSPL == 1 ? ct * 32 : 0) + l31 + hh * DC;
+    float an[NS], bn;
     {
 #pragma unroll
-      for (int s = 0; s < 9; ++s) an[s] = arow0[shoff[s]];
+      for (int s = 0; s < NS; ++s) an[s] = arow0[shoff[s]];
       bn = brow0[0];
     }
     int u = 0, r = 0, cp = 0;
     const int pairs = rows * cpr;
-    float ac[9], bc;
+    float ac[NS], bc;
 #pragma unroll
-    for (int s = 0; s < 9; ++s) ac[s] = an[s];
+    for (int s = 0; s < NS; ++s) ac[s] = an[s];
     bc = bn;
     for (int t = 0; t < pairs; ++t) {
       // advance (u, r, cp) and fetch the next pair (the last fetch re-reads pair 0: harmless)
       if (++cp == cpr) { cp = 0; if (++r == RU) { r = 0; ++u; } }
       const int un = (t + 1 < pairs) ? u : 0, rn = (t + 1 < pairs) ? r : 0, cn = (t + 1 < pairs) ? cp : 0;
       const float* ap = arow0 + (un * IMGU + rn * PW + 2 * cn) * 64;
-      const float* bp = brow0 + ((un * RU + rn) * CO + 2 * cn) * 64;
+      const float* bp = brow0 + ((un * RU + rn) * CO + 2 * cn) * DC;
 #if CMLPL_ABL != 2
 #pragma unroll
-      for (int s = 0; s < 9; ++s) an[s] = ap[shoff[s]];
+      for (int s = 0; s < NS; ++s) an[s] = ap[shoff[s]];
       bn = bp[0];
 #else
       asm volatile("" :: "v"(ap), "v"(bp));
@@ -608,38 +622,42 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
       dbacc += bc;
 #if CMLPL_ABL != 1
 #pragma unroll
-      for (int s = 0; s < 9; ++s) acc[s] = mfma32(ac[s], bc, acc[s]);
+      for (int s = 0; s < NS - 1; ++s) acc[s] = mfma32(ac[s], bc, acc[s]);
+      if (last_active) acc[NS - 1] = mfma32(ac[NS - 1], bc, acc[NS - 1]);
 #else
 #pragma unroll
-      for (int s = 0; s < 9; ++s) asm volatile("" :: "v"(ac[s]), "v"(bc));
+      for (int s = 0; s < NS; ++s) asm volatile("" :: "v"(ac[s]), "v"(bc));
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 9; ++s) ac[s] = an[s];
+      for (int s = 0; s < NS; ++s) ac[s] = an[s];
       bc = bn;
     }
   }
 
   float* part = a.part + (long long)net * a.part_ns + (size_t)g * PART3;
 #pragma unroll
-  for (int s = 0; s < 9; ++s) {
+  for (int s = 0; s < NS; ++s) {
+    const int tap = (CSPL == 1) ? s : 2 * s + wh;
+    if (tap < 9) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ci = it * 32 + acc_row(r, lane);
-      part[s * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r];
+      for (int r = 0; r < 16; ++r) {
+        const int ci = it * 32 + acc_row(r, lane);
+        part[tap * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r];
+      }
     }
   }
-  // bias gradient: waves with it == 0 (waves 0, 1) summed their B operand; fold the two pixel parities
-  if (it == 0) {
+  // bias gradient: one wave per output-channel tile summed its B operand; fold the two pixel parities
+  if (it == 0 && wh == 0) {
     const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
     if (hh == 0) part[9 * 4096 + ct * 32 + l31] = tot;
   }
 }
 
-static size_t wgrad3_lds(int RU, int U, int W) {
+static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
   const int PW = W + 2, CO = 2 * (W / 2);
   const size_t D = (size_t)U * RU * CO;
-  return ((size_t)U * (RU + 2) * PW * 64 + D * 64) * 4;
+  return ((size_t)U * (RU + 2) * PW * 64 + D * (64 / cspl)) * 4;
 }
 
 bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
@@ -659,11 +677,19 @@ bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
   int U = 1;
   while (U < 8 && wgrad3_lds(RU, U + 1, W) <= LDS_MAX && (NU + U) / (U + 1) >= 128) ++U;
   if (force_u > 0 && wgrad3_lds(RU, force_u, W) <= LDS_MAX) U = force_u;
+  // big maps with enough units: split the output channels over two workgroups and walk the units one at a
+  // time, so that 2-3 workgroups are co-resident per CU (same number of partial slots, same partial traffic)
+  static const int force_c = getenv("CMLPL_WGRAD3_CSPL") ? atoi(getenv("CMLPL_WGRAD3_CSPL")) : 0;
+  p->cspl = 1;
+  if (force_c ? (force_c == 2) : (RU * 2 * (W / 2) >= 64 && NU >= 256 && wgrad3_lds(RU, 1, W, 2) <= LDS_MAX / 2)) {
+    p->cspl = 2;
+    U = 1;
+  }
   // one pass per workgroup when that still fills the chip; never more workgroups than passes
   long long G = (NU + U - 1) / U;
+  if (p->cspl == 2) { G = (NU + 1) / 2; if (G > 128) G = 128; }   // 2 co-halves x 2 nets x 128 = 512 workgroups
   if (G > 256) G = 256;                            // per net; 2 nets -> 512 WGs
-  // keep the unit count per workgroup a multiple of U where possible
-  p->RU = RU; p->U = U; p->G = (int)G; p->lds = wgrad3_lds(RU, U, W);
+  p->RU = RU; p->U = U; p->G = (int)G; p->lds = wgrad3_lds(RU, U, W, p->cspl);
   return true;
 }
 
@@ -673,8 +699,10 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   if (!plan_wgrad3(n, H, W, &pl)) return hipErrorInvalidValue;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LDS_MAX);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -684,7 +712,8 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G;
-  hipLaunchKernelGGL(wgrad3_kernel, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
+  if (pl.cspl == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(pl.G, nets, 2), dim3(256), pl.lds, st, a);
+  else              hipLaunchKernelGGL(wgrad3_kernel<1>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
   return hipGetLastError();
 }
 

@@ -503,6 +503,18 @@ int cmlpl_extract_patches(const float* d_cube, int rows, int cols, int C, int w,
                                     (hipStream_t)stream));
 }
 
+size_t cmlpl_ntxent_workspace_bytes(int B, int D) { return (B < 1 || D < 1) ? 0 : ntxent_ws_floats(B, D) * 4; }
+
+int cmlpl_ntxent_fwd_bwd(const float* d_emb_i, const float* d_emb_j, int B, int D, float temperature, float* d_loss,
+                         float* d_grad_i, float* d_grad_j, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!d_emb_i || !d_emb_j || !d_loss || !d_grad_i || !d_grad_j || !d_workspace || B < 1 || D < 1 ||
+      !(temperature > 0.f))
+    return CMLPL_E_ARG;
+  if (ntxent_ws_floats(B, D) * 4 > workspace_bytes) return CMLPL_E_WORKSPACE;
+  return chk(launch_ntxent(d_emb_i, d_emb_j, B, D, temperature, d_loss, d_grad_i, d_grad_j, (float*)d_workspace,
+                           (hipStream_t)stream));
+}
+
 int cmlpl_timing_begin(uint32_t kernel_mask, int max_launches) {
   Timing& t = g_timing;
   if (t.on || max_launches < 1) return CMLPL_E_ARG;

@@ -109,6 +109,11 @@ hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st);
 hipError_t launch_loss_finalize(const LossArgs& a, hipStream_t st);
 hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st);
 
+// ---- ntxent.hip
+size_t ntxent_ws_floats(int B, int D);
+hipError_t launch_ntxent(const float* ei, const float* ej, int B, int D, float T, float* loss, float* gi, float* gj,
+                         float* ws, hipStream_t st);
+
 // ---- optim.hip
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,

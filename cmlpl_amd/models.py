@@ -149,3 +149,43 @@ class BaseNet2(nn.Module):
         if dropmask is not None:
             dropmask = dropmask.contiguous().float()
         return _BaseNet2Fn.apply(self, x, y, dropmask, *self._live_params())
+
+
+class _NTXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb_i, emb_j, temperature):
+        lib = _lib.load()
+        B, D = emb_i.shape
+        dev = emb_i.device
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        gi, gj = torch.empty_like(emb_i), torch.empty_like(emb_j)
+        ws = torch.empty(lib.cmlpl_ntxent_workspace_bytes(B, D), dtype=torch.uint8, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check("cmlpl_ntxent_fwd_bwd", lib.cmlpl_ntxent_fwd_bwd(
+            emb_i.data_ptr(), emb_j.data_ptr(), B, D, float(temperature), loss.data_ptr(), gi.data_ptr(),
+            gj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        ctx.save_for_backward(gi, gj)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gi, gj = ctx.saved_tensors
+        return gi * g, gj * g, None
+
+
+class ContrastiveLoss(nn.Module):
+    """Drop-in for the reference's tools.models.ContrastiveLoss (tools/models.py:14-39): same constructor
+    ``(batch_size, device='cuda', temperature=0.5)`` and ``forward(emb_i, emb_j) -> scalar``; forward and
+    backward run in libcmlpl_hip.so (cmlpl_ntxent_fwd_bwd)."""
+
+    def __init__(self, batch_size, device="cuda", temperature=0.5):
+        super().__init__()
+        self.batch_size = batch_size
+        self.register_buffer("temperature", torch.tensor(float(temperature)))
+
+    def forward(self, emb_i, emb_j):
+        if not emb_i.is_cuda:
+            raise RuntimeError("cmlpl_amd.ContrastiveLoss runs on the GPU only (no CPU fallback)")
+        if emb_i.shape != emb_j.shape or emb_i.shape[0] != self.batch_size:
+            raise ValueError("emb_i / emb_j must both be [batch_size, D]")
+        return _NTXentFn.apply(emb_i.contiguous().float(), emb_j.contiguous().float(), float(self.temperature))

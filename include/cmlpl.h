@@ -222,6 +222,14 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
 int cmlpl_extract_patches(const float* d_cube, int rows, int cols, int C, int w,
                           const int64_t* d_pixel_idx, int n, float* d_out, void* stream);
 
+/* Caller-side row N4: tools.models.ContrastiveLoss (tools/models.py:14-39) -- NT-Xent over the
+ * pairwise cosine similarity of the 2B normalised embeddings, forward + analytic backward.
+ * d_emb_i, d_emb_j [B][D]; d_loss [1]; d_grad_i, d_grad_j [B][D] = dLoss/d emb. */
+size_t cmlpl_ntxent_workspace_bytes(int B, int D);
+int cmlpl_ntxent_fwd_bwd(const float* d_emb_i, const float* d_emb_j, int B, int D, float temperature,
+                         float* d_loss, float* d_grad_i, float* d_grad_j,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Optional per-launch timing, measured with hipEvent pairs recorded on the launch stream around the
  * selected kernels (bit i of kernel_mask selects CMLPL_K_i).  cmlpl_timing_end synchronises the
  * recorded events and returns, per kernel id, the summed milliseconds and the number of launches.

@@ -419,3 +419,19 @@ def extract_patches(X: np.ndarray, w: int, pixel_idx: Optional[np.ndarray] = Non
     cc = mirror_index(c[:, None] + off[None, :], col)          # [n, w]
     patches = X[rr[:, :, None], cc[:, None, :], :]             # [n, w, w, C]
     return np.ascontiguousarray(np.moveaxis(patches, 3, 1)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# next row N4: tools.models.ContrastiveLoss  (tools/models.py:14-39, NT-Xent)
+# --------------------------------------------------------------------------- #
+def ntxent_loss(emb_i: torch.Tensor, emb_j: torch.Tensor, temperature: float = 0.5) -> torch.Tensor:
+    """Restates ContrastiveLoss.forward (models.py:22-39): rows are L2-normalised (F.normalize, eps 1e-12),
+    all-pairs cosine similarity of the 2B representations, positives on the +-B diagonals, denominator
+    over every k != i."""
+    B = emb_i.shape[0]
+    z = torch.cat([F.normalize(emb_i, dim=1), F.normalize(emb_j, dim=1)], dim=0)            # :23-26
+    sim = F.cosine_similarity(z.unsqueeze(1), z.unsqueeze(0), dim=2)                         # :27
+    pos = torch.cat([torch.diag(sim, B), torch.diag(sim, -B)], dim=0)                        # :30-32
+    neg_mask = (~torch.eye(2 * B, dtype=torch.bool)).float()                                  # :19-20
+    denom = (neg_mask * torch.exp(sim / temperature)).sum(dim=1)                              # :35
+    return (-torch.log(torch.exp(pos / temperature) / denom)).sum() / (2 * B)                 # :34,37-38

@@ -85,9 +85,15 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
   const float* bbase = wbuf + (hh * 64 + l31) * 4;
 #pragma unroll 1
   for (int s = 0; s < 9; ++s) {
+#if CMLPL_ABL == 6
+    if (s == 0) {
+#endif
     __syncthreads();  // everyone done with wbuf of tap s-1 (and, for s == 0, the staged image is complete)
     wl[tid] = w0; wl[tid + 256] = w1; wl[tid + 512] = w2; wl[tid + 768] = w3;
     __syncthreads();
+#if CMLPL_ABL == 6
+    }
+#endif
     if (s + 1 < 9) {
       const float4* wn = wg + (s + 1) * 1024 + tid;
       w0 = wn[0]; w1 = wn[256]; w2 = wn[512]; w3 = wn[768];
@@ -114,6 +120,10 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
           for (int t = 0; t < NTA; ++t) nav[t] = *(const float4*)(ib + abase[t] + (kk + 1) * 8);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if CMLPL_ABL == 5
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) asm volatile("" :: "v"(av[t].x), "v"(av[t].w), "v"(b0.x), "v"(b1.w));
+#else
 #pragma unroll
         for (int t = 0; t < NTA; ++t) {
           acc[t][0] = mfma32(av[t].x, b0.x, acc[t][0]);
@@ -125,6 +135,7 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
           acc[t][0] = mfma32(av[t].w, b0.w, acc[t][0]);
           acc[t][1] = mfma32(av[t].w, b1.w, acc[t][1]);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         b0 = nb0; b1 = nb1;
 #pragma unroll

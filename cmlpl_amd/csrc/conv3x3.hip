@@ -66,6 +66,18 @@ hipError_t launch_pack_weights(int nets, const float* params, long long pstride,
 // ------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------
+#if CMLPL_ABL == 9
+// phase timeline instrumentation (ablation build only): constant-rate 100 MHz stamps per workgroup
+__device__ unsigned long long g_stamps[3][2048][8];
+#define STAMP(MODE_, i) do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) \
+    g_stamps[MODE_][blockIdx.x + gridDim.x * blockIdx.y][i] = wall_clock64(); } while (0)
+extern "C" int cmlpl_abl_read_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#else
+#define STAMP(MODE_, i) do {} while (0)
+#endif
+
 struct Conv3Args {
   const float* in; const uint8_t* mask_in; const float* wpk; const float* bias;
   float* out; uint8_t* mask_out;
@@ -254,7 +266,9 @@ template <int MODE, int MTW>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Conv3Ctx c;
+  STAMP(MODE, 0);
   conv3_stage<MODE>(a, smem, MTW * 128, c);
+  STAMP(MODE, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
   float* img = c.img; float* wbuf = c.wbuf; int* lut = c.lut; const float4* wg = c.wg;
@@ -273,6 +287,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
+  STAMP(MODE, 2);
 
   if (MODE == 0) {
     const float* bias = a.bias + (long long)net * a.bias_ns;
@@ -316,6 +331,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
       }
     }
   }
+  STAMP(MODE, 3);
 }
 
 
@@ -665,6 +681,201 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   }
 }
 
+// Pipelined variant (the default whenever a stage of U units needs <= NI float4 per thread): LDS holds TWO
+// stages; while the 9-tap MFMA loop runs on stage g, the rows of stage g+1 are already in flight global ->
+// registers, and are written to the other LDS half after the loop.  One barrier per stage.  A workgroup has a
+// single wave per SIMD here (4 waves, 144 accumulator registers each), so nothing else would hide the staging
+// latency: measured on B2/256 conv1 the unpipelined kernel spends 10 of its 59 us staging with the MFMA pipe idle.
+template <int NI>
+__global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int net = blockIdx.y, g = blockIdx.x;
+  const int H = a.H, W = a.W, HW = H * W, PW = W + 2;
+  const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2, RO = 2 * H2, CO = 2 * W2;
+  const int RU = a.RU, U = a.U;
+  const int IMGU = (RU + 2) * PW, DU = RU * CO, D = U * DU;
+  const int UPS = (RO + RU - 1) / RU;
+  const int NU = a.n * UPS;
+  const int UPG = (NU + a.G - 1) / a.G;
+  const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
+  const int IMGF = U * IMGU * 64, BUF = IMGF + D * 64;     // floats per stage buffer: [img | dz]
+  STAMP(2, 0);
+
+  {  // borders of both buffers must be zero; interiors are rewritten every stage
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* p4 = (float4*)smem;
+    for (int i = tid; i < (2 * BUF) >> 2; i += 256) p4[i] = z;
+  }
+  const float* src = a.in + (long long)net * a.in_ns;
+  const float* dp = a.dpool + (long long)net * a.dpool_ns;
+  const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
+  const int ct = wave & 1, it = wave >> 1;
+
+  // stage items of this thread: the (unit, row, column, channel chunk) decode does not depend on the stage
+  const int RUh = RU >> 1;
+  const int itot = U * (RU + 2) * W * 16, dtot = U * RUh * W2 * 16;
+  int i_u[NI], i_ir[NI], i_g[NI], i_l[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int idx = tid + q * 256;
+    const int id = idx < itot ? idx : 0;
+    const int c4 = id & 15, p = id >> 4;
+    const int u = p / ((RU + 2) * W), rem = p - u * (RU + 2) * W, ir = rem / W, w = rem - ir * W;
+    i_u[q] = idx < itot ? u : -1; i_ir[q] = ir; i_g[q] = w * 64 + c4 * 4;
+    i_l[q] = (u * IMGU + ir * PW + w + 1) * 64 + c4 * 4;
+  }
+  int d_u, d_rh, d_g, d_l;
+  {
+    const int id = tid < dtot ? tid : 0;
+    const int c4 = id & 15, p = id >> 4;
+    const int u = p / (RUh * W2), rem = p - u * RUh * W2, rh = rem / W2, pw = rem - rh * W2;
+    d_u = tid < dtot ? u : -1; d_rh = rh; d_g = pw * 64 + c4 * 4;
+    d_l = (u * DU + 2 * rh * CO + 2 * pw) * 64 + c4 * 4;
+  }
+  struct DM { float4 d; uint32_t m; };
+  float4 pi[NI];
+  DM pd;
+  auto issue = [&](int ub) {
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const int uid = ub + (i_u[q] < 0 ? 0 : i_u[q]);
+      const int uc = (uid < uend) ? uid : ubeg;
+      const int sample = uc / UPS, j = uc - sample * UPS, row = j * RU - 1 + i_ir[q];
+      const bool ok = (i_u[q] >= 0) && (uid < uend) && row >= 0 && row < H;
+      const float4 v = *(const float4*)(src + ((size_t)sample * HW + (ok ? row : 0) * W) * 64 + i_g[q]);
+      pi[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {
+      const int uid = ub + (d_u < 0 ? 0 : d_u);
+      const int uc = (uid < uend) ? uid : ubeg;
+      const int sample = uc / UPS, j = uc - sample * UPS, prow = j * RUh + d_rh;
+      const bool ok = (d_u >= 0) && (uid < uend) && prow < H2;
+      const size_t gi = ((size_t)sample * P2 + (ok ? prow : 0) * W2) * 64 + d_g;
+      pd.d = *(const float4*)(dp + gi);
+      pd.m = ok ? *(const uint32_t*)(mk + gi) : 0u;
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int q = 0; q < NI; ++q)
+      if (i_u[q] >= 0) *(float4*)(buf + i_l[q]) = pi[q];
+    if (d_u >= 0) {
+      float* dzb = buf + IMGF + d_l;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        float4 v;
+        v.x = ((pd.m >> sub) & 1u) ? pd.d.x * 0.25f : 0.f;
+        v.y = ((pd.m >> (8 + sub)) & 1u) ? pd.d.y * 0.25f : 0.f;
+        v.z = ((pd.m >> (16 + sub)) & 1u) ? pd.d.z * 0.25f : 0.f;
+        v.w = ((pd.m >> (24 + sub)) & 1u) ? pd.d.w * 0.25f : 0.f;
+        *(float4*)(dzb + ((sub >> 1) * CO + (sub & 1)) * 64) = v;
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) acc[s] = zero16();
+  float dbacc = 0.f;
+  int shoff[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) shoff[s] = ((s / 3 - 1) * PW + (s % 3 - 1)) * 64;
+
+  if (ubeg < uend) issue(ubeg);
+  __syncthreads();                 // zero fill complete
+  if (ubeg < uend) commit(smem);
+  __syncthreads();
+  STAMP(2, 1);
+  const int rows = U * RU, cpr = CO >> 1, pairs = rows * cpr;   // rows is even, so pairs is even
+  // Operand addressing.  Pixel pair (row r, columns 2cp, 2cp+1) of unit u; lane half hh takes column 2cp+hh.
+  // Tap (kh, kw) of that pixel sits at padded position ((r + kh) * PW + 2cp + hh + kw): three row pointers and
+  // the immediate offsets 0 / 64 / 128 floats.  The running offset advances by 128 floats per pair, plus a row
+  // jump at the end of a row and a unit jump (the two halo rows) at the end of a unit; dz is contiguous.
+  const int rowjump = PW * 64 - cpr * 128, unitjump = 2 * PW * 64, rstride = PW * 64;
+  int cur = 0;
+  for (int ub = ubeg; ub < uend; ub += U) {
+    const bool more = ub + U < uend;            // workgroup-uniform
+    if (more) issue(ub + U);                    // global loads in flight across the MFMA loop below
+    const float* buf = smem + cur * BUF;
+    const float* a_base = buf + it * 32 + l31 + hh * 64;
+    const float* b_base = buf + IMGF + ct * 32 + l31 + hh * 64;
+    float a0[9], a1[9], b0, b1;                 // ping-pong operand sets: no register copies in the loop
+    int aoff = 0, boff = 0, cp = 0, r = 0;
+    // One region per MFMA, fenced by sched_barrier: the MFMA of the current pair plus ONE LDS read of the next
+    // pair.  With a single wave per SIMD nothing else keeps the MFMA pipe fed, so reads and address arithmetic
+    // must issue in the shadow of the 64-cycle MFMAs instead of in a block in front of them (measured: the
+    // blocked form ran the loop at 1025 cycles per pair against 576 cycles of MFMA).
+#define WG3_ADVANCE()                                                           \
+    {                                                                           \
+      aoff += 128; boff += 128;                                                 \
+      if (++cp == cpr) { cp = 0; aoff += rowjump; if (++r == RU) { r = 0; aoff += unitjump; } } \
+    }
+#define WG3_STEP(S, CA, CB, NA, PTR, OFF)                                       \
+    NA[S] = PTR[OFF];                                                           \
+    acc[S] = mfma32(CA[S], CB, acc[S]);                                         \
+    __builtin_amdgcn_sched_barrier(0);
+#define WG3_HALF(CA, CB, NA, NB)                                                \
+    {                                                                           \
+      const float* p0 = a_base + aoff;                                          \
+      const float* p1 = p0 + rstride;                                           \
+      const float* p2 = p1 + rstride;                                           \
+      const float* pb = b_base + boff;                                          \
+      __builtin_amdgcn_sched_barrier(0);                                        \
+      WG3_STEP(0, CA, CB, NA, p0, 0)                                            \
+      WG3_STEP(1, CA, CB, NA, p0, 64)                                           \
+      WG3_STEP(2, CA, CB, NA, p0, 128)                                          \
+      WG3_STEP(3, CA, CB, NA, p1, 0)                                            \
+      WG3_STEP(4, CA, CB, NA, p1, 64)                                           \
+      WG3_STEP(5, CA, CB, NA, p1, 128)                                          \
+      WG3_STEP(6, CA, CB, NA, p2, 0)                                            \
+      WG3_STEP(7, CA, CB, NA, p2, 64)                                           \
+      NB = pb[0];                                                               \
+      WG3_STEP(8, CA, CB, NA, p2, 128)                                          \
+      dbacc += CB;                                                              \
+    }
+    {
+      const float* p0 = a_base;
+      const float* p1 = p0 + rstride;
+      const float* p2 = p1 + rstride;
+      a0[0] = p0[0]; a0[1] = p0[64]; a0[2] = p0[128];
+      a0[3] = p1[0]; a0[4] = p1[64]; a0[5] = p1[128];
+      a0[6] = p2[0]; a0[7] = p2[64]; a0[8] = p2[128];
+      b0 = b_base[0];
+    }
+    for (int t = 0; t < pairs; t += 2) {
+      WG3_ADVANCE()
+      WG3_HALF(a0, b0, a1, b1)
+      WG3_ADVANCE()
+      if (t + 2 >= pairs) { aoff = 0; boff = 0; }   // last prefetch re-reads pair 0 (stays inside the buffer)
+      WG3_HALF(a1, b1, a0, b0)
+    }
+#undef WG3_ADVANCE
+#undef WG3_STEP
+#undef WG3_HALF
+    if (more) commit(smem + (cur ^ 1) * BUF);
+    __syncthreads();   // stage g fully read by every wave, stage g+1 fully written
+    cur ^= 1;
+  }
+  STAMP(2, 2);
+
+  float* part = a.part + (long long)net * a.part_ns + (size_t)g * PART3;
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = it * 32 + acc_row(r, lane);
+      part[s * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r];
+    }
+  }
+  if (it == 0) {
+    const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
+    if (hh == 0) part[9 * 4096 + ct * 32 + l31] = tot;
+  }
+  STAMP(2, 3);
+}
+
 static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
   const int PW = W + 2, CO = 2 * (W / 2);
   const size_t D = (size_t)U * RU * CO;
@@ -702,6 +913,34 @@ bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
   if (p->cspl == 2) { G = (NU + 1) / 2; if (G > 128) G = 128; }   // 2 co-halves x 2 nets x 128 = 512 workgroups
   if (G > 256) G = 256;                            // per net; 2 nets -> 512 WGs
   p->RU = RU; p->U = U; p->G = (int)G; p->lds = wgrad3_lds(RU, U, W, p->cspl);
+  p->NI = 0;
+  // pipelined kernel: units of 2 output rows, U of them per stage so that a stage carries >= 16 pixel pairs
+  // (amortises the per-stage barrier) but needs at most 8 float4 of prefetch registers per thread
+  static const int pipe = getenv("CMLPL_WGRAD3_PIPE") ? atoi(getenv("CMLPL_WGRAD3_PIPE")) : 1;
+  static const int force_pg = getenv("CMLPL_WGRAD3_PG") ? atoi(getenv("CMLPL_WGRAD3_PG")) : 0;
+  static const int force_pu = getenv("CMLPL_WGRAD3_PU") ? atoi(getenv("CMLPL_WGRAD3_PU")) : 0;
+  const int CO = 2 * (W / 2);
+  if (pipe && p->cspl == 1 && W <= 32 && CO >= 2) {
+    const int RUp = 2, UPSp = RO / 2;
+    int Up = (16 + CO - 1) / CO;
+    if (Up > 32 / W) Up = 32 / W;
+    if (Up < 1) Up = 1;
+    if (force_pu > 0) Up = force_pu;
+    const int items = Up * (RUp + 2) * W * 16;
+    const int NI = (items + 255) / 256;
+    const int ditems = Up * W / 2 * 16;
+    const size_t lds = 2 * wgrad3_lds(RUp, Up, W);
+    if (NI <= 8 && ditems <= 256 && lds <= LDS_MAX) {
+      const long long NUp = (long long)n * UPSp;
+      // one workgroup per CU across both networks; whole samples per workgroup
+      long long Gp = n < 128 ? n : 128;
+      if (force_pg > 0) Gp = force_pg < n ? force_pg : n;
+      const long long spg = (n + Gp - 1) / Gp;     // samples per workgroup
+      Gp = (n + spg - 1) / spg;
+      (void)NUp;
+      p->RU = RUp; p->U = Up; p->G = (int)Gp; p->lds = lds; p->NI = NI <= 4 ? 4 : (NI <= 6 ? 6 : 8);
+    }
+  }
   return true;
 }
 
@@ -724,7 +963,19 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G;
-  if (pl.cspl == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(pl.G, nets, 2), dim3(256), pl.lds, st, a);
+  if (pl.NI > 0) {
+    static bool attr_p = false;
+    if (!attr_p) {
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad3p_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad3p_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+      if (e != hipSuccess) return e;
+      attr_p = true;
+    }
+    if (pl.NI == 4)      hipLaunchKernelGGL(wgrad3p_kernel<4>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
+    else if (pl.NI == 6) hipLaunchKernelGGL(wgrad3p_kernel<6>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
+    else                 hipLaunchKernelGGL(wgrad3p_kernel<8>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
+  } else if (pl.cspl == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(pl.G, nets, 2), dim3(256), pl.lds, st, a);
   else              hipLaunchKernelGGL(wgrad3_kernel<1>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
   return hipGetLastError();
 }

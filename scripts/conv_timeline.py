@@ -1,0 +1,33 @@
+"""Ablation aid: per-workgroup phase timeline of conv3x3_kernel (needs the CMLPL_ABL=9 build of the library).
+   CMLPL_LIB=cmlpl_amd/libabl9.so python scripts/conv_timeline.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from cmlpl_amd import TrainEngine, NetShape, HyperParams, _lib
+
+shape = NetShape(103, 11, 11, 103, 9)
+eng = TrainEngine(shape, 128, 128, HyperParams(), device="cuda:0", seed=1)
+g = torch.Generator(device="cuda:0").manual_seed(0)
+XPl = torch.randn(128, 103, 11, 11, device="cuda:0", generator=g)
+XPu = torch.randn(128, 103, 11, 11, device="cuda:0", generator=g)
+Xl = torch.randn(128, 103, device="cuda:0", generator=g)
+Xu = torch.randn(128, 103, device="cuda:0", generator=g)
+Y = torch.randint(0, 9, (128,), device="cuda:0", generator=g)
+for i in range(20):
+    eng.step(XPl, Xl, Y, XPu, Xu, 1, i)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = np.zeros((3, 2048, 8), dtype=np.uint64)
+rc = lib.cmlpl_abl_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
+assert rc == 0
+for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1, last launch)", 256)):
+    t = buf[mode, :nwg, :4].astype(np.int64)
+    t0 = t[:, 0].min()
+    us = (t - t0) / 100.0
+    print(f"{name}: start skew  mean {us[:,0].mean():.2f}  max {us[:,0].max():.2f} us")
+    print(f"{name}: stage  {np.mean(us[:,1]-us[:,0]):.2f} us   taps {np.mean(us[:,2]-us[:,1]):.2f} us   "
+          f"epilogue {np.mean(us[:,3]-us[:,2]):.2f} us   last end {us[:,3].max():.2f} us")
+    print(f"   per-WG percentiles of (taps): {np.percentile(us[:,2]-us[:,1],[5,50,95])}")
+    print(f"   per-WG percentiles of (stage): {np.percentile(us[:,1]-us[:,0],[5,50,95])}")
+    print(f"   per-WG percentiles of (end): {np.percentile(us[:,3],[5,50,95])}")

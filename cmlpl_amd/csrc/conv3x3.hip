@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
 // registers, and are written to the other LDS half after the loop.  One barrier per stage.  A workgroup has a
 // single wave per SIMD here (4 waves, 144 accumulator registers each), so nothing else would hide the staging
 // latency: measured on B2/256 conv1 the unpipelined kernel spends 10 of its 59 us staging with the MFMA pipe idle.
-template <int NI>
+template <int NI, int ND>
 __global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -713,10 +713,12 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
   const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
   const int ct = wave & 1, it = wave >> 1;
 
-  // stage items of this thread: the (unit, row, column, channel chunk) decode does not depend on the stage
+  // stage items of this thread: the (unit, row, column, channel chunk) decode does not depend on the stage;
+  // the (sample, unit-in-sample) pair of every item is carried from stage to stage (no divisions in the loop)
   const int RUh = RU >> 1;
   const int itot = U * (RU + 2) * W * 16, dtot = U * RUh * W2 * 16;
-  int i_u[NI], i_ir[NI], i_g[NI], i_l[NI];
+  const int qU = U / UPS, rU = U - qU * UPS;
+  int i_u[NI], i_ir[NI], i_g[NI], i_l[NI], i_smp[NI], i_j[NI];
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
     const int idx = tid + q * 256;
@@ -725,52 +727,61 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
     const int u = p / ((RU + 2) * W), rem = p - u * (RU + 2) * W, ir = rem / W, w = rem - ir * W;
     i_u[q] = idx < itot ? u : -1; i_ir[q] = ir; i_g[q] = w * 64 + c4 * 4;
     i_l[q] = (u * IMGU + ir * PW + w + 1) * 64 + c4 * 4;
+    i_smp[q] = (ubeg + u) / UPS; i_j[q] = (ubeg + u) - i_smp[q] * UPS;
   }
-  int d_u, d_rh, d_g, d_l;
-  {
-    const int id = tid < dtot ? tid : 0;
+  int d_u[ND], d_rh[ND], d_g[ND], d_l[ND], d_smp[ND], d_j[ND];
+#pragma unroll
+  for (int q = 0; q < ND; ++q) {
+    const int idx = tid + q * 256;
+    const int id = idx < dtot ? idx : 0;
     const int c4 = id & 15, p = id >> 4;
     const int u = p / (RUh * W2), rem = p - u * RUh * W2, rh = rem / W2, pw = rem - rh * W2;
-    d_u = tid < dtot ? u : -1; d_rh = rh; d_g = pw * 64 + c4 * 4;
-    d_l = (u * DU + 2 * rh * CO + 2 * pw) * 64 + c4 * 4;
+    d_u[q] = idx < dtot ? u : -1; d_rh[q] = rh; d_g[q] = pw * 64 + c4 * 4;
+    d_l[q] = (u * DU + 2 * rh * CO + 2 * pw) * 64 + c4 * 4;
+    d_smp[q] = (ubeg + u) / UPS; d_j[q] = (ubeg + u) - d_smp[q] * UPS;
   }
   struct DM { float4 d; uint32_t m; };
   float4 pi[NI];
-  DM pd;
+  DM pd[ND];
+  // issue(ub) must be called for ub = ubeg, ubeg + U, ... in order (it advances the carried indices)
   auto issue = [&](int ub) {
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
-      const int uid = ub + (i_u[q] < 0 ? 0 : i_u[q]);
-      const int uc = (uid < uend) ? uid : ubeg;
-      const int sample = uc / UPS, j = uc - sample * UPS, row = j * RU - 1 + i_ir[q];
-      const bool ok = (i_u[q] >= 0) && (uid < uend) && row >= 0 && row < H;
-      const float4 v = *(const float4*)(src + ((size_t)sample * HW + (ok ? row : 0) * W) * 64 + i_g[q]);
+      const int row = i_j[q] * RU - 1 + i_ir[q];
+      const bool ok = (i_u[q] >= 0) && (ub + i_u[q] < uend) && row >= 0 && row < H;
+      const float4 v = *(const float4*)(src + ((size_t)(ok ? i_smp[q] : ubeg / UPS) * HW + (ok ? row : 0) * W) * 64 + i_g[q]);
       pi[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      i_smp[q] += qU; i_j[q] += rU;
+      if (i_j[q] >= UPS) { i_j[q] -= UPS; ++i_smp[q]; }
     }
-    {
-      const int uid = ub + (d_u < 0 ? 0 : d_u);
-      const int uc = (uid < uend) ? uid : ubeg;
-      const int sample = uc / UPS, j = uc - sample * UPS, prow = j * RUh + d_rh;
-      const bool ok = (d_u >= 0) && (uid < uend) && prow < H2;
-      const size_t gi = ((size_t)sample * P2 + (ok ? prow : 0) * W2) * 64 + d_g;
-      pd.d = *(const float4*)(dp + gi);
-      pd.m = ok ? *(const uint32_t*)(mk + gi) : 0u;
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+      const int prow = d_j[q] * RUh + d_rh[q];
+      const bool ok = (d_u[q] >= 0) && (ub + d_u[q] < uend) && prow < H2;
+      const size_t gi = ((size_t)(ok ? d_smp[q] : ubeg / UPS) * P2 + (ok ? prow : 0) * W2) * 64 + d_g[q];
+      pd[q].d = *(const float4*)(dp + gi);
+      pd[q].m = ok ? *(const uint32_t*)(mk + gi) : 0u;
+      d_smp[q] += qU; d_j[q] += rU;
+      if (d_j[q] >= UPS) { d_j[q] -= UPS; ++d_smp[q]; }
     }
   };
   auto commit = [&](float* buf) {
 #pragma unroll
     for (int q = 0; q < NI; ++q)
       if (i_u[q] >= 0) *(float4*)(buf + i_l[q]) = pi[q];
-    if (d_u >= 0) {
-      float* dzb = buf + IMGF + d_l;
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        float4 v;
-        v.x = ((pd.m >> sub) & 1u) ? pd.d.x * 0.25f : 0.f;
-        v.y = ((pd.m >> (8 + sub)) & 1u) ? pd.d.y * 0.25f : 0.f;
-        v.z = ((pd.m >> (16 + sub)) & 1u) ? pd.d.z * 0.25f : 0.f;
-        v.w = ((pd.m >> (24 + sub)) & 1u) ? pd.d.w * 0.25f : 0.f;
-        *(float4*)(dzb + ((sub >> 1) * CO + (sub & 1)) * 64) = v;
+    for (int q = 0; q < ND; ++q) {
+      if (d_u[q] >= 0) {
+        float* dzb = buf + IMGF + d_l[q];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          float4 v;
+          v.x = ((pd[q].m >> sub) & 1u) ? pd[q].d.x * 0.25f : 0.f;
+          v.y = ((pd[q].m >> (8 + sub)) & 1u) ? pd[q].d.y * 0.25f : 0.f;
+          v.z = ((pd[q].m >> (16 + sub)) & 1u) ? pd[q].d.z * 0.25f : 0.f;
+          v.w = ((pd[q].m >> (24 + sub)) & 1u) ? pd[q].d.w * 0.25f : 0.f;
+          *(float4*)(dzb + ((sub >> 1) * CO + (sub & 1)) * 64) = v;
+        }
       }
     }
   };
@@ -779,9 +790,6 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
 #pragma unroll
   for (int s = 0; s < 9; ++s) acc[s] = zero16();
   float dbacc = 0.f;
-  int shoff[9];
-#pragma unroll
-  for (int s = 0; s < 9; ++s) shoff[s] = ((s / 3 - 1) * PW + (s % 3 - 1)) * 64;
 
   if (ubeg < uend) issue(ubeg);
   __syncthreads();                 // zero fill complete
@@ -803,38 +811,31 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
     const float* b_base = buf + IMGF + ct * 32 + l31 + hh * 64;
     float a0[9], a1[9], b0, b1;                 // ping-pong operand sets: no register copies in the loop
     int aoff = 0, boff = 0, cp = 0, r = 0;
-    // One region per MFMA, fenced by sched_barrier: the MFMA of the current pair plus ONE LDS read of the next
-    // pair.  With a single wave per SIMD nothing else keeps the MFMA pipe fed, so reads and address arithmetic
-    // must issue in the shadow of the 64-cycle MFMAs instead of in a block in front of them (measured: the
-    // blocked form ran the loop at 1025 cycles per pair against 576 cycles of MFMA).
-#define WG3_ADVANCE()                                                           \
-    {                                                                           \
-      aoff += 128; boff += 128;                                                 \
-      if (++cp == cpr) { cp = 0; aoff += rowjump; if (++r == RU) { r = 0; aoff += unitjump; } } \
-    }
-#define WG3_STEP(S, CA, CB, NA, PTR, OFF)                                       \
+    // One region per MFMA, fenced by sched_barrier: the MFMA of the current pair, ONE LDS read of the next pair
+    // and a slice of the address bookkeeping of the pair after that.  With a single wave per SIMD nothing else
+    // keeps the MFMA pipe fed, and the wave issues in order: any block of non-MFMA instructions longer than one
+    // MFMA (64 cycles) is a bubble.  Measured per pair: 1025 cycles with reads and bookkeeping in a block in
+    // front of the MFMAs, 740 with only the reads interleaved, against 576 cycles of MFMA.
+#define WG3_REGION(S, CA, CB, NA, PTR, OFF, EXTRA)                              \
     NA[S] = PTR[OFF];                                                           \
     acc[S] = mfma32(CA[S], CB, acc[S]);                                         \
+    EXTRA;                                                                      \
     __builtin_amdgcn_sched_barrier(0);
-#define WG3_HALF(CA, CB, NA, NB)                                                \
+    // P* = operand pointers of the pair loaded in this half, Q* = those of the following pair (formed here)
+#define WG3_HALF(CA, CB, NA, NB, P0, P1, P2, PB, Q0, Q1, Q2, QB, TN)            \
     {                                                                           \
-      const float* p0 = a_base + aoff;                                          \
-      const float* p1 = p0 + rstride;                                           \
-      const float* p2 = p1 + rstride;                                           \
-      const float* pb = b_base + boff;                                          \
-      __builtin_amdgcn_sched_barrier(0);                                        \
-      WG3_STEP(0, CA, CB, NA, p0, 0)                                            \
-      WG3_STEP(1, CA, CB, NA, p0, 64)                                           \
-      WG3_STEP(2, CA, CB, NA, p0, 128)                                          \
-      WG3_STEP(3, CA, CB, NA, p1, 0)                                            \
-      WG3_STEP(4, CA, CB, NA, p1, 64)                                           \
-      WG3_STEP(5, CA, CB, NA, p1, 128)                                          \
-      WG3_STEP(6, CA, CB, NA, p2, 0)                                            \
-      WG3_STEP(7, CA, CB, NA, p2, 64)                                           \
-      NB = pb[0];                                                               \
-      WG3_STEP(8, CA, CB, NA, p2, 128)                                          \
-      dbacc += CB;                                                              \
+      WG3_REGION(0, CA, CB, NA, P0, 0,   (aoff += 128, boff += 128, ++cp))      \
+      WG3_REGION(1, CA, CB, NA, P0, 64,  { if (cp == cpr) { cp = 0; aoff += rowjump; ++r; } }) \
+      WG3_REGION(2, CA, CB, NA, P0, 128, { if (r == RU) { r = 0; aoff += unitjump; } })        \
+      WG3_REGION(3, CA, CB, NA, P1, 0,   { if ((TN) >= pairs) { aoff = 0; boff = 0; } }) \
+      WG3_REGION(4, CA, CB, NA, P1, 64,  Q0 = a_base + aoff)                    \
+      WG3_REGION(5, CA, CB, NA, P1, 128, Q1 = Q0 + rstride)                     \
+      WG3_REGION(6, CA, CB, NA, P2, 0,   Q2 = Q1 + rstride)                     \
+      WG3_REGION(7, CA, CB, NA, P2, 64,  QB = b_base + boff)                    \
+      NB = PB[0];                                                               \
+      WG3_REGION(8, CA, CB, NA, P2, 128, dbacc += CB)                           \
     }
+    const float *x0, *x1, *x2, *xb, *y0, *y1, *y2, *yb;
     {
       const float* p0 = a_base;
       const float* p1 = p0 + rstride;
@@ -843,16 +844,17 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
       a0[3] = p1[0]; a0[4] = p1[64]; a0[5] = p1[128];
       a0[6] = p2[0]; a0[7] = p2[64]; a0[8] = p2[128];
       b0 = b_base[0];
+      // pointers of pair 1
+      aoff = 128; boff = 128; cp = 1;
+      if (cp == cpr) { cp = 0; aoff += rowjump; ++r; }
+      if (r == RU) { r = 0; aoff += unitjump; }
+      x0 = a_base + aoff; x1 = x0 + rstride; x2 = x1 + rstride; xb = b_base + boff;
     }
     for (int t = 0; t < pairs; t += 2) {
-      WG3_ADVANCE()
-      WG3_HALF(a0, b0, a1, b1)
-      WG3_ADVANCE()
-      if (t + 2 >= pairs) { aoff = 0; boff = 0; }   // last prefetch re-reads pair 0 (stays inside the buffer)
-      WG3_HALF(a1, b1, a0, b0)
+      WG3_HALF(a0, b0, a1, b1, x0, x1, x2, xb, y0, y1, y2, yb, t + 2)   // MFMA pair t, load t+1, address t+2
+      WG3_HALF(a1, b1, a0, b0, y0, y1, y2, yb, x0, x1, x2, xb, t + 3)   // MFMA pair t+1, load t+2, address t+3
     }
-#undef WG3_ADVANCE
-#undef WG3_STEP
+#undef WG3_REGION
 #undef WG3_HALF
     if (more) commit(smem + (cur ^ 1) * BUF);
     __syncthreads();   // stage g fully read by every wave, stage g+1 fully written
@@ -920,25 +922,31 @@ bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
   static const int force_pg = getenv("CMLPL_WGRAD3_PG") ? atoi(getenv("CMLPL_WGRAD3_PG")) : 0;
   static const int force_pu = getenv("CMLPL_WGRAD3_PU") ? atoi(getenv("CMLPL_WGRAD3_PU")) : 0;
   const int CO = 2 * (W / 2);
-  if (pipe && p->cspl == 1 && W <= 32 && CO >= 2) {
-    const int RUp = 2, UPSp = RO / 2;
-    int Up = (16 + CO - 1) / CO;
-    if (Up > 32 / W) Up = 32 / W;
-    if (Up < 1) Up = 1;
-    if (force_pu > 0) Up = force_pu;
-    const int items = Up * (RUp + 2) * W * 16;
-    const int NI = (items + 255) / 256;
-    const int ditems = Up * W / 2 * 16;
-    const size_t lds = 2 * wgrad3_lds(RUp, Up, W);
-    if (NI <= 8 && ditems <= 256 && lds <= LDS_MAX) {
-      const long long NUp = (long long)n * UPSp;
+  if (pipe && p->cspl == 1 && CO >= 2) {
+    auto ni_of = [&](int ru, int u) { return (u * (ru + 2) * W * 16 + 255) / 256; };
+    auto nd_of = [&](int ru, int u) { return (u * (ru / 2) * (W / 2) * 16 + 255) / 256; };
+    auto fits = [&](int ru, int u) {
+      return 2 * wgrad3_lds(ru, u, W) <= LDS_MAX && ni_of(ru, u) <= 16 && nd_of(ru, u) <= 2;
+    };
+    // rows per unit: the largest even divisor of the output rows whose double buffer fits (a whole sample for
+    // 11x11 windows: two stages per workgroup instead of five)
+    int RUp = 0;
+    for (int cand = RO; cand >= 2; cand -= 2)
+      if (RO % cand == 0 && fits(cand, 1)) { RUp = cand; break; }
+    if (RUp > 0) {
+      const int ppu = RUp * CO / 2;                 // pixel pairs per unit
+      int Up = 1;
+      while (Up * ppu < 16 && fits(RUp, Up + 1)) ++Up;
+      if (force_pu > 0 && fits(RUp, force_pu)) Up = force_pu;
       // one workgroup per CU across both networks; whole samples per workgroup
       long long Gp = n < 128 ? n : 128;
       if (force_pg > 0) Gp = force_pg < n ? force_pg : n;
       const long long spg = (n + Gp - 1) / Gp;     // samples per workgroup
       Gp = (n + spg - 1) / spg;
-      (void)NUp;
-      p->RU = RUp; p->U = Up; p->G = (int)Gp; p->lds = lds; p->NI = NI <= 4 ? 4 : (NI <= 6 ? 6 : 8);
+      const int NI = ni_of(RUp, Up);
+      p->RU = RUp; p->U = Up; p->G = (int)Gp; p->lds = 2 * wgrad3_lds(RUp, Up, W);
+      p->NI = NI <= 4 ? 4 : NI <= 6 ? 6 : NI <= 8 ? 8 : NI <= 10 ? 10 : NI <= 12 ? 12 : 16;
+      p->ND = nd_of(RUp, Up);
     }
   }
   return true;
@@ -964,17 +972,22 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G;
   if (pl.NI > 0) {
-    static bool attr_p = false;
-    if (!attr_p) {
-      hipError_t e = hipFuncSetAttribute((const void*)wgrad3p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad3p_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad3p_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-      if (e != hipSuccess) return e;
-      attr_p = true;
+#define WG3P_CASE(NI_, ND_)                                                                          \
+    if (pl.NI == NI_ && pl.ND == ND_) {                                                              \
+      static bool attr_p = false;                                                                    \
+      if (!attr_p) {                                                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3p_kernel<NI_, ND_>,                    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); \
+        if (e != hipSuccess) return e;                                                               \
+        attr_p = true;                                                                               \
+      }                                                                                              \
+      hipLaunchKernelGGL((wgrad3p_kernel<NI_, ND_>), dim3(pl.G, nets), dim3(256), pl.lds, st, a);    \
+      return hipGetLastError();                                                                      \
     }
-    if (pl.NI == 4)      hipLaunchKernelGGL(wgrad3p_kernel<4>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
-    else if (pl.NI == 6) hipLaunchKernelGGL(wgrad3p_kernel<6>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
-    else                 hipLaunchKernelGGL(wgrad3p_kernel<8>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
+    WG3P_CASE(4, 1) WG3P_CASE(6, 1) WG3P_CASE(8, 1) WG3P_CASE(10, 1) WG3P_CASE(12, 1) WG3P_CASE(16, 1)
+    WG3P_CASE(4, 2) WG3P_CASE(6, 2) WG3P_CASE(8, 2) WG3P_CASE(10, 2) WG3P_CASE(12, 2) WG3P_CASE(16, 2)
+#undef WG3P_CASE
+    return hipErrorInvalidValue;
   } else if (pl.cspl == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(pl.G, nets, 2), dim3(256), pl.lds, st, a);
   else              hipLaunchKernelGGL(wgrad3_kernel<1>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
   return hipGetLastError();

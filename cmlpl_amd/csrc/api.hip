@@ -42,7 +42,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up256(bytes); return p; };
   const size_t N = (size_t)nets * n;
   Wgrad3Plan w1, w2;
-  if (!plan_wgrad3(n, d.H, d.W, &w1) || !plan_wgrad3(n, d.H2, d.W2, &w2)) return false;
+  if (!plan_wgrad3(nets, n, d.H, d.W, &w1) || !plan_wgrad3(nets, n, d.H2, d.W2, &w2)) return false;
   Conv3Plan c;
   if (!plan_conv3(0, d.H, d.W, nets * n, &c) || !plan_conv3(1, d.H, d.W, nets * n, &c) ||
       !plan_conv3(0, d.H2, d.W2, nets * n, &c) || !plan_conv3(1, d.H2, d.W2, nets * n, &c)) return false;
@@ -332,8 +332,8 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
   rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride;
-  reduce_table_add(rt, w.part1, wgrad3_G(n, d.H, d.W), PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
-  reduce_table_add(rt, w.part2, wgrad3_G(n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
+  reduce_table_add(rt, w.part1, wgrad3_G(nets, n, d.H, d.W), PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
+  reduce_table_add(rt, w.part2, wgrad3_G(nets, n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
   reduce_table_add(rt, w.part0, plan_conv0_wgrad_G(n, d.C, d.HW), conv0_partial_size(d.C), 0, d.C,
                    d_grads + L.param_off[0], d_grads + L.param_off[1]);
   return TIMED(CMLPL_K_CONV1_WRED, chk(launch_partial_reduce(nets, rt, st)));

@@ -505,7 +505,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
 struct Wgrad3Args {
   const float* in; const float* dpool; const uint8_t* mask; float* part;
   long long in_ns, dpool_ns, part_ns;
-  int n, H, W, RU, U, G;
+  int n, H, W, RU, U, G, UPG;
 };
 
 // CSPL = 1: one workgroup produces all 64 output channels (wave = (co tile, ci tile), 9 taps each).
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   const int RU = a.RU, U = a.U;
   const int IMGU = (RU + 2) * PW;          // padded rows of one unit
   const int DU = RU * CO;                  // dz slots per unit
-  const int D = U * DU;                    // dz slots per pass
+  const int D = U * DU; (void)D;           // dz slots per pass
   const int UPS = (RO + RU - 1) / RU;      // units per sample
   const int NU = a.n * UPS;
   const int UPG = (NU + a.G - 1) / a.G;
@@ -681,199 +681,239 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wgrad3Args a) {
   }
 }
 
-// Pipelined variant (the default whenever a stage of U units needs <= NI float4 per thread): LDS holds TWO
-// stages; while the 9-tap MFMA loop runs on stage g, the rows of stage g+1 are already in flight global ->
-// registers, and are written to the other LDS half after the loop.  One barrier per stage.  A workgroup has a
-// single wave per SIMD here (4 waves, 144 accumulator registers each), so nothing else would hide the staging
-// latency: measured on B2/256 conv1 the unpipelined kernel spends 10 of its 59 us staging with the MFMA pipe idle.
-template <int NI, int ND>
-__global__ __launch_bounds__(256) void wgrad3p_kernel(Wgrad3Args a) {
+// Row-split variant (default): blockIdx.z = kernel row kh, so a workgroup owns the three taps (kh, 0..2) for ALL
+// 64x64 channel pairs and walks three times as many samples as a workgroup that owns all nine taps would.  What
+// that buys on B2/256: the per-workgroup partials (and with them the kernel-end write drain and the reduce
+// kernel's input) shrink from 37.7 MB to 11.8 MB per launch; no halo rows are staged (tap row kh of output row r
+// is input row r + kh - 1, zero outside the image); one A row pointer per output row instead of three.
+//   512 threads: wave w = (pixel group kg = w >> 2, ci tile (w >> 1) & 1, co tile w & 1), 3 accumulators each
+//   (kw = 0..2).  A stage holds U units (unit = one pooled row = two output rows); pixel group kg takes the units
+//   of its parity, so the two waves of a SIMD run independent MFMA streams; the two groups are folded through LDS
+//   once, after the last stage.  Stages are double-buffered: while the MFMA loop runs on stage g, the rows of
+//   stage g+1 are in flight global -> registers and are written to the other LDS half after the loop.
+//   CPR (column pairs per output row) is a template parameter and a whole unit (2 x CPR pixel pairs) is unrolled,
+//   so every LDS operand address is a row pointer plus an immediate.  This matters more than anything else here
+//   (scripts/mfma_mix*.hip, MI355X): a lone wave issues v_mfma_f32_32x32x2 every 70 cycles, not 64; each VALU
+//   instruction between two MFMAs costs ~6-15 cycles; and scalar instructions are a CU-wide ~1/cycle resource
+//   that more waves do NOT hide -- the generic (cp, r, unit) bookkeeping, ~22 s_cmp/s_cselect per pixel pair,
+//   held the loop at 1.5x its MFMA time.
+//   Staging: the activation rows go global -> LDS directly (global_load_lds_dwordx4: one wave-instruction moves
+//   4 pixels x 64 channels = 1 KiB, no VGPR round trip, no ds_write), a stage is rows x ceil(W/4) such pieces
+//   spread over the eight waves, all bookkeeping scalar.  Only the pooled gradient (it needs the ReLU-mask
+//   multiply and the 2x2 upsample) is staged through registers, one item per thread.  With every wave staging
+//   its share through registers instead (4 float4 + address arithmetic + ds_write per thread and stage) the
+//   same kernel measured 43.5 us on B2/256: ~200 non-MFMA instructions per thread and stage are not hidden by
+//   the other wave of the SIMD.  (Also tried and slower: four dedicated loader waves, 49 us.)
+constexpr int WG3R_NTK = 4;    // LDS-DMA pieces per wave and stage (planner keeps rows x ceil(W/4) <= 32)
+typedef __attribute__((address_space(3))) void wg3r_lds_void;
+typedef __attribute__((address_space(1))) const void wg3r_gbl_void;
+template <int CPR>
+__global__ __launch_bounds__(512) void wgrad3r_kernel(Wgrad3Args a) {
+  constexpr int NT = 512, NTK = WG3R_NTK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int net = blockIdx.y, g = blockIdx.x;
+  const int net = blockIdx.y, g = blockIdx.x, kh = blockIdx.z;
   const int H = a.H, W = a.W, HW = H * W, PW = W + 2;
-  const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2, RO = 2 * H2, CO = 2 * W2;
-  const int RU = a.RU, U = a.U;
-  const int IMGU = (RU + 2) * PW, DU = RU * CO, D = U * DU;
-  const int UPS = (RO + RU - 1) / RU;
+  const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
+  constexpr int CO = 2 * CPR;
+  const int U = a.U;
+  const int IMGU = 2 * PW;
+  constexpr int DU = 2 * CO;
+  const int UPS = H2;                       // units (pooled rows) per sample
   const int NU = a.n * UPS;
-  const int UPG = (NU + a.G - 1) / a.G;
+  const int UPG = a.UPG;
   const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
-  const int IMGF = U * IMGU * 64, BUF = IMGF + D * 64;     // floats per stage buffer: [img | dz]
+  const int IMGF = U * IMGU * 64, BUF = IMGF + U * DU * 64;     // floats per stage buffer: [img | dz]
   STAMP(2, 0);
 
-  {  // borders of both buffers must be zero; interiors are rewritten every stage
+  {  // border columns of both buffers must be zero; interiors are rewritten every stage
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* p4 = (float4*)smem;
-    for (int i = tid; i < (2 * BUF) >> 2; i += 256) p4[i] = z;
+    for (int i = tid; i < (2 * BUF) >> 2; i += NT) p4[i] = z;
   }
   const float* src = a.in + (long long)net * a.in_ns;
   const float* dp = a.dpool + (long long)net * a.dpool_ns;
   const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
-  const int ct = wave & 1, it = wave >> 1;
+  const int ct = wave & 1, it = (wave >> 1) & 1, kg = wave >> 2;
 
-  // stage items of this thread: the (unit, row, column, channel chunk) decode does not depend on the stage;
-  // the (sample, unit-in-sample) pair of every item is carried from stage to stage (no divisions in the loop)
-  const int RUh = RU >> 1;
-  const int itot = U * (RU + 2) * W * 16, dtot = U * RUh * W2 * 16;
+  // LDS-DMA pieces of this wave: piece t = (stage row t / CH, 4-pixel chunk t % CH), t = wave, wave + 8, ...
+  // The decode is stage-invariant and wave-uniform; the (sample, unit-in-sample) pair of every piece and of the
+  // thread's pooled-gradient item is carried from stage to stage (no divisions per stage; 32-bit offsets, the
+  // planner checks that one network's activations stay below 2^31 elements).
+  const int CH = (W + 3) >> 2, ntask = 2 * U * CH;
   const int qU = U / UPS, rU = U - qU * UPS;
-  int i_u[NI], i_ir[NI], i_g[NI], i_l[NI], i_smp[NI], i_j[NI];
+  int t_u[NTK], t_irk[NTK], t_l[NTK], t_smp[NTK], t_j[NTK], t_lane[NTK];
 #pragma unroll
-  for (int q = 0; q < NI; ++q) {
-    const int idx = tid + q * 256;
-    const int id = idx < itot ? idx : 0;
-    const int c4 = id & 15, p = id >> 4;
-    const int u = p / ((RU + 2) * W), rem = p - u * (RU + 2) * W, ir = rem / W, w = rem - ir * W;
-    i_u[q] = idx < itot ? u : -1; i_ir[q] = ir; i_g[q] = w * 64 + c4 * 4;
-    i_l[q] = (u * IMGU + ir * PW + w + 1) * 64 + c4 * 4;
-    i_smp[q] = (ubeg + u) / UPS; i_j[q] = (ubeg + u) - i_smp[q] * UPS;
+  for (int q = 0; q < NTK; ++q) {
+    const int t = wave + 8 * q;
+    const int tt = t < ntask ? t : 0;
+    const int rowi = tt / CH, ch = tt - rowi * CH, u = rowi >> 1, ir = rowi & 1;
+    t_u[q] = t < ntask ? u : (1 << 28); t_irk[q] = ir + kh - 1;
+    t_l[q] = (u * IMGU + ir * PW + 1 + 4 * ch) * 64;                      // LDS float offset of the piece
+    t_smp[q] = (ubeg + u) / UPS; t_j[q] = (ubeg + u) - t_smp[q] * UPS;
+    const int px = 4 * ch + (lane >> 4);                                  // this lane's pixel of the row
+    t_lane[q] = px < W ? px * 64 + (lane & 15) * 4 : -1;                   // per-lane source offset (floats)
   }
-  int d_u[ND], d_rh[ND], d_g[ND], d_l[ND], d_smp[ND], d_j[ND];
-#pragma unroll
-  for (int q = 0; q < ND; ++q) {
-    const int idx = tid + q * 256;
-    const int id = idx < dtot ? idx : 0;
+  const int dtot = U * W2 * 16;          // <= 512 (planner)
+  int d_u, d_g, d_l, d_smp, d_j;
+  {
+    const int id = tid < dtot ? tid : 0;
     const int c4 = id & 15, p = id >> 4;
-    const int u = p / (RUh * W2), rem = p - u * RUh * W2, rh = rem / W2, pw = rem - rh * W2;
-    d_u[q] = idx < dtot ? u : -1; d_rh[q] = rh; d_g[q] = pw * 64 + c4 * 4;
-    d_l[q] = (u * DU + 2 * rh * CO + 2 * pw) * 64 + c4 * 4;
-    d_smp[q] = (ubeg + u) / UPS; d_j[q] = (ubeg + u) - d_smp[q] * UPS;
+    const int u = p / W2, pw = p - u * W2;
+    d_u = tid < dtot ? u : (1 << 28); d_g = pw * 64 + c4 * 4;
+    d_l = (u * DU + 2 * pw) * 64 + c4 * 4;
+    d_smp = (ubeg + u) / UPS; d_j = (ubeg + u) - d_smp * UPS;
   }
-  struct DM { float4 d; uint32_t m; };
-  float4 pi[NI];
-  DM pd[ND];
-  // issue(ub) must be called for ub = ubeg, ubeg + U, ... in order (it advances the carried indices)
-  auto issue = [&](int ub) {
+  float4 pdd;
+  uint32_t pdm;
+  bool pdok = false;
+  float4 dbsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of channels 4*(tid&15)..+3 (kernel row 0 only)
+  // issue(ub, buf): start the transfer of the stage that begins at unit ub into buf.  Must be called for
+  // ub = ubeg, ubeg + U, ... in order (it advances the carried indices).  Rows outside the image or beyond the
+  // workgroup's range are zero-filled instead (the buffer holds an older stage).
+  auto issue = [&](int ub, float* buf) {
 #pragma unroll
-    for (int q = 0; q < NI; ++q) {
-      const int row = i_j[q] * RU - 1 + i_ir[q];
-      const bool ok = (i_u[q] >= 0) && (ub + i_u[q] < uend) && row >= 0 && row < H;
-      const float4 v = *(const float4*)(src + ((size_t)(ok ? i_smp[q] : ubeg / UPS) * HW + (ok ? row : 0) * W) * 64 + i_g[q]);
-      pi[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-      i_smp[q] += qU; i_j[q] += rU;
-      if (i_j[q] >= UPS) { i_j[q] -= UPS; ++i_smp[q]; }
+    for (int q = 0; q < NTK; ++q) {
+      const int row = t_j[q] * 2 + t_irk[q];
+      const bool ex = t_u[q] < (1 << 28);                                     // wave-uniform
+      const bool ok = ex && (ub + t_u[q] < uend) && row >= 0 && row < H;      // wave-uniform
+      if (ok && (CMLPL_ABL != 12 || ub == ubeg)) {
+        if (t_lane[q] >= 0)
+#if CMLPL_ABL == 10
+          __builtin_amdgcn_global_load_lds((wg3r_gbl_void*)(src + (((0 * HW + row * W) << 6) + t_lane[q])),
+#else
+          __builtin_amdgcn_global_load_lds((wg3r_gbl_void*)(src + (((t_smp[q] * HW + row * W) << 6) + t_lane[q])),
+#endif
+                                           (wg3r_lds_void*)(buf + t_l[q]), 16, 0, 0);
+      } else if (ex) {
+        if (t_lane[q] >= 0) *(float4*)(buf + t_l[q] + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      t_smp[q] += qU; t_j[q] += rU;
+      if (t_j[q] >= UPS) { t_j[q] -= UPS; ++t_smp[q]; }
     }
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-      const int prow = d_j[q] * RUh + d_rh[q];
-      const bool ok = (d_u[q] >= 0) && (ub + d_u[q] < uend) && prow < H2;
-      const size_t gi = ((size_t)(ok ? d_smp[q] : ubeg / UPS) * P2 + (ok ? prow : 0) * W2) * 64 + d_g[q];
-      pd[q].d = *(const float4*)(dp + gi);
-      pd[q].m = ok ? *(const uint32_t*)(mk + gi) : 0u;
-      d_smp[q] += qU; d_j[q] += rU;
-      if (d_j[q] >= UPS) { d_j[q] -= UPS; ++d_smp[q]; }
+    {
+      pdok = ub + d_u < uend;
+      const int gi = pdok ? ((d_smp * P2 + d_j * W2) << 6) + d_g : 0;
+      pdd = *(const float4*)(dp + gi);         // raw: touching the value here would put the wait before the MFMAs
+      pdm = *(const uint32_t*)(mk + gi);
+      d_smp += qU; d_j += rU;
+      if (d_j >= UPS) { d_j -= UPS; ++d_smp; }
     }
   };
   auto commit = [&](float* buf) {
+    if (d_u < (1 << 28)) {
+      if (!pdok) pdm = 0u;
+      float* dzb = buf + IMGF + d_l;
 #pragma unroll
-    for (int q = 0; q < NI; ++q)
-      if (i_u[q] >= 0) *(float4*)(buf + i_l[q]) = pi[q];
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-      if (d_u[q] >= 0) {
-        float* dzb = buf + IMGF + d_l[q];
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-          float4 v;
-          v.x = ((pd[q].m >> sub) & 1u) ? pd[q].d.x * 0.25f : 0.f;
-          v.y = ((pd[q].m >> (8 + sub)) & 1u) ? pd[q].d.y * 0.25f : 0.f;
-          v.z = ((pd[q].m >> (16 + sub)) & 1u) ? pd[q].d.z * 0.25f : 0.f;
-          v.w = ((pd[q].m >> (24 + sub)) & 1u) ? pd[q].d.w * 0.25f : 0.f;
-          *(float4*)(dzb + ((sub >> 1) * CO + (sub & 1)) * 64) = v;
-        }
+      for (int sub = 0; sub < 4; ++sub) {
+        float4 v;
+        v.x = ((pdm >> sub) & 1u) ? pdd.x * 0.25f : 0.f;
+        v.y = ((pdm >> (8 + sub)) & 1u) ? pdd.y * 0.25f : 0.f;
+        v.z = ((pdm >> (16 + sub)) & 1u) ? pdd.z * 0.25f : 0.f;
+        v.w = ((pdm >> (24 + sub)) & 1u) ? pdd.w * 0.25f : 0.f;
+        *(float4*)(dzb + ((sub >> 1) * CO + (sub & 1)) * 64) = v;
+        dbsum.x += v.x; dbsum.y += v.y; dbsum.z += v.z; dbsum.w += v.w;
       }
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[3];
 #pragma unroll
-  for (int s = 0; s < 9; ++s) acc[s] = zero16();
-  float dbacc = 0.f;
+  for (int s = 0; s < 3; ++s) acc[s] = zero16();
 
-  if (ubeg < uend) issue(ubeg);
   __syncthreads();                 // zero fill complete
-  if (ubeg < uend) commit(smem);
+  if (ubeg < uend) { issue(ubeg, smem); commit(smem); }
   __syncthreads();
   STAMP(2, 1);
-  const int rows = U * RU, cpr = CO >> 1, pairs = rows * cpr;   // rows is even, so pairs is even
-  // Operand addressing.  Pixel pair (row r, columns 2cp, 2cp+1) of unit u; lane half hh takes column 2cp+hh.
-  // Tap (kh, kw) of that pixel sits at padded position ((r + kh) * PW + 2cp + hh + kw): three row pointers and
-  // the immediate offsets 0 / 64 / 128 floats.  The running offset advances by 128 floats per pair, plus a row
-  // jump at the end of a row and a unit jump (the two halo rows) at the end of a unit; dz is contiguous.
-  const int rowjump = PW * 64 - cpr * 128, unitjump = 2 * PW * 64, rstride = PW * 64;
+  // This wave's units of a stage: kg, kg + 2, ...  Pixel pair q of a unit (row r = q / CPR, columns 2cp, 2cp+1
+  // with cp = q % CPR; lane half hh takes column 2cp + hh): tap kw is padded position r * PW + 2cp + hh + kw.
+  const int rstride = PW * 64, ustep_a = 2 * IMGU * 64;
+  constexpr int ustep_b = 2 * DU * 64;
+  const int nun = U >> 1;                     // units per wave and stage
+  const int issue_at = 0;                     // every wave starts its pieces of the next stage first thing
   int cur = 0;
   for (int ub = ubeg; ub < uend; ub += U) {
     const bool more = ub + U < uend;            // workgroup-uniform
-    if (more) issue(ub + U);                    // global loads in flight across the MFMA loop below
     const float* buf = smem + cur * BUF;
-    const float* a_base = buf + it * 32 + l31 + hh * 64;
-    const float* b_base = buf + IMGF + ct * 32 + l31 + hh * 64;
-    float a0[9], a1[9], b0, b1;                 // ping-pong operand sets: no register copies in the loop
-    int aoff = 0, boff = 0, cp = 0, r = 0;
-    // One region per MFMA, fenced by sched_barrier: the MFMA of the current pair, ONE LDS read of the next pair
-    // and a slice of the address bookkeeping of the pair after that.  With a single wave per SIMD nothing else
-    // keeps the MFMA pipe fed, and the wave issues in order: any block of non-MFMA instructions longer than one
-    // MFMA (64 cycles) is a bubble.  Measured per pair: 1025 cycles with reads and bookkeeping in a block in
-    // front of the MFMAs, 740 with only the reads interleaved, against 576 cycles of MFMA.
-#define WG3_REGION(S, CA, CB, NA, PTR, OFF, EXTRA)                              \
-    NA[S] = PTR[OFF];                                                           \
-    acc[S] = mfma32(CA[S], CB, acc[S]);                                         \
-    EXTRA;                                                                      \
-    __builtin_amdgcn_sched_barrier(0);
-    // P* = operand pointers of the pair loaded in this half, Q* = those of the following pair (formed here)
-#define WG3_HALF(CA, CB, NA, NB, P0, P1, P2, PB, Q0, Q1, Q2, QB, TN)            \
-    {                                                                           \
-      WG3_REGION(0, CA, CB, NA, P0, 0,   (aoff += 128, boff += 128, ++cp))      \
-      WG3_REGION(1, CA, CB, NA, P0, 64,  { if (cp == cpr) { cp = 0; aoff += rowjump; ++r; } }) \
-      WG3_REGION(2, CA, CB, NA, P0, 128, { if (r == RU) { r = 0; aoff += unitjump; } })        \
-      WG3_REGION(3, CA, CB, NA, P1, 0,   { if ((TN) >= pairs) { aoff = 0; boff = 0; } }) \
-      WG3_REGION(4, CA, CB, NA, P1, 64,  Q0 = a_base + aoff)                    \
-      WG3_REGION(5, CA, CB, NA, P1, 128, Q1 = Q0 + rstride)                     \
-      WG3_REGION(6, CA, CB, NA, P2, 0,   Q2 = Q1 + rstride)                     \
-      WG3_REGION(7, CA, CB, NA, P2, 64,  QB = b_base + boff)                    \
-      NB = PB[0];                                                               \
-      WG3_REGION(8, CA, CB, NA, P2, 128, dbacc += CB)                           \
+    const float* a_base = buf + kg * (IMGU * 64) + it * 32 + l31 + hh * 64;
+    const float* b_base = buf + IMGF + kg * (DU * 64) + ct * 32 + l31 + hh * 64;
+    float av[2][3], bv[2];                      // ping-pong operand sets (indices fold after unrolling)
+    av[0][0] = a_base[0]; av[0][1] = a_base[64]; av[0][2] = a_base[128];
+    bv[0] = b_base[0];
+    const float* pa0 = a_base;
+    const float* pb = b_base;
+    for (int uu = 0; uu < nun; ++uu) {
+#if CMLPL_ABL != 7 && CMLPL_ABL != 8
+      if (more && uu == issue_at) issue(ub + U, smem + (cur ^ 1) * BUF);   // in flight across the MFMAs below
+#endif
+      const float* pa1 = pa0 + rstride;
+      const int nxt = (uu + 1 < nun) ? uu + 1 : 0;        // after the last unit: re-read unit 0 (unused)
+      const float* na0 = a_base + nxt * ustep_a;
+      const float* nb = b_base + nxt * ustep_b;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 2 * CPR; ++q) {
+        const int c = q & 1, n = c ^ 1;
+        const int nq = q + 1;
+        const float* pA = (nq < 2 * CPR) ? (nq >= CPR ? pa1 : pa0) : na0;
+        const float* pB = (nq < 2 * CPR) ? pb : nb;
+        const int oA = (nq < 2 * CPR) ? (nq % CPR) * 128 : 0;
+        const int oB = (nq < 2 * CPR) ? nq * 128 : 0;
+        // tap 0 of the next pair in the same row is tap 2 of this one (the pairs are two columns apart)
+        const bool same_row = (nq < 2 * CPR) && (nq % CPR != 0);
+        bv[n] = pB[oB];
+        av[n][0] = same_row ? av[c][2] : pA[oA];
+        acc[0] = mfma32(av[c][0], bv[c], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        av[n][1] = pA[oA + 64];
+        acc[1] = mfma32(av[c][1], bv[c], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        av[n][2] = pA[oA + 128];
+        acc[2] = mfma32(av[c][2], bv[c], acc[2]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      pa0 = na0; pb = nb;
     }
-    const float *x0, *x1, *x2, *xb, *y0, *y1, *y2, *yb;
-    {
-      const float* p0 = a_base;
-      const float* p1 = p0 + rstride;
-      const float* p2 = p1 + rstride;
-      a0[0] = p0[0]; a0[1] = p0[64]; a0[2] = p0[128];
-      a0[3] = p1[0]; a0[4] = p1[64]; a0[5] = p1[128];
-      a0[6] = p2[0]; a0[7] = p2[64]; a0[8] = p2[128];
-      b0 = b_base[0];
-      // pointers of pair 1
-      aoff = 128; boff = 128; cp = 1;
-      if (cp == cpr) { cp = 0; aoff += rowjump; ++r; }
-      if (r == RU) { r = 0; aoff += unitjump; }
-      x0 = a_base + aoff; x1 = x0 + rstride; x2 = x1 + rstride; xb = b_base + boff;
-    }
-    for (int t = 0; t < pairs; t += 2) {
-      WG3_HALF(a0, b0, a1, b1, x0, x1, x2, xb, y0, y1, y2, yb, t + 2)   // MFMA pair t, load t+1, address t+2
-      WG3_HALF(a1, b1, a0, b0, y0, y1, y2, yb, x0, x1, x2, xb, t + 3)   // MFMA pair t+1, load t+2, address t+3
-    }
-#undef WG3_REGION
-#undef WG3_HALF
+#if CMLPL_ABL != 7 && CMLPL_ABL != 8 && CMLPL_ABL != 11
     if (more) commit(smem + (cur ^ 1) * BUF);
+#endif
+#if CMLPL_ABL != 8
     __syncthreads();   // stage g fully read by every wave, stage g+1 fully written
+#endif
     cur ^= 1;
   }
   STAMP(2, 2);
 
+  // fold pixel group 1 into group 0 through LDS ([4 waves][48][64]); group 0 stores the partial
+  float* red = smem + (size_t)(wave & 3) * 48 * 64 + lane;
+  if (kg == 1) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(s * 16 + r) * 64] = acc[s][r];
+  }
+  float4* dbl = (float4*)(smem + 4 * 48 * 64);    // [512] per-thread bias partial sums
+  if (kh == 0) dbl[tid] = dbsum;
+  __syncthreads();
   float* part = a.part + (long long)net * a.part_ns + (size_t)g * PART3;
+  if (kg == 0) {
 #pragma unroll
-  for (int s = 0; s < 9; ++s) {
+    for (int s = 0; s < 3; ++s) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ci = it * 32 + acc_row(r, lane);
-      part[s * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r];
+      for (int r = 0; r < 16; ++r) {
+        const int ci = it * 32 + acc_row(r, lane);
+        part[(3 * kh + s) * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r] + red[(s * 16 + r) * 64];
+      }
     }
   }
-  if (it == 0) {
-    const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
-    if (hh == 0) part[9 * 4096 + ct * 32 + l31] = tot;
+  // bias gradient (kernel row 0 only): thread t holds channels 4*(t & 15)..+3; fixed-order sum over the 32 threads
+  // of each channel quad
+  if (kh == 0 && tid < 64) {
+    const int c4 = tid >> 2, e = tid & 3;
+    float sum = 0.f;
+    for (int k = 0; k < 32; ++k) sum += ((const float*)&dbl[c4 + 16 * k])[e];
+    part[9 * 4096 + tid] = sum;
   }
   STAMP(2, 3);
 }
@@ -884,7 +924,7 @@ static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
   return ((size_t)U * (RU + 2) * PW * 64 + D * (64 / cspl)) * 4;
 }
 
-bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
+bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
   const int RO = 2 * (H / 2);
   if (RO <= 0) return false;
   // rows per unit: the largest even divisor-friendly RU that fits with U = 1
@@ -915,38 +955,37 @@ bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
   if (p->cspl == 2) { G = (NU + 1) / 2; if (G > 128) G = 128; }   // 2 co-halves x 2 nets x 128 = 512 workgroups
   if (G > 256) G = 256;                            // per net; 2 nets -> 512 WGs
   p->RU = RU; p->U = U; p->G = (int)G; p->lds = wgrad3_lds(RU, U, W, p->cspl);
-  p->NI = 0;
-  // pipelined kernel: units of 2 output rows, U of them per stage so that a stage carries >= 16 pixel pairs
-  // (amortises the per-stage barrier) but needs at most 8 float4 of prefetch registers per thread
+  p->NI = 0; p->ND = 0; p->rsplit = 0; p->UPG = 0;
   static const int pipe = getenv("CMLPL_WGRAD3_PIPE") ? atoi(getenv("CMLPL_WGRAD3_PIPE")) : 1;
-  static const int force_pg = getenv("CMLPL_WGRAD3_PG") ? atoi(getenv("CMLPL_WGRAD3_PG")) : 0;
-  static const int force_pu = getenv("CMLPL_WGRAD3_PU") ? atoi(getenv("CMLPL_WGRAD3_PU")) : 0;
   const int CO = 2 * (W / 2);
-  if (pipe && p->cspl == 1 && CO >= 2) {
-    auto ni_of = [&](int ru, int u) { return (u * (ru + 2) * W * 16 + 255) / 256; };
-    auto nd_of = [&](int ru, int u) { return (u * (ru / 2) * (W / 2) * 16 + 255) / 256; };
-    auto fits = [&](int ru, int u) {
-      return 2 * wgrad3_lds(ru, u, W) <= LDS_MAX && ni_of(ru, u) <= 16 && nd_of(ru, u) <= 2;
+  // row-split kernel: blockIdx.z = kernel row; units of one pooled row, U (even) per stage
+  static const int rsp = getenv("CMLPL_WGRAD3_R") ? atoi(getenv("CMLPL_WGRAD3_R")) : 1;
+  static const int force_ru = getenv("CMLPL_WGRAD3_RU") ? atoi(getenv("CMLPL_WGRAD3_RU")) : 0;
+  static const int force_rg = getenv("CMLPL_WGRAD3_RG") ? atoi(getenv("CMLPL_WGRAD3_RG")) : 0;
+  if (pipe && rsp && p->cspl == 1 && CO >= 2) {
+    const int PW = W + 2, cpr = CO / 2;
+    auto lds_r = [&](int u) {
+      const size_t buf2 = 2 * (size_t)u * (2 * PW * 64 + 2 * CO * 64) * 4;
+      const size_t red = (size_t)(4 * 48 * 64 + 512 * 4) * 4;     // fold area + per-thread bias sums
+      return buf2 > red ? buf2 : red;
     };
-    // rows per unit: the largest even divisor of the output rows whose double buffer fits (a whole sample for
-    // 11x11 windows: two stages per workgroup instead of five)
-    int RUp = 0;
-    for (int cand = RO; cand >= 2; cand -= 2)
-      if (RO % cand == 0 && fits(cand, 1)) { RUp = cand; break; }
-    if (RUp > 0) {
-      const int ppu = RUp * CO / 2;                 // pixel pairs per unit
-      int Up = 1;
-      while (Up * ppu < 16 && fits(RUp, Up + 1)) ++Up;
-      if (force_pu > 0 && fits(RUp, force_pu)) Up = force_pu;
-      // one workgroup per CU across both networks; whole samples per workgroup
-      long long Gp = n < 128 ? n : 128;
-      if (force_pg > 0) Gp = force_pg < n ? force_pg : n;
-      const long long spg = (n + Gp - 1) / Gp;     // samples per workgroup
-      Gp = (n + spg - 1) / spg;
-      const int NI = ni_of(RUp, Up);
-      p->RU = RUp; p->U = Up; p->G = (int)Gp; p->lds = 2 * wgrad3_lds(RUp, Up, W);
-      p->NI = NI <= 4 ? 4 : NI <= 6 ? 6 : NI <= 8 ? 8 : NI <= 10 ? 10 : NI <= 12 ? 12 : 16;
-      p->ND = nd_of(RUp, Up);
+    auto ni_r = [&](int u) { return (2 * u * ((W + 3) / 4) + 7) / 8; };        // LDS-DMA pieces per wave
+    auto nd_r = [&](int u) { return (u * (W / 2) * 16 + 511) / 512; };
+    auto fits_r = [&](int u) { return lds_r(u) <= LDS_MAX && ni_r(u) <= WG3R_NTK && nd_r(u) <= 1 && cpr <= 16 &&
+             (long long)n * H * W * 64 < (1LL << 31); };
+    int Ur = 2 * ((16 + 2 * cpr - 1) / (2 * cpr));           // >= 16 pixel pairs per wave and stage
+    if (force_ru > 0) Ur = force_ru & ~1;
+    while (Ur > 2 && !fits_r(Ur)) Ur -= 2;
+    if (Ur >= 2 && fits_r(Ur)) {
+      const long long NUr = (long long)n * (H / 2);
+      long long Gt = 256 / (3 * nets);                        // one workgroup per CU over (chunks, nets, 3 rows)
+      if (force_rg > 0) Gt = force_rg;
+      if (Gt < 1) Gt = 1;
+      long long upg = (NUr + Gt - 1) / Gt;
+      upg = ((upg + Ur - 1) / Ur) * Ur;
+      const long long Gr = (NUr + upg - 1) / upg;
+      p->RU = 2; p->U = Ur; p->G = (int)Gr; p->UPG = (int)upg; p->lds = lds_r(Ur);
+      p->NI = ni_r(Ur); p->ND = 1; p->rsplit = cpr;          // rsplit = template parameter CPR
     }
   }
   return true;
@@ -955,7 +994,7 @@ bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p) {
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st) {
   Wgrad3Plan pl;
-  if (!plan_wgrad3(n, H, W, &pl)) return hipErrorInvalidValue;
+  if (!plan_wgrad3(nets, n, H, W, &pl)) return hipErrorInvalidValue;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -970,32 +1009,35 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.in_ns = (long long)n * H * W * 64;
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
-  a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G;
-  if (pl.NI > 0) {
-#define WG3P_CASE(NI_, ND_)                                                                          \
-    if (pl.NI == NI_ && pl.ND == ND_) {                                                              \
-      static bool attr_p = false;                                                                    \
-      if (!attr_p) {                                                                                 \
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad3p_kernel<NI_, ND_>,                    \
+  a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G; a.UPG = pl.UPG;
+  if (pl.rsplit) {
+#define WG3R_CASE(CPR_)                                                                              \
+    case CPR_: {                                                                                     \
+      static bool attr_r = false;                                                                    \
+      if (!attr_r) {                                                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3r_kernel<CPR_>,                        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); \
         if (e != hipSuccess) return e;                                                               \
-        attr_p = true;                                                                               \
+        attr_r = true;                                                                               \
       }                                                                                              \
-      hipLaunchKernelGGL((wgrad3p_kernel<NI_, ND_>), dim3(pl.G, nets), dim3(256), pl.lds, st, a);    \
+      hipLaunchKernelGGL((wgrad3r_kernel<CPR_>), dim3(pl.G, nets, 3), dim3(512), pl.lds, st, a);     \
       return hipGetLastError();                                                                      \
     }
-    WG3P_CASE(4, 1) WG3P_CASE(6, 1) WG3P_CASE(8, 1) WG3P_CASE(10, 1) WG3P_CASE(12, 1) WG3P_CASE(16, 1)
-    WG3P_CASE(4, 2) WG3P_CASE(6, 2) WG3P_CASE(8, 2) WG3P_CASE(10, 2) WG3P_CASE(12, 2) WG3P_CASE(16, 2)
-#undef WG3P_CASE
-    return hipErrorInvalidValue;
-  } else if (pl.cspl == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(pl.G, nets, 2), dim3(256), pl.lds, st, a);
+    switch (pl.rsplit) {
+      WG3R_CASE(1) WG3R_CASE(2) WG3R_CASE(3) WG3R_CASE(4) WG3R_CASE(5) WG3R_CASE(6) WG3R_CASE(7) WG3R_CASE(8)
+      WG3R_CASE(9) WG3R_CASE(10) WG3R_CASE(11) WG3R_CASE(12) WG3R_CASE(13) WG3R_CASE(14) WG3R_CASE(15) WG3R_CASE(16)
+      default: return hipErrorInvalidValue;
+    }
+#undef WG3R_CASE
+  }
+  if (pl.cspl == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(pl.G, nets, 2), dim3(256), pl.lds, st, a);
   else              hipLaunchKernelGGL(wgrad3_kernel<1>, dim3(pl.G, nets), dim3(256), pl.lds, st, a);
   return hipGetLastError();
 }
 
-int wgrad3_G(int n, int H, int W) {
+int wgrad3_G(int nets, int n, int H, int W) {
   Wgrad3Plan pl;
-  return plan_wgrad3(n, H, W, &pl) ? pl.G : 0;
+  return plan_wgrad3(nets, n, H, W, &pl) ? pl.G : 0;
 }
 
 }  // namespace cmlpl

@@ -41,11 +41,11 @@ bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p);
 hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in, const uint8_t* mask_in,
                         const float* wpk, long long wpk_nstride, const float* bias, long long bias_nstride,
                         float* out, uint8_t* mask_out, hipStream_t st);
-struct Wgrad3Plan { int RU, U, G, cspl, NI, ND; size_t lds; };   // NI > 0: pipelined kernel, NI prefetch float4 / thread
-bool plan_wgrad3(int n, int H, int W, Wgrad3Plan* p);
+struct Wgrad3Plan { int RU, U, G, cspl, NI, ND, rsplit, UPG; size_t lds; };   // NI > 0: pipelined kernel, NI prefetch float4 / thread
+bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st);
-int wgrad3_G(int n, int H, int W);
+int wgrad3_G(int nets, int n, int H, int W);
 
 // ---- conv0.hip
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w0t, long long w0t_ns,

@@ -90,14 +90,20 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
 constexpr int C0_MAXT = 4;    // up to 8 band tiles = 256 input channels
 constexpr int C0_PB = 8;      // pixel pairs per batch (double-buffered); larger batches cost VGPRs -> occupancy (measured: 28 -> 54 us)
 
+// DMA = true (odd HW): the LDS slab is a LINEAR copy of the sample's [C][HW] block (row stride HW is odd, so the
+// column reads are conflict-free without padding) and is filled by global_load_lds_dwordx4 -- ~C*HW/256 wave
+// instructions per workgroup instead of C*HW/256 scalar load + divide + ds_write per THREAD.
+typedef __attribute__((address_space(3))) void c0_lds_void;
+typedef __attribute__((address_space(1))) const void c0_gbl_void;
+template <bool DMA>
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ xn, const float* __restrict__ da0,
                                                           float* __restrict__ part, int n, int C, int HW, int G) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // xs[Ct][HWp]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // xs[Ct][HWp] (+ 64 zero floats)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, g = blockIdx.x;
   const int NT = (C + 31) >> 5, Ct = NT * 32;
-  const int HWp = (HW + 2) | 1;             // odd, >= HW+1 (one zero pad column for odd HW)
+  const int HWp = DMA ? HW : ((HW + 2) | 1);   // odd; without DMA >= HW+1 (one zero pad column for odd HW)
   const int SPG = (n + G - 1) / G;
   const int sbeg = g * SPG, send = (sbeg + SPG < n) ? sbeg + SPG : n;
   const int ct = wave & 1, it0 = wave >> 1;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   for (int t = 0; t < C0_MAXT; ++t) acc[t] = zero16();
   float dbacc = 0.f;
   // rows >= C and columns >= HW stay zero for the whole kernel
-  for (int i = tid; i < Ct * HWp; i += 256) smem[i] = 0.f;
+  for (int i = tid; i < Ct * HWp + 64; i += 256) smem[i] = 0.f;
   const int pairs = (HW + 1) >> 1;
 
   for (int s = sbeg; s < send; ++s) {
@@ -116,16 +122,27 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 #pragma unroll
       for (int q = 0; q < C0_PB; ++q) {
         const int p = 2 * (t0 + q) + hh;
-        const bool ok = p < HW;
-        const float v = brow[(long long)(ok ? p : 0) * 64];
-        buf[q] = ok ? v : 0.f;
+        buf[q] = brow[(long long)(p < HW ? p : 0) * 64];   // raw (masked at use): a select here would wait for the load
       }
     };
     fetch(bc, 0);   // in flight while the slab is staged
     __syncthreads();
     const float* xs = xn + ((long long)net * n + s) * C * HW;
-    staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
-                           [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
+    if (DMA) {
+      // (the pixel past the end of an odd row is the first element of the next row: finite, and its B operand
+      // is zero; the row after the last one is the zeroed tail)
+      const int nf4 = (C * HW) >> 2;
+      for (int q = wave; q * 64 < nf4; q += 4) {
+        const int f = q * 64 + lane;
+        if (f < nf4)
+          __builtin_amdgcn_global_load_lds((c0_gbl_void*)(xs + 4 * f), (c0_lds_void*)(smem + q * 256), 16, 0, 0);
+      }
+      const int rem = C * HW - 4 * nf4;
+      if (tid < rem) smem[4 * nf4 + tid] = xs[4 * nf4 + tid];
+    } else {
+      staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
+                             [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
+    }
     __syncthreads();
     for (int t0 = 0; t0 < pairs; t0 += C0_PB) {
       if (t0 + C0_PB < pairs) fetch(bn, t0 + C0_PB);
@@ -133,11 +150,12 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
       for (int q = 0; q < C0_PB; ++q) {
         if (t0 + q < pairs) {   // uniform
           const int p = 2 * (t0 + q) + hh;
-          dbacc += bc[q];
+          const float bq = (p < HW) ? bc[q] : 0.f;
+          dbacc += bq;
 #pragma unroll
           for (int k = 0; k < C0_MAXT; ++k) {
             const int tile = it0 + 2 * k;
-            if (tile < NT) acc[k] = mfma32(smem[(tile * 32 + l31) * HWp + p], bc[q], acc[k]);
+            if (tile < NT) acc[k] = mfma32(smem[(tile * 32 + l31) * HWp + p], bq, acc[k]);
           }
         }
       }
@@ -229,18 +247,24 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
                               hipStream_t st) {
   const int NT = (C + 31) / 32, Ct = NT * 32;
   if (NT > 2 * C0_MAXT) return hipErrorInvalidValue;
-  const int HWp = (HW + 2) | 1;
-  const size_t lds = (size_t)Ct * HWp * 4;
+  static const bool dma_off = getenv("CMLPL_CONV0_DMA") && atoi(getenv("CMLPL_CONV0_DMA")) == 0;
+  const bool dma = (HW & 1) && !dma_off;
+  const int HWp = dma ? HW : ((HW + 2) | 1);
+  const size_t lds = ((size_t)Ct * HWp + 64) * 4;
   if (lds > LDS_MAX) return hipErrorInvalidValue;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv0_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_MAX);
+    hipError_t e = hipFuncSetAttribute((const void*)conv0_wgrad_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv0_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)LDS_MAX);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int G = plan_conv0_wgrad_G(n, C, HW);
-  hipLaunchKernelGGL(conv0_wgrad_kernel, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);
+  if (dma) hipLaunchKernelGGL(conv0_wgrad_kernel<true>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);
+  else     hipLaunchKernelGGL(conv0_wgrad_kernel<false>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);
   return hipGetLastError();
 }
 

@@ -247,17 +247,28 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c) {
   float* out = a.out + (long long)c.net * a.out_ns;
   uint8_t* mo = a.mask_out + (long long)c.net * a.mask_out_ns;
-  const int tot = c.S * c.P2 * 64;
+  // one (pooled pixel, 4 channels) item per thread and pass: four ds_read_b128, one 16-B and one 4-B store
+  const int tot = c.S * c.P2 * 16;
   for (int idx = c.tid; idx < tot; idx += 256) {
-    const int co = idx & 63, pp = idx >> 6;
+    const int c4 = idx & 15, pp = idx >> 4;
     const int s = pp / c.P2, q = pp - s * c.P2, ph = q / c.W2, pw = q - ph * c.W2;
     const int sample = c.s0 + s;
     if (sample < a.n) {
-      const float* p = c.img + (size_t)(s * c.IMG + (2 * ph + 1) * c.PW + 2 * pw + 1) * CS + co;
-      const float v00 = p[0], v01 = p[CS], v10 = p[c.PW * CS], v11 = p[c.PW * CS + CS];
-      const size_t g = ((size_t)sample * c.P2 + q) * 64 + co;
-      out[g] = (v00 + v01 + v10 + v11) * 0.25f;
-      mo[g] = (uint8_t)((v00 > 0.f ? 1 : 0) | (v01 > 0.f ? 2 : 0) | (v10 > 0.f ? 4 : 0) | (v11 > 0.f ? 8 : 0));
+      const float* p = c.img + (size_t)(s * c.IMG + (2 * ph + 1) * c.PW + 2 * pw + 1) * CS + c4 * 4;
+      const float4 v00 = *(const float4*)p, v01 = *(const float4*)(p + CS);
+      const float4 v10 = *(const float4*)(p + c.PW * CS), v11 = *(const float4*)(p + c.PW * CS + CS);
+      const size_t g = ((size_t)sample * c.P2 + q) * 64 + c4 * 4;
+      float4 o;
+      o.x = (v00.x + v01.x + v10.x + v11.x) * 0.25f;
+      o.y = (v00.y + v01.y + v10.y + v11.y) * 0.25f;
+      o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
+      o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
+      *(float4*)(out + g) = o;
+#define CMLPL_NIB(A, B, C, D) ((uint32_t)((A > 0.f ? 1 : 0) | (B > 0.f ? 2 : 0) | (C > 0.f ? 4 : 0) | (D > 0.f ? 8 : 0)))
+      const uint32_t m = CMLPL_NIB(v00.x, v01.x, v10.x, v11.x) | (CMLPL_NIB(v00.y, v01.y, v10.y, v11.y) << 8) |
+                         (CMLPL_NIB(v00.z, v01.z, v10.z, v11.z) << 16) | (CMLPL_NIB(v00.w, v01.w, v10.w, v11.w) << 24);
+#undef CMLPL_NIB
+      *(uint32_t*)(mo + g) = m;
     }
   }
 }

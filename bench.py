@@ -26,11 +26,19 @@ WORKLOADS = {   # name: (C, H, W, bands, K)   -- SURVEY.md section 8d
     "B5": (48, 15, 15, 48, 20),     # Houston2018-shaped
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-# HBM bytes per launch of the dominant kernel (conv1 wgrad3_kernel, B2, 128+128 rows, both networks) from
-# rocprofv3 PMC, separate passes: FETCH_SIZE 9917.5 KB x 2 (gfx950 reports half of wide coalesced reads)
-# + WRITE_SIZE 36928 KB; profiles/r01_c_final_pmc_hbm_traffic.txt.  Algorithmic bytes: 20.0 MB in
-# (a0 + dpool + masks) + 37.8 MB of partials out = 57.8 MB, i.e. no wasted re-reads.
-DOMINANT_TRAFFIC_B2_256 = (2 * 9917.5 + 36928.0) * 1024
+# HBM bytes per launch of the three conv1 kernels (B2, 128+128 rows, both networks) from rocprofv3 PMC, separate
+# passes: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, in KB as printed in
+# profiles/r01_d_pmc_hbm_traffic.txt (scripts/pmc_summary.py).  Algorithmic bytes beside them in DESIGN.md 5.
+TRAFFIC_B2_256 = {
+    "conv1_fwd": (2 * 8984.5 + 4000.0) * 1024,       # 22.5 MB (algorithmic: a0 15.9 + weights 0.3 + p1 3.2 + masks 0.8)
+    "conv1_dgrad": (2 * 3252.5 + 15488.0) * 1024,    # 22.5 MB (algorithmic: dp1 3.2 + masks 0.8 + weights 0.3 + da0 15.9)
+    "conv1_wgrad": (2 * 9994.8 + 11540.0) * 1024,    # 32.3 MB (algorithmic: a0 15.9 + dp1 3.2 + masks 0.8 + partials 11.8)
+}
+CONV1_KERNELS = {
+    "conv1_fwd": "conv3x3_kernel<FWD> (conv1 forward: 3x3 conv + bias + residual + ReLU + avgpool, both networks)",
+    "conv1_dgrad": "conv3x3_kernel<DGRAD> (conv1 data gradient, both networks)",
+    "conv1_wgrad": "wgrad3r_kernel (conv1 weight gradient, both networks)",
+}
 
 
 def synth(shape, bt, btu, seed, device):
@@ -148,16 +156,27 @@ def main():
 
     run(args.warmup, 0)
     barrier()
-    # the dominant kernel is bracketed by hipEvent pairs on the launch stream inside the timed region
+    # Which kernel is the dominant one is decided by measurement: a short calibration window (untimed) brackets
+    # the three conv1 launches with hipEvent pairs on the launch stream; the longest one is then bracketed inside
+    # the timed region (one event pair per step keeps the perturbation of the step time below 1 %).
     import ctypes as C
-    dom_id = _lib.KERNEL_NAMES.index("conv1_wgrad")
+    nk = len(_lib.KERNEL_NAMES)
+    ms = (C.c_double * nk)()
+    cnt = (C.c_int64 * nk)()
+    ids = {k: _lib.KERNEL_NAMES.index(k) for k in CONV1_KERNELS}
+    calib_steps = 10
+    _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(sum(1 << i for i in ids.values()), 3 * calib_steps + 8))
+    run(calib_steps, args.warmup)
+    barrier()
+    _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
+    calib = {k: ms[i] / max(cnt[i], 1) for k, i in ids.items()}
+    dom_name = max(calib, key=calib.get)
+    dom_id = ids[dom_name]
     _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(1 << dom_id, args.steps + 8))
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    run(args.steps, args.warmup + calib_steps)
     barrier()
     dt = time.perf_counter() - t0
-    ms = (C.c_double * len(_lib.KERNEL_NAMES))()
-    cnt = (C.c_int64 * len(_lib.KERNEL_NAMES))()
     _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -171,6 +190,7 @@ def main():
     dom_ms = ms[dom_id] / max(cnt[dom_id], 1)
     flops = conv1_flops(shape, n_local)
     achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    b2_256 = args.workload == "B2" and n_local == 256
     out = {
         "metric": "HSI patches/sec per training step", "value": patches / dt, "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -180,18 +200,25 @@ def main():
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
                                f"bank + Adam, epoch 1 (memory-bank smoothing active), Philox noise/dropout",
                    "global_batch": n_local * world, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "wgrad3_kernel (conv1 weight gradient, both networks)",
+        "roofline": {"bound": "mfma", "kernel": CONV1_KERNELS[dom_name],
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": DOMINANT_TRAFFIC_B2_256 if (args.workload == "B2" and n_local == 256) else None,
+                     "traffic": TRAFFIC_B2_256[dom_name] if b2_256 else None,
                      "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                      "flops_per_launch": flops, "ms_per_launch": dom_ms, "launches_timed": int(cnt[dom_id])},
+        # the other two conv1 kernels (same algorithmic FLOPs), from the calibration window
+        "roofline_others": [
+            {"kernel": CONV1_KERNELS[k], "ms_per_launch": calib[k], "launches_timed": calib_steps,
+             "achieved": flops / (calib[k] * 1e-3) / 1e12 if calib[k] > 0 else 0.0,
+             "frac": (flops / (calib[k] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if calib[k] > 0 else 0.0,
+             "traffic": TRAFFIC_B2_256[k] if b2_256 else None}
+            for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
     }
 
     if args.breakdown and rank == 0:
         _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(0xFFFFFFFF, 40 * 24))
-        run(40, args.warmup + args.steps)
+        run(40, args.warmup + calib_steps + args.steps)
         barrier()
         _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
         tot = sum(ms[i] for i in range(len(_lib.KERNEL_NAMES)))

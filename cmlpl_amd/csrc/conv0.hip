@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   for (int t = 0; t < C0_MAXT; ++t) acc[t] = zero16();
   float dbacc = 0.f;
   // rows >= C and columns >= HW stay zero for the whole kernel
-  for (int i = tid; i < Ct * HWp + 64; i += 256) smem[i] = 0.f;
+  // (with DMA the slab rows [0, C) are overwritten in full by every sample: zero only the pad rows and the tail)
+  for (int i = (DMA ? C * HW : 0) + tid; i < Ct * HWp + 64; i += 256) smem[i] = 0.f;
   const int pairs = (HW + 1) >> 1;
 
   for (int s = sbeg; s < send; ++s) {

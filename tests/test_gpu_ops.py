@@ -16,6 +16,14 @@ SHAPES = {
     "B2": O.NetShape(103, 11, 11, 103, 9),      # BASELINE configs[1]
     "B4": O.NetShape(200, 11, 11, 200, 16),
     "B5": O.NetShape(48, 15, 15, 48, 20),
+    # other window sizes: every column-pair count of the row-split weight-gradient kernel between 2 and 11,
+    # even and odd maps, tiny and ragged channel counts
+    "W8": O.NetShape(8, 8, 8, 12, 5),
+    "W9": O.NetShape(33, 9, 9, 7, 4),
+    "W12": O.NetShape(5, 12, 12, 9, 3),
+    "W13": O.NetShape(5, 13, 13, 7, 4),
+    "W16": O.NetShape(6, 16, 16, 10, 3),
+    "W18": O.NetShape(3, 18, 18, 5, 3),
 }
 
 
@@ -27,7 +35,9 @@ def _module(shape, params, dropout):
     return net
 
 
-@pytest.mark.parametrize("name,n", [("P", 5), ("P", 64), ("B2", 37), ("B2", 256), ("B4", 16), ("B5", 23)])
+@pytest.mark.parametrize("name,n", [("P", 5), ("P", 64), ("B2", 37), ("B2", 256), ("B4", 16), ("B5", 23),
+                                    ("W8", 19), ("W9", 50), ("W12", 11), ("W13", 7), ("W16", 9), ("W18", 6),
+                                    ("B2", 1), ("B2", 300)])
 def test_basenet2_forward_backward(name, n):
     shape = SHAPES[name]
     params = O.closed_form_params(shape, 7)
@@ -57,6 +67,15 @@ def test_basenet2_forward_backward(name, n):
         report("grad " + k, hip[k].grad, pr[k].grad, 2e-4, 2e-5 * max(scale, 1e-3))
     for k in ("feat_ss.weight", "feat_ss2.bias", "feat_ss3.weight"):
         assert hip[k].grad is None          # dead parameters, like the reference
+
+
+def test_window_too_large_for_lds_fails_loudly():
+    """a 22x22 window needs a 24x24x68-float LDS image (157 KB) + tap buffer: no silent fallback, a shape error"""
+    from cmlpl_amd import _lib
+    shape = O.NetShape(4, 22, 22, 6, 3)
+    net = _module(shape, O.closed_form_params(shape, 1), dropout=0.0)
+    with pytest.raises(_lib.CmlplError):
+        net(torch.zeros(2, 4, 22, 22, device=DEV), torch.zeros(2, 6, device=DEV))
 
 
 def test_basenet2_eval_matches_oracle_and_state_dict_keys():

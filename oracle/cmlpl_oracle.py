@@ -435,3 +435,157 @@ def ntxent_loss(emb_i: torch.Tensor, emb_j: torch.Tensor, temperature: float = 0
     neg_mask = (~torch.eye(2 * B, dtype=torch.bool)).float()                                  # :19-20
     denom = (neg_mask * torch.exp(sim / temperature)).sum(dim=1)                              # :35
     return (-torch.log(torch.exp(pos / temperature) / denom)).sum() / (2 * B)                 # :34,37-38
+
+
+# --------------------------------------------------------------------------- #
+# next row N2: loss_helper.py  (memory-bank InfoNCE + entropy-filtered CE)
+# --------------------------------------------------------------------------- #
+MB_DELTA_P = 0.3        # loss_helper.py:56  current_class_threshold
+MB_DELTA_N = 1.0        # :57  current_class_negative_threshold
+MB_LOW_RANK, MB_HIGH_RANK = 3, 9   # :58
+MB_TEMP = 0.5           # :59
+MB_QUERIES = 256        # :60
+MB_NEGATIVES = 50       # :61
+IGNORE = 255            # :229,253
+
+
+def memobank_enqueue(keys: torch.Tensor, queue: torch.Tensor, ptr: int, size: int):
+    """dequeue_and_enqueue (loss_helper.py:19-36) as a pure function: the bank of one class is a FIFO of at most
+    `size` rows -- append the new keys, keep the LAST `size` rows.  The pointer becomes `size` once the bank is
+    full, (ptr + m) % size before that.  Returns (queue, ptr, m)."""
+    m = int(keys.shape[0])
+    joined = torch.cat((queue, keys.detach().clone()), dim=0)
+    if joined.shape[0] >= size:
+        return joined[joined.shape[0] - size:], size, m
+    return joined, (int(ptr) + m) % size, m
+
+
+def class_ranks(prob: torch.Tensor) -> torch.Tensor:
+    """rank[n, c] = position of class c when row n is sorted by descending probability (what
+    torch.sort(prob, 1, True)[1] encodes, loss_helper.py:77,81); ties broken by class index."""
+    gt = (prob.unsqueeze(1) > prob.unsqueeze(2)).sum(dim=2)                       # [n, c]: #{j: p_j > p_c}
+    K = prob.shape[1]
+    earlier = torch.tril(torch.ones(K, K, dtype=torch.bool), diagonal=-1)         # [c, j]: j < c
+    eq = ((prob.unsqueeze(1) == prob.unsqueeze(2)) & earlier.unsqueeze(0)).sum(dim=2)
+    return gt + eq
+
+
+def percentile_threshold(values: np.ndarray, percent: float):
+    """np.percentile(values, percent) (loss_helper.py:250-252), default 'linear' method."""
+    return np.percentile(values, percent)
+
+
+def unsupervised_loss(predict: torch.Tensor, target: torch.Tensor, percent: float, pred_teacher: torch.Tensor):
+    """compute_unsupervised_loss (loss_helper.py:242-261).  Rows whose teacher entropy is at or above the
+    `percent`-th percentile of the valid rows' entropies are set to IGNORE; the loss is
+    (B / #kept) * mean-over-kept CE(predict, target).  Returns (loss, target_after) -- the reference edits
+    `target` in place."""
+    B = predict.shape[0]
+    with torch.no_grad():
+        p = torch.softmax(pred_teacher, dim=1)
+        entropy = -(p * torch.log(p + 1e-10)).sum(dim=1)                          # :247-248
+        valid = target != IGNORE
+        thresh = percentile_threshold(entropy[valid].numpy().flatten(), percent)  # :250-252
+        drop = (entropy >= float(thresh)) & valid                                 # :253
+        tgt = torch.where(drop, torch.full_like(target, IGNORE), target)          # :255
+        kept = tgt != IGNORE
+        weight = B / kept.sum()                                                   # :256
+    logp = F.log_softmax(predict, dim=1)
+    picked = logp.gather(1, torch.where(kept, tgt, torch.zeros_like(tgt)).unsqueeze(1)).squeeze(1)
+    ce = -(picked * kept.float()).sum() / kept.sum()                              # :258 (ignore_index mean)
+    return weight * ce, tgt
+
+
+def contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, memobank, ptrs, sizes,
+                         rep_teacher, anchor_idx=None, neg_idx=None, momentum_prototype=None, i_iter=0):
+    """compute_contra_memobank_loss (loss_helper.py:39-219) with the random draws injected.
+
+    rep, rep_teacher [N, D]; label_* one-hot [*, K]; prob_* [*, K]; low_mask / high_mask [N, 1];
+    memobank: list (per class) of [m_c, D] tensors; ptrs / sizes: lists of ints.
+    anchor_idx[c] int64 [256]: positions into class c's low-entropy list (the reference's first randint, :164);
+    neg_idx[c] int64 [256*50]: rows of the class's bank AFTER this call's enqueue (second randint, :179).
+    Returns dict(loss, new_keys, memobank, ptrs, valid_classes, prototype).
+
+    Kept quirk (:158-190): the loop over the `valid_seg` valid classes indexes the per-class anchor lists and
+    prototypes by POSITION i (0..valid_seg-1), but the bank by valid_classes[i]."""
+    K = label_l.shape[1]
+    Nl = label_l.shape[0]
+    D = rep.shape[1]
+    label = torch.cat((label_l, label_u), dim=0)
+    low_valid = label * low_mask                                                   # :67
+    high_valid = label * high_mask                                                 # :68
+    prob = torch.cat((prob_l, prob_u), dim=0)                                      # :86
+    rank_l, rank_u = class_ranks(prob_l), class_ranks(prob_u)
+    anchors_pool, protos, new_keys, valid_classes, counts = [], [], [], [], []
+    bank = [b.clone() for b in memobank]
+    ptr_out = list(ptrs)
+    for c in range(K):
+        lv = low_valid[:, c].bool()
+        hv = high_valid[:, c].bool()
+        low_entropy = (prob[:, c] > MB_DELTA_P) & lv                               # :95
+        high_entropy = (prob[:, c] < MB_DELTA_N) & hv                              # :96
+        anchors_pool.append(rep[low_entropy])                                      # :99
+        protos.append(rep_teacher[lv].detach().mean(dim=0, keepdim=True))          # :102-106 (NaN row if empty)
+        in_u = (rank_u[:, c] >= MB_LOW_RANK) & (rank_u[:, c] < MB_HIGH_RANK)       # :110-112
+        in_l = (rank_l[:, c] < MB_LOW_RANK) & (label_l[:, c] == 0)                 # :117-121
+        negative = high_entropy & torch.cat((in_l, in_u), dim=0)                   # :123
+        bank[c], ptr_out[c], m = memobank_enqueue(rep_teacher[negative].detach(), bank[c], ptr_out[c], sizes[c])
+        new_keys.append(m)                                                         # :126-133
+        if int(lv.sum()) > 0:                                                      # :135-137
+            counts.append(int(lv.sum()))
+            valid_classes.append(c)
+    out = dict(new_keys=new_keys, memobank=bank, ptrs=ptr_out, valid_classes=valid_classes, prototype=None)
+    if len(counts) <= 1:                                                           # :139-145
+        out["loss"] = 0.0 * rep.sum()
+        return out
+    proto = torch.cat(protos, dim=0)                                               # :149  [K, D]
+    valid_seg = len(counts)
+    prototype = torch.zeros(K, MB_QUERIES, 1, D)
+    total = torch.zeros(())
+    for i in range(valid_seg):
+        vc = valid_classes[i]
+        if anchors_pool[i].shape[0] == 0 or bank[vc].shape[0] == 0:                # :158-172
+            total = total + 0.0 * rep.sum()
+            continue
+        anchor = anchors_pool[i][anchor_idx[i]]                                    # :164-168  [Q, D]
+        with torch.no_grad():
+            negs = bank[vc][neg_idx[i]].reshape(MB_QUERIES, MB_NEGATIVES, D)       # :176-185
+            pos = proto[i].view(1, 1, D).repeat(MB_QUERIES, 1, 1)                  # :186-192
+            if momentum_prototype is not None:                                     # :194-203
+                if not bool((momentum_prototype == 0).all()):
+                    ema = min(1 - 1 / i_iter, 0.999)
+                    pos = (1 - ema) * pos + ema * momentum_prototype[vc]
+                prototype[vc] = pos.clone()
+            keys = torch.cat((pos, negs), dim=1)                                   # :205-207  [Q, 51, D]
+        logits = torch.cosine_similarity(anchor.unsqueeze(1), keys, dim=2)         # :209-211
+        total = total + F.cross_entropy(logits / MB_TEMP, torch.zeros(MB_QUERIES, dtype=torch.long))  # :213-215
+    out["loss"] = total / valid_seg                                                # :217-219
+    if momentum_prototype is not None:
+        out["prototype"] = prototype
+    return out
+
+
+def contra_draw_plan(label_l, label_u, prob_l, prob_u, low_mask, high_mask, memobank, sizes, rep_teacher_rows=None):
+    """Which loop positions of compute_contra_memobank_loss draw random indices, and from what ranges
+    (loss_helper.py:158-183): a list of (position i, anchor pool size, bank rows of valid_classes[i] after this
+    call's enqueue); empty when at most one class is valid."""
+    K = label_l.shape[1]
+    label = torch.cat((label_l, label_u), dim=0)
+    prob = torch.cat((prob_l, prob_u), dim=0)
+    low_valid = label * low_mask
+    high_valid = label * high_mask
+    rank_l, rank_u = class_ranks(prob_l), class_ranks(prob_u)
+    pool, rows, valid = [], [], []
+    for c in range(K):
+        lv = low_valid[:, c].bool()
+        pool.append(int(((prob[:, c] > MB_DELTA_P) & lv).sum()))
+        in_u = (rank_u[:, c] >= MB_LOW_RANK) & (rank_u[:, c] < MB_HIGH_RANK)
+        in_l = (rank_l[:, c] < MB_LOW_RANK) & (label_l[:, c] == 0)
+        neg = ((prob[:, c] < MB_DELTA_N) & high_valid[:, c].bool()) & torch.cat((in_l, in_u), dim=0)
+        rows.append(min(int(memobank[c].shape[0]) + int(neg.sum()), int(sizes[c])))
+        if int(lv.sum()) > 0:
+            valid.append(c)
+    if len(valid) <= 1:
+        return []
+    return [(i, pool[i], rows[valid[i]]) for i in range(len(valid)) if pool[i] > 0 and rows[valid[i]] > 0]
+

@@ -27,6 +27,8 @@ EXPORTS = (
     "cmlpl_basenet2_fwd", "cmlpl_basenet2_bwd", "cmlpl_loss_fwd_bwd", "cmlpl_adam_step", "cmlpl_train_step",
     "cmlpl_debug_region", "cmlpl_timing_begin", "cmlpl_timing_end", "cmlpl_loss_phase1", "cmlpl_loss_phase2",
     "cmlpl_dist_unpack", "cmlpl_loss_workspace_bytes", "cmlpl_extract_patches", "cmlpl_ntxent_workspace_bytes", "cmlpl_ntxent_fwd_bwd",
+    "cmlpl_unsup_workspace_bytes", "cmlpl_unsup_loss", "cmlpl_memobank_select", "cmlpl_memobank_proto",
+    "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -130,13 +132,24 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_ntxent_workspace_bytes.argtypes = [i32, i32]
     lib.cmlpl_ntxent_workspace_bytes.restype = sz
     lib.cmlpl_ntxent_fwd_bwd.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp, sz, vp]
+    lib.cmlpl_unsup_workspace_bytes.argtypes = [i32]
+    lib.cmlpl_unsup_workspace_bytes.restype = sz
+    lib.cmlpl_unsup_loss.argtypes = [vp, vp, vp, i32, i32, C.c_double, vp, vp, vp, sz, vp]
+    lib.cmlpl_memobank_select.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.cmlpl_memobank_proto.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.cmlpl_memobank_enqueue.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
+    lib.cmlpl_memobank_push.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+    lib.cmlpl_memobank_infonce.argtypes = [vp, i32, i32, vp, i32, vp, vp, i64, vp, i32, i32, i32, vp, i32, i32, f32, f32,
+                                           vp, vp, vp, vp]
+    lib.cmlpl_memobank_sum.argtypes = [vp, i32, vp, vp]
     lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]
     lib.cmlpl_timing_begin.argtypes = [C.c_uint32, i32]
     lib.cmlpl_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(i64)]
     for s in EXPORTS[1:]:
-        if s not in ("cmlpl_workspace_bytes", "cmlpl_loss_workspace_bytes", "cmlpl_ntxent_workspace_bytes"):
+        if s not in ("cmlpl_workspace_bytes", "cmlpl_loss_workspace_bytes", "cmlpl_ntxent_workspace_bytes",
+                     "cmlpl_unsup_workspace_bytes"):
             getattr(lib, s).restype = i32
     if lib.cmlpl_abi_version() != ABI_VERSION:
         raise CmlplLibraryError(f"ABI version mismatch: library {lib.cmlpl_abi_version()}, binding {ABI_VERSION}")

@@ -515,6 +515,70 @@ int cmlpl_ntxent_fwd_bwd(const float* d_emb_i, const float* d_emb_j, int B, int 
                            (hipStream_t)stream));
 }
 
+// ---- loss_helper.py
+size_t cmlpl_unsup_workspace_bytes(int B) { return B < 1 ? 0 : unsup_ws_bytes(B); }
+
+int cmlpl_unsup_loss(const float* d_predict, int64_t* d_target, const float* d_pred_teacher, int B, int K,
+                     double percent, float* d_loss, float* d_dpredict, void* d_workspace, size_t workspace_bytes,
+                     void* stream) {
+  if (!d_predict || !d_target || !d_pred_teacher || !d_loss || !d_dpredict || !d_workspace || B < 1 || K < 1 ||
+      !(percent >= 0.0 && percent <= 100.0))
+    return CMLPL_E_ARG;
+  if (unsup_ws_bytes(B) > workspace_bytes) return CMLPL_E_WORKSPACE;
+  return chk(launch_unsup(d_predict, (long long*)d_target, d_pred_teacher, B, K, percent, d_loss, d_dpredict,
+                          d_workspace, (hipStream_t)stream));
+}
+
+int cmlpl_memobank_select(const float* d_prob, const float* d_label, const float* d_low_mask, const float* d_high_mask,
+                          int N, int n_labeled, int K, int32_t* d_lists, int32_t* d_counts, void* stream) {
+  if (!d_prob || !d_label || !d_low_mask || !d_high_mask || !d_lists || !d_counts || N < 1 || n_labeled < 0 ||
+      n_labeled > N || K < 1 || K > 1024)
+    return CMLPL_E_ARG;
+  return chk(launch_mb_select(d_prob, d_label, d_low_mask, d_high_mask, N, n_labeled, K, d_lists, d_counts,
+                              (hipStream_t)stream));
+}
+
+int cmlpl_memobank_proto(const float* d_rep_teacher, int N, int D, int K, const int32_t* d_lists,
+                         const int32_t* d_counts, float* d_proto, void* stream) {
+  if (!d_rep_teacher || !d_lists || !d_counts || !d_proto || N < 1 || D < 1 || K < 1) return CMLPL_E_ARG;
+  return chk(launch_mb_proto(d_rep_teacher, D, d_lists, d_counts, N, K, d_proto, (hipStream_t)stream));
+}
+
+int cmlpl_memobank_enqueue(const float* d_rep_teacher, int N, int D, int K, const int32_t* d_lists,
+                           const int32_t* d_counts, float* d_bank, int32_t* d_state, const int32_t* d_capacity,
+                           int capacity_stride, void* stream) {
+  if (!d_rep_teacher || !d_lists || !d_counts || !d_bank || !d_state || !d_capacity || N < 1 || D < 1 || K < 1 ||
+      capacity_stride < 1)
+    return CMLPL_E_ARG;
+  return chk(launch_mb_enqueue(d_rep_teacher, D, d_lists, d_counts, N, K, d_bank, d_state, d_capacity,
+                               capacity_stride, (hipStream_t)stream));
+}
+
+int cmlpl_memobank_push(const float* d_keys, int m, int D, float* d_bank_c, int32_t* d_state_c, int capacity,
+                        void* stream) {
+  if ((m > 0 && !d_keys) || !d_bank_c || !d_state_c || m < 0 || D < 1 || capacity < 1) return CMLPL_E_ARG;
+  return chk(launch_mb_push(d_keys, m, D, d_bank_c, d_state_c, capacity, (hipStream_t)stream));
+}
+
+int cmlpl_memobank_infonce(const float* d_rep, int N, int D, const int32_t* d_pool, int pool_rows,
+                           const int64_t* d_anchor_draw, const float* d_pos, int64_t pos_qstride,
+                           const float* d_bank_c, int capacity, int bank_rows, int head, const int64_t* d_neg_draw,
+                           int queries, int negatives, float temperature, float scale, float* d_lossq,
+                           float* d_ganchor, float* d_drep, void* stream) {
+  if (!d_rep || !d_pool || !d_anchor_draw || !d_pos || !d_bank_c || !d_neg_draw || !d_lossq || !d_ganchor ||
+      N < 1 || D < 1 || pool_rows < 1 || pool_rows > N || capacity < 1 || bank_rows < 1 || bank_rows > capacity ||
+      head < 0 || head >= capacity || queries < 1 || negatives < 1 || negatives > 127 || !(temperature > 0.f))
+    return CMLPL_E_ARG;
+  return chk(launch_mb_infonce(d_rep, D, d_pool, (const long long*)d_anchor_draw, d_pos, pos_qstride, d_bank_c,
+                               capacity, head, (const long long*)d_neg_draw, queries, negatives, temperature, scale,
+                               d_lossq, d_ganchor, d_drep, (hipStream_t)stream));
+}
+
+int cmlpl_memobank_sum(const float* d_v, int n, float* d_out, void* stream) {
+  if (!d_v || !d_out || n < 1) return CMLPL_E_ARG;
+  return chk(launch_mb_sum(d_v, n, d_out, (hipStream_t)stream));
+}
+
 int cmlpl_timing_begin(uint32_t kernel_mask, int max_launches) {
   Timing& t = g_timing;
   if (t.on || max_launches < 1) return CMLPL_E_ARG;

@@ -119,4 +119,22 @@ hipError_t launch_adam(int nets, float* params, long long pstride, const float* 
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
                        float* packed, const PackInfo& pi, hipStream_t st);
 
+
+// ---- memobank.hip  (loss_helper.py)
+hipError_t launch_mb_select(const float* prob, const float* label, const float* low_mask, const float* high_mask, int N,
+                            int Nl, int K, int* lists, int* counts, hipStream_t st);
+hipError_t launch_mb_proto(const float* rep_t, int D, const int* lists, const int* counts, int N, int K, float* proto,
+                           hipStream_t st);
+hipError_t launch_mb_enqueue(const float* rep_t, int D, const int* lists, const int* counts, int N, int K, float* bank,
+                             int* state, const int* caps, int cap_stride, hipStream_t st);
+hipError_t launch_mb_push(const float* keys, int m, int D, float* bank_c, int* state_c, int cap, hipStream_t st);
+hipError_t launch_mb_infonce(const float* rep, int D, const int* pool, const long long* anchor_draw, const float* pos,
+                             long long pos_qstride, const float* bank_c, int cap, int head, const long long* neg_draw,
+                             int Qn, int NN, float temp, float scale, float* lossq, float* ganchor, float* drep,
+                             hipStream_t st);
+hipError_t launch_mb_sum(const float* v, int n, float* out, hipStream_t st);
+size_t unsup_ws_bytes(int B);
+hipError_t launch_unsup(const float* predict, long long* target, const float* teacher, int B, int K, double percent,
+                        float* loss, float* dpredict, void* ws, hipStream_t st);
+
 }  // namespace cmlpl

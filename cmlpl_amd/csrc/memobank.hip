@@ -1,0 +1,432 @@
+// loss_helper.py of the reference on gfx950:
+//   dequeue_and_enqueue          (:19-36)    per-class FIFO memory bank
+//   compute_contra_memobank_loss (:39-219)   class-wise anchor / negative selection + cosine InfoNCE
+//   compute_unsupervised_loss    (:242-261)  entropy-percentile-filtered cross entropy
+// All of it is gather / reduction work: bound by HBM/L2 latency, no MFMA.  Everything is deterministic
+// (ordered compaction, fixed-order sums, no float atomics).
+//
+// Memory bank of one class: a physical ring [cap][D] with (rows, head); LOGICAL row i -- what the reference's
+// `queue[0][i]` holds after its cat + [-size:] -- is ring slot (head + i) % cap.  The reference copies the whole
+// bank on every call; the ring writes only the new keys.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace cmlpl {
+
+// ------------------------------------------------------------------------------------------
+// per-class selection (loss_helper.py:67-123): ordered index lists
+//   list 0: low_valid rows            (prototype mean, :102-106; count decides "valid class", :135)
+//   list 1: low-entropy anchor pool   (prob > 0.3 and low_valid, :95,99)
+//   list 2: negative keys             (prob < 1, high_valid, rank window, :96,110-123)
+// One workgroup per class walks the rows in order; positions come from ballot prefix sums.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mb_select_kernel(const float* __restrict__ prob, const float* __restrict__ label,
+                                                        const float* __restrict__ low_mask,
+                                                        const float* __restrict__ high_mask, int N, int Nl, int K,
+                                                        float delta_p, float delta_n, int low_rank, int high_rank,
+                                                        int* __restrict__ lists, int* __restrict__ counts) {
+  __shared__ int wtot[3][4];
+  __shared__ int base[3];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 3) base[tid] = 0;
+  __syncthreads();
+  int* l0 = lists + ((size_t)c * 3 + 0) * N;
+  int* l1 = lists + ((size_t)c * 3 + 1) * N;
+  int* l2 = lists + ((size_t)c * 3 + 2) * N;
+  for (int n0 = 0; n0 < N; n0 += 256) {
+    const int n = n0 + tid;
+    bool f0 = false, f1 = false, f2 = false;
+    if (n < N) {
+      const float* pr = prob + (size_t)n * K;
+      const float pc = pr[c], lab = label[(size_t)n * K + c];
+      f0 = (lab * low_mask[n]) != 0.f;
+      const bool hv = (lab * high_mask[n]) != 0.f;
+      f1 = (pc > delta_p) && f0;
+      int rank = 0;                                   // position of class c in the descending sort of the row
+      for (int j = 0; j < K; ++j) rank += (pr[j] > pc || (pr[j] == pc && j < c)) ? 1 : 0;
+      const bool cm = (n < Nl) ? (rank < low_rank && lab == 0.f) : (rank >= low_rank && rank < high_rank);
+      f2 = (pc < delta_n) && hv && cm;
+    }
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) { wtot[0][wave] = __popcll(b0); wtot[1][wave] = __popcll(b1); wtot[2][wave] = __popcll(b2); }
+    __syncthreads();
+    int o0 = base[0], o1 = base[1], o2 = base[2];
+    for (int w = 0; w < wave; ++w) { o0 += wtot[0][w]; o1 += wtot[1][w]; o2 += wtot[2][w]; }
+    if (f0) l0[o0 + __popcll(b0 & below)] = n;
+    if (f1) l1[o1 + __popcll(b1 & below)] = n;
+    if (f2) l2[o2 + __popcll(b2 & below)] = n;
+    __syncthreads();
+    if (tid < 3) base[tid] += wtot[tid][0] + wtot[tid][1] + wtot[tid][2] + wtot[tid][3];
+    __syncthreads();
+  }
+  if (tid < 3) counts[c * 3 + tid] = base[tid];
+}
+
+// prototype of every class: mean of the teacher features of its low_valid rows (NaN for an empty class, like
+// torch.mean of an empty selection)
+__global__ __launch_bounds__(256) void mb_proto_kernel(const float* __restrict__ rep_t, int D, const int* __restrict__ lists,
+                                                       const int* __restrict__ counts, int N, float* __restrict__ proto) {
+  const int c = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const int cnt = counts[c * 3 + 0];
+  const int* l0 = lists + ((size_t)c * 3 + 0) * N;
+  float s = 0.f;
+  for (int i = 0; i < cnt; ++i) s += rep_t[(size_t)l0[i] * D + d];
+  proto[(size_t)c * D + d] = cnt > 0 ? s / (float)cnt : __builtin_nanf("");
+}
+
+// enqueue the negative keys of every class into its ring (only the last `cap` of them can survive)
+__global__ __launch_bounds__(256) void mb_enqueue_kernel(const float* __restrict__ rep_t, int D, const int* __restrict__ lists,
+                                                         const int* __restrict__ counts, int N, float* __restrict__ bank,
+                                                         const int* __restrict__ state, const int* __restrict__ caps,
+                                                         int cap_stride) {
+  const int c = blockIdx.y;
+  const int cap = caps[c];
+  const int m = counts[c * 3 + 2], rows = state[c * 2 + 0], head = state[c * 2 + 1];
+  const int* l2 = lists + ((size_t)c * 3 + 2) * N;
+  const int j0 = m > cap ? m - cap : 0;
+  const long long tot = (long long)(m - j0) * D;
+  float* bc = bank + (size_t)c * cap_stride * D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+    const int j = j0 + (int)(e / D), d = (int)(e - (long long)(j - j0) * D);
+    const int slot = (int)(((long long)head + rows + j) % cap);
+    bc[(size_t)slot * D + d] = rep_t[(size_t)l2[j] * D + d];
+  }
+}
+
+__global__ void mb_state_kernel(const int* __restrict__ counts, int* __restrict__ state, int K,
+                                const int* __restrict__ caps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K) return;
+  const int cap = caps[c];
+  const int m = counts[c * 3 + 2], rows = state[c * 2 + 0], head = state[c * 2 + 1];
+  const long long total = (long long)rows + m;
+  const long long dropped = total > cap ? total - cap : 0;
+  state[c * 2 + 0] = (int)(total > cap ? cap : total);
+  state[c * 2 + 1] = (int)(((long long)head + dropped) % cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// InfoNCE of one loop position (loss_helper.py:164-215): one workgroup per query.
+//   anchor  = rep[pool[anchor_draw[q]]]                       (gradient flows here only)
+//   keys    = [ positive(q) ; bank[(head + neg_draw[q][j]) % cap], j < NN ]
+//   logits  = cos(anchor, key) / temp, target 0, mean over queries; `scale` = 1 / valid_seg
+// torch.cosine_similarity normalises each vector by max(|x|, 1e-8) and then takes the dot product.
+// ------------------------------------------------------------------------------------------
+constexpr int MB_MAXKEYS = 128;
+
+__global__ __launch_bounds__(256) void mb_infonce_kernel(const float* __restrict__ rep, int D, const int* __restrict__ pool,
+                                                         const long long* __restrict__ anchor_draw,
+                                                         const float* __restrict__ pos, long long pos_qstride,
+                                                         const float* __restrict__ bank_c, int cap, int head,
+                                                         const long long* __restrict__ neg_draw, int NN, float temp,
+                                                         float scale, int Qn, float* __restrict__ lossq,
+                                                         float* __restrict__ ganchor) {
+  __shared__ float s_dot[MB_MAXKEYS], s_kn[MB_MAXKEYS], s_w[MB_MAXKEYS];
+  __shared__ const float* s_key[MB_MAXKEYS];
+  __shared__ float s_an2[4], s_misc[2];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NK = NN + 1;
+  const float* a = rep + (size_t)pool[anchor_draw[q]] * D;
+  for (int j = tid; j < NK; j += 256) {
+    if (j == 0) s_key[0] = pos + (long long)q * pos_qstride;
+    else {
+      const long long r = neg_draw[(long long)q * NN + (j - 1)];
+      s_key[j] = bank_c + (size_t)(((long long)head + r) % cap) * D;
+    }
+  }
+  {  // |a|^2
+    float s = 0.f;
+    for (int d = tid; d < D; d += 256) { const float v = a[d]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) s_an2[wave] = s;
+  }
+  __syncthreads();
+  const float an = sqrtf((s_an2[0] + s_an2[1]) + (s_an2[2] + s_an2[3]));
+  const float anc = fmaxf(an, 1e-8f);
+  for (int j = wave; j < NK; j += 4) {           // one wave per key: a . k and |k|^2
+    const float* k = s_key[j];
+    float dt = 0.f, kn = 0.f;
+    for (int d = lane; d < D; d += 64) { const float kv = k[d]; dt += a[d] * kv; kn += kv * kv; }
+    dt = wave_sum(dt); kn = wave_sum(kn);
+    if (lane == 0) { s_dot[j] = dt; s_kn[j] = fmaxf(sqrtf(kn), 1e-8f); }
+  }
+  __syncthreads();
+  if (wave == 0) {                               // softmax over the NK logits (NK <= 128: two per lane)
+    float l0 = -3.0e38f, l1 = -3.0e38f, c0 = 0.f, c1 = 0.f;
+    if (lane < NK) { c0 = s_dot[lane] / (anc * s_kn[lane]); l0 = c0 / temp; }
+    if (lane + 64 < NK) { c1 = s_dot[lane + 64] / (anc * s_kn[lane + 64]); l1 = c1 / temp; }
+    const float mx = wave_max(fmaxf(l0, l1));
+    const float e0 = lane < NK ? expf(l0 - mx) : 0.f, e1 = lane + 64 < NK ? expf(l1 - mx) : 0.f;
+    const float se = wave_sum(e0 + e1);
+    const float first = __shfl(l0, 0, 64);
+    // d loss / d cos_j = (softmax_j - [j == 0]) / temp * scale / Qn
+    const float g = scale / ((float)Qn * temp);
+    const float w0 = (e0 / se - (lane == 0 ? 1.f : 0.f)) * g, w1 = (e1 / se) * g;
+    float wc = 0.f;
+    if (lane < NK) { s_w[lane] = w0 / (anc * s_kn[lane]); wc += w0 * c0; }
+    if (lane + 64 < NK) { s_w[lane + 64] = w1 / (anc * s_kn[lane + 64]); wc += w1 * c1; }
+    wc = wave_sum(wc);
+    if (lane == 0) {
+      lossq[q] = (mx + logf(se) - first) * scale / (float)Qn;
+      s_misc[0] = wc / (anc * anc);              // sum_j w_j cos_j / |a|^2
+      s_misc[1] = (an >= 1e-8f) ? 1.f : 0.f;     // below the clamp the normalisation is a constant: no a-term
+    }
+  }
+  __syncthreads();
+  const float selfc = s_misc[0] * s_misc[1];
+  float* go = ganchor + (size_t)q * D;
+  for (int d = tid; d < D; d += 256) {
+    float s = 0.f;
+    for (int j = 0; j < NK; ++j) s += s_w[j] * s_key[j][d];
+    go[d] = s - selfc * a[d];
+  }
+}
+
+// d rep[row] += sum of the anchor gradients of the queries that drew that row, in query order.  One workgroup per
+// query: it proceeds only if no earlier query drew the same row (the "leader"), collects the later duplicates in
+// order, and does the single read-modify-write of its row -- distinct leaders own distinct rows, so the result
+// does not depend on scheduling.
+__global__ __launch_bounds__(256) void mb_scatter_kernel(const float* __restrict__ ganchor, const int* __restrict__ pool,
+                                                         const long long* __restrict__ anchor_draw, int Qn, int D,
+                                                         float* __restrict__ drep) {
+  extern __shared__ int s_mem[];                  // rows[Qn] | dup flags[Qn]
+  __shared__ int s_follower;
+  int* s_row = s_mem;
+  int* s_dup = s_mem + Qn;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_follower = 0;
+  for (int p = tid; p < Qn; p += 256) s_row[p] = pool[anchor_draw[p]];
+  __syncthreads();
+  const int r = s_row[q];
+  for (int p = tid; p < Qn; p += 256) {
+    const bool same = s_row[p] == r;
+    s_dup[p] = (same && p > q) ? 1 : 0;
+    if (same && p < q) s_follower = 1;            // benign race: every writer stores 1
+  }
+  __syncthreads();
+  if (s_follower) return;
+  for (int d = tid; d < D; d += 256) {
+    float s = ganchor[(size_t)q * D + d];
+    for (int p = q + 1; p < Qn; ++p)
+      if (s_dup[p]) s += ganchor[(size_t)p * D + d];
+    drep[(size_t)r * D + d] += s;
+  }
+}
+
+__global__ void mb_sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += v[i];
+    out[0] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// compute_unsupervised_loss (loss_helper.py:242-261)
+//   ws: ent[B] | sel[2] (a[lo], a[hi]) | info[4] (n_valid, kept, loss_sum, thresh)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void us_entropy_kernel(const float* __restrict__ teacher, const long long* __restrict__ target,
+                                                         int B, int K, float* __restrict__ ent, int* __restrict__ nvalid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool valid = false;
+  if (i < B) {
+    const float* t = teacher + (size_t)i * K;
+    float mx = -3.0e38f;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, t[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(t[k] - mx);
+    float e = 0.f;
+    for (int k = 0; k < K; ++k) { const float p = expf(t[k] - mx) / se; e -= p * logf(p + 1e-10f); }
+    ent[i] = e;
+    valid = target[i] != 255;
+  }
+  const unsigned long long b = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(nvalid, __popcll(b));     // integer count: order-independent
+}
+
+// order statistics a[lo], a[hi] of the valid entropies by rank counting (stable: ties by row index)
+__global__ __launch_bounds__(256) void us_select_kernel(const float* __restrict__ ent, const long long* __restrict__ target, int B,
+                                                        double percent, const int* __restrict__ nvalid,
+                                                        float* __restrict__ sel) {
+  __shared__ float s_e[256];
+  __shared__ int s_v[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = *nvalid;
+  if (n <= 0) return;
+  const double vidx = (double)(n - 1) * percent / 100.0;
+  const int lo = (int)floor(vidx), hi = lo + 1 < n ? lo + 1 : n - 1;
+  const bool mine = i < B && target[i] != 255;
+  const float ei = i < B ? ent[i] : 0.f;
+  int rank = 0;
+  for (int j0 = 0; j0 < B; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    __syncthreads();
+    s_e[threadIdx.x] = j < B ? ent[j] : 0.f;
+    s_v[threadIdx.x] = (j < B && target[j] != 255) ? 1 : 0;
+    __syncthreads();
+    const int lim = B - j0 < 256 ? B - j0 : 256;
+    for (int t = 0; t < lim; ++t)
+      if (s_v[t]) rank += (s_e[t] < ei || (s_e[t] == ei && j0 + t < i)) ? 1 : 0;
+  }
+  if (mine) {
+    if (rank == lo) sel[0] = ei;
+    if (rank == hi) sel[1] = ei;
+  }
+}
+
+// threshold (numpy 'linear' percentile, evaluated in double like numpy does for a float32 array and a float64
+// fraction, then rounded to float32 for the comparison with the float32 entropies), drop mask, kept count, CE sum
+__global__ __launch_bounds__(256) void us_mask_kernel(const float* __restrict__ predict, long long* __restrict__ target,
+                                                      const float* __restrict__ ent, int B, int K, double percent,
+                                                      const int* __restrict__ nvalid, const float* __restrict__ sel,
+                                                      float* __restrict__ rowloss, int* __restrict__ kept) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = *nvalid;
+  float thr = 3.0e38f;
+  if (n > 0) {
+    const double vidx = (double)(n - 1) * percent / 100.0;
+    const double g = vidx - floor(vidx);
+    const double a = (double)sel[0], b = (double)sel[1], diff = b - a;
+    double t = a + diff * g;
+    if (g >= 0.5) t = b - diff * (1.0 - g);
+    if (diff == 0.0) t = a;
+    thr = (float)t;
+  }
+  bool keep = false;
+  if (i < B) {
+    long long tg = target[i];
+    if (tg != 255 && ent[i] >= thr) { tg = 255; target[i] = 255; }
+    keep = tg != 255;
+    float l = 0.f;
+    if (keep) {
+      const float* p = predict + (size_t)i * K;
+      float mx = -3.0e38f;
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) se += expf(p[k] - mx);
+      l = mx + logf(se) - p[tg];
+    }
+    rowloss[i] = l;
+  }
+  const unsigned long long bm = __ballot(keep);
+  if ((threadIdx.x & 63) == 0 && bm) atomicAdd(kept, __popcll(bm));
+}
+
+__global__ __launch_bounds__(256) void us_grad_kernel(const float* __restrict__ predict, const long long* __restrict__ target,
+                                                      const float* __restrict__ rowloss, int B, int K,
+                                                      const int* __restrict__ kept, float* __restrict__ loss,
+                                                      float* __restrict__ dpredict) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float kf = (float)(*kept);
+  const float weight = (float)B / kf;                    // :256 (inf / NaN when nothing is kept, like the reference)
+  if (i == 0) {
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) s += rowloss[r];         // fixed order
+    loss[0] = weight * (s / kf);
+  }
+  if (i < B) {
+    const long long tg = target[i];
+    const float* p = predict + (size_t)i * K;
+    float* g = dpredict + (size_t)i * K;
+    if (tg == 255) {
+      for (int k = 0; k < K; ++k) g[k] = 0.f;
+    } else {
+      float mx = -3.0e38f;
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) se += expf(p[k] - mx);
+      const float sc = weight / kf;
+      for (int k = 0; k < K; ++k) g[k] = sc * (expf(p[k] - mx) / se - (k == (int)tg ? 1.f : 0.f));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+hipError_t launch_mb_select(const float* prob, const float* label, const float* low_mask, const float* high_mask, int N,
+                            int Nl, int K, int* lists, int* counts, hipStream_t st) {
+  hipLaunchKernelGGL(mb_select_kernel, dim3(K), dim3(256), 0, st, prob, label, low_mask, high_mask, N, Nl, K, 0.3f, 1.0f,
+                     3, 9, lists, counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_mb_proto(const float* rep_t, int D, const int* lists, const int* counts, int N, int K, float* proto,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(mb_proto_kernel, dim3((D + 255) / 256, K), dim3(256), 0, st, rep_t, D, lists, counts, N, proto);
+  return hipGetLastError();
+}
+
+hipError_t launch_mb_enqueue(const float* rep_t, int D, const int* lists, const int* counts, int N, int K, float* bank,
+                             int* state, const int* caps, int cap_stride, hipStream_t st) {
+  hipLaunchKernelGGL(mb_enqueue_kernel, dim3(32, K), dim3(256), 0, st, rep_t, D, lists, counts, N, bank, state, caps,
+                     cap_stride);
+  hipLaunchKernelGGL(mb_state_kernel, dim3((K + 63) / 64), dim3(64), 0, st, counts, state, K, caps);
+  return hipGetLastError();
+}
+
+// dequeue_and_enqueue for ONE class with the keys given directly (m known on the host)
+__global__ __launch_bounds__(256) void mb_push_kernel(const float* __restrict__ keys, int m, int D, float* __restrict__ bank_c,
+                                                      const int* __restrict__ state_c, int cap) {
+  const int rows = state_c[0], head = state_c[1];
+  const int j0 = m > cap ? m - cap : 0;
+  const long long tot = (long long)(m - j0) * D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+    const int j = j0 + (int)(e / D), d = (int)(e - (long long)(j - j0) * D);
+    const int slot = (int)(((long long)head + rows + j) % cap);
+    bank_c[(size_t)slot * D + d] = keys[(size_t)j * D + d];
+  }
+}
+
+__global__ void mb_push_state_kernel(int m, int* __restrict__ state_c, int cap) {
+  const long long total = (long long)state_c[0] + m;
+  const long long dropped = total > cap ? total - cap : 0;
+  const int head = state_c[1];
+  state_c[0] = (int)(total > cap ? cap : total);
+  state_c[1] = (int)(((long long)head + dropped) % cap);
+}
+
+hipError_t launch_mb_push(const float* keys, int m, int D, float* bank_c, int* state_c, int cap, hipStream_t st) {
+  if (m > 0) hipLaunchKernelGGL(mb_push_kernel, dim3(64), dim3(256), 0, st, keys, m, D, bank_c, state_c, cap);
+  hipLaunchKernelGGL(mb_push_state_kernel, dim3(1), dim3(1), 0, st, m, state_c, cap);
+  return hipGetLastError();
+}
+
+hipError_t launch_mb_infonce(const float* rep, int D, const int* pool, const long long* anchor_draw, const float* pos,
+                             long long pos_qstride, const float* bank_c, int cap, int head, const long long* neg_draw,
+                             int Qn, int NN, float temp, float scale, float* lossq, float* ganchor, float* drep,
+                             hipStream_t st) {
+  if (NN + 1 > MB_MAXKEYS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mb_infonce_kernel, dim3(Qn), dim3(256), 0, st, rep, D, pool, anchor_draw, pos, pos_qstride, bank_c,
+                     cap, head, neg_draw, NN, temp, scale, Qn, lossq, ganchor);
+  if (drep)
+    hipLaunchKernelGGL(mb_scatter_kernel, dim3(Qn), dim3(256), (size_t)2 * Qn * sizeof(int), st, ganchor, pool,
+                       anchor_draw, Qn, D, drep);
+  return hipGetLastError();
+}
+
+hipError_t launch_mb_sum(const float* v, int n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(mb_sum_kernel, dim3(1), dim3(64), 0, st, v, n, out);
+  return hipGetLastError();
+}
+
+size_t unsup_ws_bytes(int B) { return ((size_t)2 * B + 16) * 4; }
+
+hipError_t launch_unsup(const float* predict, long long* target, const float* teacher, int B, int K, double percent,
+                        float* loss, float* dpredict, void* ws, hipStream_t st) {
+  float* ent = (float*)ws;
+  float* rowloss = ent + B;
+  float* sel = rowloss + B;           // [2]
+  int* info = (int*)(sel + 2);        // nvalid, kept
+  hipError_t e = hipMemsetAsync(sel, 0, 14 * 4, st);
+  if (e != hipSuccess) return e;
+  const int nb = (B + 255) / 256;
+  hipLaunchKernelGGL(us_entropy_kernel, dim3(nb), dim3(256), 0, st, teacher, target, B, K, ent, info);
+  hipLaunchKernelGGL(us_select_kernel, dim3(nb), dim3(256), 0, st, ent, target, B, percent, info, sel);
+  hipLaunchKernelGGL(us_mask_kernel, dim3(nb), dim3(256), 0, st, predict, target, ent, B, K, percent, info, sel,
+                     rowloss, info + 1);
+  hipLaunchKernelGGL(us_grad_kernel, dim3(nb), dim3(256), 0, st, predict, target, rowloss, B, K, info + 1, loss, dpredict);
+  return hipGetLastError();
+}
+
+}  // namespace cmlpl

@@ -230,6 +230,51 @@ int cmlpl_ntxent_fwd_bwd(const float* d_emb_i, const float* d_emb_j, int B, int 
                          float* d_loss, float* d_grad_i, float* d_grad_j,
                          void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * loss_helper.py of the reference.  The reference keeps one FIFO per class as a Python list
+ * of tensors; here a class's bank is a physical ring d_bank[c][capacity_stride][D] (capacity[c] slots used) with
+ * d_state[c] = {rows, head}:
+ * LOGICAL row i (what loss_helper.py's queue[0][i] holds) is ring slot (head + i) % capacity.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* compute_unsupervised_loss (loss_helper.py:242-261): rows whose teacher entropy reaches the `percent`-th percentile
+ * (numpy 'linear') of the valid rows are set to 255 IN d_target; d_loss[0] = (B / kept) * mean-over-kept CE;
+ * d_dpredict [B][K] = d loss / d predict. */
+size_t cmlpl_unsup_workspace_bytes(int B);
+int cmlpl_unsup_loss(const float* d_predict, int64_t* d_target, const float* d_pred_teacher, int B, int K,
+                     double percent, float* d_loss, float* d_dpredict, void* d_workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Per-class selection of compute_contra_memobank_loss (loss_helper.py:67-123).  d_prob / d_label [N][K] are the
+ * labelled rows followed by the unlabelled ones (n_labeled first), masks [N].  d_lists [K][3][N] receives, in row
+ * order: 0 low_valid rows, 1 low-entropy anchor pool, 2 negative-key rows; d_counts [K][3] their lengths. */
+int cmlpl_memobank_select(const float* d_prob, const float* d_label, const float* d_low_mask, const float* d_high_mask,
+                          int N, int n_labeled, int K, int32_t* d_lists, int32_t* d_counts, void* stream);
+/* class prototypes (loss_helper.py:102-106): d_proto[c] = mean of d_rep_teacher over list 0 (NaN when empty) */
+int cmlpl_memobank_proto(const float* d_rep_teacher, int N, int D, int K, const int32_t* d_lists,
+                         const int32_t* d_counts, float* d_proto, void* stream);
+/* dequeue_and_enqueue (loss_helper.py:19-36, call site :126-133) for every class: list 2 of d_rep_teacher is appended,
+ * the last d_capacity[c] rows survive (queue_size may differ per class; class c's ring starts at
+ * d_bank + c * capacity_stride * D) */
+int cmlpl_memobank_enqueue(const float* d_rep_teacher, int N, int D, int K, const int32_t* d_lists,
+                           const int32_t* d_counts, float* d_bank, int32_t* d_state, const int32_t* d_capacity,
+                           int capacity_stride, void* stream);
+/* dequeue_and_enqueue for one class with the keys given directly */
+int cmlpl_memobank_push(const float* d_keys, int m, int D, float* d_bank_c, int32_t* d_state_c, int capacity,
+                        void* stream);
+/* one loop position of loss_helper.py:158-215: `queries` anchors rep[d_pool[d_anchor_draw[q]]], key 0 =
+ * d_pos + q * pos_qstride, keys 1.. = logical bank rows d_neg_draw[q][j]; cosine similarity / temperature, CE with
+ * target 0.  d_lossq[q] = scale * CE_q / queries; d_ganchor [queries][D]; if d_drep is given the anchor gradients
+ * are added into it (rows drawn repeatedly are summed in query order: deterministic).  Indices must be in range. */
+int cmlpl_memobank_infonce(const float* d_rep, int N, int D, const int32_t* d_pool, int pool_rows,
+                           const int64_t* d_anchor_draw, const float* d_pos, int64_t pos_qstride,
+                           const float* d_bank_c, int capacity, int bank_rows, int head, const int64_t* d_neg_draw,
+                           int queries, int negatives, float temperature, float scale, float* d_lossq,
+                           float* d_ganchor, float* d_drep, void* stream);
+/* fixed-order sum of n floats (the loss of all loop positions) */
+int cmlpl_memobank_sum(const float* d_v, int n, float* d_out, void* stream);
+
+
 /* Optional per-launch timing, measured with hipEvent pairs recorded on the launch stream around the
  * selected kernels (bit i of kernel_mask selects CMLPL_K_i).  cmlpl_timing_end synchronises the
  * recorded events and returns, per kernel id, the summed milliseconds and the number of launches.

@@ -73,3 +73,88 @@ def test_oracle_enqueue_is_a_sliding_window():
     assert torch.equal(out, torch.cat((q, keys))[-8:])
     out, ptr, m = O.memobank_enqueue(keys[:1], q, 6, 8)
     assert (ptr, out.shape[0]) == (7, 7)
+
+
+# ------------------------------------------------------------------------------------------ GPU parity
+def _bank_from_inputs(inp, cfg, dev):
+    from cmlpl_amd.memobank import MemoryBank
+    ptrs = [torch.tensor([p], dtype=torch.long) for p in inp["ptrs"]]
+    return MemoryBank.from_lists([[b] for b in inp["bank"]], ptrs, inp["sizes"], cfg["D"], dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES_UNSUP))
+def test_hip_unsupervised_loss_matches_oracle(name):
+    import loss_helper as LH
+    cfg = CASES_UNSUP[name]
+    predict, target, teacher = unsup_inputs(cfg)
+    pr = predict.clone().requires_grad_(True)
+    ref_loss, ref_tgt = O.unsupervised_loss(pr, target.clone(), cfg["percent"], teacher)
+    ref_loss.backward()
+    gp = predict.cuda().requires_grad_(True)
+    gt = target.clone().cuda()
+    loss = LH.compute_unsupervised_loss(gp, gt, cfg["percent"], teacher.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(gt.cpu(), ref_tgt)                                   # the dropped set is exact
+    assert abs(loss.item() - ref_loss.item()) <= 2e-6 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    assert torch.allclose(gp.grad.cpu(), pr.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES_CONTRA))
+@pytest.mark.parametrize("style", ["bank", "lists"])
+def test_hip_contra_memobank_loss_matches_oracle(name, style):
+    import loss_helper as LH
+    cfg, inp, res, grad, (anchor_idx, neg_idx, _) = run_oracle_contra(name)
+    K, D = cfg["K"], cfg["D"]
+    dev = torch.device("cuda")
+    rep = inp["rep"].cuda().requires_grad_(True)
+    args = [inp[k].cuda() for k in ("label_l", "label_u", "prob_l", "prob_u", "low_mask", "high_mask")]
+    mp = inp["momentum"].cuda() if cfg.get("momentum") else None
+    if style == "bank":
+        bank = _bank_from_inputs(inp, cfg, dev)
+        out = LH.compute_contra_memobank_loss(rep, *args, bank, None, None, inp["rep_teacher"].cuda(),
+                                              momentum_prototype=mp, i_iter=cfg.get("i_iter", 0),
+                                              _draws=(anchor_idx, neg_idx))
+        rows_after = [bank.rows(c).cpu() for c in range(K)]
+        ptrs_after = list(bank.ptrs)
+    else:
+        memobank = [[b.clone().cuda()] for b in inp["bank"]]
+        ptrs = [torch.tensor([p], dtype=torch.long) for p in inp["ptrs"]]
+        out = LH.compute_contra_memobank_loss(rep, *args, memobank, ptrs, list(inp["sizes"]),
+                                              inp["rep_teacher"].cuda(), momentum_prototype=mp,
+                                              i_iter=cfg.get("i_iter", 0), _draws=(anchor_idx, neg_idx))
+        rows_after = [memobank[c][0].cpu() for c in range(K)]
+        ptrs_after = [int(p[0]) for p in ptrs]
+    if mp is None:
+        new_keys, loss = out
+    else:
+        prototype, new_keys, loss = out
+        assert torch.allclose(prototype.cpu(), res["prototype"], rtol=1e-5, atol=1e-6, equal_nan=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert new_keys == res["new_keys"]
+    assert ptrs_after == res["ptrs"]
+    for c in range(K):
+        assert torch.equal(rows_after[c], res["memobank"][c]), f"bank of class {c}"     # pure copies: bit-exact
+    ref = res["loss"].item()
+    assert abs(loss.item() - ref) <= 1e-5 * max(abs(ref), 1e-6), (loss.item(), ref)
+    g = rep.grad.cpu() if rep.grad is not None else torch.zeros_like(grad)
+    err = (g - grad).abs().max().item()
+    assert err <= 2e-4 * max(grad.abs().max().item(), 1e-9) + 1e-9, (err, grad.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_hip_enqueue_sliding_window():
+    import loss_helper as LH
+    rng = np.random.Generator(np.random.PCG64(9))
+    q_ref = torch.zeros(0, 8)
+    queue, ptr = [torch.zeros(0, 8).cuda()], torch.zeros(1, dtype=torch.long)
+    p_ref = 0
+    for m in (3, 0, 5, 7, 40, 1, 13):                      # capacity 12: fills, wraps, and one batch larger than it
+        keys = torch.from_numpy(rng.standard_normal((m, 8)).astype(np.float32))
+        q_ref, p_ref, n_ref = O.memobank_enqueue(keys, q_ref, p_ref, 12)
+        n = LH.dequeue_and_enqueue(keys.cuda(), queue, ptr, 12)
+        assert n == n_ref and int(ptr[0]) == p_ref
+        assert torch.equal(queue[0].cpu(), q_ref)

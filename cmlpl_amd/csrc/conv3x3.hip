@@ -5,7 +5,8 @@
 //                           (models.py:134-136 / 138-140, fused)
 //   conv3x3_kernel<DGRAD> : dz = mask * upsample(dpool)/4 (avgpool+relu backward, formed while staging)
 //                           out = conv_transpose(dz) + dz      (residual branch adds dz itself)
-//   wgrad3_kernel         : dW[s][ci][co] = sum_pix in[pix+s][ci] * dz[pix][co], db[co] = sum dz
+//   wgrad3r_kernel        : dW[s][ci][co] = sum_pix in[pix+s][ci] * dz[pix][co], db[co] = sum dz  (row-split,
+//                           double-buffered, LDS-DMA staging; wgrad3_kernel is the general fallback)
 //
 // Data layout: activations are pixel-major / channel-last  [net][sample][pixel][64] so that
 // the 64 channels of a pixel are one 256-B line; the padded image of S samples sits in LDS
@@ -13,6 +14,8 @@
 // step (pack_weights_kernel) to [tap][ci/4][co][4] so that both MFMA operands are ds_read_b128.
 #include <stdlib.h>
 
+// Ablation / timeline builds (scripts/conv_timeline.py): -DCMLPL_ABL=n removes one ingredient
+// of a kernel (results are then wrong on purpose) or adds per-workgroup phase stamps (9).  0 = the product.
 #ifndef CMLPL_ABL
 #define CMLPL_ABL 0
 #endif

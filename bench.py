@@ -164,12 +164,16 @@ def main():
     ms = (C.c_double * nk)()
     cnt = (C.c_int64 * nk)()
     ids = {k: _lib.KERNEL_NAMES.index(k) for k in CONV1_KERNELS}
+    id_conv0 = _lib.KERNEL_NAMES.index("conv0_fwd")
     calib_steps = 10
-    _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(sum(1 << i for i in ids.values()), 3 * calib_steps + 8))
+    _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(sum(1 << i for i in ids.values()) | (1 << id_conv0),
+                                                            4 * calib_steps + 8))
     run(calib_steps, args.warmup)
     barrier()
     _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
     calib = {k: ms[i] / max(cnt[i], 1) for k, i in ids.items()}
+    # no separate conv0 launch => the forward kernel is the fused conv0 + conv1 one and carries both FLOP counts
+    fused_fwd = cnt[id_conv0] == 0
     dom_name = max(calib, key=calib.get)
     dom_id = ids[dom_name]
     _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(1 << dom_id, args.steps + 8))
@@ -188,7 +192,13 @@ def main():
     n_local = args.bt + args.btu
     patches = n_local * world * args.steps
     dom_ms = ms[dom_id] / max(cnt[dom_id], 1)
-    flops = conv1_flops(shape, n_local)
+    kflops = {k: conv1_flops(shape, n_local) for k in CONV1_KERNELS}
+    labels = dict(CONV1_KERNELS)
+    if fused_fwd:
+        kflops["conv1_fwd"] += 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64      # conv0: 2*nets*n*HW*C*64
+        labels["conv1_fwd"] = ("conv3x3_kernel<FWD0> (conv0 1x1 + conv1 3x3 forward fused: conv + bias + residual + "
+                               "ReLU + avgpool, both networks)")
+    flops = kflops[dom_name]
     achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     b2_256 = args.workload == "B2" and n_local == 256
     out = {
@@ -200,7 +210,7 @@ def main():
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
                                f"bank + Adam, epoch 1 (memory-bank smoothing active), Philox noise/dropout",
                    "global_batch": n_local * world, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": CONV1_KERNELS[dom_name],
+        "roofline": {"bound": "mfma", "kernel": labels[dom_name],
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": TRAFFIC_B2_256[dom_name] if b2_256 else None,
@@ -208,9 +218,10 @@ def main():
                      "flops_per_launch": flops, "ms_per_launch": dom_ms, "launches_timed": int(cnt[dom_id])},
         # the other two conv1 kernels (same algorithmic FLOPs), from the calibration window
         "roofline_others": [
-            {"kernel": CONV1_KERNELS[k], "ms_per_launch": calib[k], "launches_timed": calib_steps,
-             "achieved": flops / (calib[k] * 1e-3) / 1e12 if calib[k] > 0 else 0.0,
-             "frac": (flops / (calib[k] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if calib[k] > 0 else 0.0,
+            {"kernel": labels[k], "ms_per_launch": calib[k], "launches_timed": calib_steps,
+             "flops_per_launch": kflops[k],
+             "achieved": kflops[k] / (calib[k] * 1e-3) / 1e12 if calib[k] > 0 else 0.0,
+             "frac": (kflops[k] / (calib[k] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if calib[k] > 0 else 0.0,
              "traffic": TRAFFIC_B2_256[k] if b2_256 else None}
             for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},

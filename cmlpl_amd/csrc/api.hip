@@ -259,10 +259,18 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
                                    d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
     }
   }
-  if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
-                                 d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
-  if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV,
-                             pk_ns, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
+  if (conv3_fused_ok(d.H, d.W, d.C, nets * n)) {
+    // conv0 + conv1 in one launch: a0 never makes the HBM round trip between them (it is still written once,
+    // for the backward pass)
+    if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, d_xn, d_packed + pack_off_w0t(),
+                               pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + 0 * PACK_CONV, pk_ns,
+                               d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
+  } else {
+    if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
+                                   d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
+    if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV,
+                               pk_ns, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
+  }
   if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + 2 * PACK_CONV,
                              pk_ns, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
   join_from(main_st, 0, 1);

@@ -86,16 +86,24 @@ struct Conv3Args {
   float* out; uint8_t* mask_out;
   long long in_ns, mask_in_ns, wpk_ns, bias_ns, out_ns, mask_out_ns;  // per-net strides (elements)
   int n, H, W, S;
+  // MODE 2 (conv0 fused into the conv1 forward): `in` is xn [net][n][C][HW]; a0 is produced here
+  const float* w0t; const float* b0; float* a0out;
+  long long w0t_ns, b0_ns;
+  int C, CC;
 };
 
 // The 9-tap main loop.  NTA = number of this wave's M tiles that carry real pixels (wave-uniform, so
 // the loop body is branch-free and the compiler can hoist the ds_read_b128 of step kk+1 above the
 // MFMAs of step kk).  Tap weights go global -> registers (prefetched one tap ahead) -> LDS.
-template <int MTW, int NTA>
+struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
+
+// `side(s)` runs once per tap right after the tap's weights are queued: the fused forward drains its deferred
+// a0 stores there, two rows per tap, instead of bursting them in front of the loop.
+template <int MTW, int NTA, class Side = NoSide>
 __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float* __restrict__ wbuf,
                                            const float4* __restrict__ wg, float4 w0, float4 w1, float4 w2,
                                            float4 w3, const int (&abase)[MTW], f32x16 (&acc)[MTW][2], int PW,
-                                           int tid, int l31, int hh) {
+                                           int tid, int l31, int hh, Side side = Side()) {
   float4* wl = (float4*)wbuf;
   const float* bbase = wbuf + (hh * 64 + l31) * 4;
 #pragma unroll 1
@@ -113,6 +121,7 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
       const float4* wn = wg + (s + 1) * 1024 + tid;
       w0 = wn[0]; w1 = wn[256]; w2 = wn[512]; w3 = wn[768];
     }
+    side(s);
     if (NTA > 0) {
       const int kh = s / 3, kw = s - kh * 3;
       const float* ib = img + ((kh - 1) * PW + (kw - 1)) * CS;
@@ -167,6 +176,8 @@ struct Conv3Ctx {
   int tid, lane, l31, hh, wave, net, s0, H, W, HW, PW, IMG, H2, W2, P2, RO, CO, PX, S, npx;
   float* img; float* wbuf; int* lut; const float4* wg;
   float4 wp0, wp1, wp2, wp3;
+  f32x16 z0, z1;          // MODE 2: this wave's a0 tile (+ bias), stored to HBM from inside the tap loop
+  float* a0g;
 };
 
 template <int MODE>
@@ -176,28 +187,129 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   const int net = blockIdx.y, s0 = blockIdx.x * a.S;
   const int H = a.H, W = a.W, HW = H * W, PW = W + 2, IMG = (H + 2) * PW;
   const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
-  const int RO = (MODE == 0) ? 2 * H2 : H, CO = (MODE == 0) ? 2 * W2 : W;
+  const int RO = (MODE != 1) ? 2 * H2 : H, CO = (MODE != 1) ? 2 * W2 : W;
   const int PX = RO * CO, S = a.S, npx = S * PX;
   float* img = smem;                       // [S][IMG][CS]
   float* wbuf = img + (size_t)S * IMG * CS;  // [16][64][4]
   int* lut = (int*)(wbuf + 4096);          // padded-image position of output pixel m
-  {  // zero the padded images (border must be zero; interior overwritten below)
+  if (MODE != 2) {  // zero the padded images (border must be zero; interior overwritten below)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* p = (float4*)img;
     const int tot = S * IMG * (CS / 4);
     for (int i = tid; i < tot; i += 256) p[i] = z;
   }
-  for (int m = tid; m < lut_entries; m += 256) {
-    const int mm = (m < npx) ? m : 0;
-    const int s = mm / PX, rem = mm - s * PX, r = rem / CO, c = rem - r * CO;
-    lut[m] = s * IMG + (r + 1) * PW + (c + 1);
+  if (MODE != 2) {
+    for (int m = tid; m < lut_entries; m += 256) {
+      const int mm = (m < npx) ? m : 0;
+      const int s = mm / PX, rem = mm - s * PX, r = rem / CO, c = rem - r * CO;
+      lut[m] = s * IMG + (r + 1) * PW + (c + 1);
+    }
   }
   const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
   // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
   c.wp0 = wg[tid]; c.wp1 = wg[tid + 256]; c.wp2 = wg[tid + 512]; c.wp3 = wg[tid + 768];
   __syncthreads();
 
-  if (MODE == 0) {
+  if (MODE == 2) {
+    // conv0 (1x1, C -> 64, tools/models.py:102,132) fused in: a0 of this workgroup's sample (S == 1) is computed
+    // here, written into the LDS image (the conv1 input) and to HBM (the backward pass reads it).  The image and
+    // tap-weight regions are idle until then, so the sample's whole [C][HW] slab is copied into them linearly by
+    // global_load_lds_dwordx4 -- every piece in flight at once, ONE wait -- and only afterwards is the region
+    // re-initialised as the zero-bordered image.  wave = M tile of 32 pixels; A[pixel][band] = slab[band][pixel]
+    // (ds_read_b32, consecutive lanes = consecutive pixels); B = the k-major w0T rows straight from L2, fetched
+    // 16 k-steps ahead.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    const int C = a.C, Cp = (C + 1) & ~1, KK = Cp >> 1;
+    float* slab = smem;                                   // [Cp][HW] (+64), aliases img | wbuf | lut
+    float* w0l = smem + Cp * HW + 64;                     // [Cp][64] k-major conv0 weights (pad row is zero)
+    const float* xs = a.in + ((long long)net * a.n + s0) * (long long)C * HW;
+    const float* w0 = a.w0t + (long long)net * a.w0t_ns;
+    {
+      const int nfl = C * HW, nf4 = nfl >> 2;
+      for (int q = wave; q * 64 < nf4; q += 4) {
+        const int f = q * 64 + lane;
+        if (f < nf4) __builtin_amdgcn_global_load_lds((gbl_void*)(xs + 4 * f), (lds_void*)(slab + q * 256), 16, 0, 0);
+      }
+      const int wf4 = Cp * 16;                            // w0T is 16-B aligned and a multiple of 64 floats
+      for (int q = wave; q * 64 < wf4; q += 4) {
+        const int f = q * 64 + lane;
+        if (f < wf4) __builtin_amdgcn_global_load_lds((gbl_void*)(w0 + 4 * f), (lds_void*)(w0l + q * 256), 16, 0, 0);
+      }
+      if (tid < nfl - 4 * nf4) slab[4 * nf4 + tid] = xs[4 * nf4 + tid];
+      // the pad band (odd C) meets a zero weight row, but must be finite; so must the tail a clamped lane reads
+      for (int i = nfl + tid; i < Cp * HW + 64; i += 256) slab[i] = 0.f;
+    }
+    f32x16 z0 = zero16(), z1 = zero16();
+    const int pixA = (wave * 32 + l31 < HW) ? wave * 32 + l31 : HW - 1;
+    __syncthreads();                                      // slab + weights complete (the barrier waits for the DMA)
+    STAMP(0, 4);
+    {
+      const float* ap = slab + hh * HW + pixA;
+      const float* bp = w0l + hh * 64 + l31;
+      // operands of the next 8 k-steps are fetched from LDS while the 16 MFMAs of the current 8 run
+      float av[8], b0v[8], b1v[8], an[8], b0n[8], b1n[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = (q < KK) ? q : 0;
+        av[q] = ap[2 * k * HW]; b0v[q] = bp[2 * k * 64]; b1v[q] = bp[2 * k * 64 + 32];
+      }
+      for (int k0 = 0; k0 < KK; k0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = (k0 + 8 + q < KK) ? k0 + 8 + q : 0;
+          an[q] = ap[2 * k * HW]; b0n[q] = bp[2 * k * 64]; b1n[q] = bp[2 * k * 64 + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (k0 + q < KK) {                              // uniform
+            z0 = mfma32(av[q], b0v[q], z0);
+            z1 = mfma32(av[q], b1v[q], z1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { av[q] = an[q]; b0v[q] = b0n[q]; b1v[q] = b1n[q]; }
+      }
+    }
+    __syncthreads();                                      // every wave is done with the slab
+    STAMP(0, 5);
+    {  // now the region becomes the zero-bordered image (the interior is written just below) and the LUT
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int nbp = 2 * PW + 2 * H;                     // border pixels: top row, bottom row, left / right columns
+      for (int i = tid; i < nbp * (CS / 4); i += 256) {
+        const int bp = i / (CS / 4), f = i - bp * (CS / 4);
+        int pos;
+        if (bp < PW) pos = bp;
+        else if (bp < 2 * PW) pos = (H + 1) * PW + (bp - PW);
+        else { const int k = bp - 2 * PW; pos = (1 + (k >> 1)) * PW + ((k & 1) ? W + 1 : 0); }
+        ((float4*)img)[pos * (CS / 4) + f] = z;
+      }
+      for (int m = tid; m < lut_entries; m += 256) {
+        const int mm = (m < npx) ? m : 0;
+        const int r = mm / CO, cc = mm - r * CO;
+        lut[m] = (r + 1) * PW + (cc + 1);
+      }
+    }
+    STAMP(0, 6);
+    const float* b0 = a.b0 + (long long)net * a.b0_ns;
+    const float bv0 = b0[l31], bv1 = b0[32 + l31];
+    const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for m < 128, W <= 128 (checked on the host)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      z0[r] += bv0; z1[r] += bv1;
+      const int m = wave * 32 + acc_row(r, lane);
+      if (m < HW) {
+        const int h = (m * magic) >> 16, w = m - h * W;
+        float* p = img + (size_t)((h + 1) * PW + w + 1) * CS;
+        p[l31] = z0[r]; p[32 + l31] = z1[r];
+      }
+    }
+    c.z0 = z0; c.z1 = z1;
+    c.a0g = a.a0out + ((long long)net * a.n + s0) * (long long)HW * 64;
+    __syncthreads();                                      // the LUT (and the image) are complete
+  } else if (MODE == 0) {
     const float* src = a.in + (long long)net * a.in_ns;
     staged_copy<8, float4>(S * HW * 16, tid,
         [&](int idx) {
@@ -280,9 +392,9 @@ template <int MODE, int MTW>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Conv3Ctx c;
-  STAMP(MODE, 0);
+  STAMP(MODE & 1, 0);
   conv3_stage<MODE>(a, smem, MTW * 128, c);
-  STAMP(MODE, 1);
+  STAMP(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
   float* img = c.img; float* wbuf = c.wbuf; int* lut = c.lut; const float4* wg = c.wg;
@@ -298,12 +410,29 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   }
 
   // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
-  if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
+  if (MODE == 2) {
+    // MTW == 1 here.  Rows 2s, 2s+1 of this wave's a0 tile go to HBM while tap s runs.
+    const f32x16 z0 = c.z0, z1 = c.z1;
+    float* a0g = c.a0g;
+    auto side = [&](int s) {
+      if (s < 8) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if ((r >> 1) == s) {                           // s is uniform: two of the sixteen rows per tap
+            const int m = wave * 32 + acc_row(r, lane);
+            if (m < HW) { a0g[(size_t)m * 64 + l31] = z0[r]; a0g[(size_t)m * 64 + 32 + l31] = z1[r]; }
+          }
+        }
+      }
+    };
+    if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
+    else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
+  } else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
-  STAMP(MODE, 2);
+  STAMP(MODE & 1, 2);
 
-  if (MODE == 0) {
+  if (MODE != 1) {
     const float* bias = a.bias + (long long)net * a.bias_ns;
     const float bv0 = bias[l31], bv1 = bias[32 + l31];
 #pragma unroll
@@ -345,7 +474,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
       }
     }
   }
-  STAMP(MODE, 3);
+  STAMP(MODE & 1, 3);
 }
 
 
@@ -490,6 +619,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   if (mode == 0) { a.in_ns = (long long)n * HW * 64; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns; a.mask_in_ns = 0; }
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.CC = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
@@ -511,6 +641,42 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   }
   if (mode == 0) { CMLPL_DISPATCH(0) } else { CMLPL_DISPATCH(1) }
 #undef CMLPL_DISPATCH
+}
+
+// conv0 fused into the conv1 forward (MODE 2).  Possible when the plain forward plan is one sample per workgroup
+// with one pixel tile per wave (H*W <= 128) and two workgroups still fit a CU with the slab + conv0 weights in LDS.
+// LDS of the fused kernel: the plain forward's regions, or slab [Cp][HW] + 64 + weights [Cp][64] if that is larger
+static size_t conv3_fused_lds(int H, int W, int C, size_t plain) {
+  const size_t Cp = (size_t)((C + 1) & ~1);
+  const size_t need = (Cp * H * W + 64 + Cp * 64) * 4;
+  return need > plain ? need : plain;
+}
+
+bool conv3_fused_ok(int H, int W, int C, int rows) {
+  static const bool off = getenv("CMLPL_FUSE_CONV0") && atoi(getenv("CMLPL_FUSE_CONV0")) == 0;
+  if (off || C < 1) return false;
+  Conv3Plan pl;
+  if (!plan_conv3(0, H, W, rows, &pl)) return false;
+  if (pl.S != 1 || pl.MTW != 1 || H * W > 128) return false;
+  for (int m = 0; m < 128; ++m)                       // the magic-number divide of the kernel
+    if (((m * ((65536 + W - 1) / W)) >> 16) != m / W) return false;
+  return 2 * conv3_fused_lds(H, W, C, pl.lds) <= LDS_MAX;
+}
+
+hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const float* xn, const float* w0t, long long w0t_ns,
+                              const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
+                              const float* bias, long long bias_ns, float* out, uint8_t* mask_out, hipStream_t st) {
+  Conv3Plan pl;
+  if (!conv3_fused_ok(H, W, C, nets * n) || !plan_conv3(0, H, W, nets * n, &pl)) return hipErrorInvalidValue;
+  const int HW = H * W, P2 = (H / 2) * (W / 2);
+  Conv3Args a;
+  a.in = xn; a.mask_in = nullptr; a.wpk = wpk; a.bias = bias; a.out = out; a.mask_out = mask_out;
+  a.wpk_ns = wpk_ns; a.bias_ns = bias_ns;
+  a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
+  a.n = n; a.H = H; a.W = W; a.S = 1;
+  a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.CC = 0;
+  (void)HW;
+  return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -41,6 +41,10 @@ bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p);
 hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in, const uint8_t* mask_in,
                         const float* wpk, long long wpk_nstride, const float* bias, long long bias_nstride,
                         float* out, uint8_t* mask_out, hipStream_t st);
+bool conv3_fused_ok(int H, int W, int C, int rows);
+hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const float* xn, const float* w0t, long long w0t_ns,
+                              const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
+                              const float* bias, long long bias_ns, float* out, uint8_t* mask_out, hipStream_t st);
 struct Wgrad3Plan { int RU, U, G, cspl, NI, ND, rsplit, UPG; size_t lds; };   // NI > 0: pipelined kernel, NI prefetch float4 / thread
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,

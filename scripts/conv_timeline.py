@@ -23,7 +23,13 @@ rc = lib.cmlpl_abl_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1, last launch)", 240)):
     t = buf[mode, :nwg, :4].astype(np.int64)
+    full = buf[mode, :nwg, :].astype(np.int64)
+    full = full[t[:, 0] > 0]
     t = t[t[:, 0] > 0]
+    if mode == 0 and full[:, 4].max() > 0:
+        f = (full - full[:, :1]) / 100.0
+        print(f"fwd fused prologue (us from workgroup start): slab landed {f[:,4].mean():.2f}  conv0 MFMAs done {f[:,5].mean():.2f}  "
+              f"image zeroed {f[:,6].mean():.2f}  a0 written / stage end {f[:,1].mean():.2f}")
     t0 = t[:, 0].min()
     us = (t - t0) / 100.0
     print(f"{name}: start skew  mean {us[:,0].mean():.2f}  max {us[:,0].max():.2f} us")

@@ -165,15 +165,17 @@ def main():
     cnt = (C.c_int64 * nk)()
     ids = {k: _lib.KERNEL_NAMES.index(k) for k in CONV1_KERNELS}
     id_conv0 = _lib.KERNEL_NAMES.index("conv0_fwd")
+    id_conv0w = _lib.KERNEL_NAMES.index("conv0_wgrad")
     calib_steps = 10
-    _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(sum(1 << i for i in ids.values()) | (1 << id_conv0),
-                                                            4 * calib_steps + 8))
+    _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(
+        sum(1 << i for i in ids.values()) | (1 << id_conv0) | (1 << id_conv0w), 5 * calib_steps + 8))
     run(calib_steps, args.warmup)
     barrier()
     _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
     calib = {k: ms[i] / max(cnt[i], 1) for k, i in ids.items()}
     # no separate conv0 launch => the forward kernel is the fused conv0 + conv1 one and carries both FLOP counts
     fused_fwd = cnt[id_conv0] == 0
+    fused_bwd = cnt[id_conv0w] == 0
     dom_name = max(calib, key=calib.get)
     dom_id = ids[dom_name]
     _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(1 << dom_id, args.steps + 8))
@@ -198,6 +200,10 @@ def main():
         kflops["conv1_fwd"] += 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64      # conv0: 2*nets*n*HW*C*64
         labels["conv1_fwd"] = ("conv3x3_kernel<FWD0> (conv0 1x1 + conv1 3x3 forward fused: conv + bias + residual + "
                                "ReLU + avgpool, both networks)")
+    if fused_bwd:
+        kflops["conv1_dgrad"] += 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64
+        labels["conv1_dgrad"] = ("conv3x3_kernel<DGRAD0> (conv1 data gradient + conv0 weight gradient fused, "
+                                 "both networks)")
     flops = kflops[dom_name]
     achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     b2_256 = args.workload == "B2" and n_local == 256

@@ -37,6 +37,11 @@ struct NetWs {
   size_t bytes;
 };
 
+// per-net conv0 weight-gradient partials: one per sample when the fused data-gradient kernel produces them
+int conv0_partials(const Dims& d, int nets, int n) {
+  return conv3_fused_bwd_ok(d.H, d.W, d.C, nets * n) ? n : plan_conv0_wgrad_G(n, d.C, d.HW);
+}
+
 bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up256(bytes); return p; };
@@ -46,7 +51,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   Conv3Plan c;
   if (!plan_conv3(0, d.H, d.W, nets * n, &c) || !plan_conv3(1, d.H, d.W, nets * n, &c) ||
       !plan_conv3(0, d.H2, d.W2, nets * n, &c) || !plan_conv3(1, d.H2, d.W2, nets * n, &c)) return false;
-  const int G0 = plan_conv0_wgrad_G(n, d.C, d.HW);
+  const int G0 = conv0_partials(d, nets, n);
   const int Ct = ((d.C + 31) / 32) * 32;
   w->a0 = (float*)take(N * d.HW * 64 * 4);
   w->p1 = (float*)take(N * d.P2 * 64 * 4);
@@ -331,10 +336,17 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
     hipStream_t st = fork_to(main_st, 0, 4);
     if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
   }
-  if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
-                             L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
-  if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
-    return rc;
+  if (conv3_fused_bwd_ok(d.H, d.W, d.C, nets * n)) {
+    // conv1 data gradient + conv0 weight gradient in one launch: da0 never goes to HBM
+    if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
+                               d_packed + 1 * PACK_CONV, L.packed_total, d_xn, w.part0,
+                               (long long)n * conv0_partial_size(d.C), st))))) return rc;
+  } else {
+    if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
+                               L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
+    if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
+      return rc;
+  }
   join_from(main_st, 0, 5);
   join_from(main_st, 1, 6);
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
@@ -342,7 +354,7 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride;
   reduce_table_add(rt, w.part1, wgrad3_G(nets, n, d.H, d.W), PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
   reduce_table_add(rt, w.part2, wgrad3_G(nets, n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
-  reduce_table_add(rt, w.part0, plan_conv0_wgrad_G(n, d.C, d.HW), conv0_partial_size(d.C), 0, d.C,
+  reduce_table_add(rt, w.part0, conv0_partials(d, nets, n), conv0_partial_size(d.C), 0, d.C,
                    d_grads + L.param_off[0], d_grads + L.param_off[1]);
   return TIMED(CMLPL_K_CONV1_WRED, chk(launch_partial_reduce(nets, rt, st)));
 }

@@ -90,6 +90,8 @@ struct Conv3Args {
   const float* w0t; const float* b0; float* a0out;
   long long w0t_ns, b0_ns;
   int C, CC;
+  // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup
+  const float* xn; float* part0; long long part0_ns;
 };
 
 // The 9-tap main loop.  NTA = number of this wave's M tiles that carry real pixels (wave-uniform, so
@@ -187,7 +189,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   const int net = blockIdx.y, s0 = blockIdx.x * a.S;
   const int H = a.H, W = a.W, HW = H * W, PW = W + 2, IMG = (H + 2) * PW;
   const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
-  const int RO = (MODE != 1) ? 2 * H2 : H, CO = (MODE != 1) ? 2 * W2 : W;
+  const int RO = !(MODE & 1) ? 2 * H2 : H, CO = !(MODE & 1) ? 2 * W2 : W;
   const int PX = RO * CO, S = a.S, npx = S * PX;
   float* img = smem;                       // [S][IMG][CS]
   float* wbuf = img + (size_t)S * IMG * CS;  // [16][64][4]
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
   STAMP(MODE & 1, 2);
 
-  if (MODE != 1) {
+  if (!(MODE & 1)) {
     const float* bias = a.bias + (long long)net * a.bias_ns;
     const float bv0 = bias[l31], bv1 = bias[32 + l31];
 #pragma unroll
@@ -454,6 +456,89 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     }
     __syncthreads();
     conv3_pool_store(a, c);
+  } else if (MODE == 3) {
+    // conv0 weight gradient fused in (S == 1, MTW == 1, C <= 128):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
+    // This wave's da0 tile = accumulators + dz (the residual branch); it goes to LDS as the B operand [pix][64]
+    // next to the sample's [C][HW] input slab, which global_load_lds_dwordx4 copies linearly into the now dead
+    // image region.  wave = band tile (A rows c = 32 wave + l31, conflict-free: row stride HW is odd or the
+    // reads are b32 over consecutive c), both co tiles.  The partial has conv0_wgrad_kernel's layout.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    const int C = a.C;
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wave * 32 + acc_row(r, lane);
+      const float* p = img + (size_t)lut[m < PX ? m : 0] * CS;
+      v0[r] = acc[0][0][r] + p[l31];
+      v1[r] = acc[0][1][r] + p[32 + l31];
+    }
+    __syncthreads();                                      // image and LUT are dead from here on
+    float* slab = smem;                                   // [C][HW]
+    float* dal = smem + C * HW;                           // [HW + 1][64]
+    const float* xs = a.xn + ((long long)net * a.n + s0) * (long long)C * HW;
+    {
+      const int nfl = C * HW, nf4 = nfl >> 2;
+      for (int q = wave; q * 64 < nf4; q += 4) {
+        const int f = q * 64 + lane;
+        if (f < nf4) __builtin_amdgcn_global_load_lds((gbl_void*)(xs + 4 * f), (lds_void*)(slab + q * 256), 16, 0, 0);
+      }
+      if (tid < nfl - 4 * nf4) slab[4 * nf4 + tid] = xs[4 * nf4 + tid];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wave * 32 + acc_row(r, lane);
+      if (m < HW) { dal[m * 64 + l31] = v0[r]; dal[m * 64 + 32 + l31] = v1[r]; }
+    }
+    if (tid < 64) dal[HW * 64 + tid] = 0.f;               // the pixel past the end of an odd map
+    __syncthreads();                                      // slab landed (the barrier waits for the DMA), da0 complete
+    f32x16 g0 = zero16(), g1 = zero16();
+    float dbacc = 0.f;
+    {
+      const int KP = (HW + 1) >> 1;                       // pixel pairs
+      const int crow = wave * 32 + l31;                   // band of this lane (rows >= C: finite garbage, dropped by the reduce)
+      const float* ap = slab + (size_t)crow * HW + hh;
+      const float* bp = dal + hh * 64 + l31;
+      float av[8], b0v[8], b1v[8], an[8], b0n[8], b1n[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = (q < KP) ? q : 0;
+        av[q] = ap[2 * k]; b0v[q] = bp[2 * k * 64]; b1v[q] = bp[2 * k * 64 + 32];
+      }
+      for (int k0 = 0; k0 < KP; k0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = (k0 + 8 + q < KP) ? k0 + 8 + q : 0;
+          an[q] = ap[2 * k]; b0n[q] = bp[2 * k * 64]; b1n[q] = bp[2 * k * 64 + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (k0 + q < KP) {                              // uniform
+            g0 = mfma32(av[q], b0v[q], g0);
+            g1 = mfma32(av[q], b1v[q], g1);
+            dbacc += (wave == 0) ? b0v[q] : b1v[q];       // waves 0 / 1 sum co tile 0 / 1 for the bias gradient
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { av[q] = an[q]; b0v[q] = b0n[q]; b1v[q] = b1n[q]; }
+      }
+    }
+    const int Ct = ((C + 31) >> 5) * 32;
+    float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Ct * 64 + 64);
+    if (wave * 32 < Ct) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = wave * 32 + acc_row(r, lane);
+        pp[(size_t)cc * 64 + l31] = g0[r];
+        pp[(size_t)cc * 64 + 32 + l31] = g1[r];
+      }
+    }
+    if (wave < 2) {
+      const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
+      if (hh == 0) pp[(size_t)Ct * 64 + wave * 32 + l31] = tot;
+    }
   } else {
     float* out = a.out + (long long)net * a.out_ns;
     const int nvalid = (a.n - s0 < S ? a.n - s0 : S) * PX;  // rows that map to real samples
@@ -620,6 +705,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.CC = 0;
+  a.xn = nullptr; a.part0 = nullptr; a.part0_ns = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
@@ -675,8 +761,45 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const float*
   a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.CC = 0;
+  a.xn = nullptr; a.part0 = nullptr; a.part0_ns = 0;
   (void)HW;
   return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
+}
+
+// conv0 weight gradient fused into the conv1 data gradient (MODE 3): same shape conditions as the fused forward,
+// at most four band tiles, and two workgroups per CU with slab [C][HW] + da0 [HW+1][64] in LDS.
+static size_t conv3_fused_bwd_lds(int H, int W, int C, size_t plain) {
+  const size_t need = ((size_t)C * H * W + (size_t)(H * W + 1) * 64) * 4;
+  return need > plain ? need : plain;
+}
+
+bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
+  static const bool off = getenv("CMLPL_FUSE_CONV0") && atoi(getenv("CMLPL_FUSE_CONV0")) == 0;
+  static const bool offb = getenv("CMLPL_FUSE_CONV0_BWD") && atoi(getenv("CMLPL_FUSE_CONV0_BWD")) == 0;
+  if (off || offb || C < 1 || C > 128) return false;
+  Conv3Plan pl;
+  if (!plan_conv3(1, H, W, rows, &pl)) return false;
+  if (pl.S != 1 || pl.MTW != 1 || H * W > 128) return false;
+  // band rows up to 127 are read (garbage rows are dropped later) and must stay inside the allocation
+  const size_t lds = conv3_fused_bwd_lds(H, W, C, pl.lds);
+  if ((size_t)128 * H * W * 4 > lds) return false;
+  return 2 * lds <= LDS_MAX;
+}
+
+hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
+                                  const float* wpk, long long wpk_ns, const float* xn, float* part0, long long part0_ns,
+                                  hipStream_t st) {
+  Conv3Plan pl;
+  if (!conv3_fused_bwd_ok(H, W, C, nets * n) || !plan_conv3(1, H, W, nets * n, &pl)) return hipErrorInvalidValue;
+  const int P2 = (H / 2) * (W / 2);
+  Conv3Args a;
+  a.in = dpool; a.mask_in = mask; a.wpk = wpk; a.bias = nullptr; a.out = nullptr; a.mask_out = nullptr;
+  a.wpk_ns = wpk_ns; a.bias_ns = 0;
+  a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
+  a.n = n; a.H = H; a.W = W; a.S = 1;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.CC = 0;
+  a.xn = xn; a.part0 = part0; a.part0_ns = part0_ns;
+  return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
 }
 
 // ------------------------------------------------------------------------------------------

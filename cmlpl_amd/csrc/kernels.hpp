@@ -45,6 +45,10 @@ bool conv3_fused_ok(int H, int W, int C, int rows);
 hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const float* xn, const float* w0t, long long w0t_ns,
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
                               const float* bias, long long bias_ns, float* out, uint8_t* mask_out, hipStream_t st);
+bool conv3_fused_bwd_ok(int H, int W, int C, int rows);
+hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
+                                  const float* wpk, long long wpk_ns, const float* xn, float* part0, long long part0_ns,
+                                  hipStream_t st);
 struct Wgrad3Plan { int RU, U, G, cspl, NI, ND, rsplit, UPG; size_t lds; };   // NI > 0: pipelined kernel, NI prefetch float4 / thread
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,

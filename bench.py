@@ -28,11 +28,16 @@ WORKLOADS = {   # name: (C, H, W, bands, K)   -- SURVEY.md section 8d
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # HBM bytes per launch of the three conv1 kernels (B2, 128+128 rows, both networks) from rocprofv3 PMC, separate
 # passes: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, in KB as printed in
-# profiles/r01_d_pmc_hbm_traffic.txt (scripts/pmc_summary.py).  Algorithmic bytes beside them in DESIGN.md 5.
-TRAFFIC_B2_256 = {
-    "conv1_fwd": (2 * 8984.5 + 4000.0) * 1024,       # 22.5 MB (algorithmic: a0 15.9 + weights 0.3 + p1 3.2 + masks 0.8)
-    "conv1_dgrad": (2 * 3252.5 + 15488.0) * 1024,    # 22.5 MB (algorithmic: dp1 3.2 + masks 0.8 + weights 0.3 + da0 15.9)
-    "conv1_wgrad": (2 * 9994.8 + 11540.0) * 1024,    # 32.3 MB (algorithmic: a0 15.9 + dp1 3.2 + masks 0.8 + partials 11.8)
+# profiles/r01_e_pmc_hbm_traffic.txt (scripts/pmc_summary.py).  Algorithmic bytes beside them in DESIGN.md 4.
+TRAFFIC_B2_256 = {   # default configuration: conv0 fused into the conv1 forward / data-gradient kernels
+    "conv1_fwd": (2 * 13954.6 + 19488.0) * 1024,     # 46.3 MB (algorithmic: xn 25.5 + weights 0.4 + a0 15.9 + p1 3.2 + masks 0.8)
+    "conv1_dgrad": (2 * 15766.0 + 16512.0) * 1024,   # 46.9 MB (algorithmic: xn 25.5 + dp1 3.2 + masks 0.8 + weights 0.3 + dW0 partials 13.8)
+    "conv1_wgrad": (2 * 9996.8 + 11540.0) * 1024,    # 30.8 MB (algorithmic: a0 15.9 + dp1 3.2 + masks 0.8 + partials 11.8)
+}
+TRAFFIC_B2_256_UNFUSED = {   # CMLPL_FUSE_CONV0=0 (profiles/r01_d_pmc_hbm_traffic.txt)
+    "conv1_fwd": (2 * 8984.5 + 4000.0) * 1024,
+    "conv1_dgrad": (2 * 3252.5 + 15488.0) * 1024,
+    "conv1_wgrad": (2 * 9994.8 + 11540.0) * 1024,
 }
 CONV1_KERNELS = {
     "conv1_fwd": "conv3x3_kernel<FWD> (conv1 forward: 3x3 conv + bias + residual + ReLU + avgpool, both networks)",
@@ -204,6 +209,8 @@ def main():
         kflops["conv1_dgrad"] += 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64
         labels["conv1_dgrad"] = ("conv3x3_kernel<DGRAD0> (conv1 data gradient + conv0 weight gradient fused, "
                                  "both networks)")
+    traffic = {k: (TRAFFIC_B2_256 if f else TRAFFIC_B2_256_UNFUSED)[k]
+               for k, f in (("conv1_fwd", fused_fwd), ("conv1_dgrad", fused_bwd), ("conv1_wgrad", True))}
     flops = kflops[dom_name]
     achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     b2_256 = args.workload == "B2" and n_local == 256
@@ -219,7 +226,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": labels[dom_name],
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": TRAFFIC_B2_256[dom_name] if b2_256 else None,
+                     "traffic": traffic[dom_name] if b2_256 else None,
                      "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                      "flops_per_launch": flops, "ms_per_launch": dom_ms, "launches_timed": int(cnt[dom_id])},
         # the other two conv1 kernels (same algorithmic FLOPs), from the calibration window
@@ -228,7 +235,7 @@ def main():
              "flops_per_launch": kflops[k],
              "achieved": kflops[k] / (calib[k] * 1e-3) / 1e12 if calib[k] > 0 else 0.0,
              "frac": (kflops[k] / (calib[k] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if calib[k] > 0 else 0.0,
-             "traffic": TRAFFIC_B2_256[k] if b2_256 else None}
+             "traffic": traffic[k] if b2_256 else None}
             for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
     }

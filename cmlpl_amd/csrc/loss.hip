@@ -21,6 +21,8 @@
 //     finalize_kernel   : bank write of the GLOBAL batch (modulo Q) + this shard's share of the logged
 //                         scalars (:266,270,274-278); shares are additive across shards
 //     gemm_tn           : dfeat_s(local rows) = G . fU_w ; dfeat_w(all rows, partial) = G^T . fU_s(local)
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -153,6 +155,38 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const int CT = (a.Q + 31) >> 5, ctile = c0 >> 5;
   float* rs = a.rs_part + ((long long)prob * CT + ctile) * nunl;
   float* ep = a.ep_part + ((long long)prob * CT + ctile) * nunl * K;
+  if (K <= 32) {
+    // row sums and E . bank_probs as a small LDS product instead of 5 shuffles per (row, class): the tile E
+    // [32][33] and the probability tile [32 cols][33] go to LDS (`red` is dead after the barrier), each thread
+    // then forms whole outputs, columns summed in index order
+    __syncthreads();                                   // all reads of `red` are done
+    float* ew = lds;                                   // [32][33]
+    float* pw = lds + 32 * 33;                         // [32][33]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ew[acc_row(wave * 4 + q, lane) * 33 + l31] = e[q];
+    for (int i = tid; i < 32 * K; i += 256) {
+      const int c = i / K, k = i - c * K;
+      pw[c * 33 + k] = (c0 + c < NB) ? a.bank_p[prob][(long long)(c0 + c) * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int o = tid; o < 32 * (K + 1); o += 256) {
+      const int row = o & 31, kk = o >> 5;             // kk == K: the plain row sum
+      const float* er = ew + row * 33;
+      float sum = 0.f;
+      if (kk < K) {
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) sum += er[c] * pw[c * 33 + kk];
+      } else {
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) sum += er[c];
+      }
+      const int ir = r0 + row;
+      if (ir < nunl) {
+        if (kk < K) ep[(long long)ir * K + kk] = sum; else rs[ir] = sum;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float sum = half_sum(e[q]);
@@ -165,6 +199,150 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
     for (int q = 0; q < 4; ++q) {
       const float sum = half_sum(e[q] * pv);
       if (l31 == 0 && irow[q] < nunl) ep[(long long)irow[q] * K + k] = sum;
+    }
+  }
+}
+
+// Tall-tile variant for wide products (data parallelism: the banks hold 10 x the GLOBAL labelled batch, so a rank's
+// 128 local rows meet W x more columns).  One workgroup = up to 128 local rows x 32 columns; wave w owns rows
+// 32w..32w+31 over the WHOLE contraction, so there is no cross-wave reduction and the column tile is read once
+// instead of once per 32 rows.  K is walked in 32-float lines staged in LDS (whole 128-B lines per row, row stride
+// PT floats), double-buffered, one barrier per line, the next line's loads in flight in registers.
+__global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2][(128 + 32) * PT];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prob = blockIdx.z;
+  if (prob < 2 && !a.smooth) return;
+  const int n = a.bt + a.btu, btu = a.btu, nunl = a.nunl, K = a.K;
+  const float* fU_s = a.feat + (long long)a.bt * FD;
+  const float* fU_w = a.feat + ((long long)n + a.bt) * FD;
+  const float* A = ((prob == 0) ? fU_w : fU_s) + (long long)a.unl0 * FD;
+  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : fU_w;
+  const int NB = (prob < 2) ? a.Q : btu;
+  const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 32;
+  if (c0 >= NB || r0 >= nunl) return;
+  const int jb = c0 + l31;
+  // loader: thread -> (row lr = tid >> 3 of a 32-row group, 16-byte chunk c8 = tid & 7)
+  const int lr = tid >> 3, c8 = tid & 7;
+#define CMLPL_ROWPTR(base, r, lim) ((base) + (long long)((r) < (lim) ? (r) : 0) * FD + c8 * 4)
+  const float* pa0 = CMLPL_ROWPTR(A, r0 + lr, nunl);
+  const float* pa1 = CMLPL_ROWPTR(A, r0 + 32 + lr, nunl);
+  const float* pa2 = CMLPL_ROWPTR(A, r0 + 64 + lr, nunl);
+  const float* pa3 = CMLPL_ROWPTR(A, r0 + 96 + lr, nunl);
+  const float* pb = CMLPL_ROWPTR(B, c0 + lr, NB);
+#undef CMLPL_ROWPTR
+  // two register sets: set 0 carries the even lines, set 1 the odd ones, each requested TWO lines before it is
+  // written to LDS (one line is only 16 MFMAs per wave -- not enough to cover an L2 round trip)
+  float4 va0 = *(const float4*)pa0, va1 = *(const float4*)pa1, va2 = *(const float4*)pa2, va3 = *(const float4*)pa3;
+  float4 vb = *(const float4*)pb;
+  float4 wa0 = *(const float4*)(pa0 + 32), wa1 = *(const float4*)(pa1 + 32), wa2 = *(const float4*)(pa2 + 32),
+         wa3 = *(const float4*)(pa3 + 32);
+  float4 wb = *(const float4*)(pb + 32);
+  const int wo = lr * PT + c8 * 4;
+  f32x16 acc = zero16();
+#define CMLPL_M4(PA, PB)                                                            \
+    acc = mfma32(PA.x, PB.x, acc); acc = mfma32(PA.y, PB.y, acc);                   \
+    acc = mfma32(PA.z, PB.z, acc); acc = mfma32(PA.w, PB.w, acc);
+#define CMLPL_LINE(LN, R0, R1, R2, R3, RB)                                          \
+  {                                                                                 \
+    float* buf = lds[(LN) & 1];                                                     \
+    *(float4*)(buf + wo) = R0; *(float4*)(buf + wo + 32 * PT) = R1;                 \
+    *(float4*)(buf + wo + 64 * PT) = R2; *(float4*)(buf + wo + 96 * PT) = R3;       \
+    *(float4*)(buf + wo + 128 * PT) = RB;                                           \
+    if ((LN) + 2 < FD / 32) {                                                       \
+      const int o = ((LN) + 2) * 32;                                                \
+      R0 = *(const float4*)(pa0 + o); R1 = *(const float4*)(pa1 + o);               \
+      R2 = *(const float4*)(pa2 + o); R3 = *(const float4*)(pa3 + o);               \
+      RB = *(const float4*)(pb + o);                                                \
+    }                                                                               \
+    __syncthreads(); /* line staged; the other buffer (read during the previous line) is free */ \
+    const float* rA = buf + (wave * 32 + l31) * PT + hh * 16;                       \
+    const float* rB = buf + (128 + l31) * PT + hh * 16;                             \
+    const float4 x0 = *(const float4*)(rA), x1 = *(const float4*)(rA + 4), x2 = *(const float4*)(rA + 8), \
+                 x3 = *(const float4*)(rA + 12);                                    \
+    const float4 y0 = *(const float4*)(rB), y1 = *(const float4*)(rB + 4), y2 = *(const float4*)(rB + 8), \
+                 y3 = *(const float4*)(rB + 12);                                    \
+    CMLPL_M4(x0, y0) CMLPL_M4(x1, y1) CMLPL_M4(x2, y2) CMLPL_M4(x3, y3)             \
+  }
+  // fully unrolled: across a loop back-edge hipcc loses count of the outstanding loads and waits vmcnt(0) before the
+  // LDS writes, i.e. for the prefetch it has just issued
+#pragma unroll
+  for (int ln = 0; ln < FD / 32; ln += 2) {
+    CMLPL_LINE(ln, va0, va1, va2, va3, vb)
+    CMLPL_LINE(ln + 1, wa0, wa1, wa2, wa3, wb)
+  }
+#undef CMLPL_LINE
+#undef CMLPL_M4
+  // epilogue: this wave's 32 rows x 32 columns (lane = column jb, register r = row)
+  const bool jv = jb < NB;
+  const int rw = r0 + wave * 32;
+  if (prob == 2) {
+    if (rw >= nunl) return;
+    if (jv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ir = rw + acc_row(r, lane);
+        if (ir < nunl) a.Smat[(long long)ir * btu + jb] = expf(acc[r] / a.T);
+      }
+    }
+    return;
+  }
+  const int CT = (a.Q + 31) >> 5, ctile = c0 >> 5;
+  float* rs = a.rs_part + ((long long)prob * CT + ctile) * nunl;
+  float* ep = a.ep_part + ((long long)prob * CT + ctile) * nunl * K;
+  // Row sums and E . bank_probs of this wave's 32 x 32 tile.  Reducing over the 32 columns (= lanes) with
+  // shuffles costs 5 ds_bpermute per (row, class): ~800 per wave here.  Instead E and the [32][K] probability
+  // tile go to LDS (the staging buffers are free now) and each lane forms whole outputs: a [32x32].[32x(K+1)]
+  // product, columns summed in index order.
+  __syncthreads();                                       // every wave has finished its last line
+  if (rw >= nunl) return;
+  float* ew = &lds[0][0] + wave * (2 * 32 * 33);         // [32 rows][33]
+  float* pw = ew + 32 * 33;                              // [32 cols][33], K <= 32 (else: shuffle path below)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ew[acc_row(r, lane) * 33 + l31] = jv ? expf(acc[r] / a.T) : 0.f;
+  if (K <= 32) {
+    for (int i = lane; i < 32 * K; i += 64) {
+      const int c = i / K, k = i - c * K;
+      pw[c * 33 + k] = (c0 + c < NB) ? a.bank_p[prob][(long long)(c0 + c) * K + k] : 0.f;
+    }
+    // wave-private region, but other lanes wrote what this lane reads: wait for the LDS writes
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    for (int o = lane; o < 32 * (K + 1); o += 64) {
+      const int row = o & 31, kk = o >> 5;               // kk == K: the plain row sum
+      const float* er = ew + row * 33;
+      float sum = 0.f;
+      if (kk < K) {
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) sum += er[c] * pw[c * 33 + kk];
+      } else {
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) sum += er[c];
+      }
+      const int ir = rw + row;
+      if (ir < nunl) {
+        if (kk < K) ep[(long long)ir * K + kk] = sum; else rs[ir] = sum;
+      }
+    }
+    return;
+  }
+  const float* bpr = a.bank_p[prob] + (long long)(jv ? jb : 0) * K;
+  float e[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    e[r] = jv ? expf(acc[r] / a.T) : 0.f;
+    const float sum = half_sum(e[r]);
+    const int ir = rw + acc_row(r, lane);
+    if (l31 == 0 && ir < nunl) rs[ir] = sum;
+  }
+  for (int k = 0; k < K; ++k) {
+    const float pv = jv ? bpr[k] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sum = half_sum(e[r] * pv);
+      const int ir = rw + acc_row(r, lane);
+      if (l31 == 0 && ir < nunl) ep[(long long)ir * K + k] = sum;
     }
   }
 }
@@ -270,19 +448,30 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   }
 }
 
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// One workgroup per local unlabelled row (under data parallelism a row meets W x more columns; a single wavefront
+// walking them in three passes was 32 us at W = 8): the 256 threads stride the columns, sums are folded per wave
+// and then across the four waves in a fixed order.
 __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // per wave: gq[btu], pp[btu]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int btu = a.btu, K = a.K, i = blockIdx.x * 4 + wave;    // local row
-  if (i >= a.nunl) return;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // gq[btu], pp[btu]
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int btu = a.btu, K = a.K, i = blockIdx.x;               // local row
   const int ig = a.unl0 + i;                                    // global row (diagonal position)
   const int RL = a.nlab > a.nunl ? a.nlab : a.nunl;
-  float* gq = smem + (size_t)wave * 2 * btu;
+  float* gq = smem;
   float* pp = gq + btu;
   const float* psi = prob_row(a, 1, ig);                        // smoothed p_s ("probs1"), row i
   const float* Srow = a.Smat + (long long)i * btu;
   float sQ = 0.f, sN = 0.f, R = 0.f, npos = 0.f, nneg = 0.f;
-  for (int j = lane; j < btu; j += 64) {
+  for (int j = tid; j < btu; j += 256) {
     const float* pwj = prob_row(a, 0, j);                       // smoothed p_w ("probs"), row j
     float q0 = 0.f;
     for (int k = 0; k < K; ++k) q0 = fmaf(psi[k], pwj[k], q0);                      // train.py:249
@@ -293,12 +482,11 @@ __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
     npos += isp ? 1.f : 0.f; nneg += isn ? 1.f : 0.f;
     gq[j] = pos; pp[j] = neg;
   }
-  sQ = wave_sum(sQ); sN = wave_sum(sN); R = wave_sum(R);
-  npos = wave_sum(npos); nneg = wave_sum(nneg);
-  __builtin_amdgcn_wave_barrier();
+  sQ = block_sum(sQ, red, tid); sN = block_sum(sN, red, tid); R = block_sum(R, red, tid);
+  npos = block_sum(npos, red, tid); nneg = block_sum(nneg, red, tid);
   float lp = 0.f, ln = 0.f, gp = 0.f;
   const float inv_btu = 1.f / (float)btu;
-  for (int j = lane; j < btu; j += 64) {
+  for (int j = tid; j < btu; j += 256) {            // each thread revisits exactly the columns it wrote
     const float P = Srow[j] / R;                    // sim_probs (:247)
     const float Qv = gq[j] / sQ;                    // :253
     const float Qn = pp[j] / (sN + 1e-8f);          // :256
@@ -308,27 +496,18 @@ __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
     gp = fmaf(g, P, gp);
     gq[j] = g; pp[j] = P;
   }
-  lp = wave_sum(lp); ln = wave_sum(ln); gp = wave_sum(gp);
-  __builtin_amdgcn_wave_barrier();
+  lp = block_sum(lp, red, tid); ln = block_sum(ln, red, tid); gp = block_sum(gp, red, tid);
   const float scale = a.w_contrast / a.T;
-  for (int j = lane; j < btu; j += 64) {
+  for (int j = tid; j < btu; j += 256) {
     const float Gij = pp[j] * (gq[j] - gp) * scale;   // softmax backward, then d(sim)/d(f.f/T)
     a.G[(long long)i * btu + j] = Gij;                // [nunl][btu]
     a.GT[(long long)j * a.nunl + i] = Gij;            // [btu][nunl]
   }
-  if (lane == 0) {
+  if (tid == 0) {
     a.rowloss[RL_CTR * RL + i] = lp + ln;
     a.rowloss[RL_NPOS * RL + i] = npos;
     a.rowloss[RL_NNEG * RL + i] = nneg;
   }
-}
-
-__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(LossArgs a) {
@@ -389,17 +568,27 @@ hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
   hipError_t e;
   const int nl = a.nlab + a.nunl;
   const int maxc = (a.smooth && a.Q > a.btu) ? a.Q : a.btu;
-  dim3 g1((maxc + 31) / 32, (a.nunl + 31) / 32, 3);
-  hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);
+  // wide products (many column tiles): tall tiles; narrow ones: 32x32 tiles with the contraction split over the waves
+  static const int force_tall = getenv("CMLPL_PAIR_TALL") ? atoi(getenv("CMLPL_PAIR_TALL")) : -1;
+  const int ctiles = (maxc + 31) / 32;
+  // measured per rank (scripts/rank_cost.py, B2, 128 local rows): 32x32 tiles 25.6 / 39.2 / 55.5 / 89.4 us at
+  // W = 1 / 2 / 4 / 8 against 37.9 / 39.3 / 56.8 / 81.6 us for tall tiles
+  const bool tall = force_tall >= 0 ? force_tall != 0 : (ctiles >= 256 && a.nunl >= 64);
+  if (tall) {
+    hipLaunchKernelGGL(pair_exp_tall_kernel, dim3(ctiles, (a.nunl + 127) / 128, 3), dim3(256), 0, st, a);
+  } else {
+    dim3 g1(ctiles, (a.nunl + 31) / 32, 3);
+    hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);
+  }
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(loss_rows_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)4 * 2 * a.btu * 4;
+  const size_t lds = (size_t)2 * a.btu * 4;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(graph_loss_kernel, dim3((a.nunl + 3) / 4), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(graph_loss_kernel, dim3(a.nunl), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ struct Conv3Args {
   // MODE 2 (conv0 fused into the conv1 forward): `in` is xn [net][n][C][HW]; a0 is produced here
   const float* w0t; const float* b0; float* a0out;
   long long w0t_ns, b0_ns;
-  int C, CC;
+  int C;
   // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup
   const float* xn; float* part0; long long part0_ns;
 };
@@ -704,7 +704,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   if (mode == 0) { a.in_ns = (long long)n * HW * 64; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns; a.mask_in_ns = 0; }
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.CC = 0;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0;
   a.xn = nullptr; a.part0 = nullptr; a.part0_ns = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
@@ -760,7 +760,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const float*
   a.wpk_ns = wpk_ns; a.bias_ns = bias_ns;
   a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
   a.n = n; a.H = H; a.W = W; a.S = 1;
-  a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.CC = 0;
+  a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C;
   a.xn = nullptr; a.part0 = nullptr; a.part0_ns = 0;
   (void)HW;
   return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
@@ -797,7 +797,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.wpk_ns = wpk_ns; a.bias_ns = 0;
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.CC = 0;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C;
   a.xn = xn; a.part0 = part0; a.part0_ns = part0_ns;
   return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
 }
@@ -1134,7 +1134,6 @@ __global__ __launch_bounds__(512) void wgrad3r_kernel(Wgrad3Args a) {
   const int rstride = PW * 64, ustep_a = 2 * IMGU * 64;
   constexpr int ustep_b = 2 * DU * 64;
   const int nun = U >> 1;                     // units per wave and stage
-  const int issue_at = 0;                     // every wave starts its pieces of the next stage first thing
   int cur = 0;
   for (int ub = ubeg; ub < uend; ub += U) {
     const bool more = ub + U < uend;            // workgroup-uniform
@@ -1148,7 +1147,7 @@ __global__ __launch_bounds__(512) void wgrad3r_kernel(Wgrad3Args a) {
     const float* pb = b_base;
     for (int uu = 0; uu < nun; ++uu) {
 #if CMLPL_ABL != 7 && CMLPL_ABL != 8
-      if (more && uu == issue_at) issue(ub + U, smem + (cur ^ 1) * BUF);   // in flight across the MFMAs below
+      if (more && uu == 0) issue(ub + U, smem + (cur ^ 1) * BUF);   // first thing: in flight across the MFMAs below
 #endif
       const float* pa1 = pa0 + rstride;
       const int nxt = (uu + 1 < nun) ? uu + 1 : 0;        // after the last unit: re-read unit 0 (unused)
@@ -1258,14 +1257,13 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
   if (p->cspl == 2) { G = (NU + 1) / 2; if (G > 128) G = 128; }   // 2 co-halves x 2 nets x 128 = 512 workgroups
   if (G > 256) G = 256;                            // per net; 2 nets -> 512 WGs
   p->RU = RU; p->U = U; p->G = (int)G; p->lds = wgrad3_lds(RU, U, W, p->cspl);
-  p->NI = 0; p->ND = 0; p->rsplit = 0; p->UPG = 0;
-  static const int pipe = getenv("CMLPL_WGRAD3_PIPE") ? atoi(getenv("CMLPL_WGRAD3_PIPE")) : 1;
+  p->rsplit = 0; p->UPG = 0;
   const int CO = 2 * (W / 2);
   // row-split kernel: blockIdx.z = kernel row; units of one pooled row, U (even) per stage
   static const int rsp = getenv("CMLPL_WGRAD3_R") ? atoi(getenv("CMLPL_WGRAD3_R")) : 1;
   static const int force_ru = getenv("CMLPL_WGRAD3_RU") ? atoi(getenv("CMLPL_WGRAD3_RU")) : 0;
   static const int force_rg = getenv("CMLPL_WGRAD3_RG") ? atoi(getenv("CMLPL_WGRAD3_RG")) : 0;
-  if (pipe && rsp && p->cspl == 1 && CO >= 2) {
+  if (rsp && p->cspl == 1 && CO >= 2) {
     const int PW = W + 2, cpr = CO / 2;
     auto lds_r = [&](int u) {
       const size_t buf2 = 2 * (size_t)u * (2 * PW * 64 + 2 * CO * 64) * 4;
@@ -1288,7 +1286,7 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
       upg = ((upg + Ur - 1) / Ur) * Ur;
       const long long Gr = (NUr + upg - 1) / upg;
       p->RU = 2; p->U = Ur; p->G = (int)Gr; p->UPG = (int)upg; p->lds = lds_r(Ur);
-      p->NI = ni_r(Ur); p->ND = 1; p->rsplit = cpr;          // rsplit = template parameter CPR
+      p->rsplit = cpr;                                          // = template parameter CPR of wgrad3r_kernel
     }
   }
   return true;

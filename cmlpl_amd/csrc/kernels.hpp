@@ -49,7 +49,7 @@ bool conv3_fused_bwd_ok(int H, int W, int C, int rows);
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
                                   const float* wpk, long long wpk_ns, const float* xn, float* part0, long long part0_ns,
                                   hipStream_t st);
-struct Wgrad3Plan { int RU, U, G, cspl, NI, ND, rsplit, UPG; size_t lds; };   // NI > 0: pipelined kernel, NI prefetch float4 / thread
+struct Wgrad3Plan { int RU, U, G, cspl, rsplit, UPG; size_t lds; };   // rsplit > 0: row-split kernel with CPR = rsplit, UPG units per workgroup
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st);

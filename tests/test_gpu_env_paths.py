@@ -1,0 +1,31 @@
+"""Kernel variants that the default planners do not pick at test sizes -- the tall-tile pair_exp kernel (chosen for
+>= 256 bank column tiles, i.e. data-parallel jobs of 8 ranks), the general weight-gradient fallback, the unfused
+conv0 kernels on a fusable shape -- are forced through their environment switches (read once per process, hence a
+child process each) and must pass the same parity tests."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra, select):
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + select
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"{env_extra}: {r.stdout[-2000:]}\n{r.stderr[-1000:]}"
+
+
+def test_tall_pair_exp_kernel_passes_loss_parity():
+    _run({"CMLPL_PAIR_TALL": "1"}, ["tests/test_gpu_ops.py", "-k", "loss_block", "tests/test_gpu_distributed.py"])
+
+
+def test_general_wgrad_fallback_passes_backward_parity():
+    _run({"CMLPL_WGRAD3_R": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
+
+
+def test_unfused_conv0_kernels_pass_on_a_fusable_shape():
+    _run({"CMLPL_FUSE_CONV0": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward and B2"])

@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- CMLPL training-step throughput on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload B2|P|B4|B5]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload B2|B3|P|B4|B5] [--global-batch BT+BTU]
+
+N > 1 works both ways: typed as above, the parent starts N ranks itself (cmlpl_amd/launch.py: fresh child
+processes with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, before anything touches the GPU) and relays rank 0's
+line; launched under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks are
+used as they come.  Default: 128+128 rows PER GPU ("scaling": "weak").  `--global-batch 512+512` fixes the
+GLOBAL batch and shards it over the ranks ("scaling": "strong"): BASELINE configs[2] is `--workload B3`
+(= B2 shape, global 512+512 -> 64+64 per rank at 8 GPUs), configs[4] is `--workload B5 --global-batch 64+512`
+(-> 8+64 per rank).
 
 A "step" is one pass of the hot path (reference train.py:150-278: noise augmentation, two BaseNet2
 forwards, loss block, bank write, two backwards, two Adam steps) over one synthetic batch that is
@@ -17,28 +24,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 WORKLOADS = {   # name: (C, H, W, bands, K)   -- SURVEY.md section 8d
     "B2": (103, 11, 11, 103, 9),    # BASELINE.json configs[1]: PaviaU 11x11x103, batch 256
+    "B3": (103, 11, 11, 103, 9),    # BASELINE.json configs[2]: same shape, GLOBAL batch 512+512 sharded over the GPUs
     "P": (60, 20, 20, 103, 9),      # the reference's own (PCA-60, 20x20) shape
     "B4": (200, 11, 11, 200, 16),   # Indian-Pines-shaped
     "B5": (48, 15, 15, 48, 20),     # Houston2018-shaped
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-# HBM bytes per launch of the three conv1 kernels (B2, 128+128 rows, both networks) from rocprofv3 PMC, separate
-# passes: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, in KB as printed in
-# profiles/r01_e_pmc_hbm_traffic.txt (scripts/pmc_summary.py).  Algorithmic bytes beside them in DESIGN.md 4.
-TRAFFIC_B2_256 = {   # default configuration: conv0 fused into the conv1 forward / data-gradient kernels
-    "conv1_fwd": (2 * 13954.6 + 19488.0) * 1024,     # 46.3 MB (algorithmic: xn 25.5 + weights 0.4 + a0 15.9 + p1 3.2 + masks 0.8)
-    "conv1_dgrad": (2 * 15766.0 + 16512.0) * 1024,   # 46.9 MB (algorithmic: xn 25.5 + dp1 3.2 + masks 0.8 + weights 0.3 + dW0 partials 13.8)
-    "conv1_wgrad": (2 * 9996.8 + 11540.0) * 1024,    # 30.8 MB (algorithmic: a0 15.9 + dp1 3.2 + masks 0.8 + partials 11.8)
-}
-TRAFFIC_B2_256_UNFUSED = {   # CMLPL_FUSE_CONV0=0 (profiles/r01_d_pmc_hbm_traffic.txt)
-    "conv1_fwd": (2 * 8984.5 + 4000.0) * 1024,
-    "conv1_dgrad": (2 * 3252.5 + 15488.0) * 1024,
-    "conv1_wgrad": (2 * 9994.8 + 11540.0) * 1024,
-}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # written by scripts/pmc_summary.py --json
 CONV1_KERNELS = {
     "conv1_fwd": "conv3x3_kernel<FWD> (conv1 forward: 3x3 conv + bias + residual + ReLU + avgpool, both networks)",
     "conv1_dgrad": "conv3x3_kernel<DGRAD> (conv1 data gradient, both networks)",
@@ -46,8 +40,43 @@ CONV1_KERNELS = {
 }
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="B2", choices=sorted(WORKLOADS))
+    ap.add_argument("--bt", type=int, default=128, help="labelled rows per GPU (weak scaling)")
+    ap.add_argument("--btu", type=int, default=128, help="unlabelled rows per GPU (weak scaling)")
+    ap.add_argument("--global-batch", default=None, metavar="BT+BTU",
+                    help="fix the GLOBAL batch (labelled+unlabelled) and shard it over the GPUs: strong scaling")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.workload == "B3" and args.global_batch is None:
+        args.global_batch = "512+512"
+    return args
+
+
+def per_rank_batch(args, world):
+    """(bt, btu) rows per rank and the scaling mode.  A global batch must divide evenly: equal shards are what
+    makes local means / W equal the global mean."""
+    if args.global_batch is None:
+        return args.bt, args.btu, "weak"
+    try:
+        gbt, gbtu = (int(v) for v in args.global_batch.split("+"))
+    except ValueError:
+        raise SystemExit("--global-batch wants BT+BTU, e.g. 512+512")
+    if gbt < world or gbtu < world or gbt % world or gbtu % world:
+        raise SystemExit(f"--global-batch {args.global_batch} does not shard evenly over {world} GPUs")
+    return gbt // world, gbtu // world, "strong"
+
+
 def synth(shape, bt, btu, seed, device):
     """XP, X ~ N(0,1), Y ~ U{0..K-1} from torch.Generator(seed) (reference seed 1088, train.py:50)."""
+    import torch
     C, H, W, bands, K = shape
     g = torch.Generator().manual_seed(seed)
     d = dict(XPl=torch.randn(bt, C, H, W, generator=g), Xl=torch.randn(bt, bands, generator=g),
@@ -63,10 +92,21 @@ def conv1_flops(shape, n, nets=2):
     return 2.0 * nets * n * H * W * 64 * 576
 
 
-def cpu_baseline(shape, bt, btu, budget_s=20.0):
-    """The oracle (CPU restatement of the reference step, verified against the reference's own outputs)
-    timed on this host's cores on the same workload; bounded sample."""
-    from oracle import cmlpl_oracle as O
+def recorded_traffic(workload, n_local):
+    """HBM bytes per launch of the conv1 kernels as measured by rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate
+    passes; scripts/pmc_summary.py --json writes the file).  The record carries the hash of the kernel sources it
+    was measured on: if the sources changed since, or the workload differs, the figure is stale -> None."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE))
+        from cmlpl_amd.build_ext import source_hash
+        if rec.get("source_hash") != source_hash() or rec.get("workload") != workload or rec.get("n_local") != n_local:
+            return {}, rec.get("profile")
+        return {k: float(v) for k, v in rec["bytes_per_launch"].items()}, rec.get("profile")
+    except Exception:
+        return {}, None
+
+
+def _host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -77,57 +117,80 @@ def cpu_baseline(shape, bt, btu, budget_s=20.0):
             cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
     except Exception:
         pass
-    cores = min(cores, int(os.environ.get("CMLPL_CPU_THREADS", "32")))   # torch intra-op scaling flattens beyond this
-    torch.set_num_threads(cores)
+    return min(cores, int(os.environ.get("CMLPL_CPU_THREADS", "32")))   # torch intra-op scaling flattens beyond this
+
+
+def cpu_baseline(shape, bt, btu, budget_s=14.0, budget_1t_s=8.0):
+    """The oracle (CPU restatement of the reference step, verified against the reference's own outputs)
+    timed on this host's cores on the same workload; bounded sample.  All host cores, then one thread
+    (SURVEY.md 8d asks for both figures)."""
+    import torch
+    from oracle import cmlpl_oracle as O
     s = O.NetShape(*shape)
     hp = O.HyperParams()
     st = O.StepState.create(s, O.closed_form_params(s, 1), O.closed_form_params(s, 2), bt, hp)
     batches = [O.synthetic_batch(s, bt, btu, 1088 + i) for i in range(2)]
-    times = []
-    t_start = time.perf_counter()
-    i = 0
-    while True:
-        b = batches[i % 2]
-        t0 = time.perf_counter()
-        # the reference draws noise and the dropout mask inside the step (train.py:157-182, models.py:148)
-        noise = [torch.randn_like(t) for t in b["noise"]]
-        keep = 1.0 - hp.dropout
-        dm = [(torch.rand(bt + btu, s.cls_in) < keep).float() / keep for _ in range(2)]
-        O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], noise, dm, 1, i, hp)
-        times.append(time.perf_counter() - t0)
-        i += 1
-        if i >= 3 and (time.perf_counter() - t_start > budget_s or i >= 200):
-            break
-    times = times[2:] if len(times) > 4 else times
-    med = sorted(times)[len(times) // 2]
+
+    def sample(threads, budget, warm):
+        torch.set_num_threads(threads)
+        times = []
+        t_start = time.perf_counter()
+        i = 0
+        while True:
+            b = batches[i % 2]
+            t0 = time.perf_counter()
+            # the reference draws noise and the dropout mask inside the step (train.py:157-182, models.py:148)
+            noise = [torch.randn_like(t) for t in b["noise"]]
+            keep = 1.0 - hp.dropout
+            dm = [(torch.rand(bt + btu, s.cls_in) < keep).float() / keep for _ in range(2)]
+            O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], noise, dm, 1, i, hp)
+            times.append(time.perf_counter() - t0)
+            i += 1
+            if i >= warm + 1 and (time.perf_counter() - t_start > budget or i >= 200):
+                break
+        times = times[warm:]
+        return sorted(times)[len(times) // 2], len(times)
+
+    cores = _host_cores()
+    med, k = sample(cores, budget_s, 2)
+    med1, k1 = sample(1, budget_1t_s, 1)
     return {"value": (bt + btu) / med, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} steps of the same {bt}+{btu} workload after 2 warm-up steps, median "
-                      f"{med * 1e3:.1f} ms/step, PyTorch-CPU {torch.__version__}, {cores} threads"}
+            "sample": f"{k} steps of the same {bt}+{btu} workload after 2 warm-up steps, median "
+                      f"{med * 1e3:.1f} ms/step, PyTorch-CPU {torch.__version__}, {cores} threads",
+            "value_1thread": (bt + btu) / med1,
+            "sample_1thread": f"{k1} steps after 1 warm-up step, median {med1 * 1e3:.1f} ms/step, 1 thread"}
 
 
-def main():
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` typed directly: start N ranks of this same program (no GPU call was made in
+    this process), relay rank 0's JSON line, fail if any rank fails."""
+    from cmlpl_amd.launch import spawn_ranks
+    extra = {"CMLPL_FORCE_DIST": "1"} if args.gpus == 1 else None
+    rc, out = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + list(argv), extra_env=extra)
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 1
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def run_rank(args):
     # RCCL / HIP runtime banners go to stdout; the contract is ONE JSON line there.  Keep the real stdout
     # aside and point fd 1 at stderr for everything else.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="B2", choices=sorted(WORKLOADS))
-    ap.add_argument("--bt", type=int, default=128, help="labelled rows per GPU")
-    ap.add_argument("--btu", type=int, default=128, help="unlabelled rows per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr")
-    args = ap.parse_args()
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    bt, btu, scaling = per_rank_batch(args, world)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -141,11 +204,11 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29513", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
         from cmlpl_amd.distributed import DistTrainEngine
-        eng = DistTrainEngine(NetShape(*shape), args.bt, args.btu, hp, device=device, seed=1088)
+        eng = DistTrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088)
     else:
-        eng = TrainEngine(NetShape(*shape), args.bt, args.btu, hp, device=device, seed=1088)
+        eng = TrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088)
     eng.init_params_default(1088)
-    batches = [synth(shape, args.bt, args.btu, 1088 + 7919 * rank + i, device) for i in range(4)]
+    batches = [synth(shape, bt, btu, 1088 + 7919 * rank + i, device) for i in range(4)]
     lib = _lib.load()
 
     def run(k, first_index):
@@ -194,9 +257,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     scal = eng.read_scalars()
-    assert os.environ.get("CMLPL_LIB") or all(v == v for v in scal.values()), f"non-finite loss: {scal}"
+    if not all(v == v and abs(v) != float("inf") for v in scal.values()):
+        raise SystemExit(f"bench.py: non-finite loss after the timed region: {scal}")
 
-    n_local = args.bt + args.btu
+    n_local = bt + btu
     patches = n_local * world * args.steps
     dom_ms = ms[dom_id] / max(cnt[dom_id], 1)
     kflops = {k: conv1_flops(shape, n_local) for k in CONV1_KERNELS}
@@ -209,25 +273,24 @@ def main():
         kflops["conv1_dgrad"] += 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64
         labels["conv1_dgrad"] = ("conv3x3_kernel<DGRAD0> (conv1 data gradient + conv0 weight gradient fused, "
                                  "both networks)")
-    traffic = {k: (TRAFFIC_B2_256 if f else TRAFFIC_B2_256_UNFUSED)[k]
-               for k, f in (("conv1_fwd", fused_fwd), ("conv1_dgrad", fused_bwd), ("conv1_wgrad", True))}
+    traffic, traffic_src = recorded_traffic(args.workload, n_local)
     flops = kflops[dom_name]
     achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    b2_256 = args.workload == "B2" and n_local == 256
     out = {
         "metric": "HSI patches/sec per training step", "value": patches / dt, "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic PaviaU-shaped patches {shape[1]}x{shape[2]}x{shape[0]}, "
-                               f"spectrum {shape[3]}, {shape[4]} classes, {args.bt} labelled + {args.btu} unlabelled "
+                               f"spectrum {shape[3]}, {shape[4]} classes, {bt} labelled + {btu} unlabelled "
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
                                f"bank + Adam, epoch 1 (memory-bank smoothing active), Philox noise/dropout",
                    "global_batch": n_local * world, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": labels[dom_name],
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic[dom_name] if b2_256 else None,
-                     "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                     "traffic": traffic.get(dom_name),
+                     "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; recorded in "
+                                     f"{traffic_src or 'profiles/'}, null when the kernel sources changed since)",
                      "flops_per_launch": flops, "ms_per_launch": dom_ms, "launches_timed": int(cnt[dom_id])},
         # the other two conv1 kernels (same algorithmic FLOPs), from the calibration window
         "roofline_others": [
@@ -235,32 +298,42 @@ def main():
              "flops_per_launch": kflops[k],
              "achieved": kflops[k] / (calib[k] * 1e-3) / 1e12 if calib[k] > 0 else 0.0,
              "frac": (kflops[k] / (calib[k] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if calib[k] > 0 else 0.0,
-             "traffic": traffic[k] if b2_256 else None}
+             "traffic": traffic.get(k)}
             for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
     }
 
-    if args.breakdown and rank == 0:
+    if args.breakdown:     # every rank runs the extra steps (they contain collectives); rank 0 prints
         _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(0xFFFFFFFF, 40 * 24))
         run(40, args.warmup + calib_steps + args.steps)
         barrier()
         _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
         tot = sum(ms[i] for i in range(len(_lib.KERNEL_NAMES)))
-        print(f"per-kernel device time over 40 steps (hipEvent pairs; sum {tot / 40 * 1e3:.1f} us/step):", file=sys.stderr)
-        for i, nm in enumerate(_lib.KERNEL_NAMES):
-            if cnt[i]:
-                print(f"  {nm:12s} {ms[i] / cnt[i] * 1e3:9.1f} us/launch  x{cnt[i] // 40}/step  "
-                      f"{100 * ms[i] / tot:5.1f} %", file=sys.stderr)
+        if rank == 0:
+            print(f"per-kernel device time over 40 steps (hipEvent pairs; sum {tot / 40 * 1e3:.1f} us/step):",
+                  file=sys.stderr)
+            for i, nm in enumerate(_lib.KERNEL_NAMES):
+                if cnt[i]:
+                    print(f"  {nm:12s} {ms[i] / cnt[i] * 1e3:9.1f} us/launch  x{cnt[i] // 40}/step  "
+                          f"{100 * ms[i] / tot:5.1f} %", file=sys.stderr)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape, args.bt, args.btu)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    if dist is not None:
+        barrier()
+        dist.destroy_process_group()
     if rank == 0:
+        # on rank 0 at N = 1 only; a bounded sample (about 20 s) of the same workload on the host cores
+        out["cpu_baseline"] = cpu_baseline(shape, bt, btu) if (world == 1 and not args.no_cpu_baseline) else None
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    from cmlpl_amd.launch import launched_by_rendezvous_env
+    if not launched_by_rendezvous_env() and (args.gpus > 1 or os.environ.get("CMLPL_BENCH_SPAWN")):
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

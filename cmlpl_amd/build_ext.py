@@ -17,6 +17,19 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and the C ABI header (sorted by name): identifies the code a recorded
+    profile (profiles/pmc_traffic.json) was measured on; .git does not travel to the GPU box."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    files.append(os.path.join(HERE, "..", "include", "cmlpl.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -1,0 +1,87 @@
+"""One process per GPU: start the ranks of a single-node job as fresh child processes.
+
+The reference is single-process (train.py:12 pins one device); this launcher is the build's own.  The parent
+never touches the GPU (no HIP call, no ``torch.cuda`` use): it only sets the rendezvous environment
+(``RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT``, as ``torch.distributed.run`` would), starts
+``world`` children of the same program, relays rank 0's stdout and waits for all of them.  If any child
+fails, the others are terminated (by PID) and the parent reports the failure.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launched_by_rendezvous_env(env=os.environ) -> bool:
+    """True when this process already is one rank of a job (torchrun or spawn_ranks set the variables)."""
+    return "RANK" in env and "WORLD_SIZE" in env
+
+
+def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
+    return env
+
+
+def spawn_ranks(world: int, argv: Sequence[str], extra_env: Optional[Dict[str, str]] = None,
+                timeout: Optional[float] = None, poll_s: float = 0.05) -> Tuple[int, str]:
+    """Run ``argv`` as ``world`` ranks; returns (exit code, rank 0's stdout).  Ranks > 0 write their stdout to
+    this process's stderr; every rank's stderr is inherited.  Exit code = first non-zero child code, else 0;
+    124 on timeout."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    port = free_port()
+    procs: List[subprocess.Popen] = []
+    for r in range(world):
+        env = rank_env(r, world, port)
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=None, text=(r == 0)))
+    t0 = time.monotonic()
+    rc = 0
+    out0 = ""
+    pending = set(range(world))
+    try:
+        # rank 0's pipe is drained by communicate() at the end; its output is one short line, far below the
+        # pipe buffer, so polling here cannot dead-lock on a full pipe
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+            if rc != 0:
+                break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                rc = 124
+                break
+            if pending:
+                time.sleep(poll_s)
+    finally:
+        for r in pending:                       # a rank failed or timed out: stop exactly the PIDs we started
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        try:
+            out0, _ = procs[0].communicate(timeout=10)
+        except Exception:
+            out0 = ""
+    return rc, out0 or ""

@@ -145,26 +145,40 @@ def l2norm(x: torch.Tensor) -> torch.Tensor:
     return x.div(norm)
 
 
+def _relu(z: torch.Tensor, gate: Optional[torch.Tensor]) -> torch.Tensor:
+    """ReLU; with ``gate`` (bool, same shape) the activation pattern is GIVEN instead of derived from sign(z):
+    out = z where gate else 0, d out / d z = gate.  Tests use it to make the oracle take the device's ReLU
+    decisions where a pre-activation sits within rounding of zero (fp32 summation order decides the sign there),
+    so that gradients can be compared at a tight tolerance; every gate/sign disagreement is separately required
+    to sit at |z| < 2e-5 (tests/gpu_util.py)."""
+    if gate is None:
+        return F.relu(z)
+    return torch.where(gate, z, torch.zeros_like(z))
+
+
 def basenet2_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor,
-                     dropmask: Optional[torch.Tensor] = None, taps: Optional[dict] = None):
+                     dropmask: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
+                     relu_gates: Optional[dict] = None):
     """x: [n,C,H,W], y: [n,bands].  ``dropmask`` is the explicit dropout
     multiplier ([n, cls_in], values 0 or 1/(1-p)); None = eval / p==0.
+    ``relu_gates``: optional {"z1","z2","zy"} -> bool activation patterns (see _relu).
     Returns (logits [n,K], feat [n,1024])."""
+    g = relu_gates or {}
     x = F.conv2d(x, p["conv0.weight"], p["conv0.bias"])                    # :132
     x_res = x
     x = F.conv2d(x, p["conv1.weight"], p["conv1.bias"], padding=1)         # :134
     if taps is not None: taps["z1"] = (x + x_res).detach()                 # pre-ReLU, for mask audits
-    x = F.relu(x + x_res)                                                   # :135
+    x = _relu(x + x_res, g.get("z1"))                                       # :135
     x = F.avg_pool2d(x, 2, 2)                                               # :136
     x_res = x
     x = F.conv2d(x, p["conv2.weight"], p["conv2.bias"], padding=1)         # :138
     if taps is not None: taps["z2"] = (x + x_res).detach()
-    x = F.relu(x + x_res)                                                   # :139
+    x = _relu(x + x_res, g.get("z2"))                                       # :139
     x = F.avg_pool2d(x, 2, 2)                                               # :140
     x = x.reshape(x.size(0), -1)                                            # :141
     y = F.linear(y, p["feat_spe.weight"], p["feat_spe.bias"])              # :142
     if taps is not None: taps["zy"] = y.detach()
-    y = F.relu(y)                                                           # :143
+    y = _relu(y, g.get("zy"))                                               # :143
     cat = torch.cat([x, y], 1)                                              # :144
     feat = l2norm(y)                                                        # :145-146
     if dropmask is not None:
@@ -278,9 +292,11 @@ def loss_block(z_s, f_s, z_w, f_w, Y, bt: int, bank_feats, bank_probs,
     with torch.no_grad():
         Q0 = torch.mm(p_s, p_w.t())                                         # :249
         Q0.fill_diagonal_(1)                                                # :250
-        Q = Q0 * (Q0 >= hp.pos_thr).float()                                 # :251-252
+        pos_mask = (Q0 >= hp.pos_thr).float()                               # :251
+        Q = Q0 * pos_mask                                                   # :252
         Q = Q / Q.sum(1, keepdim=True)                                      # :253
-        Qn = (1 - Q0) * (Q0 <= hp.neg_thr).float()                          # :254-255
+        neg_mask = (Q0 <= hp.neg_thr).float()                               # :254
+        Qn = (1 - Q0) * neg_mask                                            # :255
         Qn = Qn / (Qn.sum(1, keepdim=True) + 1e-8)                          # :256
     sim1 = torch.exp(torch.mm(fU_s.detach(), fU_w.t()) / T)                 # :257
     P1 = sim1 / sim1.sum(1, keepdim=True)                                   # :258
@@ -293,7 +309,8 @@ def loss_block(z_s, f_s, z_w, f_w, Y, bt: int, bank_feats, bank_probs,
     return dict(total_s=total_s, total_w=total_w, cls_s=cls_s, cls_w=cls_w,
                 con_s=con_s, con_w=con_w, ctr_s=ctr_s, ctr_w=ctr_w, acc=acc,
                 p_w=p_w, p_s=p_s, p_w0=p_w0, p_s0=p_s0, mask_w=mask_w, mask_s=mask_s,
-                Q=Q, Qn=Qn, P=P.detach(), bank0_rows=bank0_rows, bank1_rows=bank1_rows)
+                Q=Q, Qn=Qn, P=P.detach(), bank0_rows=bank0_rows, bank1_rows=bank1_rows,
+                n_pos=float(pos_mask.sum()), n_neg=float(neg_mask.sum()))
 
 
 # --------------------------------------------------------------------------- #
@@ -301,11 +318,13 @@ def loss_block(z_s, f_s, z_w, f_w, Y, bt: int, bank_feats, bank_probs,
 # --------------------------------------------------------------------------- #
 def train_step(state: StepState, XPl, Xl, Y, XPu, Xu, noise: Sequence[torch.Tensor],
                dropmask: Sequence[Optional[torch.Tensor]], epoch: int, batch_index: int,
-               hp: Optional[HyperParams] = None, apply_update: bool = True):
+               hp: Optional[HyperParams] = None, apply_update: bool = True,
+               relu_gates: Optional[Sequence[Optional[dict]]] = None):
     """``noise``: the 8 N(0,1) draws in reference order
         [XPl->Base, Xl->Base, XPl->Base1, Xl->Base1, XPu->Base, Xu->Base, XPu->Base1, Xu->Base1]
     (train.py:157,158,163,164,170,171,181,182).  ``dropmask``: per-network
-    explicit dropout multiplier [n, cls_in] (or None).  Mutates ``state``."""
+    explicit dropout multiplier [n, cls_in] (or None).  ``relu_gates``: per-network
+    activation patterns for basenet2_forward (tests only).  Mutates ``state``."""
     hp = hp or HyperParams()
     bt = XPl.shape[0]
     btu = XPu.shape[0]
@@ -321,8 +340,9 @@ def train_step(state: StepState, XPl, Xl, Y, XPu, Xu, noise: Sequence[torch.Tens
         ps.append({k: (v.detach().clone().requires_grad_(True) if k in LIVE_KEYS else v)
                    for k, v in state.params[net].items()})
     taps = [{}, {}]
-    z_s, f_s = basenet2_forward(ps[0], XP_b_all, X_b_all, dropmask[0], taps[0])   # :175
-    z_w, f_w = basenet2_forward(ps[1], XP_e_all, X_e_all, dropmask[1], taps[1])   # :185
+    rg = relu_gates or (None, None)
+    z_s, f_s = basenet2_forward(ps[0], XP_b_all, X_b_all, dropmask[0], taps[0], rg[0])   # :175
+    z_w, f_w = basenet2_forward(ps[1], XP_e_all, X_e_all, dropmask[1], taps[1], rg[1])   # :185
 
     smooth = (epoch > 0) or (batch_index > hp.queue_batch)                  # :212
     adap_mask = hp.thr * hp.adap_thr(epoch)                                 # :221
@@ -390,6 +410,23 @@ def synthetic_batch(shape: NetShape, bt: int, btu: int, seed: int, with_noise: b
         else:
             out["dropmask"] = [None, None]
     return out
+
+
+def kill_spectral_rows(params: Sequence[Dict[str, torch.Tensor]], batch: dict, lab_row: int, unl_row: int) -> None:
+    """Input generator for the dead-ReLU regime (tools/models.py:87-90 divides by a zero
+    norm): make feat_spe's bias non-positive in every given parameter set and zero one labelled and one unlabelled
+    spectrum together with their noise draws, so that exactly those rows leave the spectral ReLU all-zero and
+    Normalize returns 0/0 = NaN for them.  In place."""
+    for p in params:
+        p["feat_spe.bias"] = -p["feat_spe.bias"].abs()
+    if lab_row >= 0:
+        batch["Xl"][lab_row] = 0
+        batch["noise"][1][lab_row] = 0
+        batch["noise"][3][lab_row] = 0
+    if unl_row >= 0:
+        batch["Xu"][unl_row] = 0
+        batch["noise"][5][unl_row] = 0
+        batch["noise"][7][unl_row] = 0
 
 
 # --------------------------------------------------------------------------- #

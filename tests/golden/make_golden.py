@@ -87,7 +87,7 @@ LIVE = O.LIVE_KEYS
 
 
 def run_case(name, shape, bt, btu, steps, seed, epoch0=0, batch_index0=0, dropout=0.8,
-             cls_scale=1.0, separable=0.0, full_steps=(0,), num_epochs=20, thr=1.0):
+             cls_scale=1.0, separable=0.0, full_steps=(0,), num_epochs=20, thr=1.0, dead=(-1, -1)):
     hp = O.HyperParams(num_epochs=num_epochs, thr=thr, dropout=dropout)
     args = types.SimpleNamespace(noise=hp.noise, queue_batch=hp.queue_batch, temperature=hp.temperature,
                                  alpha=hp.alpha, thr=hp.thr, labeled_batch_size=bt,
@@ -97,6 +97,9 @@ def run_case(name, shape, bt, btu, steps, seed, epoch0=0, batch_index0=0, dropou
     if cls_scale != 1.0:
         p0["classifier.weight"] *= cls_scale
         p1["classifier.weight"] *= cls_scale
+    if dead != (-1, -1):      # dead-ReLU regime: bias made non-positive here, the rows zeroed per batch below
+        O.kill_spectral_rows([p0, p1], dict(Xl=torch.zeros(bt, 1), Xu=torch.zeros(btu, 1),
+                                            noise=[torch.zeros(max(bt, btu), 1)] * 8), -1, -1)
     Base = build_ref_net(shape, p0, dropout)
     Base1 = build_ref_net(shape, p1, dropout)
     tp = TorchProxy()
@@ -112,12 +115,14 @@ def run_case(name, shape, bt, btu, steps, seed, epoch0=0, batch_index0=0, dropou
               queue_ptr1=0, num_classes=shape.K, print_per_batches=10, num_batches=10 ** 9,
               torch=tp, np=np, F=F, time=__import__("time"))
     rec = {k: [] for k in ("hist", "extra", "ptr", "counts", "logit_sums", "grad_norms",
-                           "param_sums", "bank_sums")}
+                           "param_sums", "bank_sums", "grad_nan", "bank_nan")}
     full = {}
     for s in range(steps):
         epoch = epoch0
         batch_index = batch_index0 + s
         b = O.synthetic_batch(shape, bt, btu, seed * 1000 + s, dropout=dropout, separable=separable)
+        if dead != (-1, -1):
+            O.kill_spectral_rows([], b, dead[0], dead[1])
         tp.queue = list(b["noise"])
         Base.drop.mask, Base1.drop.mask = b["dropmask"]
         ns.update(epoch=epoch, batch_index=batch_index,
@@ -134,13 +139,17 @@ def run_case(name, shape, bt, btu, steps, seed, epoch0=0, batch_index0=0, dropou
                               ns["pos_mask"].sum().item(), ns["neg_mask"].sum().item()])
         rec["logit_sums"].append([ns["un_b_output_all"].sum().item(), ns["un_b_output_all"].abs().sum().item(),
                                   ns["un_e_output_all"].sum().item(), ns["un_e_output_all"].abs().sum().item()])
-        gn, psum = [], []
+        gn, psum, gnan = [], [], []
         for net in (Base, Base1):
             sd = dict(net.named_parameters())
             gn.append([sd[k].grad.double().norm().item() for k in LIVE])
             psum.append([sd[k].detach().double().sum().item() for k in LIVE])
+            gnan.append([int(torch.isnan(sd[k].grad).sum()) for k in LIVE])
         rec["grad_norms"].append(gn)
         rec["param_sums"].append(psum)
+        rec["grad_nan"].append(gnan)          # where NaN lands (dead-ReLU regime), element counts
+        rec["bank_nan"].append([int(torch.isnan(ns[k]).sum()) for k in
+                                ("queue_feats", "queue_probs", "queue_feats1", "queue_probs1")])
         rec["bank_sums"].append([ns["queue_feats"].double().sum().item(), ns["queue_probs"].double().sum().item(),
                                  ns["queue_feats1"].double().sum().item(), ns["queue_probs1"].double().sum().item()])
         for net in (Base, Base1):
@@ -163,6 +172,7 @@ def run_case(name, shape, bt, btu, steps, seed, epoch0=0, batch_index0=0, dropou
                              epoch0, batch_index0, num_epochs], dtype=np.int64)
     out["cfg_f"] = np.asarray([dropout, cls_scale, separable, thr], dtype=np.float64)
     out["full_steps"] = np.asarray(full_steps, dtype=np.int64)
+    out["cfg_dead"] = np.asarray(dead, dtype=np.int64)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: {steps} steps, last hist={rec['hist'][-1]}, counts={rec['counts'][-1]}, "
@@ -190,7 +200,34 @@ def main():
     run_case("b2_b256", B2, 128, 128, steps=3, seed=22, epoch0=1, full_steps=(2,))
     run_case("b4_64", B4, 32, 32, steps=3, seed=23, epoch0=1, full_steps=(2,))
     run_case("b5_64", B5, 32, 32, steps=3, seed=24, epoch0=1, full_steps=(2,))
+    round2()
+
+
+def round2(only=None):
+    """Fixtures added in round 2 (the round-1 files are left byte-identical)."""
+    B2 = O.NetShape(103, 11, 11, 103, 9)
+    B5 = O.NetShape(48, 15, 15, 48, 20)
+    cases = dict(
+        # the headline configuration (B2, 128+128) in the regime where thresholds, pos/neg masks, the mid band and
+        # the mutual loss all fire (con_s != 0)
+        b2_peaky_256=lambda: run_case("b2_peaky_256", B2, 128, 128, steps=4, seed=31, epoch0=12, cls_scale=30.0,
+                                      separable=1.5, full_steps=(0, 3), thr=0.9),
+        # BASELINE configs[4]: 64 labelled + 512 unlabelled (1:8) on the 15x15x48 shape.  The reference's bank
+        # slice-assign (train.py:232-236) only fits at ptr = 0: it runs exactly ONE step at this split and raises
+        # at the next (SURVEY.md D5), so one step is all the reference can pin here.
+        b5_1to8=lambda: run_case("b5_1to8", B5, 64, 512, steps=1, seed=32, epoch0=1, full_steps=(0,)),
+        # (v) dead spectral ReLU rows: Normalize divides by a zero norm (tools/models.py:87-90) -> NaN features
+        # for one labelled and one unlabelled row, propagated through sim / losses / gradients / banks
+        b2_deadrelu_64=lambda: run_case("b2_deadrelu_64", B2, 32, 32, steps=2, seed=33, epoch0=1, full_steps=(0, 1),
+                                        dead=(3, 5)),
+    )
+    for k, f in cases.items():
+        if only is None or k in only:
+            f()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--round2":
+        round2(sys.argv[2:] or None)
+    else:
+        main()

@@ -28,6 +28,7 @@ class GoldenCase:
         self.dropout, self.cls_scale, self.separable, self.thr = map(float, f)
         self.full_steps = [int(s) for s in self.z["full_steps"]]
         self.hp = O.HyperParams(num_epochs=self.num_epochs, thr=self.thr, dropout=self.dropout)
+        self.dead = tuple(int(v) for v in self.z["cfg_dead"]) if "cfg_dead" in self.z.files else (-1, -1)
 
     def params(self):
         p0 = O.closed_form_params(self.shape, self.seed)
@@ -35,11 +36,17 @@ class GoldenCase:
         if self.cls_scale != 1.0:
             p0["classifier.weight"] *= self.cls_scale
             p1["classifier.weight"] *= self.cls_scale
+        if self.dead != (-1, -1):
+            for p in (p0, p1):
+                p["feat_spe.bias"] = -p["feat_spe.bias"].abs()
         return p0, p1
 
     def batch(self, s):
-        return O.synthetic_batch(self.shape, self.bt, self.btu, self.seed * 1000 + s,
-                                 dropout=self.dropout, separable=self.separable)
+        b = O.synthetic_batch(self.shape, self.bt, self.btu, self.seed * 1000 + s,
+                              dropout=self.dropout, separable=self.separable)
+        if self.dead != (-1, -1):
+            O.kill_spectral_rows([], b, self.dead[0], self.dead[1])
+        return b
 
     def epoch_bi(self, s):
         return self.epoch0, self.batch_index0 + s
@@ -52,6 +59,16 @@ def rel_close(a, b, rtol, atol=0.0):
 
 
 def rel_err(a, b, floor=1e-12):
+    """max relative error; NaN/inf must sit at the same places with the same sign (then they count as equal),
+    otherwise the result is inf."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.max(np.abs(a - b) / (np.abs(b) + floor))) if a.size else 0.0
+    if not a.size:
+        return 0.0
+    fin = np.isfinite(a) & np.isfinite(b)
+    same_nonfinite = (np.isnan(a) & np.isnan(b)) | ((a == b) & ~fin)
+    if not np.all(fin | same_nonfinite):
+        return float("inf")
+    if not fin.any():
+        return 0.0
+    return float(np.max(np.abs(a[fin] - b[fin]) / (np.abs(b[fin]) + floor)))

@@ -43,6 +43,29 @@ def cuda_batch(b):
     return out
 
 
+def hip_relu_gates(eng, shape, n):
+    """The ReLU decisions the HIP forward took, as the oracle's ``relu_gates`` (per network {"z1","z2","zy"} bool
+    tensors in the oracle's NCHW layout), read from the saved masks m1 / m2 (u8 per pooled element, bit
+    (h&1)*2+(w&1)) and the spectral ReLU output y.  Pixels the floor-pooling drops (last row / column of an odd
+    map) are never computed on the device and never reach a gradient: their gate is left True."""
+    H2, W2 = shape.H // 2, shape.W // 2
+    H4, W4 = H2 // 2, W2 // 2
+    out = []
+    for net in range(2):
+        g = {}
+        for name, key, hh, ww, HH, WW in (("m1", "z1", H2, W2, shape.H, shape.W), ("m2", "z2", H4, W4, H2, W2)):
+            m = eng.debug_region(name, torch.uint8).view(2, n, hh, ww, 64)[net].cpu()
+            gate = torch.ones(n, 64, HH, WW, dtype=torch.bool)
+            for dh in range(2):
+                for dw in range(2):
+                    bit = ((m >> (dh * 2 + dw)) & 1).bool()                    # [n, hh, ww, 64]
+                    gate[:, :, dh:2 * hh:2, dw:2 * ww:2] = bit.permute(0, 3, 1, 2)
+            g[key] = gate
+        g["zy"] = eng.debug_region("y").view(2, n, 1024)[net].cpu() > 0
+        out.append(g)
+    return out
+
+
 def relu_mask_audit(eng, taps, shape, n, ztol=2e-5):
     """Compare the ReLU masks the HIP forward saved (workspace regions m1, m2, y) with the signs of
     the oracle's pre-activations.  fp32 summation order differs between the two, so an element whose

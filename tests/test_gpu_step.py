@@ -8,12 +8,12 @@ import torch
 
 from oracle import cmlpl_oracle as O
 from tests.golden_util import GoldenCase, golden_cases, rel_err
-from tests.gpu_util import (DEV, cuda_batch, relu_mask_audit, report, sync_engine_from_oracle, to_hp,
-                            to_shape)
+from tests.gpu_util import DEV, cuda_batch, hip_relu_gates, relu_mask_audit, report, to_hp, to_shape
 
 pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-4          # north_star: loss parity within 1e-4 relative
+GOLDEN_GRAD_RTOL = 2e-3   # gradient norms vs the reference run (other host / thread count): same ReLU decisions assumed
 
 
 def _engine(g):
@@ -25,7 +25,10 @@ def _engine(g):
     return eng, p0, p1
 
 
-@pytest.mark.parametrize("name", golden_cases())
+NAN_CASES = ("b2_deadrelu_64",)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if n not in NAN_CASES])
 def test_step_matches_golden_and_oracle(name):
     g = GoldenCase(name)
     eng, p0, p1 = _engine(g)
@@ -33,14 +36,19 @@ def test_step_matches_golden_and_oracle(name):
     z = g.z
     steps = min(g.steps, 8) if name != "p_traj_32" else g.steps
     total_flips = 0
+    n = g.bt + g.btu
     for s in range(steps):
         b = g.batch(s)
         epoch, bi = g.epoch_bi(s)
-        ref = O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"],
-                           epoch, bi, g.hp)
         cb = cuda_batch(b)
         eng.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], epoch, bi, noise=cb["noise"],
                  dropmask=cb["dropmask"])
+        # The oracle takes the device's ReLU decisions (they can differ from sign(z_oracle) only where
+        # |z| < 2e-5 -- audited below -- because fp32 summation order differs between MFMA and the CPU), so
+        # every gradient is compared at the tight bound and both sides stay on one trajectory.
+        gates = hip_relu_gates(eng, g.shape, n)
+        ref = O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"],
+                           epoch, bi, g.hp, relu_gates=gates)
         sc = eng.read_scalars()
         row = [sc[k] for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc")]
         extra = [sc[k] for k in ("total_w", "cls_w", "con_w", "ctr_w")]
@@ -49,7 +57,7 @@ def test_step_matches_golden_and_oracle(name):
         assert rel_err(row, z["hist"][s], 1e-7) < LOSS_RTOL, (s, row, z["hist"][s])
         assert rel_err(extra, z["extra"][s], 1e-7) < LOSS_RTOL, (s, extra, z["extra"][s])
         assert eng.ptr == [int(v) for v in z["ptr"][s]]
-        assert [sc["n_mask_w"], sc["n_mask_s"], sc["n_pos"]] == list(z["counts"][s][:3])
+        assert [sc["n_mask_w"], sc["n_mask_s"], sc["n_pos"], sc["n_neg"]] == list(z["counts"][s])
         # (b) oracle, tensor by tensor
         lo, fe = eng.outputs()
         lo_ref = torch.stack(ref["logits"])
@@ -57,26 +65,17 @@ def test_step_matches_golden_and_oracle(name):
         report("feat", fe, torch.stack(ref["feats"]), 1e-5, 3e-6)
         # ReLU masks saved by the HIP forward vs the oracle's pre-activation signs: a mismatch is only
         # tolerated exactly at the activation boundary (|z| < 2e-5), where fp32 summation order decides
-        flips = relu_mask_audit(eng, ref["taps"], g.shape, g.bt + g.btu)
+        flips = relu_mask_audit(eng, ref["taps"], g.shape, n)
         total_flips += sum(sum(f.values()) for f in flips)
         for net in range(2):
-            f = flips[net]
             for k in O.LIVE_KEYS:
                 gr = ref["grads"][net][k]
                 mx = max(float(gr.abs().max()), 1e-4)
-                hit = (k.startswith("conv") and (f["z1"] or f["z2"]) and not (k.startswith("conv2") and not f["z2"])) \
-                    or (k.startswith("feat_spe") and f["zy"])
-                if hit:      # one flipped mask bit moves these sums by one term (seen: up to 3% of max)
-                    report(f"grad[{net}] {k} (mask flips {f})", eng.grad(net, k), gr, 0.0, 0.15 * mx)
-                else:
-                    report(f"grad[{net}] {k}", eng.grad(net, k), gr, 5e-4, 5e-5 * mx)
-            if not any(f.values()):
+                report(f"grad[{net}] {k}", eng.grad(net, k), gr, 5e-4, 5e-5 * mx)
+            if not any(flips[net].values()):
+                # the golden run took sign(z) decisions: comparable whenever the device took the same ones
                 gn = [float(eng.grad(net, k).double().norm()) for k in O.LIVE_KEYS]
-                # golden grads come from a run on another host (different thread count / summation order): the
-                # oracle-on-this-host vs golden can itself differ by a ReLU flip, hence the loose bound here
-                assert rel_err(gn, z["grad_norms"][s][net], 1e-9) < 5e-2, (s, net, gn, z["grad_norms"][s][net])
-        if any(any(f.values()) for f in flips):
-            sync_engine_from_oracle(eng, st)
+                assert rel_err(gn, z["grad_norms"][s][net], 1e-9) < GOLDEN_GRAD_RTOL, (s, net, gn, z["grad_norms"][s][net])
         if s in g.full_steps:
             # later steps of the golden run carry another host's ReLU-boundary decisions (see above)
             gtol = 2e-5 if s == 0 else 5e-3
@@ -92,6 +91,51 @@ def test_step_matches_golden_and_oracle(name):
     for i in range(2):
         report(f"bank{i} feats", eng.bank_feats[i], st.bank_feats[i], 1e-5, 5e-6)
         report(f"bank{i} probs", eng.bank_probs[i], st.bank_probs[i], 1e-4, 2e-4)   # softmax of |logits|~100 (peaky case)
+
+
+@pytest.mark.parametrize("name", NAN_CASES)
+def test_dead_relu_rows_propagate_nan_like_the_reference(name):
+    """SURVEY.md section 4 regime (v): a sample whose spectral ReLU output is all zero makes Normalize
+    (tools/models.py:87-90, no epsilon) return 0/0 = NaN.  The reference then carries NaN through the similarity
+    matrices, the smoothed probabilities, both contrastive and both mutual losses, EVERY gradient element and two
+    rows of each bank; CE and accuracy of the first step stay finite.  The HIP path must land NaN on exactly the
+    same places and keep the finite values."""
+    g = GoldenCase(name)
+    eng, p0, p1 = _engine(g)
+    st = O.StepState.create(g.shape, p0, p1, g.bt, g.hp)
+    z = g.z
+    for s in range(g.steps):
+        b = g.batch(s)
+        epoch, bi = g.epoch_bi(s)
+        cb = cuda_batch(b)
+        ref = O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"], epoch, bi, g.hp)
+        eng.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], epoch, bi, noise=cb["noise"],
+                 dropmask=cb["dropmask"])
+        sc = eng.read_scalars()
+        row = [sc[k] for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc")]
+        extra = [sc[k] for k in ("total_w", "cls_w", "con_w", "ctr_w")]
+        print(f"[{name}] step {s}: hip={row} golden={list(z['hist'][s])}")
+        assert rel_err(row, z["hist"][s], 1e-7) < LOSS_RTOL, (s, row, z["hist"][s])        # NaN at the same places
+        assert rel_err(extra, z["extra"][s], 1e-7) < LOSS_RTOL, (s, extra, z["extra"][s])
+        assert [sc["n_mask_w"], sc["n_mask_s"], sc["n_pos"], sc["n_neg"]] == list(z["counts"][s])
+        lo, fe = eng.outputs()
+        if s == 0:
+            report("logits", lo, torch.stack(ref["logits"]), 2e-4, 5e-5)                      # finite in step 0
+            fr = torch.stack(ref["feats"])
+            assert torch.equal(torch.isnan(fe).cpu(), torch.isnan(fr))
+            assert int(torch.isnan(fr).sum()) == 2 * 2 * 1024                                  # 2 dead rows per net
+            ok = ~torch.isnan(fr)
+            report("feat (live rows)", fe.cpu()[ok], fr[ok], 1e-5, 3e-6)
+        for net in range(2):
+            got = [int(torch.isnan(eng.grad(net, k)).sum()) for k in O.LIVE_KEYS]
+            assert got == [int(v) for v in z["grad_nan"][s][net]], (s, net, got)
+        got = [int(torch.isnan(t).sum()) for t in (eng.bank_feats[0], eng.bank_probs[0], eng.bank_feats[1],
+                                                   eng.bank_probs[1])]
+        assert got == [int(v) for v in z["bank_nan"][s]], (s, got, z["bank_nan"][s])
+        if s == 0:      # the finite part of the banks is still exact
+            for i in range(2):
+                fin = ~torch.isnan(st.bank_feats[i])
+                report(f"bank{i} feats (finite part)", eng.bank_feats[i].cpu()[fin], st.bank_feats[i][fin], 1e-5, 5e-6)
 
 
 def test_full_batch_properties_b2():

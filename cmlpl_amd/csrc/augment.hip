@@ -159,12 +159,10 @@ hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, 
                                   float* out, hipStream_t st) {
   const size_t lds = (size_t)w * w * (C | 1) * 4;
   if (lds > LDS_MAX) return hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)extract_patches_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+  static DevOnce attr_once;
+  {
+    hipError_t e = ensure_max_lds(attr_once, extract_patches_kernel);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   hipLaunchKernelGGL(extract_patches_kernel, dim3(n), dim3(256), lds, st, cube, rows, cols, C, w, idx, n, out);
   return hipGetLastError();

@@ -253,15 +253,10 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
   const int HWp = dma ? HW : ((HW + 2) | 1);
   const size_t lds = ((size_t)Ct * HWp + 64) * 4;
   if (lds > LDS_MAX) return hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv0_wgrad_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv0_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)LDS_MAX);
+  static DevOnce attr_once;
+  {
+    hipError_t e = ensure_max_lds(attr_once, conv0_wgrad_kernel<false>, conv0_wgrad_kernel<true>);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   const int G = plan_conv0_wgrad_G(n, C, HW);
   if (dma) hipLaunchKernelGGL(conv0_wgrad_kernel<true>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);

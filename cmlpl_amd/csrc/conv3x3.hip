@@ -681,12 +681,10 @@ bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
 
 template <int MODE, int MTW>
 static hipError_t launch_conv3_t(const Conv3Args& a, dim3 grid, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<MODE, MTW>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+  static DevOnce attr_once;
+  {
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<MODE, MTW>);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   hipLaunchKernelGGL((conv3x3_kernel<MODE, MTW>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
@@ -710,13 +708,9 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
     case 0: {                                                                  \
-      static bool attr0 = false;                                               \
-      if (!attr0) {                                                            \
-        hipError_t e0 = hipFuncSetAttribute((const void*)conv3x3_small_kernel<M>,                          \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);      \
-        if (e0 != hipSuccess) return e0;                                       \
-        attr0 = true;                                                          \
-      }                                                                        \
+      static DevOnce attr0;                                                    \
+      hipError_t e0 = ensure_max_lds(attr0, conv3x3_small_kernel<M>);          \
+      if (e0 != hipSuccess) return e0;                                         \
       hipLaunchKernelGGL((conv3x3_small_kernel<M>), grid, dim3(256), pl.lds, st, a);                        \
       return hipGetLastError();                                                \
     }                                                                          \
@@ -1296,14 +1290,10 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
                          float* part, hipStream_t st) {
   Wgrad3Plan pl;
   if (!plan_wgrad3(nets, n, H, W, &pl)) return hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_MAX);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+  static DevOnce attr_once;
+  {
+    hipError_t e = ensure_max_lds(attr_once, wgrad3_kernel<1>, wgrad3_kernel<2>);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   Wgrad3Args a;
   a.in = in; a.dpool = dpool; a.mask = mask; a.part = part;
@@ -1314,13 +1304,9 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   if (pl.rsplit) {
 #define WG3R_CASE(CPR_)                                                                              \
     case CPR_: {                                                                                     \
-      static bool attr_r = false;                                                                    \
-      if (!attr_r) {                                                                                 \
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad3r_kernel<CPR_>,                        \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); \
-        if (e != hipSuccess) return e;                                                               \
-        attr_r = true;                                                                               \
-      }                                                                                              \
+      static DevOnce attr_r;                                                                         \
+      hipError_t e = ensure_max_lds(attr_r, wgrad3r_kernel<CPR_>);                                   \
+      if (e != hipSuccess) return e;                                                                 \
       hipLaunchKernelGGL((wgrad3r_kernel<CPR_>), dim3(pl.G, nets, 3), dim3(512), pl.lds, st, a);     \
       return hipGetLastError();                                                                      \
     }

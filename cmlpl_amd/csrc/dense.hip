@@ -53,12 +53,10 @@ hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const flo
   const int BP = (bands + 2) | 1;
   const size_t lds = (size_t)160 * BP * 4;
   if (lds > LDS_MAX) return hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)spe_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_MAX);
+  static DevOnce attr_once;
+  {
+    hipError_t e = ensure_max_lds(attr_once, spe_fwd_kernel);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   dim3 grid((n + 31) / 32, FD / 128, nets);
   hipLaunchKernelGGL(spe_fwd_kernel, grid, dim3(256), lds, st, sn, w, b, pstride, y, n, bands);

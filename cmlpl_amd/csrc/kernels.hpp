@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 
 namespace cmlpl {
 
@@ -19,6 +20,23 @@ __host__ __device__ inline long long pack_total(int C, int bands) { return pack_
 struct PackInfo { long long stride, off_w0, off_w1, off_w2, off_ws; int C, bands; };
 constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci][co] + db[co]
 constexpr size_t LDS_MAX = 160 * 1024;
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// DEVICE (the attribute lives with the device's code object): a per-call-site bit mask indexed by hipGetDevice().
+struct DevOnce { std::atomic<uint64_t> mask{0}; };
+template <class... Ks>
+inline hipError_t ensure_max_lds(DevOnce& once, Ks... kernels) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (once.mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+  const void* ks[] = {(const void*)kernels...};
+  for (const void* k : ks)
+    if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX)) != hipSuccess) return e;
+  once.mask.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 // ---- augment.hip
 hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,

@@ -16,7 +16,8 @@ rows, and a step exchanges exactly what crosses samples:
      losses are normalised by GLOBAL counts inside the kernels, so the sum IS the global gradient
   9. Adam on every rank (replicated, deterministic)
 
-Four collectives per step, all NCCL(=RCCL)-over-xGMI through torch.distributed; message sizes are
+Four collectives per step (the gradient bucket is ONE buffer holding the live tensors of both
+networks), all NCCL(=RCCL)-over-xGMI through torch.distributed; message sizes are
 1-4 MB, i.e. latency-bound on 7 x 153 GB/s links, hence one packed bucket per exchange rather than
 one collective per tensor.  W-rank results equal the 1-rank results on the same global batch up to
 fp32 summation order (tests/test_distributed_*.py).
@@ -81,12 +82,15 @@ def drive_step(engine, comm, *fwd_args, **fwd_kw) -> None:
 
 class DistTrainEngine(TrainEngine):
     """TrainEngine whose step is sharded by sample over ``comm.world`` ranks.  Batch sizes given to
-    the constructor are PER RANK; banks are sized from the global labelled batch (train.py:138)."""
+    the constructor are PER RANK (the largest shard a step may bring); banks are sized from the global
+    labelled batch (train.py:138).  A step may bring fewer rows (the last short batch of an epoch,
+    train.py:134 keeps it) as long as EVERY rank brings the same number: shards are equal by construction,
+    which is what makes the sum of the ranks' shares the global mean."""
 
     STAGES = ("forward", "phase1", "phase2", "backward", "update")
 
     def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
-                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, comm=None):
+                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, comm=None, hist_rows: int = 1):
         if comm is None:
             import torch.distributed as dist
             comm = TorchDistComm() if (dist.is_available() and dist.is_initialized()) else SingleComm()
@@ -94,30 +98,62 @@ class DistTrainEngine(TrainEngine):
         W = self.world = comm.world
         self.rank = comm.rank
         super().__init__(shape, labeled_batch_size, unlabeled_batch_size, hp, device, seed,
-                         bank_labeled=labeled_batch_size * W)
+                         bank_labeled=labeled_batch_size * W, hist_rows=hist_rows)
         bt_l, btu_l, K = self.bt_max, self.btu_max, shape.K
         n_l = bt_l + btu_l
-        self.bt_g, self.btu_g, self.n_g = bt_l * W, btu_l * W, n_l * W
         dev = self.device
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        self.pack_len = 2 * n_l * K + 2 * n_l * FEAT_DIM + bt_l
-        self.pack, self.recv = z(self.pack_len), z(W * self.pack_len)
-        self.logits_l = self.pack[:2 * n_l * K].view(2, n_l, K)
-        self.feat_l = self.pack[2 * n_l * K: 2 * n_l * K + 2 * n_l * FEAT_DIM].view(2, n_l, FEAT_DIM)
-        self.labels_f = self.pack[2 * n_l * K + 2 * n_l * FEAT_DIM:]
-        self.logits_g, self.feat_g = z(2, self.n_g, K), z(2, self.n_g, FEAT_DIM)
-        self.labels_g = torch.zeros(self.bt_g, dtype=torch.int64, device=dev)
-        self.probs_l, self.probs_g = z(4, btu_l, K), z(W, 4, btu_l, K)
-        self.dlogits_l, self.dfeat_l = z(2, n_l, K), z(2, n_l, FEAT_DIM)
-        self.dfw_part = z(self.btu_g, FEAT_DIM)
-        self.xn, self.sn = z(2, n_l, shape.C * shape.H * shape.W), z(2, n_l, shape.bands)
-        self.snT = z(2, shape.bands, n_l)
-        self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
-        lw = self.lib.cmlpl_loss_workspace_bytes(C.byref(self.cshape), C.byref(self.cshard), self.Q)
+        # ONE gradient bucket: the live tensors of both networks back to back ([2][live], the kernels take the
+        # per-network stride as an argument) -> one all-reduce of 2 x 207,881 floats instead of two
+        self.live = int(self.layout.param_live)
+        self.grads = z(2, self.live)
+        # flat max-size buffers; a step's tensors are views of their heads (see _bind)
+        self._pack = z(2 * n_l * K + 2 * n_l * FEAT_DIM + bt_l)
+        self._recv = z(W * self._pack.numel())
+        self._logits_g, self._feat_g = z(2 * n_l * W * K), z(2 * n_l * W * FEAT_DIM)
+        self._labels_g = torch.zeros(bt_l * W, dtype=torch.int64, device=dev)
+        self._probs_l, self._probs_g = z(4 * btu_l * K), z(W * 4 * btu_l * K)
+        self._dlogits_l, self._dfeat_l = z(2 * n_l * K), z(2 * n_l * FEAT_DIM)
+        self._dfw_part = z(btu_l * W * FEAT_DIM)
+        self._xn, self._sn = z(2 * n_l * shape.C * shape.H * shape.W), z(2 * n_l * shape.bands)
+        self._snT = z(2 * shape.bands * n_l)
+        lw = self.lib.cmlpl_loss_workspace_bytes(
+            C.byref(self.cshape), C.byref(_lib.Shard(bt_l * W, btu_l * W, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)),
+            self.Q)
         if lw == 0:
             raise _lib.CmlplError("cmlpl_loss_workspace_bytes", -2)
         self.loss_ws = torch.empty(lw, dtype=torch.uint8, device=dev)
+        self._bound = None
+        self._bind(bt_l, btu_l)
         self._ctx = None
+
+    def _bind(self, bt_l: int, btu_l: int) -> None:
+        """Views for a step of bt_l + btu_l rows on every rank."""
+        if self._bound == (bt_l, btu_l):
+            return
+        W, K, s = self.world, self.shape.K, self.shape
+        n_l = bt_l + btu_l
+        self.bt_l, self.btu_l = bt_l, btu_l
+        self.bt_g, self.btu_g, self.n_g = bt_l * W, btu_l * W, n_l * W
+        nk, nf = 2 * n_l * K, 2 * n_l * FEAT_DIM
+        self.pack_len = nk + nf + bt_l
+        self.pack, self.recv = self._pack[:self.pack_len], self._recv[:W * self.pack_len]
+        self.logits_l = self.pack[:nk].view(2, n_l, K)
+        self.feat_l = self.pack[nk:nk + nf].view(2, n_l, FEAT_DIM)
+        self.labels_f = self.pack[nk + nf:]
+        self.logits_g = self._logits_g[:2 * self.n_g * K].view(2, self.n_g, K)
+        self.feat_g = self._feat_g[:2 * self.n_g * FEAT_DIM].view(2, self.n_g, FEAT_DIM)
+        self.labels_g = self._labels_g[:self.bt_g]
+        self.probs_l = self._probs_l[:4 * btu_l * K].view(4, btu_l, K)
+        self.probs_g = self._probs_g[:W * 4 * btu_l * K].view(W, 4, btu_l, K)
+        self.dlogits_l = self._dlogits_l[:nk].view(2, n_l, K)
+        self.dfeat_l = self._dfeat_l[:nf].view(2, n_l, FEAT_DIM)
+        self.dfw_part = self._dfw_part[:self.btu_g * FEAT_DIM].view(self.btu_g, FEAT_DIM)
+        self.xn = self._xn[:2 * n_l * s.C * s.H * s.W].view(2, n_l, s.C * s.H * s.W)
+        self.sn = self._sn[:2 * n_l * s.bands].view(2, n_l, s.bands)
+        self.snT = self._snT[:2 * s.bands * n_l].view(2, s.bands, n_l)
+        self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
+        self._bound = (bt_l, btu_l)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -135,10 +171,17 @@ class DistTrainEngine(TrainEngine):
     # ------------------------------------------------------------------ stages (no communication inside)
     def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True):
         s, lib = self.shape, self.lib
-        bt_l, btu_l = self.bt_max, self.btu_max
+        bt_l, btu_l = int(XPl.shape[0]), int(XPu.shape[0])
+        if bt_l < 1 or btu_l < 1 or bt_l > self.bt_max or btu_l > self.btu_max:
+            raise ValueError(f"shard {bt_l}+{btu_l} outside the engine's capacity {self.bt_max}+{self.btu_max} per rank")
+        if self.Q < (bt_l + btu_l) * self.world:
+            raise ValueError("bank smaller than the global batch")
+        self._bind(bt_l, btu_l)
         n_l = bt_l + btu_l
         _chk_f32(XPl, (bt_l, s.C, s.H, s.W), "XPl"); _chk_f32(Xl, (bt_l, s.bands), "Xl")
         _chk_f32(XPu, (btu_l, s.C, s.H, s.W), "XPu"); _chk_f32(Xu, (btu_l, s.bands), "Xu")
+        if Y.dtype != torch.int64 or tuple(Y.shape) != (bt_l,) or not Y.is_cuda:
+            raise ValueError("Y: need int64 cuda tensor [bt]")
         st = self._stream()
         self._ensure_packed(st)
         keep = None
@@ -148,6 +191,7 @@ class DistTrainEngine(TrainEngine):
             noise8 = C.cast(keep, C.POINTER(C.c_void_p))
         if dropmask is not None:
             _chk_f32(dropmask, (2, n_l, s.cls_in), "dropmask")
+        self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
         self._ctx = dict(epoch=epoch, batch_index=batch_index, apply_update=apply_update, dropmask=dropmask,
                          smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
                          adap=float(self.hp.thr * self.hp.adap_thr(epoch)), keep=keep)
@@ -166,7 +210,7 @@ class DistTrainEngine(TrainEngine):
     def stage_phase1(self):
         c, st = self._ctx, self._stream()
         _lib.check("cmlpl_dist_unpack", self.lib.cmlpl_dist_unpack(
-            C.byref(self.cshape), self.world, self.bt_max, self.btu_max, self.recv.data_ptr(),
+            C.byref(self.cshape), self.world, self.bt_l, self.btu_l, self.recv.data_ptr(),
             self.logits_g.data_ptr(), self.feat_g.data_ptr(), self.labels_g.data_ptr(), st))
         banks = self._banks()
         _lib.check("cmlpl_loss_phase1", self.lib.cmlpl_loss_phase1(
@@ -181,44 +225,42 @@ class DistTrainEngine(TrainEngine):
         _lib.check("cmlpl_loss_phase2", self.lib.cmlpl_loss_phase2(
             C.byref(self.cshape), C.byref(self.cshard), self.logits_g.data_ptr(), self.feat_g.data_ptr(),
             self.labels_g.data_ptr(), C.byref(banks), c["smooth"], c["adap"], C.byref(self._chp),
-            self.probs_g.data_ptr(), self.btu_max, self.scalars.data_ptr(), self.dfeat_l.data_ptr(),
+            self.probs_g.data_ptr(), self.btu_l, self.scalars.data_ptr(), self.dfeat_l.data_ptr(),
             self.dfw_part.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
 
     def stage_backward(self):
         c, st = self._ctx, self._stream()
-        n_l = self.bt_max + self.btu_max
+        n_l = self.bt_l + self.btu_l
         dm = c["dropmask"]
         _lib.check("cmlpl_basenet2_bwd", self.lib.cmlpl_basenet2_bwd(
             C.byref(self.cshape), 2, n_l, self.params.data_ptr(), self.P, self.packed.data_ptr(), self.xn.data_ptr(),
             self.sn.data_ptr(), None if dm is None else dm.data_ptr(), self.hp.dropout, 1,
-            self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.grads.data_ptr(), self.P,
+            self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.grads.data_ptr(), self.live,
             self.workspace.data_ptr(), self.workspace.numel(), st))
 
     def stage_update(self):
         c, st = self._ctx, self._stream()
         if c["apply_update"]:
             _lib.check("cmlpl_adam_step", self.lib.cmlpl_adam_step(
-                C.byref(self.cshape), 2, self.params.data_ptr(), self.P, self.grads.data_ptr(), self.P,
+                C.byref(self.cshape), 2, self.params.data_ptr(), self.P, self.grads.data_ptr(), self.live,
                 self.m.data_ptr(), self.v.data_ptr(), self.adam_t + 1, C.byref(self._chp), self.packed.data_ptr(), st))
             self.adam_t += 1
         p0 = (self.ptr[0] + self.hp.bank_step) % self.Q                 # train.py:234,237
         self.ptr = [p0, (p0 + self.hp.bank_step) % self.Q]
         self.step_count += 1
-        self._last_n = self.bt_max + self.btu_max
+        self._last_n = self.bt_l + self.btu_l
         self._ctx = None
 
     # the collective that follows each stage: (output, input, kind)
     def exchange_after(self, stage: str):
-        n_l = self.bt_max + self.btu_max
-        live = int(self.layout.param_live)
         if stage == "forward":
             return [("all_gather", self.recv, self.pack)]
         if stage == "phase1":
             return [("all_gather", self.probs_g, self.probs_l)]
         if stage == "phase2":   # backward of "gather the keys": sum the partials, keep this rank's rows
-            return [("reduce_scatter", self.dfeat_l[1, self.bt_max:], self.dfw_part)]
-        if stage == "backward":  # one flat bucket per network's live tensors
-            return [("all_reduce", self.grads[0, :live], None), ("all_reduce", self.grads[1, :live], None)]
+            return [("reduce_scatter", self.dfeat_l[1, self.bt_l:], self.dfw_part)]
+        if stage == "backward":  # one flat bucket: the live tensors of both networks
+            return [("all_reduce", self.grads, None)]
         return []
 
     # ------------------------------------------------------------------ the step
@@ -241,3 +283,8 @@ class DistTrainEngine(TrainEngine):
         t = self.scalars.clone()
         self.comm.all_reduce(t)
         return t[:5].tolist()
+
+    def _reduce_rows(self, rows):
+        rows = rows.contiguous()
+        self.comm.all_reduce(rows)          # one collective per printed window
+        return rows

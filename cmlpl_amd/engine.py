@@ -41,7 +41,8 @@ class TrainEngine:
     """
 
     def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
-                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, bank_labeled: int = 0):
+                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, bank_labeled: int = 0,
+                 hist_rows: int = 1):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("cmlpl_amd.TrainEngine needs a GPU (no CPU fallback)")
@@ -63,7 +64,12 @@ class TrainEngine:
         self.packed = z(2, int(L.packed_total))
         self.bank_feats, self.bank_probs = z(2, self.Q, FEAT_DIM), z(2, self.Q, shape.K)   # train.py:139-144
         self.ptr = [0, 0]                                                   # train.py:141,145
-        self.scalars = z(16)
+        # Scalars of step i land in row i % hist_rows of a device-side ring (loss_hist of train.py:136,274-278 without
+        # the reference's five .item() syncs per step): the step writes its row directly, the host reads a window
+        # back once per print_per_batches steps.
+        self.hist_rows = max(1, int(hist_rows))
+        self.scalar_hist = z(self.hist_rows, 16)
+        self.scalars = self.scalar_hist[0]
         self.logits, self.feat = z(2, self.n_max, shape.K), z(2, self.n_max, FEAT_DIM)
         ws = self.lib.cmlpl_workspace_bytes(C.byref(self.cshape), 2, self.n_max, self.Q)
         if ws == 0:
@@ -178,6 +184,7 @@ class TrainEngine:
             io.banks.d_probs[i] = self.bank_probs[i].data_ptr()
             io.banks.ptr[i] = self.ptr[i]
         io.banks.Q = self.Q
+        self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
         io.d_scalars = self.scalars.data_ptr()
         # outputs are laid out [2][n][..] for THIS n (views of the max-size buffers)
         io.d_logits, io.d_feat = self.logits.data_ptr(), self.feat.data_ptr()
@@ -222,3 +229,15 @@ class TrainEngine:
     def loss_row(self):
         """[loss_contrast, total_loss, cls_loss, con_loss, acc] -- loss_hist row, train.py:274-278."""
         return self.scalars[:5].tolist()
+
+    def loss_window(self, k: int):
+        """loss_hist[index_i-k+1 : index_i+1] (train.py:285-289) as a float64 numpy array [k,5]: the rows of the
+        last k steps, oldest first.  One synchronising read-back."""
+        if k < 1 or k > self.hist_rows or k > self.step_count:
+            raise ValueError(f"window of {k} steps not held (hist_rows={self.hist_rows}, steps={self.step_count})")
+        idx = [(self.step_count - k + j) % self.hist_rows for j in range(k)]
+        rows = self.scalar_hist[torch.tensor(idx, device=self.device)]
+        return self._reduce_rows(rows)[:, :5].double().cpu().numpy()
+
+    def _reduce_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        return rows

@@ -12,6 +12,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -48,15 +49,16 @@ def spawn_ranks(world: int, argv: Sequence[str], extra_env: Optional[Dict[str, s
         env = rank_env(r, world, port)
         if extra_env:
             env.update(extra_env)
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                      stderr=None, text=(r == 0)))
+        # ranks > 0: stdout -> fd 2 (this process's stderr, also when sys.stderr has been replaced by a capture)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else 2, stderr=None,
+                                      text=(r == 0)))
+    chunks: List[str] = []
+    reader = threading.Thread(target=lambda: chunks.extend(iter(procs[0].stdout.readline, "")), daemon=True)
+    reader.start()                    # rank 0's pipe is drained while we wait, whatever it prints
     t0 = time.monotonic()
     rc = 0
-    out0 = ""
     pending = set(range(world))
     try:
-        # rank 0's pipe is drained by communicate() at the end; its output is one short line, far below the
-        # pipe buffer, so polling here cannot dead-lock on a full pipe
         while pending:
             for r in sorted(pending):
                 code = procs[r].poll()
@@ -80,8 +82,5 @@ def spawn_ranks(world: int, argv: Sequence[str], extra_env: Optional[Dict[str, s
                 procs[r].wait(timeout=10)
             except subprocess.TimeoutExpired:
                 procs[r].kill()
-        try:
-            out0, _ = procs[0].communicate(timeout=10)
-        except Exception:
-            out0 = ""
-    return rc, out0 or ""
+        reader.join(timeout=10)
+    return rc, "".join(chunks)

@@ -55,8 +55,6 @@ class _BaseNet2Fn(torch.autograd.Function):
         lib = _lib.load()
         mod, n = ctx.mod, ctx.n
         x, y, dropmask, flat, packed, ws = ctx.saved_tensors
-        if mod._ws_owner is None or mod._ws_owner.data_ptr() != ws.data_ptr():
-            raise RuntimeError("BaseNet2 workspace was reused by a later forward before backward ran")
         dlogits = dlogits.contiguous() if dlogits is not None else torch.zeros(n, mod.shape.K, device=x.device)
         dfeat_ptr = None
         if dfeat is not None:
@@ -97,7 +95,6 @@ class BaseNet2(nn.Module):
         self._cshape = _lib.Shape(self.shape.C, H, W, self.shape.bands, self.shape.K)
         self._layout = None
         self._cache = None
-        self._ws_owner = None
         self._calls = 0
 
     def _live_params(self):
@@ -132,9 +129,9 @@ class BaseNet2(nn.Module):
         if need == 0:
             raise _lib.CmlplError("cmlpl_workspace_bytes", -2)
         dev = self.conv0.weight.device
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        self._ws_owner = ws
-        return ws
+        # one workspace per forward call, kept alive by the autograd context that saved it: any number of
+        # forwards may run before their backwards (gradient accumulation, an eval pass in between), like nn.Module
+        return torch.empty(need, dtype=torch.uint8, device=dev)
 
     def forward(self, x, y, dropmask=None):
         """x: [n, C, H, W] patch windows, y: [n, bands] spectra -> (logits [n,K], feat [n,1024]).
@@ -182,6 +179,8 @@ class ContrastiveLoss(nn.Module):
         super().__init__()
         self.batch_size = batch_size
         self.register_buffer("temperature", torch.tensor(float(temperature)))
+        # state_dict() parity with the reference (models.py:19-20); the kernel masks the diagonal itself
+        self.register_buffer("negatives_mask", (~torch.eye(batch_size * 2, batch_size * 2, dtype=torch.bool)).float())
 
     def forward(self, emb_i, emb_j):
         if not emb_i.is_cuda:

@@ -12,6 +12,9 @@
  *     across streams (no implicit synchronisation, graph-capturable);
  *   - return 0 = ok, negative = argument error (CMLPL_E_*), positive = hipError_t;
  *   - all arithmetic is fp32; labels are int64 (torch.long).
+ *   - the library expects ONE calling thread per process at a time (one process per GPU is the deployment
+ *     model); the lazily-set kernel attributes are tracked per device, so engines on several devices of one
+ *     process work, but cmlpl_timing_begin/_end state is process-global and not thread-safe.
  *   - `nets` is 1 or 2: kernels are batched over the two networks Base/Base1
  *     (train.py:118-125) through a grid dimension; per-network buffers are
  *     laid out [net][...] with the strides returned by cmlpl_layout().

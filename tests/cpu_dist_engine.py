@@ -25,15 +25,22 @@ class CpuDistEngine:
         self.Q, self.ptr = Q, [0, 0]
         self.bank_feats = [torch.zeros(Q, FD), torch.zeros(Q, FD)]
         self.bank_probs = [torch.zeros(Q, K), torch.zeros(Q, K)]
+        self.sizes = [self.params[0][k].numel() for k in O.LIVE_KEYS]
+        self.grads = torch.zeros(2, sum(self.sizes))
+        self.scalars = torch.zeros(16)
+        self.rebind(bt_l, btu_l)
+
+    def rebind(self, bt_l, btu_l):
+        """(Re)allocate the buffers whose size follows the shard of the current step (a short last batch)."""
+        W, K = self.world, self.shape.K
+        self.bt_l, self.btu_l, self.n_l = bt_l, btu_l, bt_l + btu_l
+        self.bt_g, self.btu_g, self.n_g = bt_l * W, btu_l * W, (bt_l + btu_l) * W
         n_l = self.n_l
         self.pack_len = 2 * n_l * K + 2 * n_l * FD + bt_l
         self.pack, self.recv = torch.zeros(self.pack_len), torch.zeros(W * self.pack_len)
         self.probs_l, self.probs_g = torch.zeros(4, btu_l, K), torch.zeros(W, 4, btu_l, K)
         self.dlogits_l, self.dfeat_l = torch.zeros(2, n_l, K), torch.zeros(2, n_l, FD)
         self.dfw_part = torch.zeros(self.btu_g, FD)
-        self.sizes = [self.params[0][k].numel() for k in O.LIVE_KEYS]
-        self.grads = torch.zeros(2, sum(self.sizes))
-        self.scalars = torch.zeros(16)
 
     # --------------------------------------------------------------
     def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update=True):
@@ -160,5 +167,47 @@ class CpuDistEngine:
         if stage == "phase2":
             return [("reduce_scatter", self.dfeat_l[1, self.bt_l:], self.dfw_part)]
         if stage == "backward":
-            return [("all_reduce", self.grads[0], None), ("all_reduce", self.grads[1], None)]
+            return [("all_reduce", self.grads, None)]
         return []
+
+
+class CpuLoopEngine:
+    """TEST-ONLY: the part of DistTrainEngine's interface that train.py's loop uses (step / loss_window /
+    step_count / state_dict / init_params_default), on top of CpuDistEngine + the real drive_step and communicator.
+    Lets `train.py` run as two gloo ranks on CPU, so the sharding decisions of its loop (equal shards decided on the
+    global batch, the short last batch, the loss_hist windows) are exercised across real processes."""
+
+    def __init__(self, shape, bt_l, btu_l, hp, comm, hist_rows=1):
+        from cmlpl_amd.distributed import drive_step
+        self._drive = drive_step
+        self.oshape = O.NetShape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+        self.hp = O.HyperParams(**{k: getattr(hp, k) for k in O.HyperParams.__dataclass_fields__})
+        self.comm, self.bt_max, self.btu_max = comm, bt_l, btu_l
+        self.n_max = bt_l + btu_l
+        self.hist_rows, self.rows, self.step_count = hist_rows, [], 0
+        self.eng = None
+
+    def init_params_default(self, seed=1088):
+        p0, p1 = O.closed_form_params(self.oshape, seed), O.closed_form_params(self.oshape, seed + 1)
+        self.eng = CpuDistEngine(self.oshape, self.bt_max, self.btu_max, self.hp, self.comm.world, self.comm.rank, p0, p1)
+
+    def step(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index):
+        e = self.eng
+        bt_l, btu_l = XPl.shape[0], XPu.shape[0]
+        if bt_l > self.bt_max or btu_l > self.btu_max:
+            raise ValueError("shard larger than the engine's capacity")
+        if (bt_l, btu_l) != (e.bt_l, e.btu_l):
+            e.rebind(bt_l, btu_l)
+        zl = [torch.zeros_like(XPl), torch.zeros_like(Xl)] * 2 + [torch.zeros_like(XPu), torch.zeros_like(Xu)] * 2
+        self._drive(e, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, zl, [None, None])
+        row = e.scalars.clone()
+        self.comm.all_reduce(row)
+        self.rows.append(row)
+        self.step_count += 1
+
+    def loss_window(self, k):
+        assert 1 <= k <= self.hist_rows and k <= self.step_count
+        return torch.stack(self.rows[-k:])[:, :5].double().numpy()
+
+    def state_dict(self, net):
+        return {k: v.clone() for k, v in self.eng.params[net].items()}

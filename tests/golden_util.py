@@ -13,7 +13,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_cases():
     """step-trajectory fixtures (patches_ref.npz belongs to the patch-extraction row, N3)"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("patches", "ntxent", "losshelper"))]
+    return [n for n in names if not n.startswith(("patches", "ntxent", "losshelper", "hsiloader"))]
 
 
 class GoldenCase:

@@ -33,6 +33,22 @@ def report(name, got, want, rtol, atol):
     return float(np.nanmax(err))
 
 
+def report_params(name, got, want, steps, lr, rtol=1e-4, atol=3e-5, loose_frac=5e-4):
+    """Parameters after `steps` Adam updates.  Adam's update is lr * m / (sqrt(v) + eps): for an element whose
+    gradient is near zero it behaves like lr * sign(g), so a gradient difference at rounding level can move that
+    element by up to 2 * lr in one step (on ANY two hosts, the reference's included).  Hence: every element within
+    2 * lr * steps, and all but a `loose_frac` fraction within the tight bound."""
+    got = np.asarray(got.detach().cpu().double()); want = np.asarray(want.detach().cpu().double())
+    assert got.shape == want.shape
+    err = np.abs(got - want)
+    bad = ~(err <= atol + rtol * np.abs(want))
+    msg = f"{name}: max|err|={np.nanmax(err):.3e} outside tight bound {int(bad.sum())}/{bad.size}"
+    print(msg)
+    assert not np.isnan(err).any(), msg
+    assert err.max() <= 2.0 * lr * steps + atol, msg
+    assert bad.sum() <= max(1, int(loose_frac * bad.size)), msg
+
+
 def cuda_batch(b):
     out = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
     if "noise" in b:

@@ -31,6 +31,25 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
-    assert rf["launches_timed"] == 12 and rf["traffic"] and rf["traffic"] > 1e6
+    assert rf["launches_timed"] == 12
+    assert rf["traffic"] is None or rf["traffic"] > 1e6     # null when the kernels changed since the recorded PMC pass
     assert len(d["roofline_others"]) == 2
     assert all(v == v for v in d["final_losses"].values())                               # finite
+
+
+def test_bench_self_launch_path():
+    """`python bench.py --gpus N` typed directly starts its own ranks (cmlpl_amd/launch.py).  One GPU here, so the
+    spawn path is exercised at N = 1 (CMLPL_BENCH_SPAWN=1 forces it): the child is a real rank with its own
+    rendezvous environment, runs the data-parallel engine on RCCL at world size 1, and the parent relays its line."""
+    env = dict(os.environ, CMLPL_BENCH_SPAWN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+                        "--workload", "B5", "--global-batch", "64+512"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["global_batch"] == 576
+    assert d["config"]["parallelism"] == "dp1" and d["value"] > 0

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import cmlpl_oracle as O
-from tests.gpu_util import DEV, cuda_batch, report, to_hp, to_shape
+from tests.gpu_util import DEV, cuda_batch, report, report_params, to_hp, to_shape
 
 pytestmark = pytest.mark.gpu
 SCALARS = ("ctr_s", "total_s", "cls_s", "con_s", "acc", "total_w", "cls_w", "con_w", "ctr_w",
@@ -216,6 +216,6 @@ def test_eight_rank_baseline_configs_match_the_oracle(cfg):
         for e in (engines[0], engines[-1]):
             sd = e.state_dict(net)
             for k in O.LIVE_KEYS:
-                report(f"param[{net}] {k}", sd[k], st.params[net][k], 1e-4, 3e-5)
+                report_params(f"param[{net}] {k}", sd[k], st.params[net][k], steps, hp.lr)
     for e in engines[1:]:
         assert torch.equal(e.params, engines[0].params)       # replicas stay bit-identical

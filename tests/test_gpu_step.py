@@ -8,7 +8,8 @@ import torch
 
 from oracle import cmlpl_oracle as O
 from tests.golden_util import GoldenCase, golden_cases, rel_err
-from tests.gpu_util import DEV, cuda_batch, hip_relu_gates, relu_mask_audit, report, to_hp, to_shape
+from tests.gpu_util import (DEV, cuda_batch, hip_relu_gates, relu_mask_audit, report, report_params, to_hp,
+                            to_shape)
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +86,7 @@ def test_step_matches_golden_and_oracle(name):
     for net in range(2):
         sd = eng.state_dict(net)
         for k in O.LIVE_KEYS:
-            report(f"param[{net}] {k}", sd[k], st.params[net][k], 1e-4, 3e-5)   # Adam: |dp| <= lr = 5e-4 per step
+            report_params(f"param[{net}] {k}", sd[k], st.params[net][k], steps, g.hp.lr)
         for k in ("feat_ss.weight", "feat_ss2.weight", "feat_ss3.bias"):
             assert torch.equal(sd[k].cpu(), st.params[net][k])         # dead tensors never move
     for i in range(2):

@@ -7,10 +7,13 @@ Differences from the reference that are deliberate, MI355X-first choices:
   * the labelled / unlabelled splits live in HBM for the whole run and batches are gathered there by
     index (the reference copies every batch over PCIe and draws noise on the CPU);
   * noise and dropout come from in-kernel Philox streams seeded with the reference's seed 1088;
-  * the five logged scalars are read back once per ``print_per_batches`` steps, not five times a step.
+  * the five logged scalars of every step (loss_hist, train.py:136,274-278) are written by the step into a
+    device-side ring and read back once per ``print_per_batches`` steps, not five times a step; the printed line
+    is the mean over that window, as in train.py:281-289.
 ``--synthetic SHAPE`` (B2 | P | B4 | B5) runs without the datasets, which are not shipped.
 Multi-GPU: ``python -m torch.distributed.run --nproc-per-node N train.py ...`` shards every batch by
-sample over the ranks (cmlpl_amd.distributed)."""
+sample over the ranks (cmlpl_amd.distributed); batch sizes must be multiples of N, and a short last batch
+is cut to the largest equal shards (see shard_plan)."""
 import argparse
 import os
 import time
@@ -46,70 +49,112 @@ class DeviceLoader:
             yield self.XP[idx], self.X[idx], self.Y[idx]
 
 
-def main(args):
+def shard_plan(bt, btu, world):
+    """How a GLOBAL batch of bt + btu rows is taken by `world` ranks: (bt_l, btu_l) rows per rank, or None when the
+    batch cannot be sharded equally.  Decided from the global sizes only, so every rank decides the same way (a rank
+    that skipped a step others ran would leave them waiting in a collective).  Equal shards are required because
+    the ranks' loss shares are summed into global means; the rows that do not divide are dropped,
+    the pointer/step bookkeeping still advances on every rank alike."""
+    bt_l, btu_l = bt // world, btu // world
+    if bt_l < 1 or btu_l < 1:
+        return None
+    return bt_l, btu_l
+
+
+def main(args, make_engine=None, device=None):
+    """``make_engine`` / ``device`` are test hooks (tests/test_train_loop_gloo.py runs this loop as two gloo ranks
+    on CPU around a stand-in engine); the product path leaves them None."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(device)
+    if device is None:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(device)
     torch.manual_seed(1088)                                         # seed_torch(), train.py:50-58
     if args.synthetic:
         shape = SYNTH[args.synthetic]
         num_classes, num_features = shape[4], shape[3]
         labeled = SyntheticHSIDataSet(shape, args.num_unlabel, 'label', seed=1)
         unlabeled = SyntheticHSIDataSet(shape, args.num_unlabel, 'unlabel', seed=2)
-        whole = SyntheticHSIDataSet(shape, 4096, 'wholeset', seed=3)
-        Y_test, test_array = whole.Y.numpy(), np.arange(len(whole))
+        if not args.no_eval:
+            whole = SyntheticHSIDataSet(shape, 4096, 'wholeset', seed=3)
+            Y_test, test_array = whole.Y.numpy(), np.arange(len(whole))
     else:
         num_classes, num_features = DATASETS[int(args.dataID)]
         labeled = HSIDataSet(int(args.dataID), 'label', max_iters=args.num_unlabel)
         unlabeled = HSIDataSet(int(args.dataID), 'unlabel', max_iters=args.num_unlabel, num_unlabel=args.num_unlabel)
-        whole = HSIDataSet(int(args.dataID), 'wholeset')
-        test_array = np.load(labeled.root + 'test_array.npy')
-        Y_test = (np.load(labeled.root + 'Y.npy') - 1)[test_array]
+        if not args.no_eval:
+            whole = HSIDataSet(int(args.dataID), 'wholeset')
+            test_array = np.load(labeled.root + 'test_array.npy')
+            Y_test = (np.load(labeled.root + 'Y.npy') - 1)[test_array]
         shape = (labeled.XP.shape[1], labeled.XP.shape[2], labeled.XP.shape[3], num_features, num_classes)
 
     hp = HyperParams(lr=args.lr, num_epochs=args.num_epochs, thr=args.thr, alpha=args.alpha,
                      queue_batch=args.queue_batch, temperature=args.temperature, dropout=args.dropout,
                      noise=args.noise)
     bt, btu = args.labeled_batch_size, args.unlabeled_batch_size
-    if world > 1:
+    ppb = args.print_per_batches
+    if world > 1 and (bt % world or btu % world):
+        raise SystemExit(f"--labeled_batch_size {bt} / --unlabeled_batch_size {btu} must be multiples of the "
+                         f"number of GPUs ({world}): the batch is sharded equally by sample")
+    if make_engine is not None:
+        eng = make_engine(NetShape(*shape), bt // world, btu // world, hp, ppb)
+    elif world > 1:
         import torch.distributed as dist
         from cmlpl_amd.distributed import DistTrainEngine
         dist.init_process_group("nccl", device_id=device)
-        eng = DistTrainEngine(NetShape(*shape), bt // world, btu // world, hp, device=device, seed=1088)
+        eng = DistTrainEngine(NetShape(*shape), bt // world, btu // world, hp, device=device, seed=1088, hist_rows=ppb)
     else:
         from cmlpl_amd import TrainEngine
-        eng = TrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088)
+        eng = TrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088, hist_rows=ppb)
     eng.init_params_default(1088)
 
-    gen = torch.Generator().manual_seed(1088)
+    gen = torch.Generator().manual_seed(1088)                        # same permutations on every rank
     lab_loader = DeviceLoader(labeled.device_arrays(device), bt, gen)
     unl_loader = DeviceLoader(unlabeled.device_arrays(device), btu, gen)
     num_batches = min(len(lab_loader), len(unl_loader))              # train.py:134
-    ppb = args.print_per_batches
-    hist = []
+    num_steps = args.num_epochs * num_batches                        # train.py:135
+    loss_hist = np.zeros((num_steps, 5))                             # train.py:136
+    index_i = -1
+    pending = []                      # loss_hist rows of the steps run since the last read-back of the device ring
+
+    def read_back():
+        if pending:
+            loss_hist[pending] = eng.loss_window(len(pending))
+            pending.clear()
     t_start = time.time()
     for epoch in range(args.num_epochs):                             # train.py:146
         for batch_index, (lab, unl) in enumerate(zip(lab_loader, unl_loader)):
+            index_i += 1                                             # train.py:150
             XPl, Xl, Yl = lab
             XPu, Xu, _ = unl
-            if world > 1:                                            # shard by sample
-                XPl, Xl, Yl = (t.chunk(world)[rank].contiguous() for t in (XPl, Xl, Yl))
-                XPu, Xu = (t.chunk(world)[rank].contiguous() for t in (XPu, Xu))
-            if XPl.shape[0] < 1 or XPu.shape[0] < 1 or XPl.shape[0] + XPu.shape[0] > eng.n_max:
-                continue
-            eng.step(XPl.contiguous(), Xl.contiguous(), Yl, XPu.contiguous(), Xu.contiguous(), epoch, batch_index)
-            if (batch_index + 1) % ppb == 0:                         # train.py:281-289 (row of the last step)
-                row = eng.loss_row()
-                hist.append(row)
+            if world > 1:                                            # shard by sample; decided on GLOBAL sizes
+                plan = shard_plan(XPl.shape[0], XPu.shape[0], world)
+                if plan is None:      # fewer rows than ranks: every rank skips alike (row stays zero in loss_hist)
+                    continue
+                bl, bul = plan
+                XPl, Xl, Yl = (t[rank * bl:(rank + 1) * bl] for t in (XPl, Xl, Yl))
+                XPu, Xu = (t[rank * bul:(rank + 1) * bul] for t in (XPu, Xu))
+            eng.step(XPl.contiguous(), Xl.contiguous(), Yl.contiguous(), XPu.contiguous(), Xu.contiguous(),
+                     epoch, batch_index)
+            pending.append(index_i)
+            if (batch_index + 1) % ppb == 0 or len(pending) == ppb:
+                read_back()           # the five scalars of train.py:274-278 of those steps: one sync, not five per step
+            if (batch_index + 1) % ppb == 0:                         # train.py:281-289 (means over the window)
+                w = loss_hist[index_i - ppb + 1:index_i + 1]
                 if rank == 0:
                     print('Epoch %d/%d:  %d/%d loss_contrast= %.2f total_loss = %.4f cls_loss = %.4f con_loss = %.4f '
                           'acc = %.2f\n' % (epoch + 1, args.num_epochs, batch_index + 1, num_batches,
-                                            row[0], row[1], row[2], row[3], row[4] * 100))
-    torch.cuda.synchronize()
+                                            np.mean(w[:, 0]), np.mean(w[:, 1]), np.mean(w[:, 2]), np.mean(w[:, 3]),
+                                            np.mean(w[:, 4]) * 100))
+        read_back()                   # rows of the epoch's tail (num_batches % print_per_batches steps)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
     if rank == 0:
         steps = eng.step_count
         print('training: %d steps in %.2f s' % (steps, time.time() - t_start))
+        if args.save_loss_hist:
+            np.save(args.save_loss_hist, loss_hist)
+    if rank == 0 and not args.no_eval:
         # whole-image inference + accuracy (train.py:291-306)
         for net in range(2):
             model = BaseNet2(num_features=num_features, dropout=args.dropout, num_classes=num_classes,
@@ -124,11 +169,13 @@ def main(args):
             print('Result:\n OA%s=%.2f,Kappa=%.2f' % (tag, OA * 100, Kappa * 100))
             print('producerA%s:' % tag, producerA * 100)
             print('AA%s=%.2f' % (tag, np.mean(producerA) * 100))
-    if world > 1:
+    if world > 1 and make_engine is None:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    return loss_hist
 
 
-if __name__ == '__main__':
+def build_parser():
     parser = argparse.ArgumentParser()
     parser.add_argument('--dataID', type=int, default=1)
     parser.add_argument('--num_label', type=int, default=5)
@@ -154,4 +201,10 @@ if __name__ == '__main__':
     # this build
     parser.add_argument('--synthetic', choices=sorted(SYNTH), default=None,
                         help='run on seeded synthetic patches of this shape (datasets are not shipped)')
-    main(parser.parse_args())
+    parser.add_argument('--save_loss_hist', default=None, help='write loss_hist [num_steps,5] (train.py:136) as .npy')
+    parser.add_argument('--no_eval', action='store_true', help='skip the whole-image inference after training')
+    return parser
+
+
+if __name__ == '__main__':
+    main(build_parser().parse_args())

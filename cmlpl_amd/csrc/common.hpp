@@ -26,6 +26,11 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
+// torch.relu / threshold_backward semantics (tools/models.py:108,135,139,143): a NaN pre-activation stays NaN
+// in the forward and lets the gradient through in the backward (x <= 0 ? 0 : grad).  fmaxf would drop the NaN.
+__device__ __forceinline__ float relu_nan(float v) { return (v <= 0.f) ? 0.f : v; }
+__device__ __forceinline__ bool relu_open(float r) { return !(r <= 0.f); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -381,7 +381,7 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
       o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
       o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
       *(float4*)(out + g) = o;
-#define CMLPL_NIB(A, B, C, D) ((uint32_t)((A > 0.f ? 1 : 0) | (B > 0.f ? 2 : 0) | (C > 0.f ? 4 : 0) | (D > 0.f ? 8 : 0)))
+#define CMLPL_NIB(A, B, C, D) ((uint32_t)((relu_open(A) ? 1 : 0) | (relu_open(B) ? 2 : 0) | (relu_open(C) ? 4 : 0) | (relu_open(D) ? 8 : 0)))
       const uint32_t m = CMLPL_NIB(v00.x, v01.x, v10.x, v11.x) | (CMLPL_NIB(v00.y, v01.y, v10.y, v11.y) << 8) |
                          (CMLPL_NIB(v00.z, v01.z, v10.z, v11.z) << 16) | (CMLPL_NIB(v00.w, v01.w, v10.w, v11.w) << 24);
 #undef CMLPL_NIB
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
             float* p = img + (size_t)lut[m] * CS;
             const float v0 = acc[t][0][r] + bv0 + p[l31];
             const float v1 = acc[t][1][r] + bv1 + p[32 + l31];
-            p[l31] = fmaxf(v0, 0.f);
-            p[32 + l31] = fmaxf(v1, 0.f);
+            p[l31] = relu_nan(v0);
+            p[32 + l31] = relu_nan(v1);
           }
         }
       }
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(Conv3Args a) {
         const int m = acc_row(r, lane);
         if (m < c.npx) {
           float* p = img + (size_t)lut[m] * CS + nt * 32 + l31;
-          *p = fmaxf(acc[r] + bv + *p, 0.f);
+          *p = relu_nan(acc[r] + bv + *p);
         }
       }
     } else {

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void spe_fwd_kernel(const float* __restrict__ 
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = r0 + acc_row(r, lane);
-    if (row < n) Y[(long long)row * FD + o] = fmaxf(acc[r] + bv, 0.f);
+    if (row < n) Y[(long long)row * FD + o] = relu_nan(acc[r] + bv);
   }
 }
 
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN2 t) {
         const int row = mt * 32 + acc_row(r, lane);
         float v = (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]) * g.scale;
         if (g.bias_in != nullptr) v += g.bias_in[(long long)bz * g.bias_in_bstride + j];
-        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.relu) v = relu_nan(v);
         if (row < g.M) C[(long long)row * g.ldc + j] = v;
       }
     }

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
       const float yj = y[j];
       float g = dc;
       if (df != nullptr) g += (df[j] - (yj / norm) * dot) / norm;
-      dy[j] = (yj > 0.f) ? g : 0.f;
+      dy[j] = relu_open(yj) ? g : 0.f;
     }
   }
 }

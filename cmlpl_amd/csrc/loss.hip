@@ -375,7 +375,9 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
       }
       if (lane == 0) a.rowloss[(net == 0 ? RL_CLS_S : RL_CLS_W) * RL + il] = lse - zy;
       if (net == 1) {  // torch.max(labeled_output1, 1): first index of the maximum (train.py:194)
-        const unsigned long long bal = __ballot(kv && z == mx);
+        // a NaN logit is the maximum for torch.max, and the first one wins (dead-ReLU regime, models.py:87-90)
+        const unsigned long long nanb = __ballot(kv && z != z);
+        const unsigned long long bal = nanb ? nanb : __ballot(kv && z == mx);
         const int amax = __ffsll((long long)bal) - 1;
         if (lane == 0) a.rowloss[RL_ACC * RL + il] = (amax == yl) ? 1.f : 0.f;
       }

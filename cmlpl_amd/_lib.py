@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMLPL_LIB") or os.path.join(HERE, "libcmlpl_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_TENSORS = 16
 NUM_LIVE = 10
 
@@ -29,6 +29,7 @@ EXPORTS = (
     "cmlpl_dist_unpack", "cmlpl_loss_workspace_bytes", "cmlpl_extract_patches", "cmlpl_ntxent_workspace_bytes", "cmlpl_ntxent_fwd_bwd",
     "cmlpl_unsup_workspace_bytes", "cmlpl_unsup_loss", "cmlpl_memobank_select", "cmlpl_memobank_proto",
     "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
+    "cmlpl_forward", "cmlpl_backward",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -66,6 +67,11 @@ class Layout(C.Structure):
 
 class Shard(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("bt_g", "btu_g", "lab0", "nlab", "unl0", "nunl")]
+
+
+class Batch(C.Structure):
+    _fields_ = [("d_xpl", C.c_void_p), ("d_xl", C.c_void_p), ("d_xpu", C.c_void_p), ("d_xu", C.c_void_p),
+                ("noise8", C.POINTER(C.c_void_p)), ("bt", C.c_int32), ("btu", C.c_int32)]
 
 
 class Banks(C.Structure):
@@ -120,6 +126,9 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_basenet2_fwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, vp, f32, i32, u64, u64, SH, vp, vp, vp,
                                        sz, vp]
     lib.cmlpl_basenet2_bwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, vp, vp, vp, i64, vp, sz, vp]
+    BP = C.POINTER(Batch)
+    lib.cmlpl_forward.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, vp, sz, vp]
+    lib.cmlpl_backward.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, vp, i64, vp, sz, vp]
     lib.cmlpl_loss_fwd_bwd.argtypes = [SP, i32, i32, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp,
                                        vp, sz, vp]
     lib.cmlpl_loss_phase1.argtypes = [SP, SH, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp, sz, vp]

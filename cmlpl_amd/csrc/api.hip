@@ -224,9 +224,40 @@ int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const flo
   if (shard && (shard->nlab != bt || shard->nunl != btu)) return CMLPL_E_ARG;
   const int lab0 = shard ? shard->lab0 : 0, unl_base = shard ? shard->bt_g + shard->unl0 : bt;
   hipStream_t st = (hipStream_t)stream;
-  return TIMED(CMLPL_K_AUGMENT, chk(launch_augment(nets, bt, btu, d.C * d.HW, d.bands, lab0, unl_base, d_xpl, d_xl,
+  return TIMED(CMLPL_K_AUGMENT, chk(launch_augment(3, nets, bt, btu, d.C * d.HW, d.bands, lab0, unl_base, d_xpl, d_xl,
                             d_xpu, d_xu, noise8, sigma, seed, step, d_xn, d_sn, d_snT, st)));
 }
+
+namespace {
+// patch rows that are already augmented: [nets][n][C*HW]
+XSrc xsrc_plain(const float* d_xn, int nets, int n, long long per) {
+  XSrc x = XSrc();
+  for (int i = 0; i < 2; ++i) x.lab[i] = x.unl[i] = d_xn + (long long)(i < nets ? i : 0) * n * per;
+  x.nlab = n; x.sigma = 0.f;
+  return x;
+}
+// raw labelled / unlabelled rows + noise formed in the kernels
+XSrc xsrc_raw(const cmlpl_batch* b, float sigma, uint64_t seed, uint64_t step, const cmlpl_shard* sh) {
+  XSrc x = XSrc();
+  for (int i = 0; i < 2; ++i) {
+    x.lab[i] = b->d_xpl; x.unl[i] = b->d_xpu;
+    x.nz_lab[i] = b->noise8 ? b->noise8[2 * i] : nullptr;          // reference draw order, see cmlpl_augment
+    x.nz_unl[i] = b->noise8 ? b->noise8[4 + 2 * i] : nullptr;
+  }
+  x.sigma = sigma; x.nlab = b->bt; x.philox = b->noise8 == nullptr;
+  x.lab0 = sh ? sh->lab0 : 0; x.unl_base = sh ? sh->bt_g + sh->unl0 : b->bt;
+  x.seed = seed; x.step = step;
+  return x;
+}
+int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
+             const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_snT,
+             const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
+             const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st);
+int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
+             const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
+             float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
+             int64_t grad_stride, const NetWs& w, hipStream_t st);
+}  // namespace
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
                        const float* d_packed, const float* d_xn, const float* d_sn, const float* d_snT,
@@ -243,7 +274,15 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
   NetWs w;
   if (!carve_net(d, nets, n, (char*)d_workspace, &w)) return CMLPL_E_SHAPE;
   if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
+  return fwd_core(d, L, nets, n, d_params, param_stride, d_packed, xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW), d_xn,
+                  d_sn, d_snT, d_dropmask, dropout_p, train, seed, step, shard, d_logits, d_feat, w, (hipStream_t)stream);
+}
+
+namespace {
+int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
+             const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_snT,
+             const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
+             const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st) {
   int rc;
   hipStream_t main_st = st;
   const long long pk_ns = L.packed_total;
@@ -265,12 +304,14 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
     }
   }
   if (conv3_fused_ok(d.H, d.W, d.C, nets * n)) {
-    // conv0 + conv1 in one launch: a0 never makes the HBM round trip between them (it is still written once,
+    // conv0 + conv1 in one launch, input rows taken where they lie and augmented in LDS: neither an augmented
+    // copy of the input nor a0's round trip between the two convolutions touches HBM (a0 is still written once,
     // for the backward pass)
-    if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, d_xn, d_packed + pack_off_w0t(),
+    if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0t(),
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + 0 * PACK_CONV, pk_ns,
                                d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
   } else {
+    if (!d_xn) return CMLPL_E_ARG;
     if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
                                    d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV,
@@ -286,6 +327,7 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
                              train, seed, step, nlab, lab0, unl_base, d_params + L.param_off[8],
                              d_params + L.param_off[9], param_stride, w.catd, w.ynorm, d_logits, d_feat, st)));
 }
+}  // namespace
 
 int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
                        const float* d_packed, const float* d_xn, const float* d_sn, const float* d_dropmask,
@@ -300,7 +342,15 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   NetWs w;
   if (!carve_net(d, nets, n, (char*)d_workspace, &w)) return CMLPL_E_SHAPE;
   if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
+  return bwd_core(d, L, nets, n, d_params, param_stride, d_packed, xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW), d_xn,
+                  d_sn, d_dropmask, dropout_p, train, d_dlogits, d_dfeat, d_grads, grad_stride, w, (hipStream_t)stream);
+}
+
+namespace {
+int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
+             const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
+             float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
+             int64_t grad_stride, const NetWs& w, hipStream_t st) {
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
   // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
@@ -337,11 +387,13 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
     if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
   }
   if (conv3_fused_bwd_ok(d.H, d.W, d.C, nets * n)) {
-    // conv1 data gradient + conv0 weight gradient in one launch: da0 never goes to HBM
+    // conv1 data gradient + conv0 weight gradient in one launch: da0 never goes to HBM, and the input slab is
+    // re-formed from the raw rows with the forward's noise regenerated
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
-                               d_packed + 1 * PACK_CONV, L.packed_total, d_xn, w.part0,
+                               d_packed + 1 * PACK_CONV, L.packed_total, xs, w.part0,
                                (long long)n * conv0_partial_size(d.C), st))))) return rc;
   } else {
+    if (!d_xn) return CMLPL_E_ARG;
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
                                L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
@@ -357,6 +409,63 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   reduce_table_add(rt, w.part0, conv0_partials(d, nets, n), conv0_partial_size(d.C), 0, d.C,
                    d_grads + L.param_off[0], d_grads + L.param_off[1]);
   return TIMED(CMLPL_K_CONV1_WRED, chk(launch_partial_reduce(nets, rt, st)));
+}
+
+// does the step need an augmented copy of the patches in HBM?  (only when a conv0 pass falls back to the unfused kernels)
+bool need_xn_copy(const Dims& d, int rows) {
+  return !(conv3_fused_ok(d.H, d.W, d.C, rows) && conv3_fused_bwd_ok(d.H, d.W, d.C, rows));
+}
+bool check_batch(const cmlpl_batch* b) {
+  return b && b->bt >= 1 && b->btu >= 1 && b->d_xpl && b->d_xl && b->d_xpu && b->d_xu;
+}
+}  // namespace
+
+int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                  const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                  uint64_t step, float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes,
+                  void* stream) {
+  Dims d;
+  cmlpl_layout_t L;
+  if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
+  if (!hp || !check_batch(batch) || !d_params || !d_packed || !d_logits || !d_feat || !d_workspace) return CMLPL_E_ARG;
+  if (hp->dropout_p < 0.f || hp->dropout_p >= 1.f) return CMLPL_E_ARG;
+  const int n = batch->bt + batch->btu;
+  if (shard && (shard->nlab != batch->bt || shard->nunl != batch->btu)) return CMLPL_E_ARG;
+  NetWs nw;
+  if (!carve_net(d, 2, n, (char*)d_workspace, &nw)) return CMLPL_E_SHAPE;
+  StepWs sw;
+  carve_step(d, n, n, (char*)d_workspace + nw.bytes, &sw);
+  if (nw.bytes + ((char*)sw.dlogits - ((char*)d_workspace + nw.bytes)) > workspace_bytes) return CMLPL_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool copy = need_xn_copy(d, 2 * n);
+  const int lab0 = shard ? shard->lab0 : 0, unl_base = shard ? shard->bt_g + shard->unl0 : batch->bt;
+  int rc;
+  if ((rc = TIMED(CMLPL_K_AUGMENT, chk(launch_augment(copy ? 3 : 2, 2, batch->bt, batch->btu, d.C * d.HW, d.bands, lab0,
+                                unl_base, batch->d_xpl, batch->d_xl, batch->d_xpu, batch->d_xu, batch->noise8,
+                                hp->noise_sigma, seed, step, sw.xn, sw.sn, sw.snT, st))))) return rc;
+  return fwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
+                  copy ? sw.xn : nullptr, sw.sn, sw.snT, d_dropmask, hp->dropout_p, train, seed, step, shard, d_logits,
+                  d_feat, nw, st);
+}
+
+int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                   const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                   uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
+                   void* d_workspace, size_t workspace_bytes, void* stream) {
+  Dims d;
+  cmlpl_layout_t L;
+  if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
+  if (!hp || !check_batch(batch) || !d_params || !d_packed || !d_dlogits || !d_grads || !d_workspace) return CMLPL_E_ARG;
+  const int n = batch->bt + batch->btu;
+  NetWs nw;
+  if (!carve_net(d, 2, n, (char*)d_workspace, &nw)) return CMLPL_E_SHAPE;
+  StepWs sw;
+  carve_step(d, n, n, (char*)d_workspace + nw.bytes, &sw);
+  if (nw.bytes + ((char*)sw.dlogits - ((char*)d_workspace + nw.bytes)) > workspace_bytes) return CMLPL_E_WORKSPACE;
+  const bool copy = need_xn_copy(d, 2 * n);
+  return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
+                  copy ? sw.xn : nullptr, sw.sn, d_dropmask, hp->dropout_p, train, d_dlogits, d_dfeat, d_grads,
+                  grad_stride, nw, (hipStream_t)stream);
 }
 
 namespace {
@@ -497,18 +606,16 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
   const int train = 1;
   int rc;
   const cmlpl_shard sh = {io->bt, io->btu, 0, io->bt, 0, io->btu};
-  if ((rc = cmlpl_augment(shape, 2, io->bt, io->btu, io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->noise8,
-                          hp->noise_sigma, io->seed, io->step, &sh, sw.xn, sw.sn, sw.snT, stream))) return rc;
-  if ((rc = cmlpl_basenet2_fwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn, sw.snT,
-                               io->d_dropmask, hp->dropout_p, train, io->seed, io->step, &sh, io->d_logits,
-                               io->d_feat, io->d_workspace, nw.bytes, stream))) return rc;
+  const cmlpl_batch batch = {io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->noise8, io->bt, io->btu};
+  if ((rc = cmlpl_forward(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
+                          io->step, io->d_logits, io->d_feat, io->d_workspace, io->workspace_bytes, stream))) return rc;
   if ((rc = cmlpl_loss_fwd_bwd(shape, io->bt, io->btu, io->d_logits, io->d_feat, io->d_labels, &io->banks,
                                io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, sw.probs, sw.loss,
                                loss_ws_floats(n, n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream)))
     return rc;
-  if ((rc = cmlpl_basenet2_bwd(shape, 2, n, io->d_params, L.param_total, io->d_packed, sw.xn, sw.sn, io->d_dropmask,
-                               hp->dropout_p, train, sw.dlogits, sw.dfeat, io->d_grads, L.param_total,
-                               io->d_workspace, nw.bytes, stream))) return rc;
+  if ((rc = cmlpl_backward(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
+                           io->step, sw.dlogits, sw.dfeat, io->d_grads, L.param_total, io->d_workspace,
+                           io->workspace_bytes, stream))) return rc;
   if (io->apply_update)
     return cmlpl_adam_step(shape, 2, io->d_params, L.param_total, io->d_grads, L.param_total, io->d_m, io->d_v,
                            io->adam_t, hp, io->d_packed, stream);

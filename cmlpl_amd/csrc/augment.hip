@@ -21,16 +21,18 @@ struct AugArgs {
   int per[2];                                     // elements per sample: C*H*W, bands
   int bt, btu, lab0, unl_base;                    // local rows and their global sample indices
   float sigma; int nets; int explicit_noise; uint64_t seed, step;
+  int t0;                                         // first tensor handled by this launch (blockIdx.z = 0)
 };
 
 __global__ void augment_kernel(AugArgs a) {
-  const int t = blockIdx.z;                   // 0: XP, 1: X
+  const int t = a.t0 + blockIdx.z;            // 0: XP, 1: X
   const int per = a.per[t], s = blockIdx.y;   // local sample
-  // a block covers 1024 consecutive elements of one sample; thread t takes elements t, t+256, t+512, t+768
-  // of that span (fully coalesced 4-byte accesses); the source is read once and written once per network,
-  // each network with its own Philox block
-  const int base = blockIdx.x * 1024;
-  if (base >= per) return;
+  // a block covers 1024 consecutive elements of one sample = 256 groups of 4; thread t takes group t (one Philox
+  // block = the noise of elements 4g..4g+3: the fused forward / data-gradient kernels use the same counter, so the
+  // augmented values are identical whether this kernel or they form them).  The source is read once and written
+  // once per network, each network with its own Philox stream.
+  const int base = blockIdx.x * 1024 + 4 * threadIdx.x;
+  if (blockIdx.x * 1024 >= per) return;
   const bool lab = s < a.bt;
   const int sl = lab ? s : s - a.bt;
   const float* src = (lab ? a.srcl[t] : a.srcu[t]) + (long long)sl * per;
@@ -38,7 +40,7 @@ __global__ void augment_kernel(AugArgs a) {
   float x[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int e = base + q * 256 + threadIdx.x;
+    const int e = base + q;
     x[q] = src[e < per ? e : per - 1];
   }
   const uint64_t gs = (uint64_t)(lab ? a.lab0 + sl : a.unl_base + sl);
@@ -47,19 +49,19 @@ __global__ void augment_kernel(AugArgs a) {
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (need_noise && !a.explicit_noise) {
       const float4 nz = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
-                                       (gs << 24) | (uint64_t)(blockIdx.x * 256 + threadIdx.x));
+                                       noise_ctr(gs, (uint32_t)(base >> 2)));
       z[0] = nz.x; z[1] = nz.y; z[2] = nz.z; z[3] = nz.w;
     } else if (need_noise) {
       const float* nptr = (lab ? a.noise[2 * net + t] : a.noise[4 + 2 * net + t]) + (long long)sl * per;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int e = base + q * 256 + threadIdx.x;
+        const int e = base + q;
         z[q] = nptr[e < per ? e : per - 1];
       }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int e = base + q * 256 + threadIdx.x;
+      const int e = base + q;
       if (e < per) {
         const float v = need_noise ? x[q] + z[q] * a.sigma : x[q];
         dst[e] = v;
@@ -69,7 +71,7 @@ __global__ void augment_kernel(AugArgs a) {
   }
 }
 
-hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
+hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
                           float* xn, float* sn, float* snT, hipStream_t st) {
@@ -80,8 +82,11 @@ hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int 
   a.dst[0] = xn; a.dst[1] = sn;
   a.per[0] = per_xp; a.per[1] = per_x; a.bt = bt; a.btu = btu; a.lab0 = lab0; a.unl_base = unl_base;
   a.sigma = sigma; a.nets = nets; a.explicit_noise = noise8 != nullptr; a.seed = seed; a.step = step;
-  const int mx = per_xp > per_x ? per_xp : per_x;
-  dim3 grid((mx + 1023) / 1024, bt + btu, 2);
+  if (!(which & 3)) return hipSuccess;
+  a.t0 = (which & 1) ? 0 : 1;
+  const int nz = (which & 3) == 3 ? 2 : 1;
+  const int mx = nz == 2 ? (per_xp > per_x ? per_xp : per_x) : ((which & 1) ? per_xp : per_x);
+  dim3 grid((mx + 1023) / 1024, bt + btu, nz);
   hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

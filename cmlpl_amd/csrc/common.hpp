@@ -113,4 +113,33 @@ constexpr uint32_t STREAM_NOISE_XP = 0x100;   // + net
 constexpr uint32_t STREAM_NOISE_X = 0x200;    // + net
 constexpr uint32_t STREAM_DROPOUT = 0x300;    // + net
 
+// Counter of the Philox block that carries the noise of elements 4g .. 4g+3 of one sample's patch (or spectrum):
+// (GLOBAL sample index, group) -- the same in the augmentation kernel, the fused forward and the fused data
+// gradient (which regenerates the forward's noise instead of reading an augmented copy back from HBM), and
+// independent of how the batch is sharded over GPUs.
+__device__ __forceinline__ uint64_t noise_ctr(uint64_t global_sample, uint32_t group) {
+  return (global_sample << 24) | (uint64_t)group;
+}
+
+// Where the patch rows of one network come from (train.py:157-174,181-184): local rows [0, nlab) are rows of
+// `lab`, rows [nlab, n) rows of `unl` (the concat is an index computation, not a copy); the augmentation
+// x + sigma * N(0,1) is applied on the fly -- from explicit noise tensors (parity mode: the reference's draws)
+// or from the Philox stream.  sigma == 0: plain rows (inference, or inputs that are already augmented).
+struct XSrc {
+  const float* lab[2]; const float* unl[2];       // per network (the same pointer twice for raw inputs)
+  const float* nz_lab[2]; const float* nz_unl[2]; // explicit N(0,1) draws per network, or null
+  float sigma; int nlab, philox, lab0, unl_base;
+  uint64_t seed, step;
+};
+__device__ __forceinline__ const float* xsrc_row(const XSrc& x, int net, int s, long long per) {
+  return s < x.nlab ? x.lab[net] + (long long)s * per : x.unl[net] + (long long)(s - x.nlab) * per;
+}
+__device__ __forceinline__ const float* xsrc_noise_row(const XSrc& x, int net, int s, long long per) {
+  const float* b = s < x.nlab ? x.nz_lab[net] : x.nz_unl[net];
+  return b == nullptr ? nullptr : b + (long long)(s < x.nlab ? s : s - x.nlab) * per;
+}
+__device__ __forceinline__ uint64_t xsrc_global_sample(const XSrc& x, int s) {
+  return (uint64_t)(s < x.nlab ? x.lab0 + s : x.unl_base + (s - x.nlab));
+}
+
 }  // namespace cmlpl

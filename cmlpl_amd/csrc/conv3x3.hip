@@ -86,13 +86,86 @@ struct Conv3Args {
   float* out; uint8_t* mask_out;
   long long in_ns, mask_in_ns, wpk_ns, bias_ns, out_ns, mask_out_ns;  // per-net strides (elements)
   int n, H, W, S;
-  // MODE 2 (conv0 fused into the conv1 forward): `in` is xn [net][n][C][HW]; a0 is produced here
+  // MODE 2 (conv0 fused into the conv1 forward): the input patches come from `xs` (raw rows + noise on the fly);
+  // a0 is produced here
   const float* w0t; const float* b0; float* a0out;
   long long w0t_ns, b0_ns;
   int C;
-  // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup
-  const float* xn; float* part0; long long part0_ns;
+  // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup; the input
+  // slab is re-formed from `xs` (same noise as the forward: counter-based)
+  float* part0; long long part0_ns;
+  XSrc xs;
 };
+
+// The sample's [C][HW] input slab -> LDS as a LINEAR copy by global_load_lds_dwordx4 (1 KiB per wave-instruction,
+// every piece in flight at once), with the augmentation x + sigma * N(0,1) (train.py:157,163,170,181) applied in
+// LDS: while its pieces are in flight a lane forms the noise of exactly the elements it requested (Philox, or the
+// explicit draws in parity mode), then waits for ITS OWN pieces only (vmcnt) and adds it in place -- no augmented
+// copy of the input ever exists in HBM.  The caller's next __syncthreads() publishes the slab.
+constexpr int SLAB_MAXQ = 16;   // pieces per wave: C*HW <= 4 waves * 16 * 256 floats
+typedef __attribute__((address_space(3))) void slab_lds_void;
+typedef __attribute__((address_space(1))) const void slab_gbl_void;
+__device__ __forceinline__ void slab_issue(const XSrc& x, int net, int s, int nfl, float* slab, int wave, int lane) {
+  const float* xs = xsrc_row(x, net, s, nfl);
+  const int nf4 = nfl >> 2;
+#pragma unroll
+  for (int k = 0; k < SLAB_MAXQ; ++k) {
+    const int q = wave + 4 * k;                           // wave-uniform
+    if (q * 64 < nf4) {
+      const int f = q * 64 + lane;
+      if (f < nf4) __builtin_amdgcn_global_load_lds((slab_gbl_void*)(xs + 4 * f), (slab_lds_void*)(slab + q * 256), 16, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int nfl, float* slab, int tid, int wave,
+                                            int lane) {
+  const float* xs = xsrc_row(x, net, s, nfl);
+  const int nf4 = nfl >> 2, rem = nfl - 4 * nf4;
+  float tailv = 0.f;
+  if (tid < rem) tailv = xs[4 * nf4 + tid];
+  if (x.sigma != 0.f) {                                   // uniform
+    float4 z[SLAB_MAXQ];
+    float zt = 0.f;
+    const float* nz = xsrc_noise_row(x, net, s, nfl);
+    if (nz != nullptr) {                                  // parity mode: the reference's own draws
+#pragma unroll
+      for (int k = 0; k < SLAB_MAXQ; ++k) {
+        const int f = (wave + 4 * k) * 64 + lane;
+        const int fc = f < nf4 ? f : 0;
+        z[k] = make_float4(nz[4 * fc], nz[4 * fc + 1], nz[4 * fc + 2], nz[4 * fc + 3]);
+      }
+      if (tid < rem) zt = nz[4 * nf4 + tid];
+    } else {
+      const uint64_t gs = xsrc_global_sample(x, s);
+#pragma unroll
+      for (int k = 0; k < SLAB_MAXQ; ++k) {
+        const int q = wave + 4 * k;
+        if (q * 64 < nf4)                                  // wave-uniform
+          z[k] = philox_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)(q * 64 + lane)));
+      }
+      if (rem != 0 && tid < 64) {                          // the last, partial group: one wave computes it
+        const float4 t = philox_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)nf4));
+        zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
+#pragma unroll
+    for (int k = 0; k < SLAB_MAXQ; ++k) {
+      const int q = wave + 4 * k;
+      if (q * 64 < nf4) {
+        const int f = q * 64 + lane;
+        if (f < nf4) {
+          float4 v = *(float4*)(slab + 4 * f);
+          v.x = v.x + z[k].x * x.sigma; v.y = v.y + z[k].y * x.sigma;
+          v.z = v.z + z[k].z * x.sigma; v.w = v.w + z[k].w * x.sigma;
+          *(float4*)(slab + 4 * f) = v;
+        }
+      }
+    }
+    if (tid < rem) tailv = tailv + zt * x.sigma;
+  }
+  if (tid < rem) slab[4 * nf4 + tid] = tailv;
+}
 
 // The 9-tap main loop.  NTA = number of this wave's M tiles that carry real pixels (wave-uniform, so
 // the loop body is branch-free and the compiler can hoist the ds_read_b128 of step kk+1 above the
@@ -225,22 +298,18 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const int C = a.C, Cp = (C + 1) & ~1, KK = Cp >> 1;
     float* slab = smem;                                   // [Cp][HW] (+64), aliases img | wbuf | lut
     float* w0l = smem + Cp * HW + 64;                     // [Cp][64] k-major conv0 weights (pad row is zero)
-    const float* xs = a.in + ((long long)net * a.n + s0) * (long long)C * HW;
     const float* w0 = a.w0t + (long long)net * a.w0t_ns;
     {
-      const int nfl = C * HW, nf4 = nfl >> 2;
-      for (int q = wave; q * 64 < nf4; q += 4) {
-        const int f = q * 64 + lane;
-        if (f < nf4) __builtin_amdgcn_global_load_lds((gbl_void*)(xs + 4 * f), (lds_void*)(slab + q * 256), 16, 0, 0);
-      }
+      const int nfl = C * HW;
       const int wf4 = Cp * 16;                            // w0T is 16-B aligned and a multiple of 64 floats
       for (int q = wave; q * 64 < wf4; q += 4) {
         const int f = q * 64 + lane;
         if (f < wf4) __builtin_amdgcn_global_load_lds((gbl_void*)(w0 + 4 * f), (lds_void*)(w0l + q * 256), 16, 0, 0);
       }
-      if (tid < nfl - 4 * nf4) slab[4 * nf4 + tid] = xs[4 * nf4 + tid];
       // the pad band (odd C) meets a zero weight row, but must be finite; so must the tail a clamped lane reads
       for (int i = nfl + tid; i < Cp * HW + 64; i += 256) slab[i] = 0.f;
+      slab_issue(a.xs, net, s0, nfl, slab, wave, lane);
+      slab_finish(a.xs, net, s0, nfl, slab, tid, wave, lane);
     }
     f32x16 z0 = zero16(), z1 = zero16();
     const int pixA = (wave * 32 + l31 < HW) ? wave * 32 + l31 : HW - 1;
@@ -476,21 +545,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     __syncthreads();                                      // image and LUT are dead from here on
     float* slab = smem;                                   // [C][HW]
     float* dal = smem + C * HW;                           // [HW + 1][64]
-    const float* xs = a.xn + ((long long)net * a.n + s0) * (long long)C * HW;
-    {
-      const int nfl = C * HW, nf4 = nfl >> 2;
-      for (int q = wave; q * 64 < nf4; q += 4) {
-        const int f = q * 64 + lane;
-        if (f < nf4) __builtin_amdgcn_global_load_lds((gbl_void*)(xs + 4 * f), (lds_void*)(slab + q * 256), 16, 0, 0);
-      }
-      if (tid < nfl - 4 * nf4) slab[4 * nf4 + tid] = xs[4 * nf4 + tid];
-    }
+    slab_issue(a.xs, net, s0, C * HW, slab, wave, lane);   // the forward's input again
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = wave * 32 + acc_row(r, lane);
       if (m < HW) { dal[m * 64 + l31] = v0[r]; dal[m * 64 + 32 + l31] = v1[r]; }
     }
     if (tid < 64) dal[HW * 64 + tid] = 0.f;               // the pixel past the end of an odd map
+    slab_finish(a.xs, net, s0, C * HW, slab, tid, wave, lane);   // ... with the forward's noise regenerated
     __syncthreads();                                      // slab landed (the barrier waits for the DMA), da0 complete
     f32x16 g0 = zero16(), g1 = zero16();
     float dbacc = 0.f;
@@ -703,7 +765,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0;
-  a.xn = nullptr; a.part0 = nullptr; a.part0_ns = 0;
+  a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
@@ -737,25 +799,25 @@ bool conv3_fused_ok(int H, int W, int C, int rows) {
   if (off || C < 1) return false;
   Conv3Plan pl;
   if (!plan_conv3(0, H, W, rows, &pl)) return false;
-  if (pl.S != 1 || pl.MTW != 1 || H * W > 128) return false;
+  if (pl.S != 1 || pl.MTW != 1 || H * W > 128 || C * H * W > 4 * SLAB_MAXQ * 256) return false;
   for (int m = 0; m < 128; ++m)                       // the magic-number divide of the kernel
     if (((m * ((65536 + W - 1) / W)) >> 16) != m / W) return false;
   return 2 * conv3_fused_lds(H, W, C, pl.lds) <= LDS_MAX;
 }
 
-hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const float* xn, const float* w0t, long long w0t_ns,
+hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
                               const float* bias, long long bias_ns, float* out, uint8_t* mask_out, hipStream_t st) {
   Conv3Plan pl;
   if (!conv3_fused_ok(H, W, C, nets * n) || !plan_conv3(0, H, W, nets * n, &pl)) return hipErrorInvalidValue;
   const int HW = H * W, P2 = (H / 2) * (W / 2);
   Conv3Args a;
-  a.in = xn; a.mask_in = nullptr; a.wpk = wpk; a.bias = bias; a.out = out; a.mask_out = mask_out;
+  a.in = nullptr; a.mask_in = nullptr; a.wpk = wpk; a.bias = bias; a.out = out; a.mask_out = mask_out;
   a.wpk_ns = wpk_ns; a.bias_ns = bias_ns;
   a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C;
-  a.xn = nullptr; a.part0 = nullptr; a.part0_ns = 0;
+  a.xs = xs; a.part0 = nullptr; a.part0_ns = 0;
   (void)HW;
   return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
 }
@@ -781,7 +843,7 @@ bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
 }
 
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
-                                  const float* wpk, long long wpk_ns, const float* xn, float* part0, long long part0_ns,
+                                  const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,
                                   hipStream_t st) {
   Conv3Plan pl;
   if (!conv3_fused_bwd_ok(H, W, C, nets * n) || !plan_conv3(1, H, W, nets * n, &pl)) return hipErrorInvalidValue;
@@ -792,7 +854,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C;
-  a.xn = xn; a.part0 = part0; a.part0_ns = part0_ns;
+  a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns;
   return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
 }
 

@@ -6,6 +6,8 @@
 #include <stddef.h>
 #include <atomic>
 
+#include "common.hpp"
+
 namespace cmlpl {
 
 constexpr int PACK_CONV = 9 * 64 * 64;       // one packed 3x3 weight set
@@ -39,7 +41,8 @@ inline hipError_t ensure_max_lds(DevOnce& once, Ks... kernels) {
 }
 
 // ---- augment.hip
-hipError_t launch_augment(int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
+// which: bit 0 = the patches (xn), bit 1 = the spectra (sn, snT)
+hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
                           float* xn, float* sn, float* snT, hipStream_t st);
@@ -60,12 +63,12 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
                         const float* wpk, long long wpk_nstride, const float* bias, long long bias_nstride,
                         float* out, uint8_t* mask_out, hipStream_t st);
 bool conv3_fused_ok(int H, int W, int C, int rows);
-hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const float* xn, const float* w0t, long long w0t_ns,
+hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
                               const float* bias, long long bias_ns, float* out, uint8_t* mask_out, hipStream_t st);
 bool conv3_fused_bwd_ok(int H, int W, int C, int rows);
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
-                                  const float* wpk, long long wpk_ns, const float* xn, float* part0, long long part0_ns,
+                                  const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,
                                   hipStream_t st);
 struct Wgrad3Plan { int RU, U, G, cspl, rsplit, UPG; size_t lds; };   // rsplit > 0: row-split kernel with CPR = rsplit, UPG units per workgroup
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);

@@ -115,8 +115,6 @@ class DistTrainEngine(TrainEngine):
         self._probs_l, self._probs_g = z(4 * btu_l * K), z(W * 4 * btu_l * K)
         self._dlogits_l, self._dfeat_l = z(2 * n_l * K), z(2 * n_l * FEAT_DIM)
         self._dfw_part = z(btu_l * W * FEAT_DIM)
-        self._xn, self._sn = z(2 * n_l * shape.C * shape.H * shape.W), z(2 * n_l * shape.bands)
-        self._snT = z(2 * shape.bands * n_l)
         lw = self.lib.cmlpl_loss_workspace_bytes(
             C.byref(self.cshape), C.byref(_lib.Shard(bt_l * W, btu_l * W, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)),
             self.Q)
@@ -149,9 +147,6 @@ class DistTrainEngine(TrainEngine):
         self.dlogits_l = self._dlogits_l[:nk].view(2, n_l, K)
         self.dfeat_l = self._dfeat_l[:nf].view(2, n_l, FEAT_DIM)
         self.dfw_part = self._dfw_part[:self.btu_g * FEAT_DIM].view(self.btu_g, FEAT_DIM)
-        self.xn = self._xn[:2 * n_l * s.C * s.H * s.W].view(2, n_l, s.C * s.H * s.W)
-        self.sn = self._sn[:2 * n_l * s.bands].view(2, n_l, s.bands)
-        self.snT = self._snT[:2 * s.bands * n_l].view(2, s.bands, n_l)
         self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
         self._bound = (bt_l, btu_l)
 
@@ -192,19 +187,16 @@ class DistTrainEngine(TrainEngine):
         if dropmask is not None:
             _chk_f32(dropmask, (2, n_l, s.cls_in), "dropmask")
         self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
+        batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), noise8, bt_l, btu_l)
         self._ctx = dict(epoch=epoch, batch_index=batch_index, apply_update=apply_update, dropmask=dropmask,
                          smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
-                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)), keep=keep)
-        _lib.check("cmlpl_augment", lib.cmlpl_augment(
-            C.byref(self.cshape), 2, bt_l, btu_l, XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(),
-            noise8, self.hp.noise, self.seed, self.step_count, C.byref(self.cshard), self.xn.data_ptr(),
-            self.sn.data_ptr(), self.snT.data_ptr(), st))
-        _lib.check("cmlpl_basenet2_fwd", lib.cmlpl_basenet2_fwd(
-            C.byref(self.cshape), 2, n_l, self.params.data_ptr(), self.P, self.packed.data_ptr(), self.xn.data_ptr(),
-            self.sn.data_ptr(), self.snT.data_ptr(), None if dropmask is None else dropmask.data_ptr(), self.hp.dropout, 1,
-            self.seed,
-            self.step_count, C.byref(self.cshard), self.logits_l.data_ptr(), self.feat_l.data_ptr(),
-            self.workspace.data_ptr(), self.workspace.numel(), st))
+                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)), keep=(keep, XPl, Xl, XPu, Xu, noise),
+                         batch=batch)
+        # augmentation + both forwards; the raw rows are handed over as they are (no augmented copy in HBM)
+        _lib.check("cmlpl_forward", lib.cmlpl_forward(
+            C.byref(self.cshape), C.byref(self._chp), C.byref(batch), C.byref(self.cshard), self.params.data_ptr(),
+            self.packed.data_ptr(), None if dropmask is None else dropmask.data_ptr(), 1, self.seed, self.step_count,
+            self.logits_l.data_ptr(), self.feat_l.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), st))
         self.labels_f.copy_(Y)
 
     def stage_phase1(self):
@@ -232,9 +224,9 @@ class DistTrainEngine(TrainEngine):
         c, st = self._ctx, self._stream()
         n_l = self.bt_l + self.btu_l
         dm = c["dropmask"]
-        _lib.check("cmlpl_basenet2_bwd", self.lib.cmlpl_basenet2_bwd(
-            C.byref(self.cshape), 2, n_l, self.params.data_ptr(), self.P, self.packed.data_ptr(), self.xn.data_ptr(),
-            self.sn.data_ptr(), None if dm is None else dm.data_ptr(), self.hp.dropout, 1,
+        _lib.check("cmlpl_backward", self.lib.cmlpl_backward(
+            C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard), self.params.data_ptr(),
+            self.packed.data_ptr(), None if dm is None else dm.data_ptr(), 1, self.seed, self.step_count,
             self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.grads.data_ptr(), self.live,
             self.workspace.data_ptr(), self.workspace.numel(), st))
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CMLPL_ABI_VERSION 1
+#define CMLPL_ABI_VERSION 2
 #define CMLPL_FEAT_DIM 1024 /* tools/models.py:119 */
 #define CMLPL_CONV_CH 64    /* tools/models.py:102-107 */
 
@@ -133,6 +133,35 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n,
                        const float* d_dlogits, const float* d_dfeat,
                        float* d_grads, int64_t grad_stride,
                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* One training batch as the reference holds it (train.py:155-171): labelled and unlabelled rows in their own
+ * buffers (the concat of train.py:173-174,183-184 is an index computation in the kernels, not a copy) and the
+ * augmentation noise either drawn in-kernel (Philox, noise8 == NULL) or given as the 8 tensors of the
+ * reference's draw order (see cmlpl_augment). */
+typedef struct cmlpl_batch {
+  const float* d_xpl; const float* d_xl;   /* [bt][C][H][W], [bt][bands]   */
+  const float* d_xpu; const float* d_xu;   /* [btu][C][H][W], [btu][bands] */
+  const float* const* noise8;
+  int32_t bt, btu;
+} cmlpl_batch;
+
+/* Both networks' forward on one batch (train.py:157-189): augmentation + BaseNet2.forward for Base and Base1.
+ * Where the window fits (H*W <= 128, C <= 128) the patches are augmented inside the fused conv0+conv1 kernel and
+ * no augmented copy exists in HBM; cmlpl_backward re-forms the same noise (counter-based) for conv0's weight
+ * gradient, so it must be given the same batch / seed / step / shard and the SAME workspace (sized by
+ * cmlpl_workspace_bytes(shape, 2, bt + btu, bank_rows)), which holds the saved activations in between.
+ *   hp: noise_sigma and dropout_p are used.  Outputs as cmlpl_basenet2_fwd / _bwd with nets = 2. */
+int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                  const cmlpl_shard* shard /* NULL = one GPU */,
+                  const float* d_params /* [2][param_total] */, const float* d_packed /* [2][packed_total] */,
+                  const float* d_dropmask, int train, uint64_t seed, uint64_t step,
+                  float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes, void* stream);
+int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                   const cmlpl_shard* shard,
+                   const float* d_params, const float* d_packed,
+                   const float* d_dropmask, int train, uint64_t seed, uint64_t step,
+                   const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
+                   void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* State of the two memory banks (train.py:138-145). */
 typedef struct cmlpl_banks {

@@ -29,3 +29,24 @@ def test_general_wgrad_fallback_passes_backward_parity():
 
 def test_unfused_conv0_kernels_pass_on_a_fusable_shape():
     _run({"CMLPL_FUSE_CONV0": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward and B2"])
+
+
+def test_fused_and_unfused_conv0_form_the_same_noise():
+    """In Philox mode the fused kernels augment the raw patches in LDS (forward) and regenerate the same noise for
+    conv0's weight gradient (backward); the unfused fallback reads an augmented copy written by the augmentation
+    kernel.  Same counters => the same augmented values: losses of the first step agree to rounding of the different
+    summation orders, and both stay deterministic."""
+    outs = []
+    for env_extra in ({}, {"CMLPL_FUSE_CONV0": "0"}, {}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "tests/_philox_traj_child.py"], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln.split() for ln in r.stdout.strip().splitlines() if ln.startswith(("0x", "-0x"))])
+    fused, unfused, fused2 = outs
+    assert fused == fused2                                    # bit-identical rerun
+    f0 = [float.fromhex(v) for v in fused[0]]
+    u0 = [float.fromhex(v) for v in unfused[0]]
+    for a, b in zip(f0[:9], u0[:9]):                          # first step: same inputs, same noise
+        assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (f0, u0)
+    assert f0[9:13] == u0[9:13]                               # mask / graph counts

@@ -230,10 +230,17 @@ int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const flo
 
 namespace {
 // patch rows that are already augmented: [nets][n][C*HW]
-XSrc xsrc_plain(const float* d_xn, int nets, int n, long long per) {
+XSrc xsrc_plain(const float* d_xn, int nets, int n, long long per, uint64_t seed, uint64_t step,
+                const cmlpl_shard* sh) {
   XSrc x = XSrc();
-  for (int i = 0; i < 2; ++i) x.lab[i] = x.unl[i] = d_xn + (long long)(i < nets ? i : 0) * n * per;
-  x.nlab = n; x.sigma = 0.f;
+  const int nlab = sh ? sh->nlab : n;
+  for (int i = 0; i < 2; ++i) {
+    x.lab[i] = d_xn + (long long)(i < nets ? i : 0) * n * per;
+    x.unl[i] = x.lab[i] + (long long)nlab * per;
+  }
+  x.nlab = nlab; x.sigma = 0.f;
+  x.lab0 = sh ? sh->lab0 : 0; x.unl_base = sh ? sh->bt_g + sh->unl0 : n;   // keys of the dropout stream
+  x.seed = seed; x.step = step;
   return x;
 }
 // raw labelled / unlabelled rows + noise formed in the kernels
@@ -274,8 +281,8 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
   NetWs w;
   if (!carve_net(d, nets, n, (char*)d_workspace, &w)) return CMLPL_E_SHAPE;
   if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
-  return fwd_core(d, L, nets, n, d_params, param_stride, d_packed, xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW), d_xn,
-                  d_sn, d_snT, d_dropmask, dropout_p, train, seed, step, shard, d_logits, d_feat, w, (hipStream_t)stream);
+  return fwd_core(d, L, nets, n, d_params, param_stride, d_packed,
+                  xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW, seed, step, shard), d_xn, d_sn, d_snT, d_dropmask, dropout_p, train, seed, step, shard, d_logits, d_feat, w, (hipStream_t)stream);
 }
 
 namespace {
@@ -303,13 +310,27 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
                                    d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
     }
   }
+  if (shard && shard->nlab + shard->nunl != n) return CMLPL_E_ARG;
+  if (conv3_fused_tail_ok(d.H, d.W, d.C, nets * n, d.K)) {
+    // the whole spatial forward + head of a sample in one workgroup: conv0 + conv1 + pool + conv2 + pool + flatten /
+    // concat / dropout / classifier / L2-norm.  Needs the spectral branch output (launched above, same stream).
+    join_from(main_st, 0, 1);
+    FwdTail t;
+    t.w2f = d_packed + 4 * PACK_CONV; t.w2f_ns = pk_ns; t.b2 = d_params + L.param_off[5];
+    t.wc = d_params + L.param_off[8]; t.bc = d_params + L.param_off[9]; t.p_ns = param_stride;
+    t.y = w.y; t.dropmask = d_dropmask; t.dropgen = w.dropgen; t.catd = w.catd; t.ynorm = w.ynorm;
+    t.logits = d_logits; t.feat = d_feat; t.p2 = w.p2; t.m2 = w.m2; t.dropout_p = dropout_p; t.train = train; t.K = d.K;
+    return TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0t(),
+                               pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + 0 * PACK_CONV, pk_ns,
+                               d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, main_st)));
+  }
   if (conv3_fused_ok(d.H, d.W, d.C, nets * n)) {
     // conv0 + conv1 in one launch, input rows taken where they lie and augmented in LDS: neither an augmented
     // copy of the input nor a0's round trip between the two convolutions touches HBM (a0 is still written once,
     // for the backward pass)
     if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0t(),
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + 0 * PACK_CONV, pk_ns,
-                               d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
+                               d_params + L.param_off[3], param_stride, w.p1, w.m1, nullptr, st))))) return rc;
   } else {
     if (!d_xn) return CMLPL_E_ARG;
     if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
@@ -342,8 +363,8 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n, const float* d
   NetWs w;
   if (!carve_net(d, nets, n, (char*)d_workspace, &w)) return CMLPL_E_SHAPE;
   if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
-  return bwd_core(d, L, nets, n, d_params, param_stride, d_packed, xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW), d_xn,
-                  d_sn, d_dropmask, dropout_p, train, d_dlogits, d_dfeat, d_grads, grad_stride, w, (hipStream_t)stream);
+  return bwd_core(d, L, nets, n, d_params, param_stride, d_packed,
+                  xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW, 0, 0, nullptr), d_xn, d_sn, d_dropmask, dropout_p, train, d_dlogits, d_dfeat, d_grads, grad_stride, w, (hipStream_t)stream);
 }
 
 namespace {

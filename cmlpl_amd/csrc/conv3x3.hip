@@ -39,7 +39,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
   if (e >= pi.stride) return;
   const float* P = params + (long long)net * pstride;
   float v;
-  if (e < PACK_PER_NET) {
+  if (e < 4 * PACK_CONV) {
     const int which = (int)(e / PACK_CONV);          // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
     const int i = (int)(e - (long long)which * PACK_CONV);
     const int r = i & 3, oc = (i >> 2) & 63, q = (i >> 8) & 15, s = i >> 12;
@@ -48,6 +48,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
     const int k = 4 * q + r;
     if ((which & 1) == 0) v = W[((oc * 64 + k) * 3 + kh) * 3 + kw];                    // co=oc, ci=k
     else                  v = W[((k * 64 + oc) * 3 + (2 - kh)) * 3 + (2 - kw)];        // co=k, ci=oc
+  } else if (e < PACK_PER_NET) {                     // conv2 as 16x16x4 B fragments (inverse of conv2_frag_index)
+    const int which = (int)(e / PACK_CONV);          // 4 fwd, 5 dgrad
+    const int i = (int)(e - (long long)which * PACK_CONV);
+    const int lane = i & 63, st = (i >> 6) & 15, nq = (i >> 10) & 3, tap = i >> 12;
+    const int nn = nq * 16 + (lane & 15), k = (lane >> 4) * 16 + st;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const float* W = P + pi.off_w2;
+    if (which == 4) v = W[((nn * 64 + k) * 3 + kh) * 3 + kw];                          // co=n, ci=k
+    else            v = W[((k * 64 + nn) * 3 + (2 - kh)) * 3 + (2 - kw)];              // co=k, ci=n
   } else if (e < pack_off_wst(pi.C)) {
     const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
     v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
@@ -95,7 +104,22 @@ struct Conv3Args {
   // slab is re-formed from `xs` (same noise as the forward: counter-based)
   float* part0; long long part0_ns;
   XSrc xs;
+  // TAIL (forward): conv2 + ReLU + avgpool + flatten/concat + dropout + classifier + L2-norm for the same sample
+  // (tools/models.py:137-152), in the workgroup that has just pooled conv1's output
+  const float* w2f; long long w2f_ns;            // conv2 forward weights as 16x16x4 B fragments (kernels.hpp)
+  const float* b2; const float* wc; const float* bc; long long p_ns;   // conv2.bias, classifier.weight / .bias
+  const float* yin;                               // spectral branch output relu(feat_spe(x)) [net][n][1024]
+  const float* dropmask; float* dropgen; float* catd; float* ynorm; float* logits; float* feat;
+  float* p2out; uint8_t* m2out;
+  float dropout_p; int train, K;
 };
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: A lane l holds A[i = l&15][k = l>>4]; B lane l holds B[k = l>>4][j = l&15];
+// D reg r of lane l is D[row = 4*(l>>4) + r][col = l&15].  Exact fp32, 32 cycles.
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 
 // The sample's [C][HW] input slab -> LDS as a LINEAR copy by global_load_lds_dwordx4 (1 KiB per wave-instruction,
 // every piece in flight at once), with the augmentation x + sigma * N(0,1) (train.py:157,163,170,181) applied in
@@ -430,7 +454,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 }
 
 // avgpool2 + ReLU-mask epilogue shared by the forward kernels (img holds relu(z) at the pixel centres)
-__device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c) {
+__device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c, float* img2 = nullptr) {
   float* out = a.out + (long long)c.net * a.out_ns;
   uint8_t* mo = a.mask_out + (long long)c.net * a.mask_out_ns;
   // one (pooled pixel, 4 channels) item per thread and pass: four ds_read_b128, one 16-B and one 4-B store
@@ -450,6 +474,8 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
       o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
       o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
       *(float4*)(out + g) = o;
+      // fused tail: the pooled map also becomes the zero-bordered conv2 input image, in LDS
+      if (img2 != nullptr) *(float4*)(img2 + (size_t)((ph + 1) * (c.W2 + 2) + pw + 1) * CS + c4 * 4) = o;
 #define CMLPL_NIB(A, B, C, D) ((uint32_t)((relu_open(A) ? 1 : 0) | (relu_open(B) ? 2 : 0) | (relu_open(C) ? 4 : 0) | (relu_open(D) ? 8 : 0)))
       const uint32_t m = CMLPL_NIB(v00.x, v01.x, v10.x, v11.x) | (CMLPL_NIB(v00.y, v01.y, v10.y, v11.y) << 8) |
                          (CMLPL_NIB(v00.z, v01.z, v10.z, v11.z) << 16) | (CMLPL_NIB(v00.w, v01.w, v10.w, v11.w) << 24);
@@ -459,7 +485,149 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
   }
 }
 
-template <int MODE, int MTW>
+// The rest of BaseNet2.forward for this workgroup's sample (S == 1), entered right after conv1's pooled map p1 has
+// been written to HBM (backward needs it) and, zero-bordered, to img2 (LDS, in the dead tap-weight buffer):
+//   conv2 3x3 + bias + residual + ReLU + avgpool (models.py:137-140) on the 16x16x4 fp32 MFMA: the 4x4 output pixels
+//   that the floor-pooling keeps are ONE 16-row tile; wave w owns output channels 16w..16w+15.  A fragments are
+//   ds_read_b128 from img2, B fragments ready-made in L2 (conv2_frag_index): one coalesced 256-B load per MFMA, the
+//   next tap's sixteen in flight while this tap's MFMAs run.  No LDS weight staging, no block barrier in the loop.
+//   flatten (NCHW order) + concat with the spectral branch + dropout + classifier, and the L2-normalised spectral
+//   feature (models.py:141-152) -- head_fwd_kernel's math on the row this workgroup already holds.
+// Requires H4 == W4 == 2 and (H2+2)*(W2+2)*CS <= 4096 floats (windows 8..11).
+__device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ctx& c, float* smem) {
+  const int tid = c.tid, lane = c.lane, wave = c.wave, net = c.net, sample = c.s0;
+  const int PW2 = c.W2 + 2;
+  const float* img2 = c.wbuf;
+  float* row = smem;                         // [F] head input row (the conv1 image is dead)
+  const int SF = 256, F = SF + FD, K = a.K;
+  float* red = smem + F;                     // [4] + [4][64]
+  const long long rs = (long long)net * a.n + sample;
+  // ---- loads issued up front: tap-0 B fragments, this thread's slice of the spectral row
+  const int j = lane & 15, kg = lane >> 4;
+  const float* wq = a.w2f + (long long)net * a.w2f_ns + (size_t)wave * 1024 + lane;
+  float bcur[16], bnxt[16];
+#pragma unroll
+  for (int st = 0; st < 16; ++st) bcur[st] = wq[st * 64];
+  const float4 y4 = *(const float4*)(a.yin + rs * FD + 4 * tid);
+  const float bias2 = (a.b2 + (long long)net * a.p_ns)[wave * 16 + j];
+  __syncthreads();                           // img2 interior complete; every thread is done pooling from img
+  *(float4*)(row + SF + 4 * tid) = y4;       // spectral part of the head row (pre-dropout); row aliases the dead img
+  // ---- conv2: pixel i = lane & 15 = (oh, ow) = (i >> 2, i & 3)
+  const float* ap0 = img2 + (size_t)(((j >> 2) + 1) * PW2 + (j & 3) + 1) * CS + 16 * kg;
+  f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    if (tap + 1 < 9) {
+#pragma unroll
+      for (int st = 0; st < 16; ++st) bnxt[st] = wq[(size_t)(tap + 1) * 4096 + st * 64];
+    }
+    const float* ap = ap0 + ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * CS;
+    const float4 a0 = *(const float4*)(ap), a1 = *(const float4*)(ap + 4), a2 = *(const float4*)(ap + 8),
+                 a3 = *(const float4*)(ap + 12);
+    // two accumulator chains: a dependent 16x16x4 has 40 cycles of latency against 32 of issue
+    acc0 = mfma16(a0.x, bcur[0], acc0);  acc1 = mfma16(a0.y, bcur[1], acc1);
+    acc0 = mfma16(a0.z, bcur[2], acc0);  acc1 = mfma16(a0.w, bcur[3], acc1);
+    acc0 = mfma16(a1.x, bcur[4], acc0);  acc1 = mfma16(a1.y, bcur[5], acc1);
+    acc0 = mfma16(a1.z, bcur[6], acc0);  acc1 = mfma16(a1.w, bcur[7], acc1);
+    acc0 = mfma16(a2.x, bcur[8], acc0);  acc1 = mfma16(a2.y, bcur[9], acc1);
+    acc0 = mfma16(a2.z, bcur[10], acc0); acc1 = mfma16(a2.w, bcur[11], acc1);
+    acc0 = mfma16(a3.x, bcur[12], acc0); acc1 = mfma16(a3.y, bcur[13], acc1);
+    acc0 = mfma16(a3.z, bcur[14], acc0); acc1 = mfma16(a3.w, bcur[15], acc1);
+#pragma unroll
+    for (int st = 0; st < 16; ++st) bcur[st] = bnxt[st];
+  }
+  // ---- conv2 epilogue: lane (co = 16 wave + j, output row oh = kg) holds the 4 pixels ow = 0..3 of that row
+  {
+    const int co = wave * 16 + j;
+    const float* res = img2 + (size_t)((kg + 1) * PW2 + 1) * CS + co;   // p1 at (oh, ow = 0): the residual branch
+    float r_[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) r_[r] = relu_nan((acc0[r] + acc1[r]) + bias2 + res[r * CS]);
+    const float s0 = r_[0] + r_[1], s1 = r_[2] + r_[3];
+    const float t0 = s0 + __shfl_xor(s0, 16, 64), t1 = s1 + __shfl_xor(s1, 16, 64);   // rows oh ^ 1
+    const int dh = kg & 1;
+    uint32_t n0 = (relu_open(r_[0]) ? 1u : 0u) | (relu_open(r_[1]) ? 2u : 0u);
+    uint32_t n1 = (relu_open(r_[2]) ? 1u : 0u) | (relu_open(r_[3]) ? 2u : 0u);
+    n0 <<= 2 * dh; n1 <<= 2 * dh;
+    n0 |= (uint32_t)__shfl_xor((int)n0, 16, 64); n1 |= (uint32_t)__shfl_xor((int)n1, 16, 64);
+    if (dh == 0) {
+      const int ph = kg >> 1;
+      const float o0 = t0 * 0.25f, o1 = t1 * 0.25f;
+      float* p2 = a.p2out + (rs * 4 + ph * 2) * 64 + co;
+      uint8_t* m2 = a.m2out + (rs * 4 + ph * 2) * 64 + co;
+      p2[0] = o0; p2[64] = o1;
+      m2[0] = (uint8_t)n0; m2[64] = (uint8_t)n1;
+      row[co * 4 + ph * 2] = o0;             // canonical flatten order f = c * HW4 + hw (x.view, models.py:141)
+      row[co * 4 + ph * 2 + 1] = o1;
+    }
+  }
+  // ---- head
+  float ss = (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();                           // row[0..256) complete, red[] written
+  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  if (tid == 0) a.ynorm[rs] = norm;
+  {
+    float4 o = y4;
+    o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
+    *(float4*)(a.feat + rs * FD + 4 * tid) = o;
+  }
+  // 0 = none, 1 = explicit mask, 2 = generate (Philox) and record for the backward pass
+  const int dmode = (!a.train || a.dropout_p <= 0.f) ? 0 : (a.dropmask != nullptr ? 1 : 2);
+  const float keep_scale = 1.0f / (1.0f - a.dropout_p);
+  float* catd = a.catd + rs * F;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f0 = 1024 * q + 4 * tid;
+    if (f0 < F) {
+      float4 x = *(const float4*)(row + f0);
+      if (dmode == 1) {
+        const float4 m4 = *(const float4*)(a.dropmask + rs * F + f0);
+        x.x *= m4.x; x.y *= m4.y; x.z *= m4.z; x.w *= m4.w;
+      } else if (dmode == 2) {
+        const unsigned long long gs = xsrc_global_sample(a.xs, sample);
+        const float4 u = philox_uniform4(a.xs.seed, a.xs.step, STREAM_DROPOUT + net, (gs * F + f0) >> 2);
+        float4 m4;
+        m4.x = (u.x >= a.dropout_p) ? keep_scale : 0.f; m4.y = (u.y >= a.dropout_p) ? keep_scale : 0.f;
+        m4.z = (u.z >= a.dropout_p) ? keep_scale : 0.f; m4.w = (u.w >= a.dropout_p) ? keep_scale : 0.f;
+        *(float4*)(a.dropgen + rs * F + f0) = m4;
+        x.x *= m4.x; x.y *= m4.y; x.z *= m4.z; x.w *= m4.w;
+      }
+      *(float4*)(catd + f0) = x;
+      *(float4*)(row + f0) = x;              // same thread re-writes what it read
+    }
+  }
+  __syncthreads();
+  // logits: wave w takes the quarter [w*F4, (w+1)*F4) of the row for ALL classes (8 accumulators at a time),
+  // then the four partial dot products meet in LDS
+  const float* wc = a.wc + (long long)net * a.p_ns;
+  const float* bc = a.bc + (long long)net * a.p_ns;
+  float* part = red + 4;                     // [4 waves][64 classes]
+  const int F4 = F >> 2, fb = wave * F4, fe = fb + F4;
+  for (int kc = 0; kc < K; kc += 8) {
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int f = fb + lane; f < fe; f += 64) {
+      const float x = row[f];
+      float wv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = wc[(long long)((kc + q < K) ? kc + q : K - 1) * F + f];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = fmaf(x, wv[q], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float t = wave_sum(acc[q]);
+      if (lane == 0 && kc + q < K) part[wave * 64 + kc + q] = t;
+    }
+  }
+  __syncthreads();
+  if (tid < K) a.logits[rs * K + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bc[tid];
+}
+
+template <int MODE, int MTW, int TAIL = 0>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Conv3Ctx c;
@@ -523,8 +691,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
         }
       }
     }
+    if (TAIL) {   // the tap-weight buffer is dead: it becomes the zero-bordered conv2 input image
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid; i < 1024; i += 256) ((float4*)wbuf)[i] = z4;
+    }
     __syncthreads();
-    conv3_pool_store(a, c);
+    conv3_pool_store(a, c, TAIL ? wbuf : nullptr);
+    if (TAIL) conv3_fwd_tail(a, c, smem);
   } else if (MODE == 3) {
     // conv0 weight gradient fused in (S == 1, MTW == 1, C <= 128):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
     // This wave's da0 tile = accumulators + dz (the residual branch); it goes to LDS as the B operand [pix][64]
@@ -805,9 +978,17 @@ bool conv3_fused_ok(int H, int W, int C, int rows) {
   return 2 * conv3_fused_lds(H, W, C, pl.lds) <= LDS_MAX;
 }
 
+bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K) {
+  static const bool off = getenv("CMLPL_FUSE_TAIL") && atoi(getenv("CMLPL_FUSE_TAIL")) == 0;
+  const int H2 = H / 2, W2 = W / 2;
+  return !off && conv3_fused_ok(H, W, C, rows) && H2 / 2 == 2 && W2 / 2 == 2 && (H2 + 2) * (W2 + 2) * CS <= 4096 &&
+         K >= 1 && K <= 64;
+}
+
 hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
-                              const float* bias, long long bias_ns, float* out, uint8_t* mask_out, hipStream_t st) {
+                              const float* bias, long long bias_ns, float* out, uint8_t* mask_out,
+                              const FwdTail* tail, hipStream_t st) {
   Conv3Plan pl;
   if (!conv3_fused_ok(H, W, C, nets * n) || !plan_conv3(0, H, W, nets * n, &pl)) return hipErrorInvalidValue;
   const int HW = H * W, P2 = (H / 2) * (W / 2);
@@ -819,6 +1000,18 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0;
   (void)HW;
+  if (tail != nullptr) {
+    if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
+    a.w2f = tail->w2f; a.w2f_ns = tail->w2f_ns; a.b2 = tail->b2; a.wc = tail->wc; a.bc = tail->bc; a.p_ns = tail->p_ns;
+    a.yin = tail->y; a.dropmask = tail->dropmask; a.dropgen = tail->dropgen; a.catd = tail->catd; a.ynorm = tail->ynorm;
+    a.logits = tail->logits; a.feat = tail->feat; a.p2out = tail->p2; a.m2out = tail->m2;
+    a.dropout_p = tail->dropout_p; a.train = tail->train; a.K = tail->K;
+    static DevOnce attr_once;
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), dim3(n, nets), dim3(256), conv3_fused_lds(H, W, C, pl.lds), st, a);
+    return hipGetLastError();
+  }
   return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
 }
 

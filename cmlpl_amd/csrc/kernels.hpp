@@ -11,7 +11,16 @@
 namespace cmlpl {
 
 constexpr int PACK_CONV = 9 * 64 * 64;       // one packed 3x3 weight set
-constexpr int PACK_PER_NET = 4 * PACK_CONV;  // conv1 fwd, conv1 dgrad, conv2 fwd, conv2 dgrad
+// conv1 fwd, conv1 dgrad, conv2 fwd, conv2 dgrad ([tap][ci/4][co][4], for the 32x32x2 MFMA kernels), then conv2 fwd /
+// dgrad again as ready-made B fragments of the 16x16x4 MFMA ([tap][n-quarter][k-step][lane], see conv2_frag_index):
+// the per-sample tail / head of the fused kernels reads them straight from L2, one coalesced 256-B load per MFMA
+constexpr int PACK_PER_NET = 6 * PACK_CONV;
+// element of conv2.weight[co][ci][kh][kw] in the 16x16x4 fragment packs.  An MFMA step consumes k = 16*kg + s
+// (kg = lane >> 4, s = step 0..15) and produces the 16 outputs of one n-quarter (j = lane & 15).
+//   forward : k = ci, n = co                       dgrad: k = co, n = ci, tap flipped (transposed convolution)
+__host__ __device__ inline int conv2_frag_index(int tap, int n, int k) {
+  return (((tap * 4 + (n >> 4)) * 16 + (k & 15)) * 64) + ((k >> 4) << 4) + (n & 15);
+}
 // after the four 3x3 packs, each net's packed buffer holds k-major copies of the two "thin" weights:
 //   w0T [Cp][64]      = conv0.weight^T  (Cp = C rounded up to even, pad row zero)
 //   wsT [bands][1024] = feat_spe.weight^T
@@ -63,9 +72,17 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
                         const float* wpk, long long wpk_nstride, const float* bias, long long bias_nstride,
                         float* out, uint8_t* mask_out, hipStream_t st);
 bool conv3_fused_ok(int H, int W, int C, int rows);
+// the rest of the forward (conv2 + pool + head) in the same per-sample workgroup: see conv3_fwd_tail
+struct FwdTail {
+  const float* w2f; long long w2f_ns; const float* b2; const float* wc; const float* bc; long long p_ns;
+  const float* y; const float* dropmask; float* dropgen; float* catd; float* ynorm; float* logits; float* feat;
+  float* p2; uint8_t* m2; float dropout_p; int train, K;
+};
+bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
-                              const float* bias, long long bias_ns, float* out, uint8_t* mask_out, hipStream_t st);
+                              const float* bias, long long bias_ns, float* out, uint8_t* mask_out,
+                              const FwdTail* tail /* or null */, hipStream_t st);
 bool conv3_fused_bwd_ok(int H, int W, int C, int rows);
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
                                   const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,

@@ -44,6 +44,10 @@ __global__ void adam_kernel(float* __restrict__ params, long long pstride, const
         const int e = e0 + q, kw = e % 3, kh = (e / 3) % 3, ci = (e / 9) & 63, co = e / 576;
         pk[(((kh * 3 + kw) * 16 + (ci >> 2)) * 64 + co) * 4 + (ci & 3)] = pa[q];
         pk[PACK_CONV + ((((2 - kh) * 3 + (2 - kw)) * 16 + (co >> 2)) * 64 + ci) * 4 + (co & 3)] = pa[q];
+        if (which == 2) {   // conv2 also as 16x16x4 B fragments (fused tail / head kernels)
+          pkn[4 * PACK_CONV + conv2_frag_index(kh * 3 + kw, co, ci)] = pa[q];
+          pkn[5 * PACK_CONV + conv2_frag_index((2 - kh) * 3 + (2 - kw), ci, co)] = pa[q];
+        }
       }
     } else if (i4 >= pi.off_w0 && i4 < pi.off_w0 + 64LL * pi.C) {      // conv0.weight[co][c] -> w0T[c][co]
 #pragma unroll

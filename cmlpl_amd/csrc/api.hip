@@ -374,12 +374,9 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
              int64_t grad_stride, const NetWs& w, hipStream_t st) {
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
-  // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
-  if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,
-                                d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
   hipStream_t main_st = st;
-  {  // classifier / spectral weight gradients: independent of the spatial backward chain
-    hipStream_t st = fork_to(main_st, 0, 2);
+  const bool fused_head = conv3_fused_head_ok(d.H, d.W, d.C, nets * n, d.K);
+  auto cls_spe_wgrad = [&](hipStream_t st) -> int {
     GemmTN g;
     g.bias_in = nullptr; g.bias_in_bstride = 0; g.relu = 0;
     // dW_cls[k][f] = sum_n dlogits[n][k] * catd[n][f] ; db_cls[k] = sum_n dlogits[n][k]
@@ -394,7 +391,29 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     h.B = d_sn; h.b_bstride = (long long)n * d.bands; h.ldb = d.bands; h.N = d.bands;
     h.C = d_grads + L.param_off[6]; h.ldc = d.bands;
     h.bias = d_grads + L.param_off[7];
-    if ((rc = TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn2(g, h, st))))) return rc;
+    return TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn2(g, h, st)));
+  };
+  if (fused_head) {
+    // ONE per-sample launch for the whole data-gradient chain: head backward -> conv2 data gradient -> conv1 data
+    // gradient -> conv0 weight-gradient partial.  dp2 / dp1 / dy still go to HBM for the weight-gradient kernels
+    // that follow; da0 and the pooled-gradient hand-offs stay on chip.
+    BwdHead hd;
+    hd.dlogits = d_dlogits; hd.dfeat = d_dfeat; hd.mask = mask; hd.wc = d_params + L.param_off[8]; hd.p_ns = param_stride;
+    hd.y = w.y; hd.ynorm = w.ynorm; hd.m2 = w.m2; hd.w2d = d_packed + 5 * PACK_CONV; hd.w2d_ns = L.packed_total;
+    hd.dy = w.dy; hd.dp2 = w.dp2; hd.dp1 = w.dp1; hd.K = d.K;
+    if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
+                               d_packed + 1 * PACK_CONV, L.packed_total, xs, w.part0,
+                               (long long)n * conv0_partial_size(d.C), &hd, st))))) return rc;
+    if ((rc = cls_spe_wgrad(st))) return rc;
+    if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
+    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
+  } else {
+  // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
+  if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,
+                                d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
+  {  // classifier / spectral weight gradients: independent of the spatial backward chain
+    hipStream_t st = fork_to(main_st, 0, 2);
+    if ((rc = cls_spe_wgrad(st))) return rc;
   }
   // spatial branch: the data-gradient chain stays on the caller's stream, each weight gradient forks off
   {  // conv2 weight gradient needs only dp2/m2/p1 (ready since head_bwd): forked before conv2_dgrad is enqueued
@@ -412,7 +431,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // re-formed from the raw rows with the forward's noise regenerated
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
                                d_packed + 1 * PACK_CONV, L.packed_total, xs, w.part0,
-                               (long long)n * conv0_partial_size(d.C), st))))) return rc;
+                               (long long)n * conv0_partial_size(d.C), nullptr, st))))) return rc;
   } else {
     if (!d_xn) return CMLPL_E_ARG;
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
@@ -422,6 +441,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   }
   join_from(main_st, 0, 5);
   join_from(main_st, 1, 6);
+  }
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
   rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride;

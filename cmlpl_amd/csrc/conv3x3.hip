@@ -112,6 +112,11 @@ struct Conv3Args {
   const float* dropmask; float* dropgen; float* catd; float* ynorm; float* logits; float* feat;
   float* p2out; uint8_t* m2out;
   float dropout_p; int train, K;
+  // HEAD (backward, MODE 3 + TAIL): classifier / L2-norm / spectral-ReLU backward and the conv2 data gradient of
+  // the same sample run first; their output dp1 feeds the conv1 data gradient through LDS
+  const float* dlogits; const float* dfeat; const float* hmask;   // hmask: dropout multiplier rows or null
+  const float* ynrm; const uint8_t* m2in; const float* w2d; long long w2d_ns;
+  float* dy; float* dp2out; float* dp1out;
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -280,7 +285,8 @@ struct Conv3Ctx {
 };
 
 template <int MODE>
-__device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c) {
+__device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c,
+                                            const float* dp_lds = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, s0 = blockIdx.x * a.S;
@@ -428,7 +434,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           const bool ok = sample < a.n;
           const size_t g = ((size_t)(ok ? sample : s0) * P2 + q) * 64 + c4 * 4;
           DM r;
-          r.d = *(const float4*)(dp + g);
+          // fused backward head (S == 1): the pooled gradient was produced by this workgroup and waits in LDS
+          r.d = dp_lds != nullptr ? *(const float4*)(dp_lds + q * 64 + c4 * 4) : *(const float4*)(dp + g);
           r.m = ok ? *(const uint32_t*)(mk + g) : 0u;
           return r;
         },
@@ -627,12 +634,170 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   if (tid < K) a.logits[rs * K + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bc[tid];
 }
 
+// The first part of the backward pass of this workgroup's sample (S == 1), run in front of the conv1 data gradient:
+//   head: dcat = (dlogits . Wc) * dropout multiplier; its spatial part is the pooled conv2 gradient dp2, its
+//         spectral part joins the gradient through the L2 normalisation and the spectral ReLU (head_bwd_kernel's
+//         math): dy = relu'(y) * (dcat_y + (dfeat - feat <feat, dfeat>) / ||y||)
+//   conv2 data gradient on the 16x16x4 fp32 MFMA: dz2 = mask2 * upsample(dp2) / 4 as a zero-bordered LDS image,
+//         dp1 = conv_transpose(dz2) + dz2 for the H2 x W2 pixels (two 16-row tiles), wave w = input channels
+//         16w..16w+15, B fragments ready-made in L2.
+// dy, dp2 and dp1 also go to HBM (the weight-gradient kernels read them); dp1 stays in LDS (returned region) for the
+// conv1 staging.  LDS use: img2d in the tap-weight buffer, everything else behind the LUT (dead before the tap loop).
+__device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int net = blockIdx.y, sample = blockIdx.x;
+  const int H2 = a.H >> 1, W2 = a.W >> 1, P2 = H2 * W2, PW2 = W2 + 2;
+  const int SF = 256, F = SF + FD, K = a.K;
+  float* img2 = smem + (size_t)(a.H + 2) * (a.W + 2) * CS;        // = wbuf: [(H2+2)*(W2+2)][CS] <= 4096 floats
+  float* ext = img2 + 4096 + 128;                                  // behind the LUT
+  float* dp1s = ext;                                               // [P2][64]
+  float* dp2s = dp1s + P2 * 64;                                    // [4][64]  pooled conv2 gradient [hw][c]
+  float* dls = dp2s + 256;                                         // [64]
+  float* red = dls + 64;                                           // [4]
+  const long long rs = (long long)net * a.n + sample;
+  const int j = lane & 15, kg = lane >> 4;
+  // ---- loads up front: tap-0 B fragments of the conv2 data gradient, this thread's spectral elements
+  const float* wq = a.w2d + (long long)net * a.w2d_ns + (size_t)wave * 1024 + lane;
+  float bcur[16], bnxt[16];
+#pragma unroll
+  for (int st = 0; st < 16; ++st) bcur[st] = wq[st * 64];
+  if (tid < 64) dls[tid] = (tid < K) ? a.dlogits[rs * K + tid] : 0.f;
+  const float* y = a.yin + rs * FD;
+  const float* df = (a.dfeat != nullptr) ? a.dfeat + rs * FD : nullptr;
+  const float norm = a.ynrm[rs];
+  float yv[4], dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    yv[q] = y[tid + 256 * q];
+    dv[q] = (df != nullptr) ? df[tid + 256 * q] : 0.f;
+  }
+  {  // the whole tap-weight buffer becomes the zero-bordered dz2 image
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 1024; i += 256) ((float4*)img2)[i] = z4;
+  }
+  float dot = 0.f;   // <feat, dfeat> with feat = y / ||y|| (same division as the forward pass)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dot = fmaf(yv[q] / norm, dv[q], dot);
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = (red[0] + red[1]) + (red[2] + red[3]);
+  const float* wc = a.wc + (long long)net * a.p_ns;
+  const float* dm = (a.hmask != nullptr) ? a.hmask + rs * F : nullptr;
+  float* dp2g = a.dp2out + rs * SF;
+  float* dyg = a.dy + rs * FD;
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {                                 // F = 1280 = 5 x 256
+    const int f = tid + 256 * it;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    const float* wf = wc + f;
+    int k = 0;
+    for (; k + 3 < K; k += 4) {
+      const float w0 = wf[(long long)k * F], w1 = wf[(long long)(k + 1) * F];
+      const float w2 = wf[(long long)(k + 2) * F], w3 = wf[(long long)(k + 3) * F];
+      d0 = fmaf(dls[k], w0, d0); d1 = fmaf(dls[k + 1], w1, d1);
+      d2 = fmaf(dls[k + 2], w2, d2); d3 = fmaf(dls[k + 3], w3, d3);
+    }
+    for (; k < K; ++k) d0 = fmaf(dls[k], wf[(long long)k * F], d0);
+    float dc = (d0 + d1) + (d2 + d3);
+    if (dm != nullptr) dc *= dm[f];
+    if (it == 0) {                                                 // f < SF: spatial part, f = c * 4 + hw
+      const int c = f >> 2, hw = f & 3;
+      dp2s[hw * 64 + c] = dc;
+      dp2g[hw * 64 + c] = dc;
+    } else {                                                       // spectral element j = f - 256 = tid + 256 (it - 1)
+      const float yj = yv[it - 1];
+      float g = dc;
+      if (df != nullptr) g += (dv[it - 1] - (yj / norm) * dot) / norm;
+      dyg[tid + 256 * (it - 1)] = relu_open(yj) ? g : 0.f;
+    }
+  }
+  __syncthreads();                                                 // dp2s complete, img2 zeroed
+  if (tid < 64) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
+    const int c4 = tid & 15, pp = tid >> 4, ph = pp >> 1, pw = pp & 1;
+    const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
+    const uint32_t m = *(const uint32_t*)(a.m2in + (rs * 4 + pp) * 64 + c4 * 4);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      float4 v;
+      v.x = ((m >> sub) & 1u) ? d.x * 0.25f : 0.f;
+      v.y = ((m >> (8 + sub)) & 1u) ? d.y * 0.25f : 0.f;
+      v.z = ((m >> (16 + sub)) & 1u) ? d.z * 0.25f : 0.f;
+      v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
+      const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
+      *(float4*)(img2 + (size_t)((h + 1) * PW2 + w + 1) * CS + c4 * 4) = v;
+    }
+  }
+  __syncthreads();
+  // ---- conv2 data gradient: output pixel p = 16 t + (lane & 15), t = 0, 1 (rows >= P2 read the zero corner)
+  const float* ap[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int p = 16 * t + j;
+    const int pos = p < P2 ? ((p / W2) + 1) * PW2 + (p % W2) + 1 : 0;
+    ap[t] = img2 + (size_t)pos * CS + 16 * kg;
+  }
+  f32x4v acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    if (tap + 1 < 9) {
+#pragma unroll
+      for (int st = 0; st < 16; ++st) bnxt[st] = wq[(size_t)(tap + 1) * 4096 + st * 64];
+    }
+    const int toff = ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * CS;
+    float4 av[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // the dummy rows (p >= P2) sit at the zero corner: a negative tap offset would leave the image, keep them there
+      const float* q = (16 * t + j < P2) ? ap[t] + toff : ap[t];
+      av[t][0] = *(const float4*)(q); av[t][1] = *(const float4*)(q + 4);
+      av[t][2] = *(const float4*)(q + 8); av[t][3] = *(const float4*)(q + 12);
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = mfma16(av[t][q4].x, bcur[4 * q4], acc[t][0]);
+        acc[t][1] = mfma16(av[t][q4].y, bcur[4 * q4 + 1], acc[t][1]);
+        acc[t][0] = mfma16(av[t][q4].z, bcur[4 * q4 + 2], acc[t][0]);
+        acc[t][1] = mfma16(av[t][q4].w, bcur[4 * q4 + 3], acc[t][1]);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) bcur[st] = bnxt[st];
+  }
+  // ---- epilogue: lane (ci = 16 wave + j) holds pixels p = 16 t + 4 kg + r; residual branch adds dz2 itself
+  {
+    const int ci = wave * 16 + j;
+    float* dp1g = a.dp1out + rs * (long long)P2 * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = 16 * t + 4 * kg + r;
+        if (p < P2) {
+          const float v = (acc[t][0][r] + acc[t][1][r]) + img2[(size_t)(((p / W2) + 1) * PW2 + (p % W2) + 1) * CS + ci];
+          dp1s[p * 64 + ci] = v;
+          dp1g[p * 64 + ci] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();                                                 // dp1s complete; img2 (= wbuf) is free again
+  return dp1s;
+}
+
 template <int MODE, int MTW, int TAIL = 0>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Conv3Ctx c;
   STAMP(MODE & 1, 0);
-  conv3_stage<MODE>(a, smem, MTW * 128, c);
+  const float* dp_lds = nullptr;
+  if (MODE == 3 && TAIL) dp_lds = conv3_bwd_head(a, smem);
+  conv3_stage<MODE>(a, smem, MTW * 128, c, dp_lds);
   STAMP(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
@@ -1035,9 +1200,22 @@ bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
   return 2 * lds <= LDS_MAX;
 }
 
+bool conv3_fused_head_ok(int H, int W, int C, int rows, int K) {
+  static const bool off = getenv("CMLPL_FUSE_TAIL") && atoi(getenv("CMLPL_FUSE_TAIL")) == 0;
+  const int H2 = H / 2, W2 = W / 2;
+  if (off || !conv3_fused_bwd_ok(H, W, C, rows) || H2 / 2 != 2 || W2 / 2 != 2 || (H2 + 2) * (W2 + 2) * CS > 4096 ||
+      H2 * W2 > 32 || K < 1 || K > 64)
+    return false;
+  // LDS behind the LUT: dp1s [P2][64] + dp2s [256] + dls [64] + red [4]
+  Conv3Plan pl;
+  if (!plan_conv3(1, H, W, rows, &pl)) return false;
+  const size_t need = ((size_t)(H + 2) * (W + 2) * CS + 4096 + 128 + (size_t)H2 * W2 * 64 + 256 + 64 + 4) * 4;
+  return need <= conv3_fused_bwd_lds(H, W, C, pl.lds);
+}
+
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
                                   const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,
-                                  hipStream_t st) {
+                                  const BwdHead* head, hipStream_t st) {
   Conv3Plan pl;
   if (!conv3_fused_bwd_ok(H, W, C, nets * n) || !plan_conv3(1, H, W, nets * n, &pl)) return hipErrorInvalidValue;
   const int P2 = (H / 2) * (W / 2);
@@ -1048,6 +1226,17 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns;
+  if (head != nullptr) {
+    if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
+    a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
+    a.yin = head->y; a.ynrm = head->ynorm; a.m2in = head->m2; a.w2d = head->w2d; a.w2d_ns = head->w2d_ns;
+    a.dy = head->dy; a.dp2out = head->dp2; a.dp1out = head->dp1; a.K = head->K;
+    static DevOnce attr_once;
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), dim3(n, nets), dim3(256), conv3_fused_bwd_lds(H, W, C, pl.lds), st, a);
+    return hipGetLastError();
+  }
   return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
 }
 

@@ -84,9 +84,16 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
                               const float* bias, long long bias_ns, float* out, uint8_t* mask_out,
                               const FwdTail* tail /* or null */, hipStream_t st);
 bool conv3_fused_bwd_ok(int H, int W, int C, int rows);
+// the head / conv2 part of the backward in the same per-sample workgroup: see conv3_bwd_head
+struct BwdHead {
+  const float* dlogits; const float* dfeat; const float* mask; const float* wc; long long p_ns;
+  const float* y; const float* ynorm; const uint8_t* m2; const float* w2d; long long w2d_ns;
+  float* dy; float* dp2; float* dp1; int K;
+};
+bool conv3_fused_head_ok(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
                                   const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,
-                                  hipStream_t st);
+                                  const BwdHead* head /* or null */, hipStream_t st);
 struct Wgrad3Plan { int RU, U, G, cspl, rsplit, UPG; size_t lds; };   // rsplit > 0: row-split kernel with CPR = rsplit, UPG units per workgroup
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,

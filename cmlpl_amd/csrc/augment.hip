@@ -48,7 +48,7 @@ __global__ void augment_kernel(AugArgs a) {
     float* dst = a.dst[t] + ((long long)net * (a.bt + a.btu) + s) * per;
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (need_noise && !a.explicit_noise) {
-      const float4 nz = philox_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
+      const float4 nz = noise_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
                                        noise_ctr(gs, (uint32_t)(base >> 2)));
       z[0] = nz.x; z[1] = nz.y; z[2] = nz.z; z[3] = nz.w;
     } else if (need_noise) {

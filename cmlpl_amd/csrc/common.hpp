@@ -101,6 +101,37 @@ __device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t step, u
   __sincosf(6.283185307179586f * u3, &s1, &c1);
   return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
 }
+// Bulk augmentation noise (6.4 M normals per step at B2): PCG4D (Jarzynski & Olano, "Hash Functions for GPU
+// Rendering", JCGT 2020), a counter-based 4 x 32 -> 4 x 32 bit hash -- 12 multiply-adds against the 20 64-bit
+// multiplies of Philox4x32-10, which on CDNA are quarter-rate instructions and made the generator, not the memory
+// system, the bound of the augmentation (measured: 8-12 us per fused kernel with Philox).  Inputs: the counter
+// (group, sample), the stream and the step, each whitened with the seed.  Dropout keeps Philox.
+__device__ __forceinline__ uint4 pcg4d(uint4 v) {
+  v.x = v.x * 1664525u + 1013904223u; v.y = v.y * 1664525u + 1013904223u;
+  v.z = v.z * 1664525u + 1013904223u; v.w = v.w * 1664525u + 1013904223u;
+  v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+  v.x ^= v.x >> 16; v.y ^= v.y >> 16; v.z ^= v.z >> 16; v.w ^= v.w >> 16;
+  v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+  return v;
+}
+// 4 standard normals for elements 4g..4g+3 of a sample (Box-Muller on the four hash words)
+__device__ __forceinline__ float4 noise_normal4(uint64_t seed, uint64_t step, uint32_t stream, uint64_t ctr) {
+  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  const uint4 r = pcg4d(make_uint4((uint32_t)ctr ^ s0, (uint32_t)(ctr >> 32) ^ s1,
+                                   (stream * 0x9E3779B9u) ^ (uint32_t)(step >> 32) ^ (s1 * 0x85EBCA6Bu),
+                                   (uint32_t)step ^ (s0 * 0xC2B2AE35u)));
+  // Box-Muller on the hardware transcendentals directly: u in (0, 1] -> radius sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+  // (v_log_f32 is log2, u >= 2^-32 is a normal number), angle in REVOLUTIONS (what v_sin_f32 / v_cos_f32 take).
+  // The library forms (denormal scaling for log, correctly rounded sqrt, radian range reduction) cost 3x the
+  // instructions and buy nothing for augmentation noise.
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = fminf(fmaf((float)r.x, k, k), 1.0f), u2 = fminf(fmaf((float)r.z, k, k), 1.0f);
+  const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+  const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  const float a0 = (float)r.y * k, a1 = (float)r.w * k;
+  return make_float4(r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0),
+                     r1 * __builtin_amdgcn_cosf(a1), r1 * __builtin_amdgcn_sinf(a1));
+}
 __device__ __forceinline__ float4 philox_uniform4(uint64_t seed, uint64_t step, uint32_t stream, uint64_t idx) {
   uint4 c = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), stream, (uint32_t)step);
   uint2 k = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));

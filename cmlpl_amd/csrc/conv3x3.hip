@@ -80,7 +80,7 @@ hipError_t launch_pack_weights(int nets, const float* params, long long pstride,
 // ------------------------------------------------------------------------------------------
 #if CMLPL_ABL == 9
 // phase timeline instrumentation (ablation build only): constant-rate 100 MHz stamps per workgroup
-__device__ unsigned long long g_stamps[3][2048][8];
+__device__ unsigned long long g_stamps[3][2048][16];
 #define STAMP(MODE_, i) do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) \
     g_stamps[MODE_][blockIdx.x + gridDim.x * blockIdx.y][i] = wall_clock64(); } while (0)
 extern "C" int cmlpl_abl_read_stamps(unsigned long long* host) {
@@ -170,10 +170,10 @@ __device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int n
       for (int k = 0; k < SLAB_MAXQ; ++k) {
         const int q = wave + 4 * k;
         if (q * 64 < nf4)                                  // wave-uniform
-          z[k] = philox_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)(q * 64 + lane)));
+          z[k] = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)(q * 64 + lane)));
       }
       if (rem != 0 && tid < 64) {                          // the last, partial group: one wave computes it
-        const float4 t = philox_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)nf4));
+        const float4 t = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)nf4));
         zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
       }
     }
@@ -286,7 +286,7 @@ struct Conv3Ctx {
 
 template <int MODE>
 __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c,
-                                            const float* dp_lds = nullptr) {
+                                            const float* dp_lds = nullptr, const uint32_t* mpre = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, s0 = blockIdx.x * a.S;
@@ -297,13 +297,14 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   float* img = smem;                       // [S][IMG][CS]
   float* wbuf = img + (size_t)S * IMG * CS;  // [16][64][4]
   int* lut = (int*)(wbuf + 4096);          // padded-image position of output pixel m
-  if (MODE != 2) {  // zero the padded images (border must be zero; interior overwritten below)
+  // (fused backward head, dp_lds != null: image zero fill and LUT were done before the head, under its loads)
+  if (MODE != 2 && dp_lds == nullptr) {  // zero the padded images (border must be zero; interior overwritten below)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* p = (float4*)img;
     const int tot = S * IMG * (CS / 4);
     for (int i = tid; i < tot; i += 256) p[i] = z;
   }
-  if (MODE != 2) {
+  if (MODE != 2 && dp_lds == nullptr) {
     for (int m = tid; m < lut_entries; m += 256) {
       const int mm = (m < npx) ? m : 0;
       const int s = mm / PX, rem = mm - s * PX, r = rem / CO, c = rem - r * CO;
@@ -423,6 +424,28 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           const int c4 = idx & 15, p = idx >> 4, s = p / HW, pix = p - s * HW, h = pix / W, w = pix - h * W;
           *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
         });
+  } else if (dp_lds != nullptr) {
+    // fused backward head (S == 1): the pooled gradient was produced by this workgroup and waits in LDS, the ReLU
+    // mask words were fetched at kernel start; one (pooled pixel, 4 channels) item -> its 2x2 window
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < P2 * 16) {
+        const int c4 = idx & 15, pp = idx >> 4, ph = pp / W2, pw = pp - ph * W2;
+        const float4 d = *(const float4*)(dp_lds + pp * 64 + c4 * 4);
+        const uint32_t m = mpre[q];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          float4 v;
+          v.x = ((m >> sub) & 1u) ? d.x * 0.25f : 0.f;
+          v.y = ((m >> (8 + sub)) & 1u) ? d.y * 0.25f : 0.f;
+          v.z = ((m >> (16 + sub)) & 1u) ? d.z * 0.25f : 0.f;
+          v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
+          const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
+          *(float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+        }
+      }
+    }
   } else {
     const float* dp = a.in + (long long)net * a.in_ns;
     const uint8_t* mk = a.mask_in + (long long)net * a.mask_in_ns;
@@ -434,8 +457,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           const bool ok = sample < a.n;
           const size_t g = ((size_t)(ok ? sample : s0) * P2 + q) * 64 + c4 * 4;
           DM r;
-          // fused backward head (S == 1): the pooled gradient was produced by this workgroup and waits in LDS
-          r.d = dp_lds != nullptr ? *(const float4*)(dp_lds + q * 64 + c4 * 4) : *(const float4*)(dp + g);
+          r.d = *(const float4*)(dp + g);
           r.m = ok ? *(const uint32_t*)(mk + g) : 0u;
           return r;
         },
@@ -543,6 +565,7 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
 #pragma unroll
     for (int st = 0; st < 16; ++st) bcur[st] = bnxt[st];
   }
+  STAMP(0, 8);
   // ---- conv2 epilogue: lane (co = 16 wave + j, output row oh = kg) holds the 4 pixels ow = 0..3 of that row
   {
     const int co = wave * 16 + j;
@@ -606,27 +629,32 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
     }
   }
   __syncthreads();
+  STAMP(0, 9);
   // logits: wave w takes the quarter [w*F4, (w+1)*F4) of the row for ALL classes (8 accumulators at a time),
   // then the four partial dot products meet in LDS
   const float* wc = a.wc + (long long)net * a.p_ns;
   const float* bc = a.bc + (long long)net * a.p_ns;
   float* part = red + 4;                     // [4 waves][64 classes]
-  const int F4 = F >> 2, fb = wave * F4, fe = fb + F4;
-  for (int kc = 0; kc < K; kc += 8) {
-    float acc[8];
+  const int F4 = F >> 2, fb = wave * F4;   // 320 features per wave = 5 per lane
+  float xr[5];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    for (int f = fb + lane; f < fe; f += 64) {
-      const float x = row[f];
-      float wv[8];
+  for (int i = 0; i < 5; ++i) xr[i] = row[fb + lane + 64 * i];
+  for (int kc = 0; kc < K; kc += 16) {
+    // 16 classes x 5 features: all 80 weight loads are issued before the first is used (one L2 round trip per
+    // chunk; a load -> fma -> load loop here cost ~7 us per workgroup)
+    float wv[16][5];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) wv[q] = wc[(long long)((kc + q < K) ? kc + q : K - 1) * F + f];
+    for (int q = 0; q < 16; ++q) {
+      const float* wr = wc + (long long)((kc + q < K) ? kc + q : K - 1) * F + fb + lane;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] = fmaf(x, wv[q], acc[q]);
+      for (int i = 0; i < 5; ++i) wv[q][i] = wr[64 * i];
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float t = wave_sum(acc[q]);
+    for (int q = 0; q < 16; ++q) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc = fmaf(xr[i], wv[q][i], acc);
+      const float t = wave_sum(acc);
       if (lane == 0 && kc + q < K) part[wave * 64 + kc + q] = t;
     }
   }
@@ -643,7 +671,7 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
 //         16w..16w+15, B fragments ready-made in L2.
 // dy, dp2 and dp1 also go to HBM (the weight-gradient kernels read them); dp1 stays in LDS (returned region) for the
 // conv1 staging.  LDS use: img2d in the tap-weight buffer, everything else behind the LUT (dead before the tap loop).
-__device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float* smem) {
+__device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float* smem, uint32_t (&mpre)[2]) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, sample = blockIdx.x;
@@ -672,9 +700,39 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     yv[q] = y[tid + 256 * q];
     dv[q] = (df != nullptr) ? df[tid + 256 * q] : 0.f;
   }
-  {  // the whole tap-weight buffer becomes the zero-bordered dz2 image
+  // conv1's ReLU-mask words of this thread's staging items (consumed after the conv2 data gradient)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 256 * q;
+    mpre[q] = (idx < P2 * 16) ? *(const uint32_t*)(a.mask_in + (long long)net * a.mask_in_ns + ((size_t)sample * P2 + (idx >> 4)) * 64 + (idx & 15) * 4) : 0u;
+  }
+  const float* wc = a.wc + (long long)net * a.p_ns;
+  const float* dm = (a.hmask != nullptr) ? a.hmask + rs * F : nullptr;
+  float dmv[5];
+#pragma unroll
+  for (int it = 0; it < 5; ++it) dmv[it] = (dm != nullptr) ? dm[tid + 256 * it] : 1.f;
+  // classifier weights of this thread's 5 row elements f = tid + 256 it, 16 classes at a time: every load of a
+  // chunk is in flight before the first is used
+  float wv0[16][5];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float* wr = wc + (long long)(q < K ? q : K - 1) * F + tid;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) wv0[q][it] = wr[256 * it];
+  }
+  {  // while those loads fly: the whole tap-weight buffer becomes the zero-bordered dz2 image, and the conv1 image
+     // region (free until the conv1 staging) gets its zero fill and output-pixel LUT
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 1024; i += 256) ((float4*)img2)[i] = z4;
+    const int PW = a.W + 2, IMG = (a.H + 2) * PW;
+    for (int i = tid; i < IMG * (CS / 4); i += 256) ((float4*)smem)[i] = z4;
+    int* lut = (int*)(img2 + 4096);
+    const int HWl = a.H * a.W;
+    for (int m = tid; m < 128; m += 256) {
+      const int mm = (m < HWl) ? m : 0;
+      const int r = mm / a.W, cc = mm - r * a.W;
+      lut[m] = (r + 1) * PW + (cc + 1);
+    }
   }
   float dot = 0.f;   // <feat, dfeat> with feat = y / ||y|| (same division as the forward pass)
 #pragma unroll
@@ -683,36 +741,46 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   if (lane == 0) red[wave] = dot;
   __syncthreads();
   dot = (red[0] + red[1]) + (red[2] + red[3]);
-  const float* wc = a.wc + (long long)net * a.p_ns;
-  const float* dm = (a.hmask != nullptr) ? a.hmask + rs * F : nullptr;
   float* dp2g = a.dp2out + rs * SF;
   float* dyg = a.dy + rs * FD;
+  float dc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {                                 // F = 1280 = 5 x 256
-    const int f = tid + 256 * it;
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    const float* wf = wc + f;
-    int k = 0;
-    for (; k + 3 < K; k += 4) {
-      const float w0 = wf[(long long)k * F], w1 = wf[(long long)(k + 1) * F];
-      const float w2 = wf[(long long)(k + 2) * F], w3 = wf[(long long)(k + 3) * F];
-      d0 = fmaf(dls[k], w0, d0); d1 = fmaf(dls[k + 1], w1, d1);
-      d2 = fmaf(dls[k + 2], w2, d2); d3 = fmaf(dls[k + 3], w3, d3);
+  for (int q = 0; q < 16; ++q) {
+    const float dl = dls[q];                                       // zero beyond K
+#pragma unroll
+    for (int it = 0; it < 5; ++it) dc[it] = fmaf(dl, wv0[q][it], dc[it]);
+  }
+  for (int kc = 16; kc < K; kc += 16) {                            // more than 16 classes: further chunks
+    float wv[16][5];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float* wr = wc + (long long)(kc + q < K ? kc + q : K - 1) * F + tid;
+#pragma unroll
+      for (int it = 0; it < 5; ++it) wv[q][it] = wr[256 * it];
     }
-    for (; k < K; ++k) d0 = fmaf(dls[k], wf[(long long)k * F], d0);
-    float dc = (d0 + d1) + (d2 + d3);
-    if (dm != nullptr) dc *= dm[f];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float dl = dls[kc + q];
+#pragma unroll
+      for (int it = 0; it < 5; ++it) dc[it] = fmaf(dl, wv[q][it], dc[it]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {                                 // F = 1280 = 5 x 256, f = tid + 256 it
+    const int f = tid + 256 * it;
+    const float d = (dm != nullptr) ? dc[it] * dmv[it] : dc[it];
     if (it == 0) {                                                 // f < SF: spatial part, f = c * 4 + hw
       const int c = f >> 2, hw = f & 3;
-      dp2s[hw * 64 + c] = dc;
-      dp2g[hw * 64 + c] = dc;
+      dp2s[hw * 64 + c] = d;
+      dp2g[hw * 64 + c] = d;
     } else {                                                       // spectral element j = f - 256 = tid + 256 (it - 1)
       const float yj = yv[it - 1];
-      float g = dc;
+      float g = d;
       if (df != nullptr) g += (dv[it - 1] - (yj / norm) * dot) / norm;
       dyg[tid + 256 * (it - 1)] = relu_open(yj) ? g : 0.f;
     }
   }
+  STAMP(1, 10);
   __syncthreads();                                                 // dp2s complete, img2 zeroed
   if (tid < 64) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
     const int c4 = tid & 15, pp = tid >> 4, ph = pp >> 1, pw = pp & 1;
@@ -787,6 +855,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     }
   }
   __syncthreads();                                                 // dp1s complete; img2 (= wbuf) is free again
+  STAMP(1, 11);
   return dp1s;
 }
 
@@ -796,8 +865,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   Conv3Ctx c;
   STAMP(MODE & 1, 0);
   const float* dp_lds = nullptr;
-  if (MODE == 3 && TAIL) dp_lds = conv3_bwd_head(a, smem);
-  conv3_stage<MODE>(a, smem, MTW * 128, c, dp_lds);
+  uint32_t mpre[2] = {0u, 0u};
+  if (MODE == 3 && TAIL) dp_lds = conv3_bwd_head(a, smem, mpre);
+  conv3_stage<MODE>(a, smem, MTW * 128, c, dp_lds, mpre);
   STAMP(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
@@ -814,6 +884,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   }
 
   // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
+  STAMP(MODE & 1, 14);
   if (MODE == 2) {
     // MTW == 1 here.  Rows 2s, 2s+1 of this wave's a0 tile go to HBM while tap s runs.
     const f32x16 z0 = c.z0, z1 = c.z1;
@@ -833,6 +904,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
   } else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
+  STAMP(MODE & 1, 15);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
   STAMP(MODE & 1, 2);
 
@@ -843,15 +915,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     for (int t = 0; t < MTW; ++t) {
       const int tile = wave + 4 * t;
       if (tile < MT) {
+        // three passes -- positions, residual reads, writes -- so that the 16 rows' LDS round trips overlap
+        // (a row-by-row loop is a chain of dependent lut -> read -> write trips: 6 us per workgroup here)
+        int pos[16];
+        float x0[16], x1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = tile * 32 + acc_row(r, lane);
+          pos[r] = lut[m < npx ? m : 0] * CS;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { x0[r] = img[pos[r] + l31]; x1[r] = img[pos[r] + 32 + l31]; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = tile * 32 + acc_row(r, lane);
           if (m < npx) {
-            float* p = img + (size_t)lut[m] * CS;
-            const float v0 = acc[t][0][r] + bv0 + p[l31];
-            const float v1 = acc[t][1][r] + bv1 + p[32 + l31];
-            p[l31] = relu_nan(v0);
-            p[32 + l31] = relu_nan(v1);
+            img[pos[r] + l31] = relu_nan(acc[t][0][r] + bv0 + x0[r]);
+            img[pos[r] + 32 + l31] = relu_nan(acc[t][1][r] + bv1 + x1[r]);
           }
         }
       }
@@ -860,8 +940,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int i = tid; i < 1024; i += 256) ((float4*)wbuf)[i] = z4;
     }
+    STAMP(0, 10);
     __syncthreads();
+    STAMP(0, 11);
     conv3_pool_store(a, c, TAIL ? wbuf : nullptr);
+    STAMP(0, 7);
     if (TAIL) conv3_fwd_tail(a, c, smem);
   } else if (MODE == 3) {
     // conv0 weight gradient fused in (S == 1, MTW == 1, C <= 128):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
@@ -873,12 +956,17 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     typedef __attribute__((address_space(1))) const void gbl_void;
     const int C = a.C;
     float v0[16], v1[16];
+    {
+      int pos[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wave * 32 + acc_row(r, lane);
-      const float* p = img + (size_t)lut[m < PX ? m : 0] * CS;
-      v0[r] = acc[0][0][r] + p[l31];
-      v1[r] = acc[0][1][r] + p[32 + l31];
+      for (int r = 0; r < 16; ++r) {
+        const int m = wave * 32 + acc_row(r, lane);
+        pos[r] = lut[m < PX ? m : 0] * CS;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { v0[r] = img[pos[r] + l31]; v1[r] = img[pos[r] + 32 + l31]; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { v0[r] += acc[0][0][r]; v1[r] += acc[0][1][r]; }
     }
     __syncthreads();                                      // image and LUT are dead from here on
     float* slab = smem;                                   // [C][HW]
@@ -890,7 +978,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
       if (m < HW) { dal[m * 64 + l31] = v0[r]; dal[m * 64 + 32 + l31] = v1[r]; }
     }
     if (tid < 64) dal[HW * 64 + tid] = 0.f;               // the pixel past the end of an odd map
+    STAMP(1, 12);
     slab_finish(a.xs, net, s0, C * HW, slab, tid, wave, lane);   // ... with the forward's noise regenerated
+    STAMP(1, 13);
     __syncthreads();                                      // slab landed (the barrier waits for the DMA), da0 complete
     f32x16 g0 = zero16(), g1 = zero16();
     float dbacc = 0.f;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Ablation / timeline build of the library (results may be wrong on purpose, see CMLPL_ABL in conv3x3.hip):
+#   bash scripts/build_abl.sh 9    ->  cmlpl_amd/libabl9.so   (use with CMLPL_LIB=cmlpl_amd/libabl9.so)
+set -e
+N=${1:-9}
+cd "$(dirname "$0")/../cmlpl_amd"
+mkdir -p build_abl$N
+for f in api augment conv0 conv3x3 dense head loss memobank ntxent optim; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DCMLPL_ABL=$N -c csrc/$f.hip -o build_abl$N/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libabl$N.so build_abl$N/*.o
+echo cmlpl_amd/libabl$N.so

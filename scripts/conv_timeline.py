@@ -18,7 +18,7 @@ for i in range(20):
     eng.step(XPl, Xl, Y, XPu, Xu, 1, i)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = np.zeros((3, 2048, 8), dtype=np.uint64)
+buf = np.zeros((3, 2048, 16), dtype=np.uint64)
 rc = lib.cmlpl_abl_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1, last launch)", 240)):
@@ -30,6 +30,19 @@ for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1, la
         f = (full - full[:, :1]) / 100.0
         print(f"fwd fused prologue (us from workgroup start): slab landed {f[:,4].mean():.2f}  conv0 MFMAs done {f[:,5].mean():.2f}  "
               f"image zeroed {f[:,6].mean():.2f}  a0 written / stage end {f[:,1].mean():.2f}")
+    if mode == 0 and full[:, 9].max() > 0:
+        f = (full - full[:, :1]) / 100.0
+        print(f"fwd tail (us from workgroup start): taps end {f[:,2].mean():.2f}  pooled {f[:,7].mean():.2f}  conv2 MFMAs done "
+              f"{f[:,8].mean():.2f}  dropout row done {f[:,9].mean():.2f}  end {f[:,3].mean():.2f}")
+    if mode == 0 and full[:, 11].max() > 0:
+        f = (full - full[:, :1]) / 100.0
+        print(f"fwd detail: tap loop entered {f[:,14].mean():.2f}  wave-0 taps done {f[:,15].mean():.2f}  all waves done {f[:,2].mean():.2f}  "
+              f"relu written {f[:,10].mean():.2f}  barrier passed {f[:,11].mean():.2f}  pooled {f[:,7].mean():.2f}")
+    if mode == 1 and full[:, 11].max() > 0:
+        f = (full - full[:, :1]) / 100.0
+        print(f"bwd head (us from workgroup start): head done {f[:,10].mean():.2f}  conv2 dgrad done {f[:,11].mean():.2f}  stage end "
+              f"{f[:,1].mean():.2f}  taps end {f[:,2].mean():.2f}  slab issued+da0 {f[:,12].mean():.2f}  noise+landed {f[:,13].mean():.2f}  "
+              f"end {f[:,3].mean():.2f}")
     t0 = t[:, 0].min()
     us = (t - t0) / 100.0
     print(f"{name}: start skew  mean {us[:,0].mean():.2f}  max {us[:,0].max():.2f} us")

@@ -376,8 +376,9 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   int rc;
   hipStream_t main_st = st;
   const bool fused_head = conv3_fused_head_ok(d.H, d.W, d.C, nets * n, d.K);
-  auto cls_spe_wgrad = [&](hipStream_t st) -> int {
-    GemmTN g;
+  GemmTN gw_cls, gw_spe;
+  {
+    GemmTN& g = gw_cls;
     g.bias_in = nullptr; g.bias_in_bstride = 0; g.relu = 0;
     // dW_cls[k][f] = sum_n dlogits[n][k] * catd[n][f] ; db_cls[k] = sum_n dlogits[n][k]
     g.A = d_dlogits; g.a_bstride = (long long)n * d.K; g.lda = d.K; g.M = d.K;
@@ -386,12 +387,15 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     g.bias = d_grads + L.param_off[9]; g.bias_bstride = grad_stride;
     g.R = n; g.batches = nets; g.scale = 1.f;
     // dW_spe[o][b] = sum_n dy[n][o] * sn[n][b] ; db_spe[o] = sum_n dy[n][o]   (same launch)
-    GemmTN h = g;
+    GemmTN& h = gw_spe;
+    h = g;
     h.A = w.dy; h.a_bstride = (long long)n * 1024; h.lda = 1024; h.M = 1024;
     h.B = d_sn; h.b_bstride = (long long)n * d.bands; h.ldb = d.bands; h.N = d.bands;
     h.C = d_grads + L.param_off[6]; h.ldc = d.bands;
     h.bias = d_grads + L.param_off[7];
-    return TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn2(g, h, st)));
+  }
+  auto cls_spe_wgrad = [&](hipStream_t st) -> int {
+    return TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn2(gw_cls, gw_spe, st)));
   };
   if (fused_head) {
     // ONE per-sample launch for the whole data-gradient chain: head backward -> conv2 data gradient -> conv1 data
@@ -404,7 +408,6 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
                                d_packed + 1 * PACK_CONV, L.packed_total, xs, w.part0,
                                (long long)n * conv0_partial_size(d.C), &hd, st))))) return rc;
-    if ((rc = cls_spe_wgrad(st))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
   } else {
@@ -449,6 +452,8 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   reduce_table_add(rt, w.part2, wgrad3_G(nets, n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
   reduce_table_add(rt, w.part0, conv0_partials(d, nets, n), conv0_partial_size(d.C), 0, d.C,
                    d_grads + L.param_off[0], d_grads + L.param_off[1]);
+  if (fused_head)   // the classifier / feat_spe weight-gradient GEMMs ride along (independent, short)
+    return TIMED(CMLPL_K_CONV1_WRED, chk(launch_reduce_gemm(nets, rt, gw_cls, gw_spe, st)));
   return TIMED(CMLPL_K_CONV1_WRED, chk(launch_partial_reduce(nets, rt, st)));
 }
 
@@ -580,14 +585,8 @@ int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard, const 
   hipStream_t st = (hipStream_t)stream;
   int rc2 = TIMED(CMLPL_K_LOSS2, chk(launch_loss_graph(a, st)));
   if (rc2) return rc2;
-  hipStream_t main_st = st;
-  {  // bank write + scalars beside the two dfeat GEMMs
-    hipStream_t st = fork_to(main_st, 0, 7);
-    if ((rc2 = TIMED(CMLPL_K_LOSS_FIN, chk(launch_loss_finalize(a, st))))) return rc2;
-  }
-  rc2 = TIMED(CMLPL_K_LOSS_DFEAT, chk(launch_loss_dfeat(a, st)));
-  join_from(main_st, 0, 7);
-  return rc2;
+  // the two feature-gradient GEMMs + the scalar block (the bank write went with phase 1's row kernel)
+  return TIMED(CMLPL_K_LOSS_DFEAT, chk(launch_loss_dfeat(a, st)));
 }
 
 int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,

@@ -10,6 +10,7 @@
 //                       pass, partials reduced deterministically by partial_reduce_kernel)
 #include "common.hpp"
 #include "kernels.hpp"
+#include "gemm_tn.hpp"
 
 namespace cmlpl {
 
@@ -184,16 +185,14 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 // fixed summation order (bit-reproducible, unlike float atomics).  Up to 3 tensors per launch.
 // mode 0: conv0  e = c*64+co -> dW[co*C + c] (c < C), tail 64 -> db
 // mode 1: conv3x3 e = s*4096 + ci*64 + co -> dW[co*576 + ci*9 + s], tail 64 -> db
-__global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t) {
-  __shared__ float red[4][64];
+__device__ __forceinline__ void partial_reduce_block(const ReduceTable& t, int bx, int net, float (*red)[64]) {
   const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
-  const int net = blockIdx.y;
   int pi = 0;
-  if (t.count > 1 && (int)blockIdx.x >= t.p[1].blk0) pi = 1;
-  if (t.count > 2 && (int)blockIdx.x >= t.p[2].blk0) pi = 2;
+  if (t.count > 1 && bx >= t.p[1].blk0) pi = 1;
+  if (t.count > 2 && bx >= t.p[2].blk0) pi = 2;
   const ReduceProb pr = t.p[pi];
   const int G = pr.G, PS = pr.PS;
-  const int e = ((int)blockIdx.x - pr.blk0) * 64 + el;
+  const int e = (bx - pr.blk0) * 64 + el;
   const bool ev = e < PS;
   const float* p = pr.part + (long long)net * G * PS + (ev ? e : 0);
   float s0 = 0.f, s1 = 0.f;
@@ -223,6 +222,28 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t) {
       pr.dW[(long long)net * t.grad_ns + co * 576 + ci * 9 + s] = sum;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t) {
+  __shared__ float red[4][64];
+  partial_reduce_block(t, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+// The weight-gradient reduce and the two small weight-gradient GEMMs (classifier, feat_spe) are independent and
+// both short: one launch, reduce blocks first, GEMM tiles after them.
+__global__ __launch_bounds__(256) void reduce_gemm_kernel(ReduceTable t, int reduce_blocks, GemmTN2 g) {
+  __shared__ GemmTNShared sh;
+  const int bid = (int)blockIdx.x;
+  if (bid < reduce_blocks) partial_reduce_block(t, bid % t.total_blocks, bid / t.total_blocks, (float (*)[64])&sh.ared[0][0]);
+  else gemm_tn_block(g, bid - reduce_blocks, sh);
+}
+
+hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, const GemmTN& g1, hipStream_t st) {
+  GemmTN2 g;
+  g.p[0] = g0; g.p[1] = g1; g.nblk0 = gemm_tn_blocks(g0);
+  const int rb = t.total_blocks * nets, gb = g.nblk0 + gemm_tn_blocks(g1);
+  hipLaunchKernelGGL(reduce_gemm_kernel, dim3(rb + gb), dim3(256), 0, st, t, rb, g);
+  return hipGetLastError();
 }
 
 void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db) {

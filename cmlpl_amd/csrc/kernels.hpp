@@ -109,6 +109,8 @@ struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C,
 struct ReduceTable { ReduceProb p[3]; int count, total_blocks; long long grad_ns; };
 void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db);
 hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st);
+struct GemmTN;
+hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, const GemmTN& g1, hipStream_t st);
 int conv0_partial_size(int C);
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
                               hipStream_t st);
@@ -159,7 +161,6 @@ size_t loss_ws_floats(int nlab, int nunl, int btu_g, int K, int Q);
 void loss_ws_carve(LossArgs& a, float* ws);
 hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st);
 hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st);
-hipError_t launch_loss_finalize(const LossArgs& a, hipStream_t st);
 hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st);
 
 // ---- ntxent.hip

@@ -25,6 +25,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "gemm_tn.hpp"
 
 namespace cmlpl {
 
@@ -347,11 +348,50 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
   }
 }
 
+// Bank write of the GLOBAL batch (train.py:223-236), one workgroup per written row, identical on every shard:
+//   bank0 <- [fU_w ; fL_s], [p_w0 ; onehot]     bank1 <- [fU_s ; fL_w], [p_s0 ; onehot]      (rows modulo Q)
+// It runs in the loss_rows launch: pair_exp_kernel (the launch before) was the last reader of the banks, and the
+// un-smoothed probabilities p_w0 / p_s0 are just the softmax of the logits row, re-formed here with the same
+// instructions loss_rows_kernel uses (bit-identical).
+__device__ __forceinline__ void bank_write_block(const LossArgs& a, int r) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K, Q = a.Q;
+  const int d0 = (a.ptr0 + r) % Q, d1 = (a.ptr1 + r) % Q;
+  const float *s0, *s1;
+  if (r < btu) { s0 = a.feat + ((long long)n + bt + r) * FD; s1 = a.feat + ((long long)bt + r) * FD; }
+  else         { s0 = a.feat + (long long)(r - btu) * FD;    s1 = a.feat + ((long long)n + r - btu) * FD; }
+  const float4 v0 = ((const float4*)s0)[tid], v1 = ((const float4*)s1)[tid];
+  ((float4*)(a.bank_fw[0] + (long long)d0 * FD))[tid] = v0;
+  ((float4*)(a.bank_fw[1] + (long long)d1 * FD))[tid] = v1;
+  if (tid < 64) {
+    const bool kv = lane < K;
+    float q0, q1;
+    if (r < btu) {
+      const float NEG = -3.0e38f;
+      const float zs = kv ? a.logits[((long long)bt + r) * K + lane] : NEG;
+      const float zw = kv ? a.logits[((long long)n + bt + r) * K + lane] : NEG;
+      const float mxs = wave_max(zs), mxw = wave_max(zw);
+      const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
+      const float ses = wave_sum(es), sew = wave_sum(ew);
+      q0 = ew / sew; q1 = es / ses;                      // "probs" (Base1) -> bank0, "probs1" (Base) -> bank1
+    } else {
+      const int yl = (int)a.labels[r - btu];
+      q0 = q1 = (lane == yl) ? 1.f : 0.f;
+    }
+    if (kv) {
+      a.bank_pw[0][(long long)d0 * K + lane] = q0;
+      a.bank_pw[1][(long long)d1 * K + lane] = q1;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int idx = blockIdx.x * 4 + wave;
   const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K;
   const int nlab = a.nlab, nunl = a.nunl, nl = nlab + nunl;
+  const int row_blocks = (nl + 3) >> 2;
+  if ((int)blockIdx.x >= row_blocks) { bank_write_block(a, (int)blockIdx.x - row_blocks); return; }
+  const int idx = blockIdx.x * 4 + wave;
   if (idx >= nl) return;
   const int RL = nlab > nunl ? nlab : nunl;
   const bool kv = lane < K;
@@ -512,31 +552,12 @@ __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void finalize_kernel(LossArgs a) {
-  __shared__ float red[4];
+// This shard's share of the logged scalars (train.py:266,270,274-278): local sums over GLOBAL counts, additive
+// across shards.  One workgroup, appended to the launch of the two feature-gradient GEMMs (it only needs the
+// per-row losses of the launches before).
+__device__ __forceinline__ void loss_scalars_block(const LossArgs& a, float* red) {
   const int tid = threadIdx.x;
-  const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K, Q = a.Q;
-  const int r = blockIdx.x;
-  if (r < n) {
-    // GLOBAL batch: bank0 <- [fU_w ; fL_s], [p_w0 ; onehot]   bank1 <- [fU_s ; fL_w], [p_s0 ; onehot]
-    // (train.py:223-236); identical on every shard
-    const int d0 = (a.ptr0 + r) % Q, d1 = (a.ptr1 + r) % Q;
-    const float *s0, *s1;
-    if (r < btu) { s0 = a.feat + ((long long)n + bt + r) * FD; s1 = a.feat + ((long long)bt + r) * FD; }
-    else         { s0 = a.feat + (long long)(r - btu) * FD;    s1 = a.feat + ((long long)n + r - btu) * FD; }
-    const float4 v0 = ((const float4*)s0)[tid], v1 = ((const float4*)s1)[tid];
-    ((float4*)(a.bank_fw[0] + (long long)d0 * FD))[tid] = v0;
-    ((float4*)(a.bank_fw[1] + (long long)d1 * FD))[tid] = v1;
-    if (tid < K) {
-      float q0, q1;
-      if (r < btu) { q0 = prob_row(a, 2, r)[tid]; q1 = prob_row(a, 3, r)[tid]; }
-      else { const int yl = (int)a.labels[r - btu]; q0 = q1 = (tid == yl) ? 1.f : 0.f; }
-      a.bank_pw[0][(long long)d0 * K + tid] = q0;
-      a.bank_pw[1][(long long)d1 * K + tid] = q1;
-    }
-    return;
-  }
-  // this shard's share of the scalars: local sums over GLOBAL counts (additive across shards)
+  const int bt = a.bt, btu = a.btu;
   const int RL = a.nlab > a.nunl ? a.nlab : a.nunl;
   float v[RL_COUNT];
 #pragma unroll
@@ -566,6 +587,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(LossArgs a) {
   }
 }
 
+// dfeat_s / dfeat_w GEMMs (blocks [0, gemm blocks)) + the scalar block (last block)
+__global__ __launch_bounds__(256) void loss_dfeat_kernel(GemmTN2 t, int gemm_blocks, LossArgs a) {
+  __shared__ GemmTNShared sh;
+  if ((int)blockIdx.x < gemm_blocks) gemm_tn_block(t, (int)blockIdx.x, sh);
+  else loss_scalars_block(a, &sh.ared[0][0]);
+}
+
 hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
   hipError_t e;
   const int nl = a.nlab + a.nunl;
@@ -583,7 +611,8 @@ hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(loss_rows_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, a);
+  // + one workgroup per row of the global batch for the bank write
+  hipLaunchKernelGGL(loss_rows_kernel, dim3((nl + 3) / 4 + a.bt + a.btu), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -591,11 +620,6 @@ hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * a.btu * 4;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(graph_loss_kernel, dim3(a.nunl), dim3(256), lds, st, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_loss_finalize(const LossArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(a.bt + a.btu + 1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -615,7 +639,11 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   h.B = a.feat + ((long long)bt + a.unl0) * FD;
   h.C = a.dfw_part;
   (void)e;
-  return launch_gemm_tn2(g, h, st);
+  GemmTN2 t;
+  t.p[0] = g; t.p[1] = h; t.nblk0 = gemm_tn_blocks(g);
+  const int gb = t.nblk0 + gemm_tn_blocks(h);
+  hipLaunchKernelGGL(loss_dfeat_kernel, dim3(gb + 1), dim3(256), 0, st, t, gb, a);
+  return hipGetLastError();
 }
 
 }  // namespace cmlpl

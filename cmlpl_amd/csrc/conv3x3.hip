@@ -19,6 +19,12 @@
 #ifndef CMLPL_ABL
 #define CMLPL_ABL 0
 #endif
+// Tap loops stay rolled (UNR = 1).  Fully unrolling them was tried for the fused kernels: -1.4 us for the data
+// gradient in one build, but the register allocation of the unrolled loop is fragile (another build of the same
+// source went to 512 registers + scratch and 27 us slower); forming the slab's augmentation noise inside the
+// unrolled data-gradient loop, a piece per tap, bought nothing either: with the cheap generator the phase behind
+// the loop is bound by the slab DMA, which cannot start before the loop ends (the slab aliases the image).
+#define CMLPL_UNR_F 1
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -78,7 +84,7 @@ hipError_t launch_pack_weights(int nets, const float* params, long long pstride,
 // ------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------
-#if CMLPL_ABL == 9
+#if CMLPL_ABL == 9 || CMLPL_ABL >= 20
 // phase timeline instrumentation (ablation build only): constant-rate 100 MHz stamps per workgroup
 __device__ unsigned long long g_stamps[3][2048][16];
 #define STAMP(MODE_, i) do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) \
@@ -146,37 +152,44 @@ __device__ __forceinline__ void slab_issue(const XSrc& x, int net, int s, int nf
     }
   }
 }
-__device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int nfl, float* slab, int tid, int wave,
-                                            int lane) {
+// noise of this wave's piece k (elements 4f..4f+3, f = (wave + 4k) * 64 + lane) and of the last partial group
+struct SlabNoise { float4 z[SLAB_MAXQ]; float zt; };
+__device__ __forceinline__ float4 slab_noise_piece(const XSrc& x, int net, int s, int nfl, int k, int wave, int lane) {
+  const int nf4 = nfl >> 2, q = wave + 4 * k;
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x.sigma != 0.f && q * 64 < nf4) {                   // wave-uniform
+    const float* nz = xsrc_noise_row(x, net, s, nfl);
+    if (nz != nullptr) {                                  // parity mode: the reference's own draws
+      const int f = q * 64 + lane, fc = f < nf4 ? f : 0;
+      z = make_float4(nz[4 * fc], nz[4 * fc + 1], nz[4 * fc + 2], nz[4 * fc + 3]);
+    } else {
+      z = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(xsrc_global_sample(x, s), (uint32_t)(q * 64 + lane)));
+    }
+  }
+  return z;
+}
+__device__ __forceinline__ float slab_noise_tail(const XSrc& x, int net, int s, int nfl, int tid) {
+  const int nf4 = nfl >> 2, rem = nfl - 4 * nf4;
+  float zt = 0.f;
+  if (x.sigma != 0.f && rem != 0 && tid < 64) {           // the last, partial group: one wave forms it
+    const float* nz = xsrc_noise_row(x, net, s, nfl);
+    if (nz != nullptr) {
+      if (tid < rem) zt = nz[4 * nf4 + tid];
+    } else {
+      const float4 t = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(xsrc_global_sample(x, s), (uint32_t)nf4));
+      zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
+    }
+  }
+  return zt;
+}
+// wait for this wave's pieces, add the noise in place, write the tail elements
+__device__ __forceinline__ void slab_apply(const XSrc& x, int net, int s, int nfl, float* slab, int tid, int wave,
+                                           int lane, const SlabNoise& nzv) {
   const float* xs = xsrc_row(x, net, s, nfl);
   const int nf4 = nfl >> 2, rem = nfl - 4 * nf4;
   float tailv = 0.f;
   if (tid < rem) tailv = xs[4 * nf4 + tid];
   if (x.sigma != 0.f) {                                   // uniform
-    float4 z[SLAB_MAXQ];
-    float zt = 0.f;
-    const float* nz = xsrc_noise_row(x, net, s, nfl);
-    if (nz != nullptr) {                                  // parity mode: the reference's own draws
-#pragma unroll
-      for (int k = 0; k < SLAB_MAXQ; ++k) {
-        const int f = (wave + 4 * k) * 64 + lane;
-        const int fc = f < nf4 ? f : 0;
-        z[k] = make_float4(nz[4 * fc], nz[4 * fc + 1], nz[4 * fc + 2], nz[4 * fc + 3]);
-      }
-      if (tid < rem) zt = nz[4 * nf4 + tid];
-    } else {
-      const uint64_t gs = xsrc_global_sample(x, s);
-#pragma unroll
-      for (int k = 0; k < SLAB_MAXQ; ++k) {
-        const int q = wave + 4 * k;
-        if (q * 64 < nf4)                                  // wave-uniform
-          z[k] = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)(q * 64 + lane)));
-      }
-      if (rem != 0 && tid < 64) {                          // the last, partial group: one wave computes it
-        const float4 t = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(gs, (uint32_t)nf4));
-        zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
-      }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
 #pragma unroll
     for (int k = 0; k < SLAB_MAXQ; ++k) {
@@ -185,15 +198,23 @@ __device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int n
         const int f = q * 64 + lane;
         if (f < nf4) {
           float4 v = *(float4*)(slab + 4 * f);
-          v.x = v.x + z[k].x * x.sigma; v.y = v.y + z[k].y * x.sigma;
-          v.z = v.z + z[k].z * x.sigma; v.w = v.w + z[k].w * x.sigma;
+          v.x = v.x + nzv.z[k].x * x.sigma; v.y = v.y + nzv.z[k].y * x.sigma;
+          v.z = v.z + nzv.z[k].z * x.sigma; v.w = v.w + nzv.z[k].w * x.sigma;
           *(float4*)(slab + 4 * f) = v;
         }
       }
     }
-    if (tid < rem) tailv = tailv + zt * x.sigma;
+    if (tid < rem) tailv = tailv + nzv.zt * x.sigma;
   }
   if (tid < rem) slab[4 * nf4 + tid] = tailv;
+}
+__device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int nfl, float* slab, int tid, int wave,
+                                            int lane) {
+  SlabNoise nzv;
+#pragma unroll
+  for (int k = 0; k < SLAB_MAXQ; ++k) nzv.z[k] = slab_noise_piece(x, net, s, nfl, k, wave, lane);
+  nzv.zt = slab_noise_tail(x, net, s, nfl, tid);
+  slab_apply(x, net, s, nfl, slab, tid, wave, lane, nzv);
 }
 
 // The 9-tap main loop.  NTA = number of this wave's M tiles that carry real pixels (wave-uniform, so
@@ -203,14 +224,14 @@ struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
 
 // `side(s)` runs once per tap right after the tap's weights are queued: the fused forward drains its deferred
 // a0 stores there, two rows per tap, instead of bursting them in front of the loop.
-template <int MTW, int NTA, class Side = NoSide>
+template <int MTW, int NTA, class Side = NoSide, int UNR = 1>
 __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float* __restrict__ wbuf,
                                            const float4* __restrict__ wg, float4 w0, float4 w1, float4 w2,
                                            float4 w3, const int (&abase)[MTW], f32x16 (&acc)[MTW][2], int PW,
                                            int tid, int l31, int hh, Side side = Side()) {
   float4* wl = (float4*)wbuf;
   const float* bbase = wbuf + (hh * 64 + l31) * 4;
-#pragma unroll 1
+#pragma unroll UNR
   for (int s = 0; s < 9; ++s) {
 #if CMLPL_ABL == 6
     if (s == 0) {
@@ -900,8 +921,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
         }
       }
     };
-    if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
-    else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
+    if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
+    else                           conv3_taps<MTW, MTW - 1, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
   } else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
   STAMP(MODE & 1, 15);

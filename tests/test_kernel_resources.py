@@ -1,0 +1,35 @@
+"""CPU: the hot kernels must not spill.  hipcc cross-compiles conv3x3.hip for gfx950 with
+-Rpass-analysis=kernel-resource-usage; every conv3x3_kernel / wgrad3r_kernel instantiation has to report
+ScratchSize 0, and the fused per-sample kernels at least 2 waves per SIMD (they rely on two co-resident
+workgroups per CU).
+Guards against the register blow-ups that loop-unrolling experiments produced."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hot_kernels_have_no_scratch(tmp_path):
+    src = os.path.join(ROOT, "cmlpl_amd", "csrc", "conv3x3.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-c", src, "-o",
+                        str(tmp_path / "c3.o"), "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "conv3x3_kernel" not in name and "wgrad3r_kernel" not in name and "conv3x3_small_kernel" not in name:
+            continue
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        assert scratch == 0, (name, scratch)
+        if "conv3x3_kernelILi2E" in name or "conv3x3_kernelILi3E" in name:   # the fused per-sample kernels
+            assert occ >= 2, (name, occ)
+        seen += 1
+    assert seen >= 10

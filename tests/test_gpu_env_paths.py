@@ -37,7 +37,7 @@ def test_fused_and_unfused_conv0_form_the_same_noise():
     kernel.  Same counters => the same augmented values: losses of the first step agree to rounding of the different
     summation orders, and both stay deterministic."""
     outs = []
-    for env_extra in ({}, {"CMLPL_FUSE_CONV0": "0"}, {}):
+    for env_extra in ({}, {"CMLPL_FUSE_CONV0": "0", "CMLPL_FUSE_TAIL": "0"}, {}):
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, "tests/_philox_traj_child.py"], cwd=ROOT, env=env, capture_output=True,
                            text=True, timeout=600)

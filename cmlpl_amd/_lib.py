@@ -29,7 +29,7 @@ EXPORTS = (
     "cmlpl_dist_unpack", "cmlpl_loss_workspace_bytes", "cmlpl_extract_patches", "cmlpl_ntxent_workspace_bytes", "cmlpl_ntxent_fwd_bwd",
     "cmlpl_unsup_workspace_bytes", "cmlpl_unsup_loss", "cmlpl_memobank_select", "cmlpl_memobank_proto",
     "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
-    "cmlpl_forward", "cmlpl_backward",
+    "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -71,7 +71,11 @@ class Shard(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("d_xpl", C.c_void_p), ("d_xl", C.c_void_p), ("d_xpu", C.c_void_p), ("d_xu", C.c_void_p),
-                ("noise8", C.POINTER(C.c_void_p)), ("bt", C.c_int32), ("btu", C.c_int32)]
+                ("d_labels", C.c_void_p), ("noise8", C.POINTER(C.c_void_p)), ("bt", C.c_int32), ("btu", C.c_int32)]
+
+
+class Gathered(C.Structure):
+    _fields_ = [("d_recv", C.c_void_p), ("world", C.c_int32), ("bt_local", C.c_int32), ("btu_local", C.c_int32)]
 
 
 class Banks(C.Structure):
@@ -127,7 +131,10 @@ def load(path: str = LIB_PATH):
                                        sz, vp]
     lib.cmlpl_basenet2_bwd.argtypes = [SP, i32, i32, vp, i64, vp, vp, vp, vp, f32, i32, vp, vp, vp, i64, vp, sz, vp]
     BP = C.POINTER(Batch)
-    lib.cmlpl_forward.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, vp, sz, vp]
+    lib.cmlpl_forward.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, vp, vp, sz, vp]
+    GP = C.POINTER(Gathered)
+    lib.cmlpl_loss_phase1_g.argtypes = [SP, SH, GP, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp, sz, vp]
+    lib.cmlpl_loss_phase2_g.argtypes = [SP, SH, GP, C.POINTER(Banks), i32, f32, HP, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.cmlpl_backward.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, vp, i64, vp, sz, vp]
     lib.cmlpl_loss_fwd_bwd.argtypes = [SP, i32, i32, vp, vp, vp, C.POINTER(Banks), i32, f32, HP, vp, vp, vp, vp,
                                        vp, sz, vp]

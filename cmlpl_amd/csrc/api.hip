@@ -468,12 +468,13 @@ bool check_batch(const cmlpl_batch* b) {
 
 int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
                   const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
-                  uint64_t step, float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes,
-                  void* stream) {
+                  uint64_t step, float* d_logits, float* d_feat, float* d_labels_f, void* d_workspace,
+                  size_t workspace_bytes, void* stream) {
   Dims d;
   cmlpl_layout_t L;
   if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
   if (!hp || !check_batch(batch) || !d_params || !d_packed || !d_logits || !d_feat || !d_workspace) return CMLPL_E_ARG;
+  if (d_labels_f && !batch->d_labels) return CMLPL_E_ARG;
   if (hp->dropout_p < 0.f || hp->dropout_p >= 1.f) return CMLPL_E_ARG;
   const int n = batch->bt + batch->btu;
   if (shard && (shard->nlab != batch->bt || shard->nunl != batch->btu)) return CMLPL_E_ARG;
@@ -488,7 +489,8 @@ int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
   int rc;
   if ((rc = TIMED(CMLPL_K_AUGMENT, chk(launch_augment(copy ? 3 : 2, 2, batch->bt, batch->btu, d.C * d.HW, d.bands, lab0,
                                 unl_base, batch->d_xpl, batch->d_xl, batch->d_xpu, batch->d_xu, batch->noise8,
-                                hp->noise_sigma, seed, step, sw.xn, sw.sn, sw.snT, st))))) return rc;
+                                hp->noise_sigma, seed, step, sw.xn, sw.sn, sw.snT, st,
+                                (const long long*)batch->d_labels, d_labels_f))))) return rc;
   return fwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
                   copy ? sw.xn : nullptr, sw.sn, sw.snT, d_dropmask, hp->dropout_p, train, seed, step, shard, d_logits,
                   d_feat, nw, st);
@@ -517,8 +519,15 @@ int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlp
 namespace {
 int fill_loss_args(const Dims& d, const cmlpl_shard* sh, const float* d_logits, const float* d_feat,
                    const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
-                   const cmlpl_hparams* hp, void* ws, size_t ws_bytes, LossArgs* out) {
-  if (!sh || !d_logits || !d_feat || !d_labels || !banks || !hp || !ws) return CMLPL_E_ARG;
+                   const cmlpl_hparams* hp, void* ws, size_t ws_bytes, LossArgs* out,
+                   const cmlpl_gathered* gth = nullptr) {
+  if (!sh || !banks || !hp || !ws) return CMLPL_E_ARG;
+  if (gth == nullptr && (!d_logits || !d_feat || !d_labels)) return CMLPL_E_ARG;
+  if (gth != nullptr && (!gth->d_recv || gth->world < 1 || gth->bt_local < 1 || gth->btu_local < 1 ||
+                         gth->world * gth->bt_local != sh->bt_g || gth->world * gth->btu_local != sh->btu_g ||
+                         sh->nunl != gth->btu_local || sh->unl0 % gth->btu_local != 0 ||
+                         (sh->nlab != 0 && (sh->nlab != gth->bt_local || sh->lab0 % gth->bt_local != 0))))
+    return CMLPL_E_ARG;
   if (sh->bt_g < 1 || sh->btu_g < 1 || sh->btu_g > 2048 || sh->nlab < 0 || sh->nunl < 1 || sh->lab0 < 0 ||
       sh->unl0 < 0 || sh->lab0 + sh->nlab > sh->bt_g || sh->unl0 + sh->nunl > sh->btu_g)
     return CMLPL_E_ARG;
@@ -529,6 +538,11 @@ int fill_loss_args(const Dims& d, const cmlpl_shard* sh, const float* d_logits, 
   LossArgs a;
   memset(&a, 0, sizeof(a));
   a.logits = d_logits; a.feat = d_feat; a.labels = d_labels;
+  if (gth != nullptr) {
+    const long long n_l = gth->bt_local + gth->btu_local;
+    a.recv = gth->d_recv; a.bt_l = gth->bt_local; a.btu_l = gth->btu_local;
+    a.pack = 2 * n_l * d.K + 2 * n_l * 1024 + gth->bt_local;
+  }
   for (int i = 0; i < 2; ++i) {
     a.bank_f[i] = banks->d_feats[i]; a.bank_p[i] = banks->d_probs[i];
     a.bank_fw[i] = banks->d_feats[i]; a.bank_pw[i] = banks->d_probs[i];
@@ -589,6 +603,45 @@ int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard, const 
   return TIMED(CMLPL_K_LOSS_DFEAT, chk(launch_loss_dfeat(a, st)));
 }
 
+int cmlpl_loss_phase1_g(const cmlpl_shape* shape, const cmlpl_shard* shard, const cmlpl_gathered* gathered,
+                        const cmlpl_banks* banks, int smooth, float adap_mask, const cmlpl_hparams* hp,
+                        float* d_dlogits, float* d_dfeat, float* d_probs_local, void* d_workspace,
+                        size_t workspace_bytes, void* stream) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  if (!gathered) return CMLPL_E_ARG;
+  LossArgs a;
+  int rc = fill_loss_args(d, shard, nullptr, nullptr, nullptr, banks, smooth, adap_mask, hp, d_workspace,
+                          workspace_bytes, &a, gathered);
+  if (rc) return rc;
+  if (!d_dlogits || !d_dfeat || !d_probs_local) return CMLPL_E_ARG;
+  a.dlogits = d_dlogits; a.dfeat = d_dfeat; a.probs_l = d_probs_local;
+  hipStream_t st = (hipStream_t)stream;
+  return TIMED(CMLPL_K_LOSS, chk(launch_loss_phase1(a, st)));
+}
+
+int cmlpl_loss_phase2_g(const cmlpl_shape* shape, const cmlpl_shard* shard, const cmlpl_gathered* gathered,
+                        const cmlpl_banks* banks, int smooth, float adap_mask, const cmlpl_hparams* hp,
+                        const float* d_probs_global, int probs_shard_rows, float* d_scalars, float* d_dfeat,
+                        float* d_dfeat_w_partial, void* d_workspace, size_t workspace_bytes, void* stream) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  if (!gathered) return CMLPL_E_ARG;
+  LossArgs a;
+  int rc = fill_loss_args(d, shard, nullptr, nullptr, nullptr, banks, smooth, adap_mask, hp, d_workspace,
+                          workspace_bytes, &a, gathered);
+  if (rc) return rc;
+  if (!d_probs_global || !d_scalars || !d_dfeat || !d_dfeat_w_partial || probs_shard_rows < 1 ||
+      shard->btu_g % probs_shard_rows != 0)
+    return CMLPL_E_ARG;
+  a.probs_g = d_probs_global; a.pshard = probs_shard_rows; a.scalars = d_scalars; a.dfeat = d_dfeat;
+  a.dfw_part = d_dfeat_w_partial;
+  hipStream_t st = (hipStream_t)stream;
+  int rc2 = TIMED(CMLPL_K_LOSS2, chk(launch_loss_graph(a, st)));
+  if (rc2) return rc2;
+  return TIMED(CMLPL_K_LOSS_DFEAT, chk(launch_loss_dfeat(a, st)));
+}
+
 int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
                        const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
                        const cmlpl_hparams* hp, float* d_scalars, float* d_dlogits, float* d_dfeat,
@@ -646,9 +699,10 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
   const int train = 1;
   int rc;
   const cmlpl_shard sh = {io->bt, io->btu, 0, io->bt, 0, io->btu};
-  const cmlpl_batch batch = {io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->noise8, io->bt, io->btu};
+  const cmlpl_batch batch = {io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->d_labels, io->noise8, io->bt, io->btu};
   if ((rc = cmlpl_forward(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
-                          io->step, io->d_logits, io->d_feat, io->d_workspace, io->workspace_bytes, stream))) return rc;
+                          io->step, io->d_logits, io->d_feat, nullptr, io->d_workspace, io->workspace_bytes, stream)))
+    return rc;
   if ((rc = cmlpl_loss_fwd_bwd(shape, io->bt, io->btu, io->d_logits, io->d_feat, io->d_labels, &io->banks,
                                io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, sw.probs, sw.loss,
                                loss_ws_floats(n, n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream)))

@@ -22,6 +22,7 @@ struct AugArgs {
   int bt, btu, lab0, unl_base;                    // local rows and their global sample indices
   float sigma; int nets; int explicit_noise; uint64_t seed, step;
   int t0;                                         // first tensor handled by this launch (blockIdx.z = 0)
+  const long long* labels; float* labels_f;       // optional: labels as float, for the packed exchange buffer
 };
 
 __global__ void augment_kernel(AugArgs a) {
@@ -32,6 +33,8 @@ __global__ void augment_kernel(AugArgs a) {
   // augmented values are identical whether this kernel or they form them).  The source is read once and written
   // once per network, each network with its own Philox stream.
   const int base = blockIdx.x * 1024 + 4 * threadIdx.x;
+  if (a.labels_f != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < a.bt; i += 256) a.labels_f[i] = (float)a.labels[i];
   if (blockIdx.x * 1024 >= per) return;
   const bool lab = s < a.bt;
   const int sl = lab ? s : s - a.bt;
@@ -74,9 +77,9 @@ __global__ void augment_kernel(AugArgs a) {
 hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
-                          float* xn, float* sn, float* snT, hipStream_t st) {
+                          float* xn, float* sn, float* snT, hipStream_t st, const long long* labels, float* labels_f) {
   AugArgs a;
-  a.snT = snT;
+  a.snT = snT; a.labels = labels; a.labels_f = (labels != nullptr) ? labels_f : nullptr;
   a.srcl[0] = xpl; a.srcl[1] = xl; a.srcu[0] = xpu; a.srcu[1] = xu;
   for (int i = 0; i < 8; ++i) a.noise[i] = noise8 ? noise8[i] : nullptr;
   a.dst[0] = xn; a.dst[1] = sn;

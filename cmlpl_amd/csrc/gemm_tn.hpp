@@ -45,7 +45,9 @@ __device__ __forceinline__ void gemm_tn_block(const GemmTN2& t, int bid, GemmTNS
       const int r = 2 * (tb + q) + hh;
       const bool rv = (tb + q < t1) && (r < R);
       const int rc = rv ? r : 0;
-      const float a = ap[(long long)rc * g.lda], b = bp[(long long)rc * g.ldb];
+      const long long bo = g.b_seg_rows > 0 ? (long long)(rc / g.b_seg_rows) * g.b_seg_stride + (long long)(rc % g.b_seg_rows) * g.ldb
+                                            : (long long)rc * g.ldb;
+      const float a = ap[(long long)rc * g.lda], b = bp[bo];
       av[q] = (rv && iv) ? a : 0.f;
       bv[q] = (rv && jv) ? b : 0.f;
     }

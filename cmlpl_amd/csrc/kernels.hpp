@@ -54,7 +54,8 @@ inline hipError_t ensure_max_lds(DevOnce& once, Ks... kernels) {
 hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
-                          float* xn, float* sn, float* snT, hipStream_t st);
+                          float* xn, float* sn, float* snT, hipStream_t st,
+                          const long long* labels = nullptr, float* labels_f = nullptr);
 hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
                               long long* labels_g, hipStream_t st);
 
@@ -125,6 +126,7 @@ struct GemmTN {
   long long a_bstride, b_bstride, c_bstride, bias_bstride;
   int lda, ldb, ldc, M, N, R, batches;
   float scale;
+  int b_seg_rows = 0; long long b_seg_stride = 0;   // > 0: row r of B lives at (r / seg_rows) * seg_stride + (r % seg_rows) * ldb
 };
 hipError_t launch_gemm_tn(const GemmTN& g, hipStream_t st);
 hipError_t launch_gemm_tn2(const GemmTN& g0, const GemmTN& g1, hipStream_t st);   // two problems, one launch
@@ -142,7 +144,10 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
 
 // ---- loss.hip   (row-sharded: see the header of loss.hip)
 struct LossArgs {
-  const float* logits; const float* feat; const int64_t* labels;   // GLOBAL [2][n][K], [2][n][1024], [bt]
+  const float* logits; const float* feat; const int64_t* labels;   // GLOBAL [2][n][K], [2][n][1024], [bt]  (plain mode)
+  // packed mode (recv != null): the global rows are read where the all-gather left them, rank-major blocks
+  // [W][ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels as float ] with per-rank rows [labelled ; unlabelled]
+  const float* recv; long long pack; int bt_l, btu_l;
   const float* bank_f[2]; const float* bank_p[2];
   float* bank_fw[2]; float* bank_pw[2];
   int Q, ptr0, ptr1;

@@ -62,6 +62,34 @@ __device__ __forceinline__ const float* prob_row(const LossArgs& a, int which, i
   return a.probs_g + (((long long)sh * 4 + which) * a.pshard + l) * a.K;
 }
 
+// Global rows by (network, labelled/unlabelled, index): one buffer in plain mode, or the rank-major blocks of the
+// all-gather in packed mode (no re-ordering copy: the block of rank r holds that rank's rows [labelled ; unlabelled]).
+__device__ __forceinline__ const float* feat_lab(const LossArgs& a, int net, int g) {
+  if (a.recv == nullptr) return a.feat + ((long long)net * (a.bt + a.btu) + g) * FD;
+  const int r = g / a.bt_l, i = g - r * a.bt_l, n_l = a.bt_l + a.btu_l;
+  return a.recv + r * a.pack + 2LL * n_l * a.K + ((long long)net * n_l + i) * FD;
+}
+__device__ __forceinline__ const float* feat_unl(const LossArgs& a, int net, int g) {
+  if (a.recv == nullptr) return a.feat + ((long long)net * (a.bt + a.btu) + a.bt + g) * FD;
+  const int r = g / a.btu_l, i = g - r * a.btu_l, n_l = a.bt_l + a.btu_l;
+  return a.recv + r * a.pack + 2LL * n_l * a.K + ((long long)net * n_l + a.bt_l + i) * FD;
+}
+__device__ __forceinline__ const float* logit_lab(const LossArgs& a, int net, int g) {
+  if (a.recv == nullptr) return a.logits + ((long long)net * (a.bt + a.btu) + g) * a.K;
+  const int r = g / a.bt_l, i = g - r * a.bt_l, n_l = a.bt_l + a.btu_l;
+  return a.recv + r * a.pack + ((long long)net * n_l + i) * a.K;
+}
+__device__ __forceinline__ const float* logit_unl(const LossArgs& a, int net, int g) {
+  if (a.recv == nullptr) return a.logits + ((long long)net * (a.bt + a.btu) + a.bt + g) * a.K;
+  const int r = g / a.btu_l, i = g - r * a.btu_l, n_l = a.bt_l + a.btu_l;
+  return a.recv + r * a.pack + ((long long)net * n_l + a.bt_l + i) * a.K;
+}
+__device__ __forceinline__ int label_of(const LossArgs& a, int g) {
+  if (a.recv == nullptr) return (int)a.labels[g];
+  const int r = g / a.bt_l, i = g - r * a.bt_l, n_l = a.bt_l + a.btu_l;
+  return (int)(a.recv[r * a.pack + 2LL * n_l * a.K + 2LL * n_l * FD + i] + 0.5f);
+}
+
 // One workgroup per 32x32 tile of one product; the 1024-long contraction is split over the 4 waves (256
 // each = 8 lines of 128 B per row).  Loading MFMA fragments straight from memory would touch 32 different
 // 128-B lines per instruction and use a quarter of each (measured: ~500 MB of L1<->L2 traffic per launch,
@@ -77,11 +105,9 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
   if (prob < 2 && !a.smooth) return;
-  const int n = a.bt + a.btu, btu = a.btu, nunl = a.nunl, K = a.K;
-  const float* fU_s = a.feat + (long long)a.bt * FD;             // all unlabelled rows, Base
-  const float* fU_w = a.feat + ((long long)n + a.bt) * FD;       // all unlabelled rows, Base1
-  const float* A = ((prob == 0) ? fU_w : fU_s) + (long long)a.unl0 * FD;   // local rows
-  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : fU_w;
+  const int btu = a.btu, nunl = a.nunl, K = a.K;
+  const float* A = feat_unl(a, prob == 0 ? 1 : 0, a.unl0);        // local rows (one rank's block: contiguous)
+  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : nullptr;   // prob 2: fU_w, all rows
   const int NB = (prob < 2) ? a.Q : btu;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   if (c0 >= NB || r0 >= nunl) return;
@@ -93,14 +119,16 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   // (named registers, not arrays: loop-carried arrays end up in scratch)
   const long long ko = wave * 256 + c8 * 4;
 #define CMLPL_ROWPTR(base, r, lim) ((base) + (long long)((r) < (lim) ? (r) : 0) * FD + ko)
+#define CMLPL_BROW(r) ((B != nullptr ? B + (long long)((r) < NB ? (r) : 0) * FD : feat_unl(a, 1, (r) < NB ? (r) : 0)) + ko)
   const float* la0 = CMLPL_ROWPTR(A, r0 + r8, nunl);
   const float* la1 = CMLPL_ROWPTR(A, r0 + 8 + r8, nunl);
   const float* la2 = CMLPL_ROWPTR(A, r0 + 16 + r8, nunl);
   const float* la3 = CMLPL_ROWPTR(A, r0 + 24 + r8, nunl);
-  const float* lb0 = CMLPL_ROWPTR(B, c0 + r8, NB);
-  const float* lb1 = CMLPL_ROWPTR(B, c0 + 8 + r8, NB);
-  const float* lb2 = CMLPL_ROWPTR(B, c0 + 16 + r8, NB);
-  const float* lb3 = CMLPL_ROWPTR(B, c0 + 24 + r8, NB);
+  const float* lb0 = CMLPL_BROW(c0 + r8);
+  const float* lb1 = CMLPL_BROW(c0 + 8 + r8);
+  const float* lb2 = CMLPL_BROW(c0 + 16 + r8);
+  const float* lb3 = CMLPL_BROW(c0 + 24 + r8);
+#undef CMLPL_BROW
 #undef CMLPL_ROWPTR
   float4 a0 = *(const float4*)la0, a1 = *(const float4*)la1, a2 = *(const float4*)la2, a3 = *(const float4*)la3;
   float4 b0 = *(const float4*)lb0, b1 = *(const float4*)lb1, b2 = *(const float4*)lb2, b3 = *(const float4*)lb3;
@@ -215,11 +243,9 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
   if (prob < 2 && !a.smooth) return;
-  const int n = a.bt + a.btu, btu = a.btu, nunl = a.nunl, K = a.K;
-  const float* fU_s = a.feat + (long long)a.bt * FD;
-  const float* fU_w = a.feat + ((long long)n + a.bt) * FD;
-  const float* A = ((prob == 0) ? fU_w : fU_s) + (long long)a.unl0 * FD;
-  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : fU_w;
+  const int btu = a.btu, nunl = a.nunl, K = a.K;
+  const float* A = feat_unl(a, prob == 0 ? 1 : 0, a.unl0);
+  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : nullptr;
   const int NB = (prob < 2) ? a.Q : btu;
   const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 32;
   if (c0 >= NB || r0 >= nunl) return;
@@ -231,7 +257,8 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
   const float* pa1 = CMLPL_ROWPTR(A, r0 + 32 + lr, nunl);
   const float* pa2 = CMLPL_ROWPTR(A, r0 + 64 + lr, nunl);
   const float* pa3 = CMLPL_ROWPTR(A, r0 + 96 + lr, nunl);
-  const float* pb = CMLPL_ROWPTR(B, c0 + lr, NB);
+  const float* pb = (B != nullptr ? B + (long long)(c0 + lr < NB ? c0 + lr : 0) * FD
+                                  : feat_unl(a, 1, c0 + lr < NB ? c0 + lr : 0)) + c8 * 4;
 #undef CMLPL_ROWPTR
   // two register sets: set 0 carries the even lines, set 1 the odd ones, each requested TWO lines before it is
   // written to LDS (one line is only 16 MFMAs per wave -- not enough to cover an L2 round trip)
@@ -355,11 +382,11 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
 // instructions loss_rows_kernel uses (bit-identical).
 __device__ __forceinline__ void bank_write_block(const LossArgs& a, int r) {
   const int tid = threadIdx.x, lane = tid & 63;
-  const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K, Q = a.Q;
+  const int btu = a.btu, K = a.K, Q = a.Q;
   const int d0 = (a.ptr0 + r) % Q, d1 = (a.ptr1 + r) % Q;
   const float *s0, *s1;
-  if (r < btu) { s0 = a.feat + ((long long)n + bt + r) * FD; s1 = a.feat + ((long long)bt + r) * FD; }
-  else         { s0 = a.feat + (long long)(r - btu) * FD;    s1 = a.feat + ((long long)n + r - btu) * FD; }
+  if (r < btu) { s0 = feat_unl(a, 1, r); s1 = feat_unl(a, 0, r); }
+  else         { s0 = feat_lab(a, 0, r - btu); s1 = feat_lab(a, 1, r - btu); }
   const float4 v0 = ((const float4*)s0)[tid], v1 = ((const float4*)s1)[tid];
   ((float4*)(a.bank_fw[0] + (long long)d0 * FD))[tid] = v0;
   ((float4*)(a.bank_fw[1] + (long long)d1 * FD))[tid] = v1;
@@ -368,14 +395,14 @@ __device__ __forceinline__ void bank_write_block(const LossArgs& a, int r) {
     float q0, q1;
     if (r < btu) {
       const float NEG = -3.0e38f;
-      const float zs = kv ? a.logits[((long long)bt + r) * K + lane] : NEG;
-      const float zw = kv ? a.logits[((long long)n + bt + r) * K + lane] : NEG;
+      const float zs = kv ? logit_unl(a, 0, r)[lane] : NEG;
+      const float zw = kv ? logit_unl(a, 1, r)[lane] : NEG;
       const float mxs = wave_max(zs), mxw = wave_max(zw);
       const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
       const float ses = wave_sum(es), sew = wave_sum(ew);
       q0 = ew / sew; q1 = es / ses;                      // "probs" (Base1) -> bank0, "probs1" (Base) -> bank1
     } else {
-      const int yl = (int)a.labels[r - btu];
+      const int yl = label_of(a, r - btu);
       q0 = q1 = (lane == yl) ? 1.f : 0.f;
     }
     if (kv) {
@@ -398,10 +425,10 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const float NEG = -3.0e38f;
   if (idx < nlab) {
     const int il = idx, ig = a.lab0 + il;                 // local / global labelled row
-    const int yl = (int)a.labels[ig];
+    const int yl = label_of(a, ig);
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
-      const float z = kv ? a.logits[((long long)net * n + ig) * K + lane] : NEG;
+      const float z = kv ? logit_lab(a, net, ig)[lane] : NEG;
       const float mx = wave_max(z);
       const float ez = kv ? expf(z - mx) : 0.f;
       const float se = wave_sum(ez);
@@ -425,8 +452,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     return;
   }
   const int i = idx - nlab, ig = a.unl0 + i;               // local / global unlabelled row
-  const float zs = kv ? a.logits[((long long)bt + ig) * K + lane] : NEG;
-  const float zw = kv ? a.logits[((long long)n + bt + ig) * K + lane] : NEG;
+  const float zs = kv ? logit_unl(a, 0, ig)[lane] : NEG;
+  const float zw = kv ? logit_unl(a, 1, ig)[lane] : NEG;
   const float mxs = wave_max(zs), mxw = wave_max(zw);
   const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
   const float ses = wave_sum(es), sew = wave_sum(ew);
@@ -629,14 +656,29 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   // dfeat_s[local rows] = G . fU_w            : C[i][d] = sum_l GT[l][i] * fU_w[l][d]   (R = btu, M = nunl)
   GemmTN g;
   g.A = a.GT; g.lda = a.nunl; g.M = a.nunl; g.R = btu;
-  g.B = a.feat + ((long long)n + bt) * FD; g.ldb = FD; g.N = FD;
+  g.b_seg_rows = 0; g.b_seg_stride = 0;
+  if (a.recv == nullptr) {
+    g.B = a.feat + ((long long)n + bt) * FD;
+  } else {   // fU_w of all ranks, read from the rank-major blocks: row r -> block r / btu_l
+    const long long n_l = a.bt_l + a.btu_l;
+    g.B = a.recv + 2 * n_l * a.K + (n_l + a.bt_l) * FD;
+    g.b_seg_rows = a.btu_l; g.b_seg_stride = a.pack;
+  }
+  g.ldb = FD; g.N = FD;
   g.C = a.dfeat + (long long)a.nlab * FD; g.ldc = FD;
   g.a_bstride = g.b_bstride = g.c_bstride = 0; g.bias = nullptr; g.bias_bstride = 0; g.batches = 1; g.scale = 1.f;
   g.bias_in = nullptr; g.bias_in_bstride = 0; g.relu = 0;
   // dfeat_w[all rows] (this shard's partial) = G^T . fU_s[local] : C[l][d] = sum_i G[i][l] * fU_s[unl0+i][d]
   GemmTN h = g;
+  h.b_seg_rows = 0; h.b_seg_stride = 0;
   h.A = a.G; h.lda = btu; h.M = btu; h.R = a.nunl;
-  h.B = a.feat + ((long long)bt + a.unl0) * FD;
+  if (a.recv == nullptr) {
+    h.B = a.feat + ((long long)bt + a.unl0) * FD;
+  } else {   // this rank's fU_s rows: one block, contiguous
+    const long long n_l = a.bt_l + a.btu_l;
+    const int r = a.unl0 / a.btu_l, i0 = a.unl0 - r * a.btu_l;
+    h.B = a.recv + r * a.pack + 2 * n_l * a.K + (a.bt_l + i0) * FD;
+  }
   h.C = a.dfw_part;
   (void)e;
   GemmTN2 t;

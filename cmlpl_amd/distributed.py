@@ -61,6 +61,16 @@ class SingleComm:
     def all_reduce(self, t): pass
 
 
+class NoOpComm:
+    """world size 1: a one-rank collective is the identity, and the engine aliases the buffers on both sides of it
+    (see DistTrainEngine._bind), so nothing is launched."""
+    world, rank = 1, 0
+
+    def all_gather(self, out, inp): assert out.data_ptr() == inp.data_ptr()
+    def reduce_scatter(self, out, inp): assert out.data_ptr() == inp.data_ptr()
+    def all_reduce(self, t): pass
+
+
 def drive_step(engine, comm, *fwd_args, **fwd_kw) -> None:
     """Run the stages of one sharded step with the collective that follows each of them.  ``engine``
     provides STAGES, stage_<name>() and exchange_after(name) -> [(kind, out, inp)] (DistTrainEngine, or the
@@ -93,7 +103,9 @@ class DistTrainEngine(TrainEngine):
                  hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, comm=None, hist_rows: int = 1):
         if comm is None:
             import torch.distributed as dist
-            comm = TorchDistComm() if (dist.is_available() and dist.is_initialized()) else SingleComm()
+            comm = TorchDistComm() if (dist.is_available() and dist.is_initialized()) else NoOpComm()
+        if comm.world == 1 and isinstance(comm, (TorchDistComm, SingleComm)):
+            comm = NoOpComm()      # identity collectives: alias instead of launching RCCL copies
         self.comm = comm
         W = self.world = comm.world
         self.rank = comm.rank
@@ -135,7 +147,9 @@ class DistTrainEngine(TrainEngine):
         self.bt_g, self.btu_g, self.n_g = bt_l * W, btu_l * W, n_l * W
         nk, nf = 2 * n_l * K, 2 * n_l * FEAT_DIM
         self.pack_len = nk + nf + bt_l
-        self.pack, self.recv = self._pack[:self.pack_len], self._recv[:W * self.pack_len]
+        alias = isinstance(self.comm, NoOpComm)
+        self.pack = self._pack[:self.pack_len]
+        self.recv = self.pack if alias else self._recv[:W * self.pack_len]
         self.logits_l = self.pack[:nk].view(2, n_l, K)
         self.feat_l = self.pack[nk:nk + nf].view(2, n_l, FEAT_DIM)
         self.labels_f = self.pack[nk + nf:]
@@ -143,10 +157,11 @@ class DistTrainEngine(TrainEngine):
         self.feat_g = self._feat_g[:2 * self.n_g * FEAT_DIM].view(2, self.n_g, FEAT_DIM)
         self.labels_g = self._labels_g[:self.bt_g]
         self.probs_l = self._probs_l[:4 * btu_l * K].view(4, btu_l, K)
-        self.probs_g = self._probs_g[:W * 4 * btu_l * K].view(W, 4, btu_l, K)
+        self.probs_g = self.probs_l.view(1, 4, btu_l, K) if alias else self._probs_g[:W * 4 * btu_l * K].view(W, 4, btu_l, K)
         self.dlogits_l = self._dlogits_l[:nk].view(2, n_l, K)
         self.dfeat_l = self._dfeat_l[:nf].view(2, n_l, FEAT_DIM)
-        self.dfw_part = self._dfw_part[:self.btu_g * FEAT_DIM].view(self.btu_g, FEAT_DIM)
+        # world 1: the column-side gradient partial IS this rank's slice of dfeat
+        self.dfw_part = self.dfeat_l[1, bt_l:] if alias else self._dfw_part[:self.btu_g * FEAT_DIM].view(self.btu_g, FEAT_DIM)
         self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
         self._bound = (bt_l, btu_l)
 
@@ -187,37 +202,37 @@ class DistTrainEngine(TrainEngine):
         if dropmask is not None:
             _chk_f32(dropmask, (2, n_l, s.cls_in), "dropmask")
         self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
-        batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), noise8, bt_l, btu_l)
+        batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), Y.data_ptr(), noise8, bt_l, btu_l)
         self._ctx = dict(epoch=epoch, batch_index=batch_index, apply_update=apply_update, dropmask=dropmask,
                          smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
-                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)), keep=(keep, XPl, Xl, XPu, Xu, noise),
+                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)), keep=(keep, XPl, Xl, Y, XPu, Xu, noise),
                          batch=batch)
         # augmentation + both forwards; the raw rows are handed over as they are (no augmented copy in HBM)
         _lib.check("cmlpl_forward", lib.cmlpl_forward(
             C.byref(self.cshape), C.byref(self._chp), C.byref(batch), C.byref(self.cshard), self.params.data_ptr(),
             self.packed.data_ptr(), None if dropmask is None else dropmask.data_ptr(), 1, self.seed, self.step_count,
-            self.logits_l.data_ptr(), self.feat_l.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), st))
-        self.labels_f.copy_(Y)
+            self.logits_l.data_ptr(), self.feat_l.data_ptr(), self.labels_f.data_ptr(), self.workspace.data_ptr(),
+            self.workspace.numel(), st))     # logits | feat | labels land directly in the packed exchange buffer
+
+    def _gathered(self) -> _lib.Gathered:
+        return _lib.Gathered(self.recv.data_ptr(), self.world, self.bt_l, self.btu_l)
 
     def stage_phase1(self):
+        # the loss kernels read the global rows where the all-gather left them (rank-major blocks): no re-ordering copy
         c, st = self._ctx, self._stream()
-        _lib.check("cmlpl_dist_unpack", self.lib.cmlpl_dist_unpack(
-            C.byref(self.cshape), self.world, self.bt_l, self.btu_l, self.recv.data_ptr(),
-            self.logits_g.data_ptr(), self.feat_g.data_ptr(), self.labels_g.data_ptr(), st))
-        banks = self._banks()
-        _lib.check("cmlpl_loss_phase1", self.lib.cmlpl_loss_phase1(
-            C.byref(self.cshape), C.byref(self.cshard), self.logits_g.data_ptr(), self.feat_g.data_ptr(),
-            self.labels_g.data_ptr(), C.byref(banks), c["smooth"], c["adap"], C.byref(self._chp),
-            self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.probs_l.data_ptr(), self.loss_ws.data_ptr(),
-            self.loss_ws.numel(), st))
+        banks, g = self._banks(), self._gathered()
+        self._unpacked = False
+        _lib.check("cmlpl_loss_phase1_g", self.lib.cmlpl_loss_phase1_g(
+            C.byref(self.cshape), C.byref(self.cshard), C.byref(g), C.byref(banks), c["smooth"], c["adap"],
+            C.byref(self._chp), self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.probs_l.data_ptr(),
+            self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
 
     def stage_phase2(self):
         c, st = self._ctx, self._stream()
-        banks = self._banks()
-        _lib.check("cmlpl_loss_phase2", self.lib.cmlpl_loss_phase2(
-            C.byref(self.cshape), C.byref(self.cshard), self.logits_g.data_ptr(), self.feat_g.data_ptr(),
-            self.labels_g.data_ptr(), C.byref(banks), c["smooth"], c["adap"], C.byref(self._chp),
-            self.probs_g.data_ptr(), self.btu_l, self.scalars.data_ptr(), self.dfeat_l.data_ptr(),
+        banks, g = self._banks(), self._gathered()
+        _lib.check("cmlpl_loss_phase2_g", self.lib.cmlpl_loss_phase2_g(
+            C.byref(self.cshape), C.byref(self.cshard), C.byref(g), C.byref(banks), c["smooth"], c["adap"],
+            C.byref(self._chp), self.probs_g.data_ptr(), self.btu_l, self.scalars.data_ptr(), self.dfeat_l.data_ptr(),
             self.dfw_part.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
 
     def stage_backward(self):
@@ -263,7 +278,14 @@ class DistTrainEngine(TrainEngine):
         drive_step(self, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update)
 
     def outputs(self):
-        """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..]."""
+        """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..], in global row order [labelled of all
+        ranks ; unlabelled of all ranks] (re-ordered on demand from the gathered blocks; the step itself never
+        makes this copy)."""
+        if not getattr(self, "_unpacked", False):
+            _lib.check("cmlpl_dist_unpack", self.lib.cmlpl_dist_unpack(
+                C.byref(self.cshape), self.world, self.bt_l, self.btu_l, self.recv.data_ptr(),
+                self._logits_g.data_ptr(), self._feat_g.data_ptr(), self._labels_g.data_ptr(), self._stream()))
+            self._unpacked = True
         return self.logits_g, self.feat_g
 
     def read_scalars(self):

@@ -141,6 +141,7 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n,
 typedef struct cmlpl_batch {
   const float* d_xpl; const float* d_xl;   /* [bt][C][H][W], [bt][bands]   */
   const float* d_xpu; const float* d_xu;   /* [btu][C][H][W], [btu][bands] */
+  const int64_t* d_labels;                 /* [bt] (may be NULL where no entry point reads it) */
   const float* const* noise8;
   int32_t bt, btu;
 } cmlpl_batch;
@@ -155,7 +156,9 @@ int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
                   const cmlpl_shard* shard /* NULL = one GPU */,
                   const float* d_params /* [2][param_total] */, const float* d_packed /* [2][packed_total] */,
                   const float* d_dropmask, int train, uint64_t seed, uint64_t step,
-                  float* d_logits, float* d_feat, void* d_workspace, size_t workspace_bytes, void* stream);
+                  float* d_logits, float* d_feat,
+                  float* d_labels_f /* optional [bt]: the labels as float, written for the packed exchange buffer */,
+                  void* d_workspace, size_t workspace_bytes, void* stream);
 int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
                    const cmlpl_shard* shard,
                    const float* d_params, const float* d_packed,
@@ -210,6 +213,24 @@ int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard,
                       const float* d_probs_global, int probs_shard_rows,
                       float* d_scalars, float* d_dfeat, float* d_dfeat_w_partial,
                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The loss phases reading the global rows WHERE THE ALL-GATHER LEFT THEM (no re-ordering copy): d_recv holds
+ * `world` rank-major blocks [ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels as float ] (n_l = bt_local + btu_local,
+ * per-rank rows [labelled ; unlabelled]) -- the buffer cmlpl_forward's outputs and d_labels_f are laid out for.
+ * Otherwise identical to cmlpl_loss_phase1 / _phase2. */
+typedef struct cmlpl_gathered {
+  const float* d_recv;
+  int32_t world, bt_local, btu_local;
+} cmlpl_gathered;
+int cmlpl_loss_phase1_g(const cmlpl_shape* shape, const cmlpl_shard* shard, const cmlpl_gathered* gathered,
+                        const cmlpl_banks* banks, int smooth, float adap_mask, const cmlpl_hparams* hp,
+                        float* d_dlogits, float* d_dfeat, float* d_probs_local,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
+int cmlpl_loss_phase2_g(const cmlpl_shape* shape, const cmlpl_shard* shard, const cmlpl_gathered* gathered,
+                        const cmlpl_banks* banks, int smooth, float adap_mask, const cmlpl_hparams* hp,
+                        const float* d_probs_global, int probs_shard_rows,
+                        float* d_scalars, float* d_dfeat, float* d_dfeat_w_partial,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Re-order an all-gathered buffer [world][ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels as float ]
  * (n_l = bt_local + btu_local, per-rank rows [labelled ; unlabelled]) into the global row order. */

@@ -94,8 +94,8 @@ def test_sharded_step_equals_single_gpu_step(W, shape_name, bt, btu, explicit):
         assert [got[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")] == \
                [want[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")]
         lo, fe = ref.outputs()
-        report("logits_g", engines[0].logits_g, lo, 1e-5, 1e-5)     # same kernels; only the tile grouping differs
-        report("feat_g", engines[-1].feat_g, fe, 1e-5, 5e-6)     # after updates: fp32 reduction-order drift
+        report("logits_g", engines[0].outputs()[0], lo, 1e-5, 1e-5)     # same kernels; only the tile grouping differs
+        report("feat_g", engines[-1].outputs()[1], fe, 1e-5, 5e-6)     # after updates: fp32 reduction-order drift
         for net in range(2):
             for k in O.LIVE_KEYS:
                 gr = ref.grad(net, k)
@@ -191,10 +191,10 @@ def test_eight_rank_baseline_configs_match_the_oracle(cfg):
             assert rel_err([got[k] for k in ("total_w", "cls_w", "con_w", "ctr_w")], z["extra"][0], 1e-7) < 1e-4
             assert [got["n_mask_w"], got["n_mask_s"], got["n_pos"], got["n_neg"]] == list(z["counts"][0])
             assert engines[0].ptr == [int(v) for v in z["ptr"][0]]
-            report("golden logits", engines[0].logits_g, z["s0_logits"], 2e-4, 5e-5)
+            report("golden logits", engines[0].outputs()[0], z["s0_logits"], 2e-4, 5e-5)
         lo_ref = torch.stack(ref["logits"])
-        report("logits_g", engines[0].logits_g, lo_ref, 2e-4, 5e-6 * float(lo_ref.abs().max()) + 2e-5)
-        report("feat_g", engines[-1].feat_g, torch.stack(ref["feats"]), 1e-5, 3e-6)
+        report("logits_g", engines[0].outputs()[0], lo_ref, 2e-4, 5e-6 * float(lo_ref.abs().max()) + 2e-5)
+        report("feat_g", engines[-1].outputs()[1], torch.stack(ref["feats"]), 1e-5, 3e-6)
         for r, e in enumerate(engines):      # every rank's masks sit on the oracle's signs (its own rows)
             rows = list(range(r * bt_l, (r + 1) * bt_l)) + list(range(bt + r * btu_l, bt + (r + 1) * btu_l))
             taps = [{k: v[rows] for k, v in ref["taps"][net].items()} for net in range(2)]

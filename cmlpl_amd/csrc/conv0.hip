@@ -185,47 +185,58 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 // fixed summation order (bit-reproducible, unlike float atomics).  Up to 3 tensors per launch.
 // mode 0: conv0  e = c*64+co -> dW[co*C + c] (c < C), tail 64 -> db
 // mode 1: conv3x3 e = s*4096 + ci*64 + co -> dW[co*576 + ci*9 + s], tail 64 -> db
+// One block = 256 consecutive elements x 4 slices of g: a thread owns 4 consecutive elements (one 16-B load per
+// partial row, a wave reads 1 KiB of a row at a time -- the 4-B-per-lane version read 256-B pieces of rows that lie
+// tens of KB apart and reached 3.1 TB/s), 8 loads in flight, fixed summation order.
 __device__ __forceinline__ void partial_reduce_block(const ReduceTable& t, int bx, int net, float (*red)[64]) {
-  const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
   int pi = 0;
   if (t.count > 1 && bx >= t.p[1].blk0) pi = 1;
   if (t.count > 2 && bx >= t.p[2].blk0) pi = 2;
   const ReduceProb pr = t.p[pi];
-  const int G = pr.G, PS = pr.PS;
-  const int e = (bx - pr.blk0) * 64 + el;
-  const bool ev = e < PS;
-  const float* p = pr.part + (long long)net * G * PS + (ev ? e : 0);
-  float s0 = 0.f, s1 = 0.f;
+  const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
+  const int G = pr.G, PS = pr.PS;                      // PS is a multiple of 4 (64-float tail, 4096-float taps)
+  const int e0 = ((bx - pr.blk0) * 64 + el) * 4;
+  const bool ev = e0 < PS;
+  const float* p = pr.part + (long long)net * G * PS + (ev ? e0 : 0);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
   for (int g0 = sl; g0 < G; g0 += 32) {
-    float v[8];
+    float4 v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int g = g0 + 4 * q;
-      const float x = p[(size_t)(g < G ? g : 0) * PS];
-      v[q] = (g < G) ? x : 0.f;
+      const float4 x = *(const float4*)(p + (size_t)(g < G ? g : 0) * PS);
+      v[q] = (g < G) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    s0 += (v[0] + v[1]) + (v[2] + v[3]);
-    s1 += (v[4] + v[5]) + (v[6] + v[7]);
+#define CMLPL_ADD4(F) s0.F += (v[0].F + v[1].F) + (v[2].F + v[3].F); s1.F += (v[4].F + v[5].F) + (v[6].F + v[7].F);
+    CMLPL_ADD4(x) CMLPL_ADD4(y) CMLPL_ADD4(z) CMLPL_ADD4(w)
+#undef CMLPL_ADD4
   }
-  red[sl][el] = s0 + s1;
+  float4* red4 = (float4*)&red[0][0];                  // [4 slices][64] float4 = 4 KB
+  red4[sl * 64 + el] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
   __syncthreads();
   if (sl == 0 && ev) {
-    const float sum = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    const float4 a = red4[el], b = red4[64 + el], c = red4[128 + el], d = red4[192 + el];
+    const float sum[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                          (a.w + b.w) + (c.w + d.w)};
     const int body = PS - 64;
-    if (e >= body) {
-      pr.db[(long long)net * t.grad_ns + (e - body)] = sum;
-    } else if (pr.mode == 0) {
-      const int c = e >> 6, co = e & 63;
-      if (c < pr.C) pr.dW[(long long)net * t.grad_ns + co * pr.C + c] = sum;
-    } else {
-      const int s = e >> 12, ci = (e >> 6) & 63, co = e & 63;
-      pr.dW[(long long)net * t.grad_ns + co * 576 + ci * 9 + s] = sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j;
+      if (e >= body) {
+        pr.db[(long long)net * t.grad_ns + (e - body)] = sum[j];
+      } else if (pr.mode == 0) {
+        const int c2 = e >> 6, co = e & 63;
+        if (c2 < pr.C) pr.dW[(long long)net * t.grad_ns + co * pr.C + c2] = sum[j];
+      } else {
+        const int s = e >> 12, ci = (e >> 6) & 63, co = e & 63;
+        pr.dW[(long long)net * t.grad_ns + co * 576 + ci * 9 + s] = sum[j];
+      }
     }
   }
 }
 
 __global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t) {
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   partial_reduce_block(t, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t) {
 __global__ __launch_bounds__(256) void reduce_gemm_kernel(ReduceTable t, int reduce_blocks, GemmTN2 g) {
   __shared__ GemmTNShared sh;
   const int bid = (int)blockIdx.x;
-  if (bid < reduce_blocks) partial_reduce_block(t, bid % t.total_blocks, bid / t.total_blocks, (float (*)[64])&sh.ared[0][0]);
+  if (bid < reduce_blocks) partial_reduce_block(t, bid % t.total_blocks, bid / t.total_blocks, (float (*)[64])&sh.red[0][0][0]);   // 4 KB of the 12 KB
   else gemm_tn_block(g, bid - reduce_blocks, sh);
 }
 
@@ -249,7 +260,8 @@ hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, 
 void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db) {
   ReduceProb& p = t.p[t.count++];
   p.part = part; p.dW = dW; p.db = db; p.G = G; p.PS = PS; p.mode = mode; p.C = C; p.blk0 = t.total_blocks;
-  t.total_blocks += (PS + 63) / 64;
+  p.el = 256;
+  t.total_blocks += (PS + 255) / 256;
 }
 
 hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st) {

@@ -13,7 +13,7 @@ namespace cmlpl {
 constexpr int GT_DEPTH = 16;
 
 struct GemmTN2 { GemmTN p[2]; int nblk0; };
-struct GemmTNShared { float red[3][16][64]; float ared[4][64]; };
+struct GemmTNShared { __attribute__((aligned(16))) float red[3][16][64]; float ared[4][64]; };
 
 __device__ __forceinline__ void gemm_tn_block(const GemmTN2& t, int bid, GemmTNShared& sh) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;

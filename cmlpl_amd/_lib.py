@@ -29,7 +29,7 @@ EXPORTS = (
     "cmlpl_dist_unpack", "cmlpl_loss_workspace_bytes", "cmlpl_extract_patches", "cmlpl_ntxent_workspace_bytes", "cmlpl_ntxent_fwd_bwd",
     "cmlpl_unsup_workspace_bytes", "cmlpl_unsup_loss", "cmlpl_memobank_select", "cmlpl_memobank_proto",
     "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
-    "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g",
+    "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g", "cmlpl_memobank_loss",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -72,6 +72,18 @@ class Shard(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("d_xpl", C.c_void_p), ("d_xl", C.c_void_p), ("d_xpu", C.c_void_p), ("d_xu", C.c_void_p),
                 ("d_labels", C.c_void_p), ("noise8", C.POINTER(C.c_void_p)), ("bt", C.c_int32), ("btu", C.c_int32)]
+
+
+class MemobankCall(C.Structure):
+    _fields_ = ([(k, C.c_void_p) for k in ("d_rep", "d_rep_teacher", "d_prob_l", "d_prob_u", "d_label_l", "d_label_u",
+                                           "d_low_mask", "d_high_mask")] +
+                [(k, C.c_int32) for k in ("N", "n_labeled", "K", "D", "queries", "negatives")] +
+                [("d_bank", C.c_void_p), ("d_state", C.c_void_p), ("d_capacity", C.c_void_p), ("capacity_stride", C.c_int32),
+                 ("d_anchor_draw", C.c_void_p), ("d_neg_draw", C.c_void_p), ("seed", C.c_uint64), ("call", C.c_uint64),
+                 ("d_momentum", C.c_void_p), ("d_momentum_on", C.c_void_p), ("ema", C.c_float), ("d_prototype", C.c_void_p),
+                 ("temperature", C.c_float)] +
+                [(k, C.c_void_p) for k in ("d_lists", "d_counts", "d_proto", "d_keys_log", "d_lossq", "d_ganchor", "d_arow",
+                                           "d_drep", "d_total")])
 
 
 class Gathered(C.Structure):
@@ -158,6 +170,7 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_memobank_infonce.argtypes = [vp, i32, i32, vp, i32, vp, vp, i64, vp, i32, i32, i32, vp, i32, i32, f32, f32,
                                            vp, vp, vp, vp]
     lib.cmlpl_memobank_sum.argtypes = [vp, i32, vp, vp]
+    lib.cmlpl_memobank_loss.argtypes = [C.POINTER(MemobankCall), vp]
     lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]

@@ -795,6 +795,35 @@ int cmlpl_memobank_infonce(const float* d_rep, int N, int D, const int32_t* d_po
                                d_lossq, d_ganchor, d_drep, (hipStream_t)stream));
 }
 
+int cmlpl_memobank_loss(const cmlpl_memobank_call* c, void* stream) {
+  if (!c || !c->d_rep || !c->d_rep_teacher || !c->d_prob_l || !c->d_prob_u || !c->d_label_l || !c->d_label_u ||
+      !c->d_low_mask || !c->d_high_mask || !c->d_bank || !c->d_state || !c->d_capacity || !c->d_lists || !c->d_counts ||
+      !c->d_proto || !c->d_lossq || !c->d_ganchor || !c->d_arow || !c->d_drep || !c->d_total)
+    return CMLPL_E_ARG;
+  if (c->N < 1 || c->n_labeled < 0 || c->n_labeled > c->N || c->K < 1 || c->K > 1024 || c->D < 1 || c->queries < 1 ||
+      c->negatives < 1 || c->negatives > 127 || c->capacity_stride < 1 || !(c->temperature > 0.f))
+    return CMLPL_E_ARG;
+  if ((c->d_anchor_draw == nullptr) != (c->d_neg_draw == nullptr)) return CMLPL_E_ARG;
+  if (c->d_momentum && (!c->d_momentum_on || !c->d_prototype)) return CMLPL_E_ARG;
+  MbPrep p;
+  p.prob_l = c->d_prob_l; p.prob_u = c->d_prob_u; p.label_l = c->d_label_l; p.label_u = c->d_label_u;
+  p.low_mask = c->d_low_mask; p.high_mask = c->d_high_mask; p.rep_t = c->d_rep_teacher;
+  p.N = c->N; p.Nl = c->n_labeled; p.K = c->K; p.D = c->D;
+  p.lists = c->d_lists; p.counts = c->d_counts; p.proto = c->d_proto;
+  p.bank = c->d_bank; p.state = c->d_state; p.caps = c->d_capacity; p.cap_stride = c->capacity_stride;
+  p.keys_log = c->d_keys_log;
+  MbLoss l;
+  l.rep = c->d_rep; l.N = c->N; l.D = c->D; l.K = c->K; l.Q = c->queries; l.NN = c->negatives;
+  l.lists = c->d_lists; l.counts = c->d_counts; l.state = c->d_state; l.proto = c->d_proto;
+  l.bank = c->d_bank; l.caps = c->d_capacity; l.cap_stride = c->capacity_stride;
+  l.anchor_draw = (const long long*)c->d_anchor_draw; l.neg_draw = (const long long*)c->d_neg_draw;
+  l.seed = c->seed; l.call = c->call;
+  l.momentum = c->d_momentum; l.momentum_on = c->d_momentum_on; l.ema = c->ema; l.prototype = c->d_prototype;
+  l.temp = c->temperature;
+  l.lossq = c->d_lossq; l.ganchor = c->d_ganchor; l.arow = c->d_arow; l.drep = c->d_drep; l.total = c->d_total;
+  return chk(launch_mb_onepass(p, l, (hipStream_t)stream));
+}
+
 int cmlpl_memobank_sum(const float* d_v, int n, float* d_out, void* stream) {
   if (!d_v || !d_out || n < 1) return CMLPL_E_ARG;
   return chk(launch_mb_sum(d_v, n, d_out, (hipStream_t)stream));

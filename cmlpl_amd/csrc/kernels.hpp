@@ -192,6 +192,28 @@ hipError_t launch_mb_infonce(const float* rep, int D, const int* pool, const lon
                              int Qn, int NN, float temp, float scale, float* lossq, float* ganchor, float* drep,
                              hipStream_t st);
 hipError_t launch_mb_sum(const float* v, int n, float* out, hipStream_t st);
+struct MbPrep {
+  const float* prob_l; const float* prob_u; const float* label_l; const float* label_u;   // [Nl][K], [N-Nl][K]
+  const float* low_mask; const float* high_mask; const float* rep_t;
+  int N, Nl, K, D;
+  int* lists; int* counts; float* proto;
+  float* bank; int* state; const int* caps; int cap_stride;
+  int* keys_log;            // optional [K][2]: (new keys, rows after) of this call, for the host's pointer bookkeeping
+};
+
+struct MbLoss {
+  const float* rep; int N, D, K, Q, NN;
+  const int* lists; const int* counts; const int* state; const float* proto;
+  const float* bank; const int* caps; int cap_stride;
+  const long long* anchor_draw; const long long* neg_draw;   // injected [K][Q], [K][Q*NN] by loop position, or null
+  uint64_t seed, call;                                         // in-kernel draws
+  const float* momentum; const int* momentum_on; float ema;    // [K][Q][D] (or null); device flag "not all zero"
+  float* prototype;                                            // out [K][Q][D] when momentum is given
+  float temp;
+  float* lossq; float* ganchor; int* arow; float* drep; float* total;
+};
+
+hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st);
 size_t unsup_ws_bytes(int B);
 hipError_t launch_unsup(const float* predict, long long* target, const float* teacher, int B, int K, double percent,
                         float* loss, float* dpredict, void* ws, hipStream_t st);

@@ -246,34 +246,43 @@ __global__ __launch_bounds__(256) void us_entropy_kernel(const float* __restrict
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(nvalid, __popcll(b));     // integer count: order-independent
 }
 
-// order statistics a[lo], a[hi] of the valid entropies by rank counting (stable: ties by row index)
-__global__ __launch_bounds__(256) void us_select_kernel(const float* __restrict__ ent, const long long* __restrict__ target, int B,
-                                                        double percent, const int* __restrict__ nvalid,
-                                                        float* __restrict__ sel) {
+// order statistics a[lo], a[hi] of the valid entropies by rank counting (stable: ties by row index).  The B x B
+// comparisons are spread over (row block, column slice) workgroups; the partial ranks meet in integer atomics
+// (order-independent, so the result is deterministic), and a second tiny launch picks the two entropies.
+constexpr int US_SLICES = 16;
+__global__ __launch_bounds__(256) void us_rank_kernel(const float* __restrict__ ent, const long long* __restrict__ target, int B,
+                                                      int* __restrict__ rank) {
   __shared__ float s_e[256];
   __shared__ int s_v[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int n = *nvalid;
-  if (n <= 0) return;
-  const double vidx = (double)(n - 1) * percent / 100.0;
-  const int lo = (int)floor(vidx), hi = lo + 1 < n ? lo + 1 : n - 1;
-  const bool mine = i < B && target[i] != 255;
   const float ei = i < B ? ent[i] : 0.f;
-  int rank = 0;
-  for (int j0 = 0; j0 < B; j0 += 256) {
+  const int per = (((B + US_SLICES - 1) / US_SLICES) + 255) / 256 * 256;
+  const int jb = blockIdx.y * per, je = (jb + per < B) ? jb + per : B;
+  int cnt = 0;
+  for (int j0 = jb; j0 < je; j0 += 256) {
     const int j = j0 + threadIdx.x;
     __syncthreads();
-    s_e[threadIdx.x] = j < B ? ent[j] : 0.f;
-    s_v[threadIdx.x] = (j < B && target[j] != 255) ? 1 : 0;
+    s_e[threadIdx.x] = j < je ? ent[j] : 0.f;
+    s_v[threadIdx.x] = (j < je && target[j] != 255) ? 1 : 0;
     __syncthreads();
-    const int lim = B - j0 < 256 ? B - j0 : 256;
+    const int lim = je - j0 < 256 ? je - j0 : 256;
     for (int t = 0; t < lim; ++t)
-      if (s_v[t]) rank += (s_e[t] < ei || (s_e[t] == ei && j0 + t < i)) ? 1 : 0;
+      if (s_v[t]) cnt += (s_e[t] < ei || (s_e[t] == ei && j0 + t < i)) ? 1 : 0;
   }
-  if (mine) {
-    if (rank == lo) sel[0] = ei;
-    if (rank == hi) sel[1] = ei;
-  }
+  if (i < B && cnt) atomicAdd(rank + i, cnt);
+}
+
+__global__ __launch_bounds__(256) void us_select_kernel(const float* __restrict__ ent, const long long* __restrict__ target, int B,
+                                                        double percent, const int* __restrict__ nvalid,
+                                                        const int* __restrict__ rank, float* __restrict__ sel) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = *nvalid;
+  if (n <= 0 || i >= B || target[i] == 255) return;
+  const double vidx = (double)(n - 1) * percent / 100.0;
+  const int lo = (int)floor(vidx), hi = lo + 1 < n ? lo + 1 : n - 1;
+  const int r = rank[i];
+  if (r == lo) sel[0] = ent[i];
+  if (r == hi) sel[1] = ent[i];
 }
 
 // threshold (numpy 'linear' percentile, evaluated in double like numpy does for a float32 array and a float64
@@ -321,10 +330,17 @@ __global__ __launch_bounds__(256) void us_grad_kernel(const float* __restrict__ 
   const int i = blockIdx.x * 256 + threadIdx.x;
   const float kf = (float)(*kept);
   const float weight = (float)B / kf;                    // :256 (inf / NaN when nothing is kept, like the reference)
-  if (i == 0) {
+  if (blockIdx.x == 0) {                                 // fixed-order sum: per-thread strided partials, then in order
+    __shared__ float s_part[256];
     float s = 0.f;
-    for (int r = 0; r < B; ++r) s += rowloss[r];         // fixed order
-    loss[0] = weight * (s / kf);
+    for (int r = threadIdx.x; r < B; r += 256) s += rowloss[r];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 256; ++k) t += s_part[k];
+      loss[0] = weight * (t / kf);
+    }
   }
   if (i < B) {
     const long long tg = target[i];
@@ -341,6 +357,264 @@ __global__ __launch_bounds__(256) void us_grad_kernel(const float* __restrict__ 
       for (int k = 0; k < K; ++k) g[k] = sc * (expf(p[k] - mx) / se - (k == (int)tg ? 1.f : 0.f));
     }
   }
+}
+
+// ==========================================================================================
+// One-pass form of compute_contra_memobank_loss (no host read-back between the stages): three launches.
+//   mb_prepare_kernel     one workgroup per class: selection lists + counts, class prototype, enqueue of the
+//                         negative keys into the ring, ring state update
+//   mb_infonce_all_kernel one workgroup per (query, loop position): which classes are valid and what the loop
+//                         position means is worked out ON DEVICE from the counts (the reference reads them back
+//                         with .item()); draws either injected or formed in-kernel (Philox, like torch.randint
+//                         statistically); EMA blend of the positive with the momentum prototype in-kernel
+//   mb_scatter_all_kernel anchor-gradient scatter over ALL positions (duplicate rows summed in (position, query)
+//                         order: deterministic) + the fixed-order sum of the per-query losses
+// ==========================================================================================
+__global__ __launch_bounds__(256) void mb_prepare_kernel(MbPrep a) {
+  __shared__ int wtot[3][4];
+  __shared__ int base[3];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, Nl = a.Nl, K = a.K, D = a.D;
+  if (tid < 3) base[tid] = 0;
+  __syncthreads();
+  int* l0 = a.lists + ((size_t)c * 3 + 0) * N;
+  int* l1 = a.lists + ((size_t)c * 3 + 1) * N;
+  int* l2 = a.lists + ((size_t)c * 3 + 2) * N;
+  for (int n0 = 0; n0 < N; n0 += 256) {
+    const int n = n0 + tid;
+    bool f0 = false, f1 = false, f2 = false;
+    if (n < N) {
+      const float* pr = (n < Nl) ? a.prob_l + (size_t)n * K : a.prob_u + (size_t)(n - Nl) * K;
+      const float lab = (n < Nl) ? a.label_l[(size_t)n * K + c] : a.label_u[(size_t)(n - Nl) * K + c];
+      const float pc = pr[c];
+      f0 = (lab * a.low_mask[n]) != 0.f;
+      const bool hv = (lab * a.high_mask[n]) != 0.f;
+      f1 = (pc > 0.3f) && f0;
+      int rank = 0;                                   // position of class c in the descending sort of the row
+      for (int j = 0; j < K; ++j) rank += (pr[j] > pc || (pr[j] == pc && j < c)) ? 1 : 0;
+      const bool cm = (n < Nl) ? (rank < 3 && lab == 0.f) : (rank >= 3 && rank < 9);
+      f2 = (pc < 1.0f) && hv && cm;
+    }
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) { wtot[0][wave] = __popcll(b0); wtot[1][wave] = __popcll(b1); wtot[2][wave] = __popcll(b2); }
+    __syncthreads();
+    int o0 = base[0], o1 = base[1], o2 = base[2];
+    for (int w = 0; w < wave; ++w) { o0 += wtot[0][w]; o1 += wtot[1][w]; o2 += wtot[2][w]; }
+    if (f0) l0[o0 + __popcll(b0 & below)] = n;
+    if (f1) l1[o1 + __popcll(b1 & below)] = n;
+    if (f2) l2[o2 + __popcll(b2 & below)] = n;
+    __syncthreads();
+    if (tid < 3) base[tid] += wtot[tid][0] + wtot[tid][1] + wtot[tid][2] + wtot[tid][3];
+    __syncthreads();
+  }
+  const int cnt0 = base[0], m = base[2];
+  if (tid < 3) a.counts[c * 3 + tid] = base[tid];
+  // the lists were written by this workgroup: make them visible to all of its threads
+  __threadfence_block();
+  __syncthreads();
+  // prototype: mean of the teacher features of the low_valid rows (NaN for an empty class, like torch.mean)
+  for (int d = tid; d < D; d += 256) {
+    float sum = 0.f;
+    for (int i = 0; i < cnt0; ++i) sum += a.rep_t[(size_t)l0[i] * D + d];
+    a.proto[(size_t)c * D + d] = cnt0 > 0 ? sum / (float)cnt0 : __builtin_nanf("");
+  }
+  // dequeue_and_enqueue of the negative keys (only the last `cap` of them can survive)
+  const int cap = a.caps[c];
+  const int rows = a.state[c * 2 + 0], head = a.state[c * 2 + 1];
+  const int j0 = m > cap ? m - cap : 0;
+  float* bc = a.bank + (size_t)c * a.cap_stride * D;
+  for (int j = j0; j < m; ++j) {
+    const int slot = (int)(((long long)head + rows + j) % cap);
+    const float* src = a.rep_t + (size_t)l2[j] * D;
+    for (int d = tid; d < D; d += 256) bc[(size_t)slot * D + d] = src[d];
+  }
+  __syncthreads();                                    // every thread has read the old state
+  if (tid == 0) {
+    const long long total = (long long)rows + m;
+    const long long dropped = total > cap ? total - cap : 0;
+    const int rows_after = (int)(total > cap ? cap : total);
+    a.state[c * 2 + 0] = rows_after;
+    a.state[c * 2 + 1] = (int)(((long long)head + dropped) % cap);
+    if (a.keys_log != nullptr) { a.keys_log[c * 2 + 0] = m; a.keys_log[c * 2 + 1] = rows_after; }
+  }
+}
+
+// valid classes (count of low_valid rows > 0) in class order -> s_valid[0 .. nvalid); K <= 1024
+__device__ __forceinline__ int mb_valid_list(const int* counts, int K, int* s_valid, int* s_cnt, int tid) {
+  if (tid == 0) {
+    int nv = 0;
+    for (int c = 0; c < K; ++c)
+      if (counts[c * 3 + 0] > 0) s_valid[nv++] = c;
+    *s_cnt = nv;
+  }
+  __syncthreads();
+  return *s_cnt;
+}
+
+__global__ __launch_bounds__(256) void mb_infonce_all_kernel(MbLoss a) {
+  __shared__ float s_dot[MB_MAXKEYS], s_kn[MB_MAXKEYS], s_w[MB_MAXKEYS];
+  __shared__ const float* s_key[MB_MAXKEYS];
+  __shared__ float s_an2[4], s_misc[2];
+  __shared__ int s_valid[1024], s_nv;
+  extern __shared__ float s_pos[];                   // [D]: this query's positive key
+  const int q = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = a.D, NN = a.NN, NK = NN + 1, Q = a.Q;
+  const int nv = mb_valid_list(a.counts, a.K, s_valid, &s_nv, tid);
+  const int slot = i * Q + q;
+  if (nv <= 1 || i >= nv) {                          // loss_helper.py:139-145, or no such loop position
+    if (tid == 0) { a.lossq[slot] = 0.f; a.arow[slot] = -1; }
+    return;
+  }
+  const int vc = s_valid[i];
+  const int pool_rows = a.counts[i * 3 + 1];         // position i's anchor pool (the reference's quirk, :158-168)
+  const int rows = a.state[vc * 2 + 0], head = a.state[vc * 2 + 1], cap = a.caps[vc];
+  if (pool_rows == 0 || rows == 0) {                 // :158-172
+    if (tid == 0) { a.lossq[slot] = 0.f; a.arow[slot] = -1; }
+    return;
+  }
+  const float scale = 1.f / (float)nv;
+  const int* pool = a.lists + ((size_t)i * 3 + 1) * a.N;
+  long long ad;
+  if (a.anchor_draw != nullptr) {                    // injected (the caller validates the range; clamp for safety)
+    ad = a.anchor_draw[(size_t)i * Q + q];
+    ad = ad < 0 ? 0 : (ad >= pool_rows ? pool_rows - 1 : ad);
+  } else {
+    const float4 u = philox_uniform4(a.seed, a.call, 0x400 + i, (uint64_t)q);
+    ad = (long long)(u.x * (float)pool_rows);
+    if (ad >= pool_rows) ad = pool_rows - 1;
+  }
+  const int arow = pool[ad];
+  const float* av = a.rep + (size_t)arow * D;
+  const float* bank_c = a.bank + (size_t)vc * a.cap_stride * D;
+  // positive key: the class prototype of POSITION i (:186-192), blended with the momentum prototype (:194-203)
+  {
+    const float* pr = a.proto + (size_t)i * D;
+    const bool blend = a.momentum != nullptr && *a.momentum_on != 0;
+    for (int d = tid; d < D; d += 256) {
+      float v = pr[d];
+      if (blend) v = (1.f - a.ema) * v + a.ema * a.momentum[((size_t)vc * Q + q) * D + d];
+      s_pos[d] = v;
+      if (a.prototype != nullptr) a.prototype[((size_t)vc * Q + q) * D + d] = v;
+    }
+  }
+  for (int j = tid; j < NK; j += 256) {
+    if (j == 0) s_key[0] = s_pos;
+    else {
+      long long r;
+      if (a.neg_draw != nullptr) {
+        r = a.neg_draw[(size_t)i * Q * NN + (size_t)q * NN + (j - 1)];
+        r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+      } else {
+        const int jj = j - 1;
+        const float4 u = philox_uniform4(a.seed, a.call, 0x500 + i, (uint64_t)q * 64 + (jj >> 2));
+        const float uu = (jj & 3) == 0 ? u.x : (jj & 3) == 1 ? u.y : (jj & 3) == 2 ? u.z : u.w;
+        r = (long long)(uu * (float)rows);
+        if (r >= rows) r = rows - 1;
+      }
+      s_key[j] = bank_c + (size_t)(((long long)head + r) % cap) * D;
+    }
+  }
+  {  // |a|^2
+    float s = 0.f;
+    for (int d = tid; d < D; d += 256) { const float v = av[d]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) s_an2[wave] = s;
+  }
+  __syncthreads();
+  const float an = sqrtf((s_an2[0] + s_an2[1]) + (s_an2[2] + s_an2[3]));
+  const float anc = fmaxf(an, 1e-8f);
+  for (int j = wave; j < NK; j += 4) {           // one wave per key: a . k and |k|^2
+    const float* k = s_key[j];
+    float dt = 0.f, kn = 0.f;
+    for (int d = lane; d < D; d += 64) { const float kv = k[d]; dt += av[d] * kv; kn += kv * kv; }
+    dt = wave_sum(dt); kn = wave_sum(kn);
+    if (lane == 0) { s_dot[j] = dt; s_kn[j] = fmaxf(sqrtf(kn), 1e-8f); }
+  }
+  __syncthreads();
+  if (wave == 0) {                               // softmax over the NK logits (NK <= 128: two per lane)
+    float l0 = -3.0e38f, l1 = -3.0e38f, c0 = 0.f, c1 = 0.f;
+    if (lane < NK) { c0 = s_dot[lane] / (anc * s_kn[lane]); l0 = c0 / a.temp; }
+    if (lane + 64 < NK) { c1 = s_dot[lane + 64] / (anc * s_kn[lane + 64]); l1 = c1 / a.temp; }
+    const float mx = wave_max(fmaxf(l0, l1));
+    const float e0 = lane < NK ? expf(l0 - mx) : 0.f, e1 = lane + 64 < NK ? expf(l1 - mx) : 0.f;
+    const float se = wave_sum(e0 + e1);
+    const float first = __shfl(l0, 0, 64);
+    const float g = scale / ((float)Q * a.temp);
+    const float w0 = (e0 / se - (lane == 0 ? 1.f : 0.f)) * g, w1 = (e1 / se) * g;
+    float wc = 0.f;
+    if (lane < NK) { s_w[lane] = w0 / (anc * s_kn[lane]); wc += w0 * c0; }
+    if (lane + 64 < NK) { s_w[lane + 64] = w1 / (anc * s_kn[lane + 64]); wc += w1 * c1; }
+    wc = wave_sum(wc);
+    if (lane == 0) {
+      a.lossq[slot] = (mx + logf(se) - first) * scale / (float)Q;
+      a.arow[slot] = arow;
+      s_misc[0] = wc / (anc * anc);
+      s_misc[1] = (an >= 1e-8f) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();
+  const float selfc = s_misc[0] * s_misc[1];
+  float* go = a.ganchor + (size_t)slot * D;
+  for (int d = tid; d < D; d += 256) {
+    float s = 0.f;
+    for (int j = 0; j < NK; ++j) s += s_w[j] * s_key[j][d];
+    go[d] = s - selfc * av[d];
+  }
+}
+
+// d rep[row] = sum of the anchor gradients of ALL (position, query) slots that drew that row, in slot order
+// (deterministic).  One workgroup per ROW of rep: it collects the slots that drew its row by an ordered compaction
+// of the slot -> row table and writes its row of drep in full (zeros when nobody drew it).  The extra last
+// workgroup sums the per-query losses in fixed order.
+__global__ __launch_bounds__(256) void mb_scatter_all_kernel(MbLoss a, int slots) {
+  extern __shared__ int s_hit[];                  // ordered list of the slots that drew this row
+  __shared__ int wtot[4], s_n;
+  const int r = blockIdx.x, tid = threadIdx.x, D = a.D, lane = tid & 63, wave = tid >> 6;
+  if (r == a.N) {                                 // total loss
+    if (tid == 0) {
+      float t = 0.f;
+      for (int i = 0; i < slots; ++i) t += a.lossq[i];
+      a.total[0] = t;
+    }
+    return;
+  }
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int p0 = 0; p0 < slots; p0 += 256) {       // ordered compaction, 256 slots at a time
+    const int p = p0 + tid;
+    const bool hit = p < slots && a.arow[p] == r;
+    const unsigned long long bal = __ballot(hit);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int o = s_n;
+    for (int w = 0; w < wave; ++w) o += wtot[w];
+    if (hit) s_hit[o + __popcll(bal & below)] = p;
+    __syncthreads();
+    if (tid == 0) s_n += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+  }
+  const int nh = s_n;
+  for (int d = tid; d < D; d += 256) {
+    float sum = 0.f;
+    for (int k = 0; k < nh; ++k) sum += a.ganchor[(size_t)s_hit[k] * D + d];
+    a.drep[(size_t)r * D + d] = sum;
+  }
+}
+
+hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st) {
+  if (la.NN + 1 > MB_MAXKEYS || la.K > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mb_prepare_kernel, dim3(pa.K), dim3(256), 0, st, pa);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(mb_infonce_all_kernel, dim3(la.Q, la.K), dim3(256), (size_t)la.D * 4, st, la);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  const int slots = la.K * la.Q;
+  const size_t lds = (size_t)slots * sizeof(int);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mb_scatter_all_kernel, dim3(la.N + 1), dim3(256), lds, st, la, slots);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -410,7 +684,7 @@ hipError_t launch_mb_sum(const float* v, int n, float* out, hipStream_t st) {
   return hipGetLastError();
 }
 
-size_t unsup_ws_bytes(int B) { return ((size_t)2 * B + 16) * 4; }
+size_t unsup_ws_bytes(int B) { return ((size_t)3 * B + 16) * 4; }
 
 hipError_t launch_unsup(const float* predict, long long* target, const float* teacher, int B, int K, double percent,
                         float* loss, float* dpredict, void* ws, hipStream_t st) {
@@ -418,11 +692,13 @@ hipError_t launch_unsup(const float* predict, long long* target, const float* te
   float* rowloss = ent + B;
   float* sel = rowloss + B;           // [2]
   int* info = (int*)(sel + 2);        // nvalid, kept
-  hipError_t e = hipMemsetAsync(sel, 0, 14 * 4, st);
+  int* rank = (int*)(sel + 16);       // [B]
+  hipError_t e = hipMemsetAsync(sel, 0, ((size_t)B + 16) * 4, st);    // sel, info, rank
   if (e != hipSuccess) return e;
   const int nb = (B + 255) / 256;
   hipLaunchKernelGGL(us_entropy_kernel, dim3(nb), dim3(256), 0, st, teacher, target, B, K, ent, info);
-  hipLaunchKernelGGL(us_select_kernel, dim3(nb), dim3(256), 0, st, ent, target, B, percent, info, sel);
+  hipLaunchKernelGGL(us_rank_kernel, dim3(nb, US_SLICES), dim3(256), 0, st, ent, target, B, rank);
+  hipLaunchKernelGGL(us_select_kernel, dim3(nb), dim3(256), 0, st, ent, target, B, percent, info, rank, sel);
   hipLaunchKernelGGL(us_mask_kernel, dim3(nb), dim3(256), 0, st, predict, target, ent, B, K, percent, info, sel,
                      rowloss, info + 1);
   hipLaunchKernelGGL(us_grad_kernel, dim3(nb), dim3(256), 0, st, predict, target, rowloss, B, K, info + 1, loss, dpredict);

@@ -41,7 +41,21 @@ class MemoryBank:
         self.data = torch.zeros(self.K, self.stride, self.D, device=self.device)
         self.state = torch.zeros(self.K, 2, dtype=torch.int32, device=self.device)     # rows, head
         self.caps = torch.tensor(sizes, dtype=torch.int32, device=self.device)
-        self.ptrs = [0] * self.K                                                        # the reference's queue_ptr
+        self._ptrs = [0] * self.K                                                       # the reference's queue_ptr
+        self.pending = []       # device logs [K][2] = (new keys, rows after) of one-pass calls not yet folded into _ptrs
+        self.calls = 0
+
+    @property
+    def ptrs(self):
+        """the reference's queue_ptr per class; one-pass calls log their enqueue counts on the device and the
+        pointers are brought up to date here, when someone asks (one read-back for all pending calls)"""
+        if self.pending:
+            logs = torch.stack(self.pending).cpu()
+            self.pending = []
+            for log in logs:
+                for c in range(self.K):
+                    self.note_enqueued(c, int(log[c, 1]), int(log[c, 0]))
+        return self._ptrs
 
     # ---- reference-style views -------------------------------------------------------------
     def host_state(self):
@@ -61,7 +75,7 @@ class MemoryBank:
             t = q[0]
             if t.shape[0]:
                 bank.push(c, t)
-            bank.ptrs[c] = int(queue_prtlis[c][0]) if queue_prtlis is not None else bank.ptrs[c]
+            bank._ptrs[c] = int(queue_prtlis[c][0]) if queue_prtlis is not None else bank._ptrs[c]
         return bank
 
     def to_lists(self, memobank, queue_prtlis):
@@ -73,6 +87,7 @@ class MemoryBank:
     # ---- dequeue_and_enqueue (loss_helper.py:19-36) -------------------------------------------
     def push(self, c, keys):
         lib = _lib.load()
+        _ = self.ptrs                        # fold pending one-pass logs in first: pointer updates are ordered
         keys = _f32(keys, self.device)
         m = int(keys.shape[0])
         _lib.check("cmlpl_memobank_push", lib.cmlpl_memobank_push(
@@ -84,7 +99,7 @@ class MemoryBank:
 
     def note_enqueued(self, c, rows_after, m):
         """pointer rule of the reference: `size` once the bank is full, (ptr + m) % size before that"""
-        self.ptrs[c] = self.sizes[c] if rows_after >= self.sizes[c] else (self.ptrs[c] + m) % self.sizes[c]
+        self._ptrs[c] = self.sizes[c] if rows_after >= self.sizes[c] else (self._ptrs[c] + m) % self.sizes[c]
 
 
 def dequeue_and_enqueue(keys, bank: MemoryBank, c: int):
@@ -128,83 +143,77 @@ def unsupervised_loss(predict, target, percent, pred_teacher):
 
 
 def contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, bank: MemoryBank, rep_teacher,
-                         momentum_prototype=None, i_iter=0, draws=None):
-    """compute_contra_memobank_loss (loss_helper.py:39-219) on a device-resident MemoryBank.
+                         momentum_prototype=None, i_iter=0, draws=None, as_tensors=None):
+    """compute_contra_memobank_loss (loss_helper.py:39-219) on a device-resident MemoryBank, in one pass: three
+    kernel launches (cmlpl_memobank_loss) and NO host read-back -- which classes are valid, how many keys were
+    enqueued and what each loop position means is worked out on the device from the counts.
 
-    Returns (new_keys, loss) or (prototype, new_keys, loss) like the reference.  `draws`, if given, is
-    (anchor_idx, neg_idx): dicts loop position -> int64 index tensors replacing the two torch.randint calls
-    (:164, :179); otherwise they are drawn with torch.randint on the device."""
+    Returns (new_keys, loss) or (prototype, new_keys, loss) like the reference.  `new_keys` is a device int32
+    tensor [K] on this fast path (the reference's list of ints would need the read-back); with `as_tensors=False`
+    -- or when `draws` are injected, which is the parity-test path -- it is the reference's list.
+    `draws`, if given, is (anchor_idx, neg_idx): dicts loop position -> int64 index tensors replacing the two
+    torch.randint calls (:164, :179); otherwise the indices are drawn in-kernel (Philox)."""
     lib = _lib.load()
     dev = rep.device
     if dev.type != "cuda":
         raise RuntimeError("cmlpl_amd.memobank needs CUDA (ROCm) tensors: there is no CPU fallback")
+    if as_tensors is None:
+        as_tensors = draws is None
     st = _stream(dev)
     N, D = rep.shape
     K = label_l.shape[1]
     Nl = label_l.shape[0]
     assert bank.K == K and bank.D == D
-    repf = _f32(rep, dev)
-    rept = _f32(rep_teacher, dev)
-    label = torch.cat((_f32(label_l, dev), _f32(label_u, dev)), dim=0).contiguous()
-    prob = torch.cat((_f32(prob_l, dev), _f32(prob_u, dev)), dim=0).contiguous()
-    lowm = _f32(low_mask, dev).reshape(-1)
-    highm = _f32(high_mask, dev).reshape(-1)
-    lists = torch.empty(K, 3, N, dtype=torch.int32, device=dev)
-    counts = torch.empty(K, 3, dtype=torch.int32, device=dev)
-    proto = torch.empty(K, D, device=dev)
-    _lib.check("cmlpl_memobank_select", lib.cmlpl_memobank_select(_p(prob), _p(label), _p(lowm), _p(highm), N, Nl, K,
-                                                                  _p(lists), _p(counts), st))
-    _lib.check("cmlpl_memobank_proto", lib.cmlpl_memobank_proto(_p(rept), N, D, K, _p(lists), _p(counts), _p(proto), st))
-    _lib.check("cmlpl_memobank_enqueue", lib.cmlpl_memobank_enqueue(_p(rept), N, D, K, _p(lists), _p(counts),
-                                                                    _p(bank.data), _p(bank.state), _p(bank.caps),
-                                                                    bank.stride, st))
-    cnt = counts.cpu()                                    # the reference's .item() calls (:135-137)
-    rows, head = bank.host_state()
-    new_keys = [int(cnt[c, 2]) for c in range(K)]
-    for c in range(K):
-        bank.note_enqueued(c, rows[c], new_keys[c])
-    valid = [c for c in range(K) if int(cnt[c, 0]) > 0]
-    if len(valid) <= 1:                                   # :139-145
-        loss = 0.0 * rep.sum()
-        return (new_keys, loss) if momentum_prototype is None else (momentum_prototype, new_keys, loss)
-
-    valid_seg = len(valid)
-    prototype = torch.zeros(K, NUM_QUERIES, 1, D, device=dev) if momentum_prototype is not None else None
-    drep = torch.zeros(N, D, device=dev)
-    lossq = torch.zeros(valid_seg, NUM_QUERIES, device=dev)
-    ganchor = torch.empty(NUM_QUERIES, D, device=dev)
-    keep = []                                             # tensors the enqueued kernels read
-    for i in range(valid_seg):
-        vc = valid[i]
-        pool_rows = int(cnt[i, 1])                        # position i's anchor pool (the reference's quirk, :158-168)
-        if pool_rows == 0 or rows[vc] == 0:
-            continue
-        if draws is not None:
-            a_idx = draws[0][i].to(device=dev, dtype=torch.int64).contiguous()
-            n_idx = draws[1][i].to(device=dev, dtype=torch.int64).contiguous()
-            if int(a_idx.max()) >= pool_rows or int(n_idx.max()) >= rows[vc] or int(a_idx.min()) < 0 or int(n_idx.min()) < 0:
-                raise IndexError("injected draw out of range")
-        else:
-            a_idx = torch.randint(pool_rows, (NUM_QUERIES,), device=dev)
-            n_idx = torch.randint(rows[vc], (NUM_QUERIES * NUM_NEGATIVES,), device=dev)
-        pos = proto[i]                                    # [D], shared by all queries
-        qstride = 0
-        if momentum_prototype is not None:                # :194-203
-            mp = momentum_prototype.to(dev)
-            posq = pos.view(1, 1, D).repeat(NUM_QUERIES, 1, 1)
-            if not bool((mp == 0).all()):
-                ema = min(1 - 1 / i_iter, 0.999)
-                posq = (1 - ema) * posq + ema * mp[vc]
-            prototype[vc] = posq
-            pos = posq.reshape(NUM_QUERIES, D).contiguous()
-            qstride = D
-        keep += [a_idx, n_idx, pos]
-        _lib.check("cmlpl_memobank_infonce", lib.cmlpl_memobank_infonce(
-            _p(repf), N, D, _p(lists[i, 1]), pool_rows, _p(a_idx), _p(pos), qstride, _p(bank.data[vc]),
-            bank.sizes[vc], rows[vc], head[vc], _p(n_idx), NUM_QUERIES, NUM_NEGATIVES, TEMP, 1.0 / valid_seg,
-            _p(lossq[i]), _p(ganchor), _p(drep), st))
-    total = torch.empty(1, device=dev)
-    _lib.check("cmlpl_memobank_sum", lib.cmlpl_memobank_sum(_p(lossq), valid_seg * NUM_QUERIES, _p(total), st))
+    Q, NN = NUM_QUERIES, NUM_NEGATIVES
+    keep = [_f32(t, dev) for t in (rep, rep_teacher, prob_l, prob_u, label_l, label_u)]
+    keep += [_f32(low_mask, dev).reshape(-1), _f32(high_mask, dev).reshape(-1)]
+    i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
+    lists, counts, keys_log, arow = i32(K, 3, N), i32(K, 3), i32(K, 2), i32(K, Q)
+    proto, lossq = torch.empty(K, D, device=dev), torch.empty(K, Q, device=dev)
+    ganchor, drep, total = torch.empty(K, Q, D, device=dev), torch.empty(N, D, device=dev), torch.empty(1, device=dev)
+    c = _lib.MemobankCall()
+    (c.d_rep, c.d_rep_teacher, c.d_prob_l, c.d_prob_u, c.d_label_l, c.d_label_u, c.d_low_mask,
+     c.d_high_mask) = [t.data_ptr() for t in keep]
+    c.N, c.n_labeled, c.K, c.D, c.queries, c.negatives = N, Nl, K, D, Q, NN
+    c.d_bank, c.d_state, c.d_capacity, c.capacity_stride = (bank.data.data_ptr(), bank.state.data_ptr(),
+                                                            bank.caps.data_ptr(), bank.stride)
+    if draws is not None:      # dense [K][..] tensors indexed by loop position
+        a_all = torch.zeros(K, Q, dtype=torch.int64, device=dev)
+        n_all = torch.zeros(K, Q * NN, dtype=torch.int64, device=dev)
+        for i, t in draws[0].items():
+            a_all[i].copy_(t.to(device=dev, dtype=torch.int64))
+        for i, t in draws[1].items():
+            n_all[i].copy_(t.to(device=dev, dtype=torch.int64))
+        keep += [a_all, n_all]
+        c.d_anchor_draw, c.d_neg_draw = a_all.data_ptr(), n_all.data_ptr()
+    bank.calls += 1
+    c.seed, c.call = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, bank.calls
+    prototype = None
+    if momentum_prototype is not None:                    # :194-203
+        mp = _f32(momentum_prototype, dev).reshape(K, Q, D)
+        on = (mp != 0).any().to(torch.int32).reshape(1)    # "not (momentum_prototype == 0).all()", kept on device
+        if i_iter == 0 and bool(on.item()):
+            raise ZeroDivisionError("division by zero")   # ema = min(1 - 1 / i_iter, 0.999), as the reference raises
+        prototype = torch.zeros(K, Q, 1, D, device=dev)
+        keep += [mp, on]
+        c.d_momentum, c.d_momentum_on, c.d_prototype = mp.data_ptr(), on.data_ptr(), prototype.data_ptr()
+        c.ema = min(1 - 1 / i_iter, 0.999) if i_iter else 0.0
+    c.temperature = TEMP
+    (c.d_lists, c.d_counts, c.d_proto, c.d_keys_log, c.d_lossq, c.d_ganchor, c.d_arow, c.d_drep,
+     c.d_total) = [t.data_ptr() for t in (lists, counts, proto, keys_log, lossq, ganchor, arow, drep, total)]
+    _lib.check("cmlpl_memobank_loss", lib.cmlpl_memobank_loss(C.byref(c), st))
+    bank.pending.append(keys_log)                         # pointer bookkeeping is resolved when someone asks
     loss = _Scaled.apply(rep, total[0], drep)
+    if draws is not None:       # parity path: injected indices must have been in range (the kernel clamps them)
+        cnt, (rows, _) = counts.cpu(), bank.host_state()
+        valid = [k for k in range(K) if int(cnt[k, 0]) > 0]
+        if len(valid) > 1:
+            for i, vc in enumerate(valid):
+                if int(cnt[i, 1]) == 0 or rows[vc] == 0:
+                    continue
+                a_i, n_i = draws[0][i], draws[1][i]
+                if int(a_i.max()) >= int(cnt[i, 1]) or int(n_i.max()) >= rows[vc] or int(a_i.min()) < 0 or int(n_i.min()) < 0:
+                    raise IndexError("injected draw out of range")
+    new_keys = keys_log[:, 0] if as_tensors else keys_log[:, 0].tolist()
     del keep
     return (new_keys, loss) if momentum_prototype is None else (prototype, new_keys, loss)

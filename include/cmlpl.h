@@ -324,6 +324,31 @@ int cmlpl_memobank_infonce(const float* d_rep, int N, int D, const int32_t* d_po
                            const float* d_bank_c, int capacity, int bank_rows, int head, const int64_t* d_neg_draw,
                            int queries, int negatives, float temperature, float scale, float* d_lossq,
                            float* d_ganchor, float* d_drep, void* stream);
+/* compute_contra_memobank_loss (loss_helper.py:39-219) in ONE pass -- three launches, no host read-back: selection +
+ * prototypes + enqueue per class; the InfoNCE of every (query, loop position) with the valid-class bookkeeping done
+ * on device from the counts; anchor-gradient scatter + loss sum.  d_* outputs:
+ *   d_lists [K][3][N] i32, d_counts [K][3] i32, d_proto [K][D]: as cmlpl_memobank_select / _proto
+ *   d_keys_log [K][2] i32 (optional): (new keys, rows after) per class, for the caller's pointer bookkeeping
+ *   d_lossq [K][queries], d_ganchor [K][queries][D], d_arow [K][queries] i32: per (position, query) scratch
+ *   d_drep [N][D]: d loss / d rep (written in full);  d_total [1]: the loss
+ * Draws: d_anchor_draw [K][queries] / d_neg_draw [K][queries*negatives] int64 indexed by LOOP POSITION replace the two
+ * torch.randint calls (:164,:179) -- entries must be in range for the positions that exist; NULL = drawn in-kernel
+ * (Philox keyed by seed / call).  d_momentum [K][queries][D] + d_momentum_on (device int: "not all zero", :196) +
+ * ema select the prototype blend of :194-203; then d_prototype [K][queries][D] receives `prototype`. */
+typedef struct cmlpl_memobank_call {
+  const float* d_rep; const float* d_rep_teacher;
+  const float* d_prob_l; const float* d_prob_u; const float* d_label_l; const float* d_label_u;
+  const float* d_low_mask; const float* d_high_mask;
+  int32_t N, n_labeled, K, D, queries, negatives;
+  float* d_bank; int32_t* d_state; const int32_t* d_capacity; int32_t capacity_stride;
+  const int64_t* d_anchor_draw; const int64_t* d_neg_draw; uint64_t seed, call;
+  const float* d_momentum; const int32_t* d_momentum_on; float ema; float* d_prototype;
+  float temperature;
+  int32_t* d_lists; int32_t* d_counts; float* d_proto; int32_t* d_keys_log;
+  float* d_lossq; float* d_ganchor; int32_t* d_arow; float* d_drep; float* d_total;
+} cmlpl_memobank_call;
+int cmlpl_memobank_loss(const cmlpl_memobank_call* call, void* stream);
+
 /* fixed-order sum of n floats (the loss of all loop positions) */
 int cmlpl_memobank_sum(const float* d_v, int n, float* d_out, void* stream);
 

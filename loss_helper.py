@@ -31,7 +31,7 @@ def compute_contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask
                                     momentum_prototype, i_iter, _draws)
     bank = MemoryBank.from_lists(memobank, queue_prtlis, queue_size, rep.shape[1], rep.device)
     out = contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, bank, rep_teacher,
-                               momentum_prototype, i_iter, _draws)
+                               momentum_prototype, i_iter, _draws, as_tensors=False)
     bank.to_lists(memobank, queue_prtlis)
     return out
 

@@ -40,16 +40,21 @@ __device__ __forceinline__ void gemm_tn_block(const GemmTN2& t, int bid, GemmTNS
   float asum = 0.f;
   for (int tb = t0; tb < t1; tb += GT_DEPTH) {
     float av[GT_DEPTH], bv[GT_DEPTH];
+    // segmented B (rows spread over rank-major blocks): one division per batch, then carried (rows advance by 2)
+    int seg = 0, off = 0;
+    if (g.b_seg_rows > 0) { const int r0 = 2 * tb + hh; seg = r0 / g.b_seg_rows; off = r0 - seg * g.b_seg_rows; }
 #pragma unroll
     for (int q = 0; q < GT_DEPTH; ++q) {
       const int r = 2 * (tb + q) + hh;
       const bool rv = (tb + q < t1) && (r < R);
       const int rc = rv ? r : 0;
-      const long long bo = g.b_seg_rows > 0 ? (long long)(rc / g.b_seg_rows) * g.b_seg_stride + (long long)(rc % g.b_seg_rows) * g.ldb
+      const long long bo = g.b_seg_rows > 0 ? (rv ? (long long)seg * g.b_seg_stride + (long long)off * g.ldb : 0)
                                             : (long long)rc * g.ldb;
       const float a = ap[(long long)rc * g.lda], b = bp[bo];
       av[q] = (rv && iv) ? a : 0.f;
       bv[q] = (rv && jv) ? b : 0.f;
+      off += 2;
+      while (g.b_seg_rows > 0 && off >= g.b_seg_rows) { off -= g.b_seg_rows; ++seg; }
     }
 #pragma unroll
     for (int q = 0; q < GT_DEPTH; ++q) {

@@ -191,7 +191,11 @@ def run_rank(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     bt, btu, scaling = per_rank_batch(args, world)
-    device = torch.device(f"cuda:{local_rank}")
+    # CMLPL_ONE_GPU=1 + CMLPL_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a one-GPU box (all ranks on cuda:0;
+    # RCCL refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
+    one_gpu = bool(os.environ.get("CMLPL_ONE_GPU"))
+    backend = os.environ.get("CMLPL_DIST_BACKEND", "nccl")
+    device = torch.device("cuda:0" if one_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
     from cmlpl_amd import HyperParams, NetShape, TrainEngine, _lib
@@ -202,7 +206,10 @@ def run_rank(args):
         import torch.distributed as dist
         if not os.environ.get("MASTER_ADDR"):
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29513", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         from cmlpl_amd.distributed import DistTrainEngine
         eng = DistTrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088)
     else:
@@ -259,7 +266,7 @@ def run_rank(args):
     dt = time.perf_counter() - t0
     _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     scal = eng.read_scalars()

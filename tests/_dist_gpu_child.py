@@ -1,0 +1,67 @@
+"""Child of tests/test_gpu_multiprocess.py: one rank of a REAL multi-process data-parallel job on ONE GPU (every rank
+uses cuda:0; the collectives run on gloo because RCCL refuses two ranks on one device).  The sharded step --
+DistTrainEngine + TorchDistComm, the shipped classes -- runs W ranks on shards of a global batch; rank 0 also runs
+the plain TrainEngine on the whole batch and compares."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from cmlpl_amd import HyperParams, NetShape, TrainEngine  # noqa: E402
+from cmlpl_amd.distributed import DistTrainEngine  # noqa: E402
+from oracle import cmlpl_oracle as O  # noqa: E402  (input generators only)
+
+rank, W = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+shape = O.NetShape(103, 11, 11, 103, 9)
+bt, btu, steps = 32, 64, 3
+hp = HyperParams()
+p0, p1 = O.closed_form_params(shape, 51), O.closed_form_params(shape, 52)
+eng = DistTrainEngine(NetShape(103, 11, 11, 103, 9), bt // W, btu // W, hp, device=dev, seed=5)
+eng.load_state_dict(0, p0); eng.load_state_dict(1, p1)
+ref = None
+if rank == 0:
+    ref = TrainEngine(NetShape(103, 11, 11, 103, 9), bt, btu, hp, device=dev, seed=5)
+    ref.load_state_dict(0, p0); ref.load_state_dict(1, p1)
+bl, bul = bt // W, btu // W
+ls, us = slice(rank * bl, (rank + 1) * bl), slice(rank * bul, (rank + 1) * bul)
+worst = 0.0
+for s in range(steps):
+    b = O.synthetic_batch(shape, bt, btu, 800 + s, separable=1.0)
+    d = lambda t: t.to(dev).contiguous()
+    nz = b["noise"]
+    noise = [d(nz[0][ls]), d(nz[1][ls]), d(nz[2][ls]), d(nz[3][ls]), d(nz[4][us]), d(nz[5][us]), d(nz[6][us]), d(nz[7][us])]
+    dm = torch.stack([torch.cat([m[ls], m[bt:][us]]) for m in b["dropmask"]]).to(dev).contiguous()
+    eng.step(d(b["XPl"][ls]), d(b["Xl"][ls]), d(b["Y"][ls]), d(b["XPu"][us]), d(b["Xu"][us]), 1, s, noise=noise, dropmask=dm)
+    got = eng.read_scalars()                       # all-reduced over the ranks
+    if rank == 0:
+        ref.step(d(b["XPl"]), d(b["Xl"]), d(b["Y"]), d(b["XPu"]), d(b["Xu"]), 1, s, noise=[d(t) for t in nz],
+                 dropmask=torch.stack(b["dropmask"]).to(dev).contiguous())
+        want = ref.read_scalars()
+        for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc", "total_w", "cls_w", "con_w"):
+            assert abs(got[k] - want[k]) <= 1e-5 * abs(want[k]) + 1e-6, (s, k, got[k], want[k])
+        assert [got[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")] == [want[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")]
+        live = eng.live
+        for net in range(2):
+            g, r = eng.grads[net], ref.grads[net, :live]
+            err = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-9)
+            worst = max(worst, err)
+            assert err < 2e-4, (s, net, err)
+        assert eng.ptr == ref.ptr
+        for i in range(2):
+            assert float((eng.bank_feats[i] - ref.bank_feats[i]).abs().max()) < 1e-5
+            assert float((eng.bank_probs[i] - ref.bank_probs[i]).abs().max()) < 1e-5
+# replicas hold identical parameters
+psum = eng.params.double().sum().reshape(1).cpu()
+lst = [torch.zeros_like(psum) for _ in range(W)]
+dist.all_gather(lst, psum)
+assert all(float(x) == float(lst[0]) for x in lst), lst
+if rank == 0:
+    print(f"OK world={W} steps={steps} worst_grad_rel_err={worst:.2e}")
+dist.barrier()
+dist.destroy_process_group()

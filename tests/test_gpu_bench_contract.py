@@ -53,3 +53,23 @@ def test_bench_self_launch_path():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["global_batch"] == 576
     assert d["config"]["parallelism"] == "dp1" and d["value"] > 0
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver types it for N > 1 without torchrun: the parent starts two ranks, they
+    rendezvous, run the sharded step and rank 0's line comes back with n_gpus = 2 and the whole-job value.  One GPU
+    here, so both ranks share it and the collectives run on gloo (CMLPL_ONE_GPU / CMLPL_DIST_BACKEND): this checks
+    the wiring, not the speed."""
+    env = dict(os.environ, CMLPL_ONE_GPU="1", CMLPL_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "8", "--warmup", "2", "--workload", "B3"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 1024
+    assert d["config"]["parallelism"] == "dp2" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 1024 * 1000.0 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert all(v == v for v in d["final_losses"].values())

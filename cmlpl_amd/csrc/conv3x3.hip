@@ -672,11 +672,13 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      float acc = 0.f;
+      if (kc + q < K) {                      // uniform: no reduction for classes that do not exist
+        float acc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) acc = fmaf(xr[i], wv[q][i], acc);
-      const float t = wave_sum(acc);
-      if (lane == 0 && kc + q < K) part[wave * 64 + kc + q] = t;
+        for (int i = 0; i < 5; ++i) acc = fmaf(xr[i], wv[q][i], acc);
+        const float t = wave_sum(acc);
+        if (lane == 0) part[wave * 64 + kc + q] = t;
+      }
     }
   }
   __syncthreads();
@@ -727,6 +729,8 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     const int idx = tid + 256 * q;
     mpre[q] = (idx < P2 * 16) ? *(const uint32_t*)(a.mask_in + (long long)net * a.mask_in_ns + ((size_t)sample * P2 + (idx >> 4)) * 64 + (idx & 15) * 4) : 0u;
   }
+  // conv2's ReLU-mask word of this thread's dz2 item (threads 0..63: pooled pixel tid >> 4, channels 4 (tid & 15)..)
+  const uint32_t m2pre = (tid < 64) ? *(const uint32_t*)(a.m2in + (rs * 4 + (tid >> 4)) * 64 + (tid & 15) * 4) : 0u;
   const float* wc = a.wc + (long long)net * a.p_ns;
   const float* dm = (a.hmask != nullptr) ? a.hmask + rs * F : nullptr;
   float dmv[5];
@@ -806,7 +810,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   if (tid < 64) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
     const int c4 = tid & 15, pp = tid >> 4, ph = pp >> 1, pw = pp & 1;
     const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
-    const uint32_t m = *(const uint32_t*)(a.m2in + (rs * 4 + pp) * 64 + c4 * 4);
+    const uint32_t m = m2pre;
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       float4 v;

@@ -257,7 +257,8 @@ XSrc xsrc_raw(const cmlpl_batch* b, float sigma, uint64_t seed, uint64_t step, c
   return x;
 }
 int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
-             const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_snT,
+             const float* d_packed, const XSrc& xs, const XSrc* xspec, float* d_sn_out, const long long* d_labels, float* d_labels_f, const float* d_xn,
+             const float* d_sn, const float* d_snT,
              const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
              const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st);
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
@@ -282,12 +283,13 @@ int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d
   if (!carve_net(d, nets, n, (char*)d_workspace, &w)) return CMLPL_E_SHAPE;
   if (w.bytes > workspace_bytes) return CMLPL_E_WORKSPACE;
   return fwd_core(d, L, nets, n, d_params, param_stride, d_packed,
-                  xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW, seed, step, shard), d_xn, d_sn, d_snT, d_dropmask, dropout_p, train, seed, step, shard, d_logits, d_feat, w, (hipStream_t)stream);
+                  xsrc_plain(d_xn, nets, n, (long long)d.C * d.HW, seed, step, shard), nullptr, nullptr, nullptr, nullptr, d_xn, d_sn, d_snT, d_dropmask, dropout_p, train, seed, step, shard, d_logits, d_feat, w, (hipStream_t)stream);
 }
 
 namespace {
 int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
-             const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_snT,
+             const float* d_packed, const XSrc& xs, const XSrc* xspec, float* d_sn_out, const long long* d_labels, float* d_labels_f, const float* d_xn,
+             const float* d_sn, const float* d_snT,
              const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
              const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st) {
   int rc;
@@ -295,7 +297,13 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   const long long pk_ns = L.packed_total;
   {  // spectral branch (feat_spe + ReLU); with multi-stream enabled it runs beside the spatial conv stack
     hipStream_t st = fork_to(main_st, 0, 0);
-    if (d_snT != nullptr) {
+    if (xspec != nullptr) {
+      // raw spectra: augmentation + GEMM + bias + ReLU in one launch (also writes the augmented rows for the
+      // weight gradient)
+      if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fused(nets, n, d.bands, *xspec, d_packed + pack_off_wst(d.C), pk_ns,
+                                   d_params + L.param_off[7], param_stride, w.y, d_sn_out, d_labels, d_labels_f,
+                                   xspec->nlab, st))))) return rc;
+    } else if (d_snT != nullptr) {
       // y[row][o] = relu( sum_band snT[band][row] * wsT[band][o] + b[o] ): both operands k-major, K split over waves
       GemmTN g;
       g.A = d_snT; g.a_bstride = (long long)n * d.bands; g.lda = n; g.M = n;
@@ -487,13 +495,26 @@ int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
   const bool copy = need_xn_copy(d, 2 * n);
   const int lab0 = shard ? shard->lab0 : 0, unl_base = shard ? shard->bt_g + shard->unl0 : batch->bt;
   int rc;
-  if ((rc = TIMED(CMLPL_K_AUGMENT, chk(launch_augment(copy ? 3 : 2, 2, batch->bt, batch->btu, d.C * d.HW, d.bands, lab0,
+  // the augmentation launch remains only for what the fused kernels cannot take raw: the patches when a conv0 pass
+  // falls back to the unfused kernels, the spectra when the fused spectral kernel does not apply, and the label
+  // conversion for the data-parallel exchange buffer
+  const bool spe_fused = spe_fused_ok(d.bands);
+  const int which = (copy ? 1 : 0) | (spe_fused ? 0 : 2);
+  if (which &&
+      (rc = TIMED(CMLPL_K_AUGMENT, chk(launch_augment(which, 2, batch->bt, batch->btu, d.C * d.HW, d.bands, lab0,
                                 unl_base, batch->d_xpl, batch->d_xl, batch->d_xpu, batch->d_xu, batch->noise8,
                                 hp->noise_sigma, seed, step, sw.xn, sw.sn, sw.snT, st,
                                 (const long long*)batch->d_labels, d_labels_f))))) return rc;
+  XSrc xspec = xsrc_raw(batch, hp->noise_sigma, seed, step, shard);
+  for (int i = 0; i < 2; ++i) {       // the spectral rows and their draws (reference order, see cmlpl_augment)
+    xspec.lab[i] = batch->d_xl; xspec.unl[i] = batch->d_xu;
+    xspec.nz_lab[i] = batch->noise8 ? batch->noise8[2 * i + 1] : nullptr;
+    xspec.nz_unl[i] = batch->noise8 ? batch->noise8[4 + 2 * i + 1] : nullptr;
+  }
   return fwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
-                  copy ? sw.xn : nullptr, sw.sn, sw.snT, d_dropmask, hp->dropout_p, train, seed, step, shard, d_logits,
-                  d_feat, nw, st);
+                  spe_fused ? &xspec : nullptr, sw.sn, (const long long*)batch->d_labels, d_labels_f,
+                  copy ? sw.xn : nullptr, sw.sn, sw.snT, d_dropmask, hp->dropout_p,
+                  train, seed, step, shard, d_logits, d_feat, nw, st);
 }
 
 int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,

@@ -6,6 +6,8 @@
 //                    reduction index r as the slow dimension, 32 consecutive i (or j) are one
 //                    coalesced 128-B segment.  Used for dW_spe, dW_cls and the two contrastive
 //                    feature gradients (G^T.f_w, G.f_s).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "gemm_tn.hpp"
@@ -61,6 +63,104 @@ hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const flo
   }
   dim3 grid((n + 31) / 32, FD / 128, nets);
   hipLaunchKernelGGL(spe_fwd_kernel, grid, dim3(256), lds, st, sn, w, b, pstride, y, n, bands);
+  return hipGetLastError();
+}
+
+// Spectral branch of the forward with the augmentation fused in (train.py:158,164,171,182 + tools/models.py:142-143):
+//   sn = x + sigma * N(0,1)   (raw labelled / unlabelled spectra; counter hash or the explicit draws of parity mode)
+//   y  = relu(sn . Wspe^T + b)
+// Same shape as gemm_tn_block -- one workgroup per 32 x 32 output tile, the band contraction split over the four
+// waves, every operand of a wave in flight at once (one memory round trip) -- but the A fragment is FORMED in
+// registers: lane (row i, band k) loads the raw element and adds its noise.  A hash call yields the four normals of
+// bands 4g..4g+3 and a lane's bands are k = hh, 2 + hh, 4 + hh, ...: one call per two k-steps.  The column-tile-0
+// workgroups also write sn (row-major) for the weight gradient.  Replaces the augmentation launch (+ its transposed
+// copy) and the GEMM launch.  (A first version staged the augmented rows in LDS and walked the contraction
+// serially per wave: slower than the two launches it replaced.)
+constexpr int SPE_MAXP = 16;    // k-pairs per wave: bands <= 4 * 2 * 16 = 128
+
+struct SpeArgs {
+  XSrc xs; const float* wsT; long long wsT_ns; const float* bias; long long p_ns;
+  float* y; float* sn; int n, bands;
+  const long long* labels; float* labels_f; int bt;        // optional: labels as float for the exchange buffer
+};
+
+__global__ __launch_bounds__(256) void spe_fused_kernel(SpeArgs a) {
+  __shared__ float red[3][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x, mt = blockIdx.y, net = blockIdx.z;
+  if (a.labels_f != nullptr && nt == 0 && mt == 0 && net == 0)
+    for (int q = tid; q < a.bt; q += 256) a.labels_f[q] = (float)a.labels[q];
+  // the waves split the bands by whole groups of four (= two k-steps), so a noise call is never shared across waves
+  const int bands = a.bands, pairs = (bands + 1) >> 1, ppw = 2 * ((((bands + 3) >> 2) + 3) >> 2);
+  const int t0 = wave * ppw, t1 = (t0 + ppw < pairs) ? t0 + ppw : pairs;
+  const int i = mt * 32 + l31, j = nt * 32 + l31;
+  const bool iv = i < a.n;
+  const int ic = iv ? i : 0;
+  const float* x = xsrc_row(a.xs, net, ic, bands);
+  const float* nz = (a.xs.sigma != 0.f) ? xsrc_noise_row(a.xs, net, ic, bands) : nullptr;
+  const float* bp = a.wsT + (long long)net * a.wsT_ns + j;
+  float av[SPE_MAXP], bv[SPE_MAXP], zv[SPE_MAXP];
+#pragma unroll
+  for (int q = 0; q < SPE_MAXP; ++q) {
+    const int k = 2 * (t0 + q) + hh;
+    const bool kv = (t0 + q < t1) && (k < bands);
+    const int kc = kv ? k : 0;
+    const float xa = x[kc], wb = bp[(long long)kc * FD];
+    av[q] = (kv && iv) ? xa : 0.f;
+    bv[q] = kv ? wb : 0.f;
+    zv[q] = (nz != nullptr && kv) ? nz[kc] : 0.f;          // parity mode: the reference's own draws
+  }
+  if (a.xs.sigma != 0.f && nz == nullptr) {                 // in-kernel noise (uniform branch, pure ALU)
+    const uint64_t gs = xsrc_global_sample(a.xs, ic);
+#pragma unroll
+    for (int q = 0; q < SPE_MAXP; q += 2) {
+      // k-steps t0+q and t0+q+1 (t0 + q even): bands k = 4g + hh and k + 2 of the same group g
+      const int k = 2 * (t0 + q) + hh;
+      const float4 z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_X + net, noise_ctr(gs, (uint32_t)(k >> 2)));
+      zv[q] = hh ? z.y : z.x;
+      zv[q + 1] = hh ? z.w : z.z;
+    }
+  }
+  f32x16 acc = zero16();
+#pragma unroll
+  for (int q = 0; q < SPE_MAXP; ++q) {
+    const int k = 2 * (t0 + q) + hh;
+    const bool kv = (t0 + q < t1) && (k < bands);
+    const float v = (kv && iv) ? av[q] + zv[q] * a.xs.sigma : 0.f;
+    if (nt == 0 && kv && iv) a.sn[((long long)net * a.n + i) * bands + k] = v;
+    if (t0 + q < t1) acc = mfma32(v, bv[q], acc);            // uniform
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float bias = a.bias[(long long)net * a.p_ns + j];
+    float* Y = a.y + (long long)net * a.n * FD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + acc_row(r, lane);
+      const float v = (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]) + bias;
+      if (row < a.n) Y[(long long)row * FD + j] = relu_nan(v);
+    }
+  }
+}
+
+bool spe_fused_ok(int bands) {
+  static const bool off = getenv("CMLPL_FUSE_SPE") && atoi(getenv("CMLPL_FUSE_SPE")) == 0;
+  return !off && bands <= 8 * SPE_MAXP;
+}
+
+hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const float* wsT, long long wsT_ns,
+                            const float* bias, long long p_ns, float* y, float* sn, const long long* labels,
+                            float* labels_f, int bt, hipStream_t st) {
+  if (!spe_fused_ok(bands)) return hipErrorInvalidValue;
+  SpeArgs a;
+  a.labels = labels; a.labels_f = labels != nullptr ? labels_f : nullptr; a.bt = bt;
+  a.xs = xs; a.wsT = wsT; a.wsT_ns = wsT_ns; a.bias = bias; a.p_ns = p_ns; a.y = y; a.sn = sn; a.n = n; a.bands = bands;
+  hipLaunchKernelGGL(spe_fused_kernel, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -117,6 +117,10 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
                               hipStream_t st);
 
 // ---- dense.hip
+bool spe_fused_ok(int bands);
+hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const float* wsT, long long wsT_ns,
+                            const float* bias, long long p_ns, float* y, float* sn, const long long* labels,
+                            float* labels_f, int bt, hipStream_t st);
 hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const float* w, const float* b,
                           long long pstride, float* y, hipStream_t st);
 // C[b][i][j] = scale * sum_r A[b][r][i] * B[b][r][j]  (+ optional colsum of A into bias[b][i])

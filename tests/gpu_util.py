@@ -49,6 +49,24 @@ def report_params(name, got, want, steps, lr, rtol=1e-4, atol=3e-5, loose_frac=5
     assert bad.sum() <= max(1, int(loose_frac * bad.size)), msg
 
 
+def report_after_updates(name, got, want, rtol, atol, steps, lr, loose_frac=1e-4):
+    """An activation computed from parameters that went through `steps` Adam updates: the few weights report_params
+    lets move by O(lr) (gradient ~ eps) shift the activations they feed by O(lr * |input|_1).  Step 0 is held to the
+    tight bound everywhere; later steps keep the tight bound on all but a `loose_frac` fraction, and every element
+    within 20 * lr * steps relative to the largest activation."""
+    if steps == 0:
+        return report(name, got, want, rtol, atol)
+    got = np.asarray(got.detach().cpu().double()); want = np.asarray(want.detach().cpu().double())
+    assert got.shape == want.shape
+    err = np.abs(got - want)
+    bad = ~(err <= atol + rtol * np.abs(want))
+    msg = f"{name}: max|err|={np.nanmax(err):.3e} outside tight bound {int(bad.sum())}/{bad.size}"
+    print(msg)
+    assert not np.isnan(err).any(), msg
+    assert err.max() <= atol + 20.0 * lr * steps * np.abs(want).max(), msg
+    assert bad.sum() <= max(1, int(loose_frac * bad.size)), msg
+
+
 def cuda_batch(b):
     out = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
     if "noise" in b:
@@ -82,11 +100,15 @@ def hip_relu_gates(eng, shape, n):
     return out
 
 
-def relu_mask_audit(eng, taps, shape, n, ztol=2e-5):
+def relu_mask_audit(eng, taps, shape, n, ztol=2e-5, ztol_y=None):
     """Compare the ReLU masks the HIP forward saved (workspace regions m1, m2, y) with the signs of
     the oracle's pre-activations.  fp32 summation order differs between the two, so an element whose
     pre-activation is ~1 ulp from zero may legitimately land on the other side; every mismatch must
-    therefore sit at |z_oracle| < ztol -- anything else is a kernel bug.  Returns flips[net][layer]."""
+    therefore sit at |z_oracle| < ztol -- anything else is a kernel bug.  Returns flips[net][layer].
+    `ztol_y` (default ztol) bounds the spectral branch separately: after Adam updates a single feat_spe weight whose
+    gradient is ~eps may sit O(lr) away from the oracle's (see report_params), which shifts that output column by
+    O(lr * |x|)."""
+    ztol_y = ztol if ztol_y is None else ztol_y
     H2, W2 = shape.H // 2, shape.W // 2
     H4, W4 = H2 // 2, W2 // 2
     out = []
@@ -110,7 +132,7 @@ def relu_mask_audit(eng, taps, shape, n, ztol=2e-5):
         zy = taps[net]["zy"]
         diff = (y > 0) != (zy > 0)
         worst = float(zy[diff].abs().max()) if diff.any() else 0.0
-        assert worst < ztol, f"net {net} y: ReLU mask differs at |z|={worst:.3e}"
+        assert worst < ztol_y, f"net {net} y: ReLU mask differs at |z|={worst:.3e}"
         res["zy"] = int(diff.sum())
         out.append(res)
     return out

@@ -31,13 +31,17 @@ def test_unfused_conv0_kernels_pass_on_a_fusable_shape():
     _run({"CMLPL_FUSE_CONV0": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward and B2"])
 
 
+def test_unfused_spectral_branch_passes_step_parity():
+    _run({"CMLPL_FUSE_SPE": "0"}, ["tests/test_gpu_step.py", "-k", "b2_64 or b5"])
+
+
 def test_fused_and_unfused_conv0_form_the_same_noise():
     """In Philox mode the fused kernels augment the raw patches in LDS (forward) and regenerate the same noise for
-    conv0's weight gradient (backward); the unfused fallback reads an augmented copy written by the augmentation
-    kernel.  Same counters => the same augmented values: losses of the first step agree to rounding of the different
+    conv0's weight gradient (backward), and the spectral kernel augments the spectra in registers; the unfused
+    fallback reads augmented copies written by the augmentation kernel.  Same counters => the same augmented values: losses of the first step agree to rounding of the different
     summation orders, and both stay deterministic."""
     outs = []
-    for env_extra in ({}, {"CMLPL_FUSE_CONV0": "0", "CMLPL_FUSE_TAIL": "0"}, {}):
+    for env_extra in ({}, {"CMLPL_FUSE_CONV0": "0", "CMLPL_FUSE_TAIL": "0", "CMLPL_FUSE_SPE": "0"}, {}):
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, "tests/_philox_traj_child.py"], cwd=ROOT, env=env, capture_output=True,
                            text=True, timeout=600)

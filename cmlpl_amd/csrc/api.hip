@@ -329,7 +329,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     t.y = w.y; t.dropmask = d_dropmask; t.dropgen = w.dropgen; t.catd = w.catd; t.ynorm = w.ynorm;
     t.logits = d_logits; t.feat = d_feat; t.p2 = w.p2; t.m2 = w.m2; t.dropout_p = dropout_p; t.train = train; t.K = d.K;
     return TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0t(),
-                               pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + 0 * PACK_CONV, pk_ns,
+                               pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
                                d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, main_st)));
   }
   if (conv3_fused_ok(d.H, d.W, d.C, nets * n)) {
@@ -337,16 +337,16 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // copy of the input nor a0's round trip between the two convolutions touches HBM (a0 is still written once,
     // for the backward pass)
     if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0t(),
-                               pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + 0 * PACK_CONV, pk_ns,
+                               pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
                                d_params + L.param_off[3], param_stride, w.p1, w.m1, nullptr, st))))) return rc;
   } else {
     if (!d_xn) return CMLPL_E_ARG;
     if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
                                    d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
-    if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + 0 * PACK_CONV,
+    if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + pack_off_b3(d.C, d.bands, 0),
                                pk_ns, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
   }
-  if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + 2 * PACK_CONV,
+  if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + pack_off_b3(d.C, d.bands, 2),
                              pk_ns, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
   join_from(main_st, 0, 1);
   if (shard && shard->nlab + shard->nunl != n) return CMLPL_E_ARG;
@@ -414,7 +414,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     hd.y = w.y; hd.ynorm = w.ynorm; hd.m2 = w.m2; hd.w2d = d_packed + 5 * PACK_CONV; hd.w2d_ns = L.packed_total;
     hd.dy = w.dy; hd.dp2 = w.dp2; hd.dp1 = w.dp1; hd.K = d.K;
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
-                               d_packed + 1 * PACK_CONV, L.packed_total, xs, w.part0,
+                               d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,
                                (long long)n * conv0_partial_size(d.C), &hd, st))))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
@@ -431,7 +431,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     hipStream_t st = fork_to(main_st, 1, 3);
     if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
   }
-  if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + 3 * PACK_CONV,
+  if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + pack_off_b3(d.C, d.bands, 3),
                              L.packed_total, nullptr, 0, w.dp1, nullptr, st))))) return rc;
   {  // conv1 weight gradient needs dp1 (conv2_dgrad output): fork after it, runs beside conv1_dgrad
     hipStream_t st = fork_to(main_st, 0, 4);
@@ -441,11 +441,11 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // conv1 data gradient + conv0 weight gradient in one launch: da0 never goes to HBM, and the input slab is
     // re-formed from the raw rows with the forward's noise regenerated
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
-                               d_packed + 1 * PACK_CONV, L.packed_total, xs, w.part0,
+                               d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,
                                (long long)n * conv0_partial_size(d.C), nullptr, st))))) return rc;
   } else {
     if (!d_xn) return CMLPL_E_ARG;
-    if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + 1 * PACK_CONV,
+    if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + pack_off_b3(d.C, d.bands, 1),
                                L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
       return rc;

@@ -156,6 +156,18 @@ __device__ __forceinline__ uint64_t noise_ctr(uint64_t global_sample, uint32_t g
 // `lab`, rows [nlab, n) rows of `unl` (the concat is an index computation, not a copy); the augmentation
 // x + sigma * N(0,1) is applied on the fly -- from explicit noise tensors (parity mode: the reference's draws)
 // or from the Philox stream.  sigma == 0: plain rows (inference, or inputs that are already augmented).
+// fp32 value as three bf16 pieces, v = p0 + p1 + p2 EXACTLY: each piece is the truncation (top 16 bits) of what the
+// previous ones left, and truncation keeps 8 significant bits, so three pieces hold the 24-bit significand; the
+// residuals v - p0 and (v - p0) - p1 are exact in fp32.  (NaN stays NaN in every piece; +-Inf does not occur in
+// this path and would turn into NaN.)
+__device__ __forceinline__ void b3_split(float v, uint32_t (&hi16)[3]) {
+  const uint32_t u0 = __float_as_uint(v);
+  const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+  const uint32_t u1 = __float_as_uint(r1);
+  const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+  hi16[0] = u0 >> 16; hi16[1] = u1 >> 16; hi16[2] = __float_as_uint(r2) >> 16;
+}
+
 struct XSrc {
   const float* lab[2]; const float* unl[2];       // per network (the same pointer twice for raw inputs)
   const float* nz_lab[2]; const float* nz_unl[2]; // explicit N(0,1) draws per network, or null

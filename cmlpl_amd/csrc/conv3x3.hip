@@ -66,10 +66,29 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
   } else if (e < pack_off_wst(pi.C)) {
     const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
     v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
-  } else {
+  } else if (e < pack_off_b3(pi.C, pi.bands, 0)) {
     const long long i = e - pack_off_wst(pi.C);
     const int band = (int)(i >> 10), o = (int)(i & 1023);
     v = P[pi.off_ws + (long long)o * pi.bands + band];
+  } else {                                           // split-bf16 fragment sets: two bf16 per float slot
+    const long long f = e - pack_off_b3(pi.C, pi.bands, 0);
+    const int which = (int)(f / PACK_B3);            // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
+    const int i = (int)(f - (long long)which * PACK_B3) * 2;     // bf16 index (inverse of conv_b3_index), j even
+    const int j = i & 7, l31 = (i >> 3) & 31, h = (i >> 8) & 1, nt = (i >> 9) & 1, rest = i >> 10;
+    const int pc = rest % 3, kq = (rest / 3) & 3, tap = rest / 12;
+    const int kh = tap / 3, kw = tap - kh * 3, n = nt * 32 + l31;
+    const float* W = P + ((which < 2) ? pi.off_w1 : pi.off_w2);
+    uint32_t out = 0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int k = kq * 16 + h * 8 + j + d;
+      const float w = ((which & 1) == 0) ? W[((n * 64 + k) * 3 + kh) * 3 + kw]                 // co=n, ci=k
+                                         : W[((k * 64 + n) * 3 + (2 - kh)) * 3 + (2 - kw)];     // co=k, ci=n
+      uint32_t pcs[3];
+      b3_split(w, pcs);
+      out |= pcs[pc] << (16 * d);
+    }
+    v = __uint_as_float(out);
   }
   packed[(long long)net * pi.stride + e] = v;
 }
@@ -217,78 +236,128 @@ __device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int n
   slab_apply(x, net, s, nfl, slab, tid, wave, lane, nzv);
 }
 
+// ---- "fp32 on the bf16 MFMA" ------------------------------------------------------------------------------------
+// gfx950 runs the f32-input MFMA at 1/16 of the bf16 rate.  The 3x3 convolutions therefore take every fp32 operand
+// as THREE bf16 pieces, x = x1 + x2 + x3 exactly (b3_split: successive truncations, 8 significant bits each), and
+// form a . b as the six products whose weight is >= 2^-16,
+//      a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each bf16 x bf16 product is exact in fp32; what is dropped
+// (a2 b3 + a3 b2 + a3 b3) is < 3 * 2^-24 |a b| -- the size of the rounding error of ONE fp32 multiply -- and the
+// accumulator is rounded 6 times per 16 k (once per MFMA) where the f32-input MFMA rounds it 8 times.  Six bf16
+// MFMAs of 32 cycles replace eight f32 MFMAs of 64: 2.7x fewer matrix-pipe cycles for the same fp32-grade result
+// (tests/test_gpu_ops.py measures the error of both against an fp64 reference).
+// The weights are split once per step (Adam writes the fragment sets, kernels.hpp: conv_b3_index); activations are
+// split in registers right after their ds_read_b128 (the LDS image stays fp32: a split image would not leave room
+// for two workgroups per CU).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_b16(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// high halves of two dwords -> one dword (lo element in the low half)
+__device__ __forceinline__ uint32_t hi_pair(uint32_t lo_el, uint32_t hi_el) {
+  return __builtin_amdgcn_perm(hi_el, lo_el, 0x07060302u);
+}
+// eight consecutive fp32 A elements (k = 8h .. 8h+7 of this lane's row) -> the three bf16 A fragments
+__device__ __forceinline__ void a_split(const float4& x0, const float4& x1, uint4& A1, uint4& A2, uint4& A3) {
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  uint32_t u0[8], u1[8], u2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u0[j] = __float_as_uint(v[j]);
+    const float r1 = v[j] - __uint_as_float(u0[j] & 0xffff0000u);
+    u1[j] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1[j] & 0xffff0000u);
+    u2[j] = __float_as_uint(r2);
+  }
+  A1 = make_uint4(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]), hi_pair(u0[4], u0[5]), hi_pair(u0[6], u0[7]));
+  A2 = make_uint4(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]), hi_pair(u1[4], u1[5]), hi_pair(u1[6], u1[7]));
+  A3 = make_uint4(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]), hi_pair(u2[4], u2[5]), hi_pair(u2[6], u2[7]));
+}
+// one 32 x 32 x 16 step of the split product; b1..b3 = the weight pieces of this n tile
+__device__ __forceinline__ f32x16 mfma_b3(const uint4& A1, const uint4& A2, const uint4& A3, const uint4& b1,
+                                          const uint4& b2, const uint4& b3, f32x16 acc) {
+  acc = mfma_b16(A1, b3, acc);
+  acc = mfma_b16(A2, b2, acc);
+  acc = mfma_b16(A3, b1, acc);
+  acc = mfma_b16(A1, b2, acc);
+  acc = mfma_b16(A2, b1, acc);
+  acc = mfma_b16(A1, b1, acc);
+  return acc;
+}
+
+constexpr int WBUF = 6144;      // floats: one tap's weight fragments (4 k-steps x 3 pieces x 2 n tiles x 1 KiB)
+constexpr int TAPW = WBUF / 4;  // float4 per tap
+// a thread's share of one tap's weights on their way global -> LDS (named members: an array member ends up in scratch)
+struct TapRegs { float4 w0, w1, w2, w3, w4, w5; };
+__device__ __forceinline__ TapRegs tap_fetch(const float4* wg, int tap, int tid) {
+  TapRegs t;
+  const float4* wn = wg + tap * TAPW + tid;
+  t.w0 = wn[0]; t.w1 = wn[256]; t.w2 = wn[512]; t.w3 = wn[768]; t.w4 = wn[1024]; t.w5 = wn[1280];
+  return t;
+}
+__device__ __forceinline__ void tap_put(float4* wl, const TapRegs& t, int tid) {
+  wl[tid] = t.w0; wl[tid + 256] = t.w1; wl[tid + 512] = t.w2; wl[tid + 768] = t.w3; wl[tid + 1024] = t.w4;
+  wl[tid + 1280] = t.w5;
+}
+
 // The 9-tap main loop.  NTA = number of this wave's M tiles that carry real pixels (wave-uniform, so
-// the loop body is branch-free and the compiler can hoist the ds_read_b128 of step kk+1 above the
-// MFMAs of step kk).  Tap weights go global -> registers (prefetched one tap ahead) -> LDS.
+// the loop body is branch-free).  Tap weights go global -> registers (prefetched one tap ahead) -> LDS; a k-step's
+// operands (A: 2 ds_read_b128 per tile, B: 6) are fetched while the previous step's MFMAs run.
 struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
 
 // `side(s)` runs once per tap right after the tap's weights are queued: the fused forward drains its deferred
 // a0 stores there, two rows per tap, instead of bursting them in front of the loop.
 template <int MTW, int NTA, class Side = NoSide, int UNR = 1>
 __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float* __restrict__ wbuf,
-                                           const float4* __restrict__ wg, float4 w0, float4 w1, float4 w2,
-                                           float4 w3, const int (&abase)[MTW], f32x16 (&acc)[MTW][2], int PW,
-                                           int tid, int l31, int hh, Side side = Side()) {
+                                           const float4* __restrict__ wg, TapRegs w, const int (&abase)[MTW],
+                                           f32x16 (&acc)[MTW][2], int PW, int tid, int lane, Side side = Side()) {
   float4* wl = (float4*)wbuf;
-  const float* bbase = wbuf + (hh * 64 + l31) * 4;
+  const uint4* bl = (const uint4*)wbuf + lane;
+  constexpr int NT = NTA > 0 ? NTA : 1;
 #pragma unroll UNR
   for (int s = 0; s < 9; ++s) {
-#if CMLPL_ABL == 6
-    if (s == 0) {
-#endif
     __syncthreads();  // everyone done with wbuf of tap s-1 (and, for s == 0, the staged image is complete)
-    wl[tid] = w0; wl[tid + 256] = w1; wl[tid + 512] = w2; wl[tid + 768] = w3;
+    tap_put(wl, w, tid);
     __syncthreads();
-#if CMLPL_ABL == 6
-    }
-#endif
-    if (s + 1 < 9) {
-      const float4* wn = wg + (s + 1) * 1024 + tid;
-      w0 = wn[0]; w1 = wn[256]; w2 = wn[512]; w3 = wn[768];
-    }
+    if (s + 1 < 9) w = tap_fetch(wg, s + 1, tid);
     side(s);
     if (NTA > 0) {
       const int kh = s / 3, kw = s - kh * 3;
       const float* ib = img + ((kh - 1) * PW + (kw - 1)) * CS;
-      // software pipeline: the ds_read_b128 of step kk+1 are issued BEFORE the MFMAs of step kk and the
-      // order is pinned with sched_barrier (left alone, the scheduler sinks the reads below the MFMAs
-      // and every step then eats a full LDS round trip on a wave that is alone on its SIMD)
-      float4 b0 = *(const float4*)(bbase), b1 = *(const float4*)(bbase + 128);
-      float4 av[NTA > 0 ? NTA : 1];
+      float4 a0[NT], a1[NT];
+      uint4 b[6];
 #pragma unroll
-      for (int t = 0; t < NTA; ++t) av[t] = *(const float4*)(ib + abase[t]);
+      for (int t = 0; t < NTA; ++t) { a0[t] = *(const float4*)(ib + abase[t]); a1[t] = *(const float4*)(ib + abase[t] + 4); }
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        float4 nb0 = b0, nb1 = b1, nav[NTA > 0 ? NTA : 1];
+      for (int i = 0; i < 6; ++i) b[i] = bl[i * 64];
 #pragma unroll
-        for (int t = 0; t < NTA; ++t) nav[t] = av[t];
-        if (kk < 7) {
-          nb0 = *(const float4*)(bbase + (kk + 1) * 512);
-          nb1 = *(const float4*)(bbase + (kk + 1) * 512 + 128);
+      for (int kq = 0; kq < 4; ++kq) {
+        float4 na0[NT], na1[NT];
+        uint4 nb[6];
 #pragma unroll
-          for (int t = 0; t < NTA; ++t) nav[t] = *(const float4*)(ib + abase[t] + (kk + 1) * 8);
+        for (int t = 0; t < NTA; ++t) { na0[t] = a0[t]; na1[t] = a1[t]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) nb[i] = b[i];
+        if (kq < 3) {
+#pragma unroll
+          for (int t = 0; t < NTA; ++t) {
+            na0[t] = *(const float4*)(ib + abase[t] + (kq + 1) * 16);
+            na1[t] = *(const float4*)(ib + abase[t] + (kq + 1) * 16 + 4);
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) nb[i] = bl[((kq + 1) * 6 + i) * 64];
         }
-        __builtin_amdgcn_sched_barrier(0);
-#if CMLPL_ABL == 5
-#pragma unroll
-        for (int t = 0; t < NTA; ++t) asm volatile("" :: "v"(av[t].x), "v"(av[t].w), "v"(b0.x), "v"(b1.w));
-#else
 #pragma unroll
         for (int t = 0; t < NTA; ++t) {
-          acc[t][0] = mfma32(av[t].x, b0.x, acc[t][0]);
-          acc[t][1] = mfma32(av[t].x, b1.x, acc[t][1]);
-          acc[t][0] = mfma32(av[t].y, b0.y, acc[t][0]);
-          acc[t][1] = mfma32(av[t].y, b1.y, acc[t][1]);
-          acc[t][0] = mfma32(av[t].z, b0.z, acc[t][0]);
-          acc[t][1] = mfma32(av[t].z, b1.z, acc[t][1]);
-          acc[t][0] = mfma32(av[t].w, b0.w, acc[t][0]);
-          acc[t][1] = mfma32(av[t].w, b1.w, acc[t][1]);
+          uint4 A1, A2, A3;
+          a_split(a0[t], a1[t], A1, A2, A3);
+          acc[t][0] = mfma_b3(A1, A2, A3, b[0], b[2], b[4], acc[t][0]);
+          acc[t][1] = mfma_b3(A1, A2, A3, b[1], b[3], b[5], acc[t][1]);
         }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        b0 = nb0; b1 = nb1;
 #pragma unroll
-        for (int t = 0; t < NTA; ++t) av[t] = nav[t];
+        for (int t = 0; t < NTA; ++t) { a0[t] = na0[t]; a1[t] = na1[t]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b[i] = nb[i];
       }
     }
   }
@@ -300,7 +369,7 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
 struct Conv3Ctx {
   int tid, lane, l31, hh, wave, net, s0, H, W, HW, PW, IMG, H2, W2, P2, RO, CO, PX, S, npx;
   float* img; float* wbuf; int* lut; const float4* wg;
-  float4 wp0, wp1, wp2, wp3;
+  TapRegs wp;
   f32x16 z0, z1;          // MODE 2: this wave's a0 tile (+ bias), stored to HBM from inside the tap loop
   float* a0g;
 };
@@ -316,8 +385,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   const int RO = !(MODE & 1) ? 2 * H2 : H, CO = !(MODE & 1) ? 2 * W2 : W;
   const int PX = RO * CO, S = a.S, npx = S * PX;
   float* img = smem;                       // [S][IMG][CS]
-  float* wbuf = img + (size_t)S * IMG * CS;  // [16][64][4]
-  int* lut = (int*)(wbuf + 4096);          // padded-image position of output pixel m
+  float* wbuf = img + (size_t)S * IMG * CS;  // one tap's weight fragments
+  int* lut = (int*)(wbuf + WBUF);          // padded-image position of output pixel m
   // (fused backward head, dp_lds != null: image zero fill and LUT were done before the head, under its loads)
   if (MODE != 2 && dp_lds == nullptr) {  // zero the padded images (border must be zero; interior overwritten below)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -334,7 +403,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   }
   const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
   // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
-  c.wp0 = wg[tid]; c.wp1 = wg[tid + 256]; c.wp2 = wg[tid + 512]; c.wp3 = wg[tid + 768];
+  c.wp = tap_fetch(wg, 0, tid);
   __syncthreads();
 
   if (MODE == 2) {
@@ -701,7 +770,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   const int H2 = a.H >> 1, W2 = a.W >> 1, P2 = H2 * W2, PW2 = W2 + 2;
   const int SF = 256, F = SF + FD, K = a.K;
   float* img2 = smem + (size_t)(a.H + 2) * (a.W + 2) * CS;        // = wbuf: [(H2+2)*(W2+2)][CS] <= 4096 floats
-  float* ext = img2 + 4096 + 128;                                  // behind the LUT
+  float* ext = img2 + WBUF + 128;                                  // behind the LUT
   float* dp1s = ext;                                               // [P2][64]
   float* dp2s = dp1s + P2 * 64;                                    // [4][64]  pooled conv2 gradient [hw][c]
   float* dls = dp2s + 256;                                         // [64]
@@ -751,7 +820,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     for (int i = tid; i < 1024; i += 256) ((float4*)img2)[i] = z4;
     const int PW = a.W + 2, IMG = (a.H + 2) * PW;
     for (int i = tid; i < IMG * (CS / 4); i += 256) ((float4*)smem)[i] = z4;
-    int* lut = (int*)(img2 + 4096);
+    int* lut = (int*)(img2 + WBUF);
     const int HWl = a.H * a.W;
     for (int m = tid; m < 128; m += 256) {
       const int mm = (m < HWl) ? m : 0;
@@ -897,13 +966,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
   float* img = c.img; float* wbuf = c.wbuf; int* lut = c.lut; const float4* wg = c.wg;
-  const float4 wp0 = c.wp0, wp1 = c.wp1, wp2 = c.wp2, wp3 = c.wp3;
+  const TapRegs wp = c.wp;
   const int MT = (npx + 31) >> 5;
   int abase[MTW];
   f32x16 acc[MTW][2];
 #pragma unroll
   for (int t = 0; t < MTW; ++t) {
-    abase[t] = lut[(wave + 4 * t) * 32 + l31] * CS + 4 * hh;
+    abase[t] = lut[(wave + 4 * t) * 32 + l31] * CS + 8 * hh;
     acc[t][0] = zero16();
     acc[t][1] = zero16();
   }
@@ -925,10 +994,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
         }
       }
     };
-    if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
-    else                           conv3_taps<MTW, MTW - 1, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh, side);
-  } else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
-  else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp0, wp1, wp2, wp3, abase, acc, PW, tid, l31, hh);
+    if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp, abase, acc, PW, tid, lane, side);
+    else                           conv3_taps<MTW, MTW - 1, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp, abase, acc, PW, tid, lane, side);
+  } else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
+  else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   STAMP(MODE & 1, 15);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
   STAMP(MODE & 1, 2);
@@ -1089,36 +1158,35 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(Conv3Args a) {
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net;
   const int nt = wave & 1, kh2 = wave >> 1;
   float* img = c.img; float* wbuf = c.wbuf; const int* lut = c.lut;
-  const int abase = lut[l31] * CS + 4 * hh;
+  const int abase = lut[l31] * CS + 8 * hh;
   f32x16 acc = zero16();
   {
-    float4 w0 = c.wp0, w1 = c.wp1, w2 = c.wp2, w3 = c.wp3;
+    TapRegs w = c.wp;
     float4* wl = (float4*)wbuf;
-    const float* bbase = wbuf + (hh * 64 + nt * 32 + l31) * 4;
+    const uint4* bl = (const uint4*)wbuf + lane;
 #pragma unroll 1
     for (int s = 0; s < 9; ++s) {
       __syncthreads();
-      wl[tid] = w0; wl[tid + 256] = w1; wl[tid + 512] = w2; wl[tid + 768] = w3;
+      tap_put(wl, w, tid);
       __syncthreads();
-      if (s + 1 < 9) {
-        const float4* wn = c.wg + (s + 1) * 1024 + tid;
-        w0 = wn[0]; w1 = wn[256]; w2 = wn[512]; w3 = wn[768];
-      }
+      if (s + 1 < 9) w = tap_fetch(c.wg, s + 1, tid);
       const int khh = s / 3, kww = s - khh * 3;
       const float* ib = img + ((khh - 1) * c.PW + (kww - 1)) * CS + abase;
-      float4 av[4], bv[4];
+      float4 av[4];
+      uint4 bv[6];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = kh2 * 4 + q;
-        av[q] = *(const float4*)(ib + kk * 8);
-        bv[q] = *(const float4*)(bbase + kk * 512);
+      for (int q = 0; q < 2; ++q) {          // this wave's two k-steps of 16
+        const int kq = kh2 * 2 + q;
+        av[2 * q] = *(const float4*)(ib + kq * 16);
+        av[2 * q + 1] = *(const float4*)(ib + kq * 16 + 4);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bv[3 * q + pc] = bl[((kq * 3 + pc) * 2 + nt) * 64];
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc = mfma32(av[q].x, bv[q].x, acc);
-        acc = mfma32(av[q].y, bv[q].y, acc);
-        acc = mfma32(av[q].z, bv[q].z, acc);
-        acc = mfma32(av[q].w, bv[q].w, acc);
+      for (int q = 0; q < 2; ++q) {
+        uint4 A1, A2, A3;
+        a_split(av[2 * q], av[2 * q + 1], A1, A2, A3);
+        acc = mfma_b3(A1, A2, A3, bv[3 * q], bv[3 * q + 1], bv[3 * q + 2], acc);
       }
     }
   }
@@ -1162,7 +1230,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(Conv3Args a) {
 }
 
 static size_t conv3_lds(int S, int H, int W, int MTW) {
-  return ((size_t)S * (H + 2) * (W + 2) * CS + 4096 + (size_t)MTW * 128) * 4;
+  return ((size_t)S * (H + 2) * (W + 2) * CS + WBUF + (size_t)MTW * 128) * 4;
 }
 
 // Pick samples-per-workgroup S.  Cost model: MFMA tile-times queued on the busiest SIMD (workgroups
@@ -1324,7 +1392,7 @@ bool conv3_fused_head_ok(int H, int W, int C, int rows, int K) {
   // LDS behind the LUT: dp1s [P2][64] + dp2s [256] + dls [64] + red [4]
   Conv3Plan pl;
   if (!plan_conv3(1, H, W, rows, &pl)) return false;
-  const size_t need = ((size_t)(H + 2) * (W + 2) * CS + 4096 + 128 + (size_t)H2 * W2 * 64 + 256 + 64 + 4) * 4;
+  const size_t need = ((size_t)(H + 2) * (W + 2) * CS + WBUF + 128 + (size_t)H2 * W2 * 64 + 256 + 64 + 4) * 4;
   return need <= conv3_fused_bwd_lds(H, W, C, pl.lds);
 }
 

@@ -27,7 +27,20 @@ __host__ __device__ inline int conv2_frag_index(int tap, int n, int k) {
 // so that their MFMA B fragments (fixed k, 32 consecutive outputs) are coalesced 128-B global reads.
 __host__ __device__ inline long long pack_off_w0t() { return PACK_PER_NET; }
 __host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET + (long long)((C + 1) & ~1) * 64; }
-__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_wst(C) + (long long)bands * 1024; }
+// ... and, last, the 3x3 weights once more for the split-bf16 tap loops (conv3x3.hip, "fp32 on the bf16 MFMA"): conv1
+// fwd, conv1 dgrad, conv2 fwd, conv2 dgrad, each weight as three bf16 pieces w = w1 + w2 + w3 (exact, see b3_split),
+// laid out as ready-made B fragments of v_mfma_f32_32x32x16_bf16:
+//   [tap][k16 step (4)][piece (3)][n tile (2)][lane (64)][8 bf16]   lane = (n & 31) + 32 * ((k >> 3) & 1), j = k & 7
+// so a tap is one linear 24 KiB copy into LDS and a fragment one conflict-free ds_read_b128.
+constexpr int PACK_B3 = PACK_CONV * 3 / 2;   // floats occupied by one split weight set
+__host__ __device__ inline long long pack_off_b3(int C, int bands, int which) {
+  return pack_off_wst(C) + (long long)bands * 1024 + (long long)which * PACK_B3;
+}
+__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_b3(C, bands, 4); }
+// bf16 element index of (tap, k, n, piece) inside one split weight set
+__host__ __device__ inline int conv_b3_index(int tap, int k, int n, int p) {
+  return ((((tap * 4 + (k >> 4)) * 3 + p) * 2 + (n >> 5)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7);
+}
 struct PackInfo { long long stride, off_w0, off_w1, off_w2, off_ws; int C, bands; };
 constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci][co] + db[co]
 constexpr size_t LDS_MAX = 160 * 1024;

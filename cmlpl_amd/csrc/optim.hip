@@ -44,6 +44,17 @@ __global__ void adam_kernel(float* __restrict__ params, long long pstride, const
         const int e = e0 + q, kw = e % 3, kh = (e / 3) % 3, ci = (e / 9) & 63, co = e / 576;
         pk[(((kh * 3 + kw) * 16 + (ci >> 2)) * 64 + co) * 4 + (ci & 3)] = pa[q];
         pk[PACK_CONV + ((((2 - kh) * 3 + (2 - kw)) * 16 + (co >> 2)) * 64 + ci) * 4 + (co & 3)] = pa[q];
+        {                   // ... and as split-bf16 B fragments (conv3x3 tap loops)
+          uint32_t pcs[3];
+          b3_split(pa[q], pcs);
+          uint16_t* bf = (uint16_t*)(pkn + pack_off_b3(pi.C, pi.bands, which));
+          uint16_t* bd = (uint16_t*)(pkn + pack_off_b3(pi.C, pi.bands, which + 1));
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            bf[conv_b3_index(kh * 3 + kw, ci, co, pc)] = (uint16_t)pcs[pc];
+            bd[conv_b3_index((2 - kh) * 3 + (2 - kw), co, ci, pc)] = (uint16_t)pcs[pc];
+          }
+        }
         if (which == 2) {   // conv2 also as 16x16x4 B fragments (fused tail / head kernels)
           pkn[4 * PACK_CONV + conv2_frag_index(kh * 3 + kw, co, ci)] = pa[q];
           pkn[5 * PACK_CONV + conv2_frag_index((2 - kh) * 3 + (2 - kw), ci, co)] = pa[q];

@@ -77,6 +77,26 @@ def cuda_batch(b):
     return out
 
 
+class ModuleRegions:
+    """debug_region() of a cmlpl_amd.models.BaseNet2 forward: the workspace the autograd node of its output keeps
+    (one network), addressed like TrainEngine.debug_region."""
+    debug_nets = 1
+
+    def __init__(self, net, out, n):
+        import ctypes as C
+        from cmlpl_amd import _lib
+        self._C, self._lib, self.net, self.n = C, _lib, net, n
+        self.ws = out.grad_fn.saved_tensors[5]
+        assert self.ws.dtype == torch.uint8
+
+    def debug_region(self, name, dtype=torch.float32):
+        C = self._C
+        off, nbytes = C.c_size_t(), C.c_size_t()
+        self._lib.check("cmlpl_debug_region", self._lib.load().cmlpl_debug_region(
+            C.byref(self.net._cshape), 1, self.n, name.encode(), C.byref(off), C.byref(nbytes)))
+        return self.ws[off.value: off.value + nbytes.value].view(dtype)
+
+
 def hip_relu_gates(eng, shape, n):
     """The ReLU decisions the HIP forward took, as the oracle's ``relu_gates`` (per network {"z1","z2","zy"} bool
     tensors in the oracle's NCHW layout), read from the saved masks m1 / m2 (u8 per pooled element, bit
@@ -85,17 +105,18 @@ def hip_relu_gates(eng, shape, n):
     H2, W2 = shape.H // 2, shape.W // 2
     H4, W4 = H2 // 2, W2 // 2
     out = []
-    for net in range(2):
+    nets = getattr(eng, "debug_nets", 2)
+    for net in range(nets):
         g = {}
         for name, key, hh, ww, HH, WW in (("m1", "z1", H2, W2, shape.H, shape.W), ("m2", "z2", H4, W4, H2, W2)):
-            m = eng.debug_region(name, torch.uint8).view(2, n, hh, ww, 64)[net].cpu()
+            m = eng.debug_region(name, torch.uint8).view(nets, n, hh, ww, 64)[net].cpu()
             gate = torch.ones(n, 64, HH, WW, dtype=torch.bool)
             for dh in range(2):
                 for dw in range(2):
                     bit = ((m >> (dh * 2 + dw)) & 1).bool()                    # [n, hh, ww, 64]
                     gate[:, :, dh:2 * hh:2, dw:2 * ww:2] = bit.permute(0, 3, 1, 2)
             g[key] = gate
-        g["zy"] = eng.debug_region("y").view(2, n, 1024)[net].cpu() > 0
+        g["zy"] = eng.debug_region("y").view(nets, n, 1024)[net].cpu() > 0
         out.append(g)
     return out
 
@@ -112,10 +133,11 @@ def relu_mask_audit(eng, taps, shape, n, ztol=2e-5, ztol_y=None):
     H2, W2 = shape.H // 2, shape.W // 2
     H4, W4 = H2 // 2, W2 // 2
     out = []
-    for net in range(2):
+    nets = getattr(eng, "debug_nets", 2)
+    for net in range(nets):
         res = {}
         for name, zkey, hh, ww in (("m1", "z1", H2, W2), ("m2", "z2", H4, W4)):
-            m = eng.debug_region(name, torch.uint8).view(2, n, hh * ww, 64)[net].cpu()
+            m = eng.debug_region(name, torch.uint8).view(nets, n, hh * ww, 64)[net].cpu()
             z = taps[net][zkey]                                  # [n, 64, Hfull, Wfull]
             cnt, worst = 0, 0.0
             for dh in range(2):
@@ -128,7 +150,7 @@ def relu_mask_audit(eng, taps, shape, n, ztol=2e-5, ztol_y=None):
                         worst = max(worst, float(zz[diff].abs().max()))
             assert worst < ztol, f"net {net} {name}: ReLU mask differs at |z|={worst:.3e} (not a rounding flip)"
             res[zkey] = cnt
-        y = eng.debug_region("y").view(2, n, 1024)[net].cpu()
+        y = eng.debug_region("y").view(nets, n, 1024)[net].cpu()
         zy = taps[net]["zy"]
         diff = (y > 0) != (zy > 0)
         worst = float(zy[diff].abs().max()) if diff.any() else 0.0

@@ -411,7 +411,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // that follow; da0 and the pooled-gradient hand-offs stay on chip.
     BwdHead hd;
     hd.dlogits = d_dlogits; hd.dfeat = d_dfeat; hd.mask = mask; hd.wc = d_params + L.param_off[8]; hd.p_ns = param_stride;
-    hd.y = w.y; hd.ynorm = w.ynorm; hd.m2 = w.m2; hd.w2d = d_packed + 5 * PACK_CONV; hd.w2d_ns = L.packed_total;
+    hd.y = w.y; hd.ynorm = w.ynorm; hd.m2 = w.m2; hd.w2d = d_packed + pack_off_b3(d.C, d.bands, 3); hd.w2d_ns = L.packed_total;
     hd.dy = w.dy; hd.dp2 = w.dp2; hd.dp1 = w.dp1; hd.K = d.K;
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
                                d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,

@@ -259,6 +259,12 @@ __device__ __forceinline__ uint32_t hi_pair(uint32_t lo_el, uint32_t hi_el) {
 }
 // eight consecutive fp32 A elements (k = 8h .. 8h+7 of this lane's row) -> the three bf16 A fragments
 __device__ __forceinline__ void a_split(const float4& x0, const float4& x1, uint4& A1, uint4& A2, uint4& A3) {
+#if CMLPL_ABL == 21         // ablation: no split arithmetic -- wrong results
+  A1 = make_uint4(__float_as_uint(x0.x), __float_as_uint(x0.y), __float_as_uint(x0.z), __float_as_uint(x0.w));
+  A2 = make_uint4(__float_as_uint(x1.x), __float_as_uint(x1.y), __float_as_uint(x1.z), __float_as_uint(x1.w));
+  A3 = A1;
+  return;
+#endif
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
   uint32_t u0[8], u1[8], u2[8];
 #pragma unroll
@@ -300,10 +306,70 @@ __device__ __forceinline__ void tap_put(float4* wl, const TapRegs& t, int tid) {
   wl[tid + 1280] = t.w5;
 }
 
-// The 9-tap main loop.  NTA = number of this wave's M tiles that carry real pixels (wave-uniform, so
-// the loop body is branch-free).  Tap weights go global -> registers (prefetched one tap ahead) -> LDS; a k-step's
-// operands (A: 2 ds_read_b128 per tile, B: 6) are fetched while the previous step's MFMAs run.
+// The 9-tap main loop: 36 k-steps of 16 input channels.  NTA = number of this wave's M tiles that carry real pixels
+// (wave-uniform, so the loop body is branch-free).  Tap weights go global -> registers (prefetched one tap ahead)
+// -> LDS.  The steps are software-pipelined across the taps:
+//   step k issues the LDS reads of step k+1's weights (inside a tap) and of step k+2's raw activations, runs its
+//   12 MFMAs per tile, and between them splits step k+1's raw activations (landed during step k-1) into bf16 pieces;
+//   sched_group_barrier pins the interleave (4 MFMAs, then 1 MFMA : 6 VALU) -- left alone the scheduler puts each
+//   step's 44 split instructions in front of its MFMAs and the matrix pipe idles meanwhile.
+// Only a tap's first weight read is exposed (it cannot be issued before the tap's barrier).
 struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
+struct ASplit { uint4 p1, p2, p3; };
+
+// LDS float offset of k-step `step` (tap = step / 4, 16 channels (step & 3) * 16) relative to the output pixel
+__device__ __forceinline__ int tap_step_off(int step, int PW) {
+  const int s = step >> 2, kh = s / 3, kw = s - kh * 3;
+  return ((kh - 1) * PW + (kw - 1)) * CS + (step & 3) * 16;
+}
+
+// one k-step (KQ = its position inside the tap) for NTA tiles
+template <int N> struct SchedInterleave {
+  static __device__ __forceinline__ void run() {
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    SchedInterleave<N - 1>::run();
+  }
+};
+template <> struct SchedInterleave<0> { static __device__ __forceinline__ void run() {} };
+
+template <int NTA, int KQ, int MTW>
+__device__ __forceinline__ void tap_step(const float* __restrict__ img, const uint4* __restrict__ bl,
+                                         const int (&abase)[MTW], f32x16 (&acc)[MTW][2], ASplit (&cur)[NTA],
+                                         float4 (&rn0)[NTA], float4 (&rn1)[NTA], uint4 (&b)[6], int step, int PW) {
+  uint4 nb[6];
+  float4 rnn0[NTA], rnn1[NTA];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) nb[i] = b[i];
+  if (KQ < 3) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nb[i] = bl[((KQ + 1) * 6 + i) * 64];
+  }
+  {
+    const int o2 = tap_step_off(step + 2 < 36 ? step + 2 : 35, PW);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) {
+      rnn0[t] = *(const float4*)(img + abase[t] + o2);
+      rnn1[t] = *(const float4*)(img + abase[t] + o2 + 4);
+    }
+  }
+  ASplit nxt[NTA];
+#pragma unroll
+  for (int t = 0; t < NTA; ++t) {
+    acc[t][0] = mfma_b3(cur[t].p1, cur[t].p2, cur[t].p3, b[0], b[2], b[4], acc[t][0]);
+    acc[t][1] = mfma_b3(cur[t].p1, cur[t].p2, cur[t].p3, b[1], b[3], b[5], acc[t][1]);
+    a_split(rn0[t], rn1[t], nxt[t].p1, nxt[t].p2, nxt[t].p3);
+  }
+  // pin the interleave: the reads first, four MFMAs while they (and nothing else) are outstanding, then one MFMA
+  // per six split instructions
+  __builtin_amdgcn_sched_group_barrier(0x100, (KQ < 3 ? 6 : 0) + 2 * NTA, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  SchedInterleave<12 * NTA - 4>::run();
+#pragma unroll
+  for (int t = 0; t < NTA; ++t) { cur[t] = nxt[t]; rn0[t] = rnn0[t]; rn1[t] = rnn1[t]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) b[i] = nb[i];
+}
 
 // `side(s)` runs once per tap right after the tap's weights are queued: the fused forward drains its deferred
 // a0 stores there, two rows per tap, instead of bursting them in front of the loop.
@@ -314,51 +380,38 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
   float4* wl = (float4*)wbuf;
   const uint4* bl = (const uint4*)wbuf + lane;
   constexpr int NT = NTA > 0 ? NTA : 1;
+  ASplit cur[NT];                 // step k, split
+  float4 rn0[NT], rn1[NT];        // step k+1, raw
 #pragma unroll UNR
   for (int s = 0; s < 9; ++s) {
+#if CMLPL_ABL == 20         // ablation: tap-0 weights for every tap (no re-staging, no barriers) -- wrong results
+    if (s == 0) {
+#endif
     __syncthreads();  // everyone done with wbuf of tap s-1 (and, for s == 0, the staged image is complete)
     tap_put(wl, w, tid);
     __syncthreads();
     if (s + 1 < 9) w = tap_fetch(wg, s + 1, tid);
+#if CMLPL_ABL == 20
+    }
+#endif
     side(s);
-    if (NTA > 0) {
-      const int kh = s / 3, kw = s - kh * 3;
-      const float* ib = img + ((kh - 1) * PW + (kw - 1)) * CS;
-      float4 a0[NT], a1[NT];
+    if constexpr (NTA > 0) {
       uint4 b[6];
 #pragma unroll
-      for (int t = 0; t < NTA; ++t) { a0[t] = *(const float4*)(ib + abase[t]); a1[t] = *(const float4*)(ib + abase[t] + 4); }
-#pragma unroll
       for (int i = 0; i < 6; ++i) b[i] = bl[i * 64];
-#pragma unroll
-      for (int kq = 0; kq < 4; ++kq) {
-        float4 na0[NT], na1[NT];
-        uint4 nb[6];
-#pragma unroll
-        for (int t = 0; t < NTA; ++t) { na0[t] = a0[t]; na1[t] = a1[t]; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) nb[i] = b[i];
-        if (kq < 3) {
-#pragma unroll
-          for (int t = 0; t < NTA; ++t) {
-            na0[t] = *(const float4*)(ib + abase[t] + (kq + 1) * 16);
-            na1[t] = *(const float4*)(ib + abase[t] + (kq + 1) * 16 + 4);
-          }
-#pragma unroll
-          for (int i = 0; i < 6; ++i) nb[i] = bl[((kq + 1) * 6 + i) * 64];
-        }
+      if (s == 0) {               // pipeline fill: steps 0 and 1
 #pragma unroll
         for (int t = 0; t < NTA; ++t) {
-          uint4 A1, A2, A3;
-          a_split(a0[t], a1[t], A1, A2, A3);
-          acc[t][0] = mfma_b3(A1, A2, A3, b[0], b[2], b[4], acc[t][0]);
-          acc[t][1] = mfma_b3(A1, A2, A3, b[1], b[3], b[5], acc[t][1]);
+          const float* p0 = img + abase[t] + tap_step_off(0, PW);
+          a_split(*(const float4*)p0, *(const float4*)(p0 + 4), cur[t].p1, cur[t].p2, cur[t].p3);
+          const float* p1 = img + abase[t] + tap_step_off(1, PW);
+          rn0[t] = *(const float4*)p1; rn1[t] = *(const float4*)(p1 + 4);
         }
-#pragma unroll
-        for (int t = 0; t < NTA; ++t) { a0[t] = na0[t]; a1[t] = na1[t]; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) b[i] = nb[i];
       }
+      tap_step<NTA, 0>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 0, PW);
+      tap_step<NTA, 1>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 1, PW);
+      tap_step<NTA, 2>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 2, PW);
+      tap_step<NTA, 3>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 3, PW);
     }
   }
 }
@@ -776,12 +829,16 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   float* dls = dp2s + 256;                                         // [64]
   float* red = dls + 64;                                           // [4]
   const long long rs = (long long)net * a.n + sample;
-  const int j = lane & 15, kg = lane >> 4;
+  const int l31 = lane & 31, hh = lane >> 5;
+  // conv2 data gradient: wave = (output-channel tile nt, half kh2 of every tap's 64 input channels)
+  const int nt = wave & 1, kh2 = wave >> 1;
   // ---- loads up front: tap-0 B fragments of the conv2 data gradient, this thread's spectral elements
-  const float* wq = a.w2d + (long long)net * a.w2d_ns + (size_t)wave * 1024 + lane;
-  float bcur[16], bnxt[16];
+  const uint4* wq = (const uint4*)(a.w2d + (long long)net * a.w2d_ns) + lane;
+  uint4 bcur[6], bnxt[6];
 #pragma unroll
-  for (int st = 0; st < 16; ++st) bcur[st] = wq[st * 64];
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) bcur[3 * q + pc] = wq[(((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
   if (tid < 64) dls[tid] = (tid < K) ? a.dlogits[rs * K + tid] : 0.f;
   const float* y = a.yin + rs * FD;
   const float* df = (a.dfeat != nullptr) ? a.dfeat + rs * FD : nullptr;
@@ -892,56 +949,59 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     }
   }
   __syncthreads();
-  // ---- conv2 data gradient: output pixel p = 16 t + (lane & 15), t = 0, 1 (rows >= P2 read the zero corner)
-  const float* ap[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int p = 16 * t + j;
-    const int pos = p < P2 ? ((p / W2) + 1) * PW2 + (p % W2) + 1 : 0;
-    ap[t] = img2 + (size_t)pos * CS + 16 * kg;
-  }
-  f32x4v acc[2][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+  // ---- conv2 data gradient, split-bf16 on the 32x32x16 MFMA: the P2 <= 32 output pixels are ONE tile (row p = l31,
+  // rows >= P2 read the zero corner); this wave multiplies its half of the input channels of every tap into its
+  // output-channel tile.  Nothing is shared between the waves, so the B fragments go L2 -> registers directly
+  // (six 1 KiB loads per tap, the next tap's in flight) and the loop has no barrier.
+  const int posA = l31 < P2 ? ((l31 / W2) + 1) * PW2 + (l31 % W2) + 1 : 0;
+  const float* ap = img2 + (size_t)posA * CS + kh2 * 32 + hh * 8;
+  f32x16 acc = zero16();
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     if (tap + 1 < 9) {
 #pragma unroll
-      for (int st = 0; st < 16; ++st) bnxt[st] = wq[(size_t)(tap + 1) * 4096 + st * 64];
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          bnxt[3 * q + pc] = wq[(size_t)(tap + 1) * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
     }
     const int toff = ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * CS;
-    float4 av[2][4];
+    // the dummy rows (p >= P2) sit at the zero corner: a negative tap offset would leave the image, keep them there
+    const float* q = (l31 < P2) ? ap + toff : ap;
+    const float4 r0 = *(const float4*)(q), r1 = *(const float4*)(q + 4);
+    const float4 r2 = *(const float4*)(q + 16), r3 = *(const float4*)(q + 20);
+    uint4 A1, A2, A3;
+    a_split(r0, r1, A1, A2, A3);
+    acc = mfma_b3(A1, A2, A3, bcur[0], bcur[1], bcur[2], acc);
+    a_split(r2, r3, A1, A2, A3);
+    acc = mfma_b3(A1, A2, A3, bcur[3], bcur[4], bcur[5], acc);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      // the dummy rows (p >= P2) sit at the zero corner: a negative tap offset would leave the image, keep them there
-      const float* q = (16 * t + j < P2) ? ap[t] + toff : ap[t];
-      av[t][0] = *(const float4*)(q); av[t][1] = *(const float4*)(q + 4);
-      av[t][2] = *(const float4*)(q + 8); av[t][3] = *(const float4*)(q + 12);
-    }
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        acc[t][0] = mfma16(av[t][q4].x, bcur[4 * q4], acc[t][0]);
-        acc[t][1] = mfma16(av[t][q4].y, bcur[4 * q4 + 1], acc[t][1]);
-        acc[t][0] = mfma16(av[t][q4].z, bcur[4 * q4 + 2], acc[t][0]);
-        acc[t][1] = mfma16(av[t][q4].w, bcur[4 * q4 + 3], acc[t][1]);
-      }
-    }
-#pragma unroll
-    for (int st = 0; st < 16; ++st) bcur[st] = bnxt[st];
+    for (int i = 0; i < 6; ++i) bcur[i] = bnxt[i];
   }
-  // ---- epilogue: lane (ci = 16 wave + j) holds pixels p = 16 t + 4 kg + r; residual branch adds dz2 itself
+  // ---- fold the two channel halves through LDS (the dz2 image region, once every wave is done reading it) and
+  // finish: lane (ci = 32 nt + l31) holds pixels p = acc_row(r); the residual branch adds dz2 itself
   {
-    const int ci = wave * 16 + j;
-    float* dp1g = a.dp1out + rs * (long long)P2 * 64;
+    const int ci = nt * 32 + l31;
+    float res[16];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int r = 0; r < 16; ++r) {
+      const int p = acc_row(r, lane);
+      res[r] = (kh2 == 0 && p < P2) ? img2[(size_t)(((p / W2) + 1) * PW2 + (p % W2) + 1) * CS + ci] : 0.f;
+    }
+    __syncthreads();                                               // every wave has finished reading img2
+    float* xch = img2 + nt * 1024;                                 // [16][64] per output-channel tile
+    if (kh2 == 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = 16 * t + 4 * kg + r;
+      for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh2 == 0) {
+      float* dp1g = a.dp1out + rs * (long long)P2 * 64;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = acc_row(r, lane);
         if (p < P2) {
-          const float v = (acc[t][0][r] + acc[t][1][r]) + img2[(size_t)(((p / W2) + 1) * PW2 + (p % W2) + 1) * CS + ci];
+          const float v = (acc[r] + xch[r * 64 + lane]) + res[r];
           dp1s[p * 64 + ci] = v;
           dp1g[p * 64 + ci] = v;
         }

@@ -1486,6 +1486,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
 // ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
+constexpr int WG3B_MAXCPR = 11;   // wider maps: two three-piece stage buffers no longer fit in LDS
 struct Wgrad3Args {
   const float* in; const float* dpool; const uint8_t* mask; float* part;
   long long in_ns, dpool_ns, part_ns;
@@ -1901,6 +1902,238 @@ __global__ __launch_bounds__(512) void wgrad3r_kernel(Wgrad3Args a) {
   STAMP(2, 3);
 }
 
+// ---- split-bf16 weight gradient (default where it fits): wgrad3r_kernel's decomposition (blockIdx.z = kernel row,
+// 512 threads, wave = (pixel group kg, ci tile it, co tile ct), three accumulators kw = 0..2, stages of U pooled
+// rows, double-buffered) with both operands as three bf16 pieces on v_mfma_f32_32x32x16_bf16 (see "fp32 on the bf16
+// MFMA" above).  The contraction index of this GEMM is the PIXEL, and the activations arrive pixel-major /
+// channel-last -- k-major for both operands -- so the pieces are formed ONCE, while staging (global -> registers ->
+// split -> LDS), into bf16 planes [position][64 channels], and the MFMA loop fetches its fragments with the
+// transposed LDS read (ds_read_b64_tr_b16: 4 positions x 16 channels per 16 lanes), with no VALU work at all.
+//   Position order: a stage holds R = 2U image rows; the planes are COLUMN-major, pos = x * R + row, so that
+//   (1) the gradient plane dz (columns 0..CO-1 only) is one gapless k range [0, CO * R): no halo slots are
+//       multiplied, and
+//   (2) tap kw of the same k is the activation position k + kw * R: a constant offset, like every other address in
+//       the loop (k-step, piece, half-fragment): one base register per operand, the rest immediates.
+//   The 64-B channel halves of a position are swapped where (pos >> 1) & 1, which makes the four rows of a
+//   transposed read fall on four different 16-bank groups (conflict-free; probe: scripts/probes/tr_probe.hip).
+//   K = CO * R is padded to whole k-steps of 16 with zero gradient rows; pixel group kg takes steps kg, kg+2, ...
+constexpr int wg3b_U(int CPR) {      // pooled rows per stage: two buffers of three-piece planes must fit in LDS
+  const int CO = 2 * CPR;
+  int u = 97 / (2 * CO + 3);
+  if (32 / CPR < u) u = 32 / CPR;
+  if (u > 16) u = 16;
+  return u & ~1;
+}
+constexpr int wg3b_apos(int CPR) { return (2 * CPR + 3) * 2 * wg3b_U(CPR); }               // activation positions
+constexpr int wg3b_kp(int CPR) { return ((2 * CPR * 2 * wg3b_U(CPR) + 15) / 16) * 16; }    // gradient rows (padded)
+constexpr int wg3b_buf(int CPR) { return 3 * (wg3b_apos(CPR) + wg3b_kp(CPR)) * 128; }      // bytes per stage buffer
+__device__ __forceinline__ int plane_byte(int pos, int ch) {
+  return pos * 128 + (((ch >> 5) ^ ((pos >> 1) & 1)) << 6) + (ch & 31) * 2;
+}
+// four consecutive channels of one position -> the three planes
+__device__ __forceinline__ void plane_put(char* plane0, int plane_stride, int byte, const float4& v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t u0[4], u1[4], u2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u0[j] = __float_as_uint(x[j]);
+    const float r1 = x[j] - __uint_as_float(u0[j] & 0xffff0000u);
+    u1[j] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1[j] & 0xffff0000u);
+    u2[j] = __float_as_uint(r2);
+  }
+  *(uint2*)(plane0 + byte) = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
+  *(uint2*)(plane0 + plane_stride + byte) = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
+  *(uint2*)(plane0 + 2 * plane_stride + byte) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
+}
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+// one MFMA operand (8 k per lane) = two transposed reads, 4 positions apart
+__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 512));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int CPR>
+__global__ __launch_bounds__(512) void wgrad3b_kernel(Wgrad3Args a) {
+  constexpr int NT = 512, U = wg3b_U(CPR), R = 2 * U, CO = 2 * CPR;
+  constexpr int APOS = wg3b_apos(CPR), KP = wg3b_kp(CPR), NST = KP / 16;
+  constexpr int APL = APOS * 128, BPL = KP * 128, BUF = wg3b_buf(CPR);
+  constexpr int NRA = (R * (CO + 1) * 16 + NT - 1) / NT;          // activation items per thread and stage
+  static_assert(U >= 2 && U * CPR * 16 <= NT, "stage geometry");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = (char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int net = blockIdx.y, g = blockIdx.x, kh = blockIdx.z;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
+  const int UPS = H2;                       // units (pooled rows) per sample
+  const int NU = a.n * UPS;
+  const int UPG = a.UPG;
+  const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
+  STAMP(2, 0);
+  {  // halo columns, rows outside the image and the k padding must read as zero: clear both buffers once
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* p4 = (float4*)smem;
+    for (int i = tid; i < (2 * BUF) >> 4; i += NT) p4[i] = z;
+  }
+  const float* src = a.in + (long long)net * a.in_ns;
+  const float* dp = a.dpool + (long long)net * a.dpool_ns;
+  const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
+  const int ct = wave & 1, it = (wave >> 1) & 1, kg = wave >> 2;
+
+  // staging items of this thread (stage-invariant decode; the (sample, unit-in-sample) pair is carried)
+  const int qU = U / UPS, rU = U - qU * UPS;
+  int a_u[NRA], a_ir[NRA], a_src[NRA], a_dst[NRA], a_smp[NRA], a_j[NRA];
+#pragma unroll
+  for (int q = 0; q < NRA; ++q) {
+    const int t = tid + NT * q;
+    const int c4 = t & 15, pr = t >> 4;
+    const int rho = pr / W, px = pr - rho * W;
+    const bool ex = rho < R;
+    a_u[q] = ex ? (rho >> 1) : (1 << 28); a_ir[q] = (rho & 1) + kh - 1;
+    a_src[q] = px * 64 + c4 * 4;
+    a_dst[q] = plane_byte((px + 1) * R + (ex ? rho : 0), c4 * 4);
+    a_smp[q] = (ubeg + (rho >> 1)) / UPS; a_j[q] = (ubeg + (rho >> 1)) - a_smp[q] * UPS;
+  }
+  int d_u, d_g, d_smp, d_j, d_dst[4];
+  {
+    const bool ex = tid < U * W2 * 16;
+    const int id = ex ? tid : 0;
+    const int c4 = id & 15, p = id >> 4;
+    const int u = p / W2, pw = p - u * W2;
+    d_u = ex ? u : (1 << 28); d_g = pw * 64 + c4 * 4;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) d_dst[sub] = plane_byte((2 * pw + (sub & 1)) * R + 2 * u + (sub >> 1), c4 * 4);
+    d_smp = (ubeg + u) / UPS; d_j = (ubeg + u) - d_smp * UPS;
+  }
+  float4 pa[NRA];
+  float4 pdd = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t pdm = 0u;
+  float4 dbsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of channels 4*(tid&15)..+3 (kernel row 0 only)
+  // fetch(ub): the global loads of the stage that begins at unit ub (in order: it advances the carried indices)
+  auto fetch = [&](int ub) {
+#pragma unroll
+    for (int q = 0; q < NRA; ++q) {
+      const int row = a_j[q] * 2 + a_ir[q];
+      const bool ok = a_u[q] < (1 << 28) && (ub + a_u[q] < uend) && row >= 0 && row < H;
+      const float4 v = *(const float4*)(src + (ok ? ((a_smp[q] * HW + row * W) << 6) + a_src[q] : 0));
+      pa[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      a_smp[q] += qU; a_j[q] += rU;
+      if (a_j[q] >= UPS) { a_j[q] -= UPS; ++a_smp[q]; }
+    }
+    {
+      const bool ok = d_u < (1 << 28) && ub + d_u < uend;
+      const int gi = ok ? ((d_smp * P2 + d_j * W2) << 6) + d_g : 0;
+      pdd = *(const float4*)(dp + gi);
+      pdm = ok ? *(const uint32_t*)(mk + gi) : 0u;
+      d_smp += qU; d_j += rU;
+      if (d_j >= UPS) { d_j -= UPS; ++d_smp; }
+    }
+  };
+  // commit(buf): split what fetch() loaded and write the planes of one stage buffer
+  auto commit = [&](char* buf) {
+#pragma unroll
+    for (int q = 0; q < NRA; ++q)
+      if (a_u[q] < (1 << 28)) plane_put(buf, APL, a_dst[q], pa[q]);
+    if (d_u < (1 << 28)) {
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        float4 v;
+        v.x = ((pdm >> sub) & 1u) ? pdd.x * 0.25f : 0.f;
+        v.y = ((pdm >> (8 + sub)) & 1u) ? pdd.y * 0.25f : 0.f;
+        v.z = ((pdm >> (16 + sub)) & 1u) ? pdd.z * 0.25f : 0.f;
+        v.w = ((pdm >> (24 + sub)) & 1u) ? pdd.w * 0.25f : 0.f;
+        plane_put(buf + 3 * APL, BPL, d_dst[sub], v);
+        dbsum.x += v.x; dbsum.y += v.y; dbsum.z += v.z; dbsum.w += v.w;
+      }
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) acc[s] = zero16();
+  __syncthreads();                 // zero fill complete
+  if (ubeg < uend) { fetch(ubeg); commit(lds); }
+  __syncthreads();
+  STAMP(2, 1);
+  // this lane's part of a transposed read: 16-lane group gq = lane >> 4 covers k half (gq >> 1) and channel block
+  // (gq & 1) of the wave's tile; inside it lane 4q + p addresses row q, channels 4p..4p+3.  The block base is a
+  // multiple of 4 positions, so the swizzle bit of the lane's row is (q >> 1) & 1 in every read.
+  const int gq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int rowb = (8 * (gq >> 1) + qq) * 128 + 32 * (gq & 1) + 8 * pp;
+  const int sw = (qq >> 1) & 1;
+  const int a_lane = rowb + ((it ^ sw) << 6);
+  const int b_lane = 3 * APL + rowb + ((ct ^ sw) << 6);
+  int cur = 0;
+  for (int ub = ubeg; ub < uend; ub += U) {
+    const bool more = ub + U < uend;            // workgroup-uniform
+    const char* buf = lds + cur * BUF;
+    if (more) fetch(ub + U);                    // in flight across the MFMAs below
+    const char* pa_ = buf + a_lane;
+    const char* pb_ = buf + b_lane;
+#pragma unroll
+    for (int st = 0; st < (NST + 1) / 2; ++st) {
+      const int step = 2 * st + kg;             // wave-uniform
+      if (step < NST) {
+        const char* pbs = pb_ + step * 2048;
+        const bf16x8 b1 = tr_frag(pbs), b2 = tr_frag(pbs + BPL), b3 = tr_frag(pbs + 2 * BPL);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const char* pas = pa_ + step * 2048 + kw * (R * 128);
+          const bf16x8 a1 = tr_frag(pas), a2 = tr_frag(pas + APL), a3 = tr_frag(pas + 2 * APL);
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[kw], 0, 0, 0);
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[kw], 0, 0, 0);
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[kw], 0, 0, 0);
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[kw], 0, 0, 0);
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[kw], 0, 0, 0);
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[kw], 0, 0, 0);
+        }
+      }
+    }
+    if (more) commit(lds + (cur ^ 1) * BUF);
+    __syncthreads();   // stage g fully read by every wave, stage g+1 fully written
+    cur ^= 1;
+  }
+  STAMP(2, 2);
+
+  // fold pixel group 1 into group 0 through LDS ([4 waves][48][64]); group 0 stores the partial
+  float* red = smem + (size_t)(wave & 3) * 48 * 64 + lane;
+  if (kg == 1) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(s * 16 + r) * 64] = acc[s][r];
+  }
+  float4* dbl = (float4*)(smem + 4 * 48 * 64);    // [512] per-thread bias partial sums
+  if (kh == 0) dbl[tid] = dbsum;
+  __syncthreads();
+  float* part = a.part + (long long)net * a.part_ns + (size_t)g * PART3;
+  if (kg == 0) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = it * 32 + acc_row(r, lane);
+        part[(3 * kh + s) * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r] + red[(s * 16 + r) * 64];
+      }
+    }
+  }
+  // bias gradient (kernel row 0 only): thread t holds channels 4*(t & 15)..+3; fixed-order sum over the 32 threads
+  // of each channel quad
+  if (kh == 0 && tid < 64) {
+    const int c4 = tid >> 2, e = tid & 3;
+    float sum = 0.f;
+    for (int k = 0; k < 32; ++k) sum += ((const float*)&dbl[c4 + 16 * k])[e];
+    part[9 * 4096 + tid] = sum;
+  }
+  STAMP(2, 3);
+}
+
 static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
   const int PW = W + 2, CO = 2 * (W / 2);
   const size_t D = (size_t)U * RU * CO;
@@ -1938,7 +2171,7 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
   if (p->cspl == 2) { G = (NU + 1) / 2; if (G > 128) G = 128; }   // 2 co-halves x 2 nets x 128 = 512 workgroups
   if (G > 256) G = 256;                            // per net; 2 nets -> 512 WGs
   p->RU = RU; p->U = U; p->G = (int)G; p->lds = wgrad3_lds(RU, U, W, p->cspl);
-  p->rsplit = 0; p->UPG = 0;
+  p->rsplit = 0; p->UPG = 0; p->b3 = 0;
   const int CO = 2 * (W / 2);
   // row-split kernel: blockIdx.z = kernel row; units of one pooled row, U (even) per stage
   static const int rsp = getenv("CMLPL_WGRAD3_R") ? atoi(getenv("CMLPL_WGRAD3_R")) : 1;
@@ -1968,6 +2201,18 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
       const long long Gr = (NUr + upg - 1) / upg;
       p->RU = 2; p->U = Ur; p->G = (int)Gr; p->UPG = (int)upg; p->lds = lds_r(Ur);
       p->rsplit = cpr;                                          // = template parameter CPR of wgrad3r_kernel
+      // split-bf16 variant: same grid and partial layout, its own stage size and LDS
+      static const int b3on = getenv("CMLPL_WGRAD3_B3") ? atoi(getenv("CMLPL_WGRAD3_B3")) : 1;
+      p->b3 = 0;
+      if (b3on && cpr <= WG3B_MAXCPR && (long long)n * H * W * 64 < (1LL << 31)) {
+        const int Ub = wg3b_U(cpr);
+        long long upgb = (NUr + Gt - 1) / Gt;
+        upgb = ((upgb + Ub - 1) / Ub) * Ub;
+        const size_t red = (size_t)(4 * 48 * 64 + 512 * 4) * 4;
+        const size_t need = 2 * (size_t)wg3b_buf(cpr);
+        p->b3 = 1; p->U = Ub; p->UPG = (int)upgb; p->G = (int)((NUr + upgb - 1) / upgb);
+        p->lds = need > red ? need : red;
+      }
     }
   }
   return true;
@@ -1988,6 +2233,22 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G; a.UPG = pl.UPG;
+  if (pl.rsplit && pl.b3) {
+#define WG3B_CASE(CPR_)                                                                              \
+    case CPR_: {                                                                                     \
+      static DevOnce attr_b;                                                                         \
+      hipError_t e = ensure_max_lds(attr_b, wgrad3b_kernel<CPR_>);                                   \
+      if (e != hipSuccess) return e;                                                                 \
+      hipLaunchKernelGGL((wgrad3b_kernel<CPR_>), dim3(pl.G, nets, 3), dim3(512), pl.lds, st, a);     \
+      return hipGetLastError();                                                                      \
+    }
+    switch (pl.rsplit) {
+      WG3B_CASE(1) WG3B_CASE(2) WG3B_CASE(3) WG3B_CASE(4) WG3B_CASE(5) WG3B_CASE(6) WG3B_CASE(7) WG3B_CASE(8)
+      WG3B_CASE(9) WG3B_CASE(10) WG3B_CASE(11)
+      default: return hipErrorInvalidValue;
+    }
+#undef WG3B_CASE
+  }
   if (pl.rsplit) {
 #define WG3R_CASE(CPR_)                                                                              \
     case CPR_: {                                                                                     \

@@ -108,7 +108,7 @@ bool conv3_fused_head_ok(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
                                   const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,
                                   const BwdHead* head /* or null */, hipStream_t st);
-struct Wgrad3Plan { int RU, U, G, cspl, rsplit, UPG; size_t lds; };   // rsplit > 0: row-split kernel with CPR = rsplit, UPG units per workgroup
+struct Wgrad3Plan { int RU, U, G, cspl, rsplit, UPG, b3; size_t lds; };   // rsplit > 0: row-split kernel with CPR = rsplit, UPG units per workgroup
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st);

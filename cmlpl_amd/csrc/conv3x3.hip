@@ -34,9 +34,7 @@ namespace cmlpl {
 constexpr int CS = 68;  // LDS pixel stride in floats (64 + 4): conflict-free ds_read_b128 over 16 pixels
 
 // ------------------------------------------------------------------------------------------
-// weight packing: canonical W[co][ci][kh][kw] ->
-//   fwd  : wf[s][q][co][r] = W[co][4q+r][kh][kw]            s = kh*3+kw
-//   dgrad: wd[s][q][ci][r] = W[4q+r][ci][2-kh][2-kw]        (transposed + flipped)
+// weight packing: canonical W[co][ci][kh][kw] -> the fragment sets described in kernels.hpp (PACK_*)
 // ------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ params, long long pstride, PackInfo pi,
                                     float* __restrict__ packed) {
@@ -45,35 +43,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
   if (e >= pi.stride) return;
   const float* P = params + (long long)net * pstride;
   float v;
-  if (e < 4 * PACK_CONV) {
-    const int which = (int)(e / PACK_CONV);          // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
-    const int i = (int)(e - (long long)which * PACK_CONV);
-    const int r = i & 3, oc = (i >> 2) & 63, q = (i >> 8) & 15, s = i >> 12;
-    const int kh = s / 3, kw = s - kh * 3;
-    const float* W = P + ((which < 2) ? pi.off_w1 : pi.off_w2);
-    const int k = 4 * q + r;
-    if ((which & 1) == 0) v = W[((oc * 64 + k) * 3 + kh) * 3 + kw];                    // co=oc, ci=k
-    else                  v = W[((k * 64 + oc) * 3 + (2 - kh)) * 3 + (2 - kw)];        // co=k, ci=oc
-  } else if (e < PACK_PER_NET) {                     // conv2 as 16x16x4 B fragments (inverse of conv2_frag_index)
-    const int which = (int)(e / PACK_CONV);          // 4 fwd, 5 dgrad
-    const int i = (int)(e - (long long)which * PACK_CONV);
-    const int lane = i & 63, st = (i >> 6) & 15, nq = (i >> 10) & 3, tap = i >> 12;
-    const int nn = nq * 16 + (lane & 15), k = (lane >> 4) * 16 + st;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const float* W = P + pi.off_w2;
-    if (which == 4) v = W[((nn * 64 + k) * 3 + kh) * 3 + kw];                          // co=n, ci=k
-    else            v = W[((k * 64 + nn) * 3 + (2 - kh)) * 3 + (2 - kw)];              // co=k, ci=n
-  } else if (e < pack_off_wst(pi.C)) {
-    const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
-    v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
-  } else if (e < pack_off_b3(pi.C, pi.bands, 0)) {
-    const long long i = e - pack_off_wst(pi.C);
-    const int band = (int)(i >> 10), o = (int)(i & 1023);
-    v = P[pi.off_ws + (long long)o * pi.bands + band];
-  } else {                                           // split-bf16 fragment sets: two bf16 per float slot
-    const long long f = e - pack_off_b3(pi.C, pi.bands, 0);
-    const int which = (int)(f / PACK_B3);            // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
-    const int i = (int)(f - (long long)which * PACK_B3) * 2;     // bf16 index (inverse of conv_b3_index), j even
+  if (e < 4LL * PACK_B3) {                           // split-bf16 fragment sets: two bf16 per float slot
+    const int which = (int)(e / PACK_B3);            // 0 c1 fwd, 1 c1 dgrad, 2 c2 fwd, 3 c2 dgrad
+    const int i = (int)(e - (long long)which * PACK_B3) * 2;     // bf16 index (inverse of conv_b3_index), j even
     const int j = i & 7, l31 = (i >> 3) & 31, h = (i >> 8) & 1, nt = (i >> 9) & 1, rest = i >> 10;
     const int pc = rest % 3, kq = (rest / 3) & 3, tap = rest / 12;
     const int kh = tap / 3, kw = tap - kh * 3, n = nt * 32 + l31;
@@ -89,6 +61,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
       out |= pcs[pc] << (16 * d);
     }
     v = __uint_as_float(out);
+  } else if (e < PACK_PER_NET) {                     // conv2 forward as 16x16x4 B fragments (inverse of conv2_frag_index)
+    const int i = (int)(e - pack_off_frag());
+    const int lane = i & 63, st = (i >> 6) & 15, nq = (i >> 10) & 3, tap = i >> 12;
+    const int nn = nq * 16 + (lane & 15), k = (lane >> 4) * 16 + st;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    v = P[pi.off_w2 + ((nn * 64 + k) * 3 + kh) * 3 + kw];                              // co=n, ci=k
+  } else if (e < pack_off_wst(pi.C)) {
+    const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
+    v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
+  } else {
+    const long long i = e - pack_off_wst(pi.C);
+    const int band = (int)(i >> 10), o = (int)(i & 1023);
+    v = P[pi.off_ws + (long long)o * pi.bands + band];
   }
   packed[(long long)net * pi.stride + e] = v;
 }

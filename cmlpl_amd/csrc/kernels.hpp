@@ -10,37 +10,35 @@
 
 namespace cmlpl {
 
-constexpr int PACK_CONV = 9 * 64 * 64;       // one packed 3x3 weight set
-// conv1 fwd, conv1 dgrad, conv2 fwd, conv2 dgrad ([tap][ci/4][co][4], for the 32x32x2 MFMA kernels), then conv2 fwd /
-// dgrad again as ready-made B fragments of the 16x16x4 MFMA ([tap][n-quarter][k-step][lane], see conv2_frag_index):
-// the per-sample tail / head of the fused kernels reads them straight from L2, one coalesced 256-B load per MFMA
-constexpr int PACK_PER_NET = 6 * PACK_CONV;
-// element of conv2.weight[co][ci][kh][kw] in the 16x16x4 fragment packs.  An MFMA step consumes k = 16*kg + s
-// (kg = lane >> 4, s = step 0..15) and produces the 16 outputs of one n-quarter (j = lane & 15).
-//   forward : k = ci, n = co                       dgrad: k = co, n = ci, tap flipped (transposed convolution)
-__host__ __device__ inline int conv2_frag_index(int tap, int n, int k) {
-  return (((tap * 4 + (n >> 4)) * 16 + (k & 15)) * 64) + ((k >> 4) << 4) + (n & 15);
-}
-// after the four 3x3 packs, each net's packed buffer holds k-major copies of the two "thin" weights:
-//   w0T [Cp][64]      = conv0.weight^T  (Cp = C rounded up to even, pad row zero)
-//   wsT [bands][1024] = feat_spe.weight^T
-// so that their MFMA B fragments (fixed k, 32 consecutive outputs) are coalesced 128-B global reads.
-__host__ __device__ inline long long pack_off_w0t() { return PACK_PER_NET; }
-__host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET + (long long)((C + 1) & ~1) * 64; }
-// ... and, last, the 3x3 weights once more for the split-bf16 tap loops (conv3x3.hip, "fp32 on the bf16 MFMA"): conv1
-// fwd, conv1 dgrad, conv2 fwd, conv2 dgrad, each weight as three bf16 pieces w = w1 + w2 + w3 (exact, see b3_split),
-// laid out as ready-made B fragments of v_mfma_f32_32x32x16_bf16:
-//   [tap][k16 step (4)][piece (3)][n tile (2)][lane (64)][8 bf16]   lane = (n & 31) + 32 * ((k >> 3) & 1), j = k & 7
-// so a tap is one linear 24 KiB copy into LDS and a fragment one conflict-free ds_read_b128.
+constexpr int PACK_CONV = 9 * 64 * 64;       // elements of one 3x3 weight set
+// Packed (per network) weights, refreshed by the optimizer every step:
+//   four split-bf16 fragment sets for the 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (conv3x3.hip, "fp32 on the
+//   bf16 MFMA"): conv1 fwd, conv1 dgrad, conv2 fwd, conv2 dgrad; each weight as three bf16 pieces w = w1 + w2 + w3
+//   (exact, see b3_split), laid out as ready-made B fragments
+//     [tap][k16 step (4)][piece (3)][n tile (2)][lane (64)][8 bf16]   lane = (n & 31) + 32 * ((k >> 3) & 1), j = k & 7
+//   so a tap is one linear 24 KiB copy into LDS and a fragment one conflict-free ds_read_b128
+//     forward: k = ci, n = co            dgrad: k = co, n = ci, tap flipped (transposed convolution);
+//   conv2 forward once more as fp32 B fragments of the 16x16x4 MFMA ([tap][n-quarter][k-step][lane], see
+//   conv2_frag_index): the per-sample tail of the fused forward reads them straight from L2;
+//   k-major copies of the two "thin" weights, so that their MFMA B fragments (fixed k, 32 consecutive outputs) are
+//   coalesced 128-B global reads:   w0T [Cp][64] = conv0.weight^T (Cp = C rounded up to even, pad row zero),
+//                                   wsT [bands][1024] = feat_spe.weight^T
 constexpr int PACK_B3 = PACK_CONV * 3 / 2;   // floats occupied by one split weight set
-__host__ __device__ inline long long pack_off_b3(int C, int bands, int which) {
-  return pack_off_wst(C) + (long long)bands * 1024 + (long long)which * PACK_B3;
-}
-__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_b3(C, bands, 4); }
+constexpr int PACK_PER_NET = 4 * PACK_B3 + PACK_CONV;
+__host__ __device__ inline long long pack_off_b3(int /*C*/, int /*bands*/, int which) { return (long long)which * PACK_B3; }
+__host__ __device__ inline long long pack_off_frag() { return 4LL * PACK_B3; }
 // bf16 element index of (tap, k, n, piece) inside one split weight set
 __host__ __device__ inline int conv_b3_index(int tap, int k, int n, int p) {
   return ((((tap * 4 + (k >> 4)) * 3 + p) * 2 + (n >> 5)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7);
 }
+// element of conv2.weight[co][ci][kh][kw] in the 16x16x4 fragment pack.  An MFMA step consumes k = 16*kg + s
+// (kg = lane >> 4, s = step 0..15) and produces the 16 outputs of one n-quarter (j = lane & 15); k = ci, n = co.
+__host__ __device__ inline int conv2_frag_index(int tap, int n, int k) {
+  return (((tap * 4 + (n >> 4)) * 16 + (k & 15)) * 64) + ((k >> 4) << 4) + (n & 15);
+}
+__host__ __device__ inline long long pack_off_w0t() { return PACK_PER_NET; }
+__host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET + (long long)((C + 1) & ~1) * 64; }
+__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_wst(C) + (long long)bands * 1024; }
 struct PackInfo { long long stride, off_w0, off_w1, off_w2, off_ws; int C, bands; };
 constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci][co] + db[co]
 constexpr size_t LDS_MAX = 160 * 1024;

@@ -31,34 +31,27 @@ __global__ void adam_kernel(float* __restrict__ params, long long pstride, const
   *(float4*)mm = make_float4(ma[0], ma[1], ma[2], ma[3]);
   *(float4*)vv = make_float4(va[0], va[1], va[2], va[3]);
   *(float4*)p = make_float4(pa[0], pa[1], pa[2], pa[3]);
-  // the 3x3 kernels read re-packed weights ([tap][ci/4][co][4], forward and transposed+flipped): refresh
-  // them here instead of a separate launch (same mapping as pack_weights_kernel)
+  // the 3x3 kernels read re-packed weights (split-bf16 MFMA fragments, forward and transposed+flipped; kernels.hpp):
+  // refresh them here instead of a separate launch (same mapping as pack_weights_kernel)
   if (packed != nullptr) {
     float* pkn = packed + (long long)net * pi.stride;
     const int which = (i4 >= pi.off_w1 && i4 < pi.off_w1 + PACK_CONV) ? 0 : (i4 >= pi.off_w2 && i4 < pi.off_w2 + PACK_CONV) ? 2 : -1;
     if (which >= 0) {
-      float* pk = pkn + which * PACK_CONV;
       const int e0 = (int)(i4 - (which == 0 ? pi.off_w1 : pi.off_w2));
+      uint16_t* bf = (uint16_t*)(pkn + pack_off_b3(pi.C, pi.bands, which));        // forward fragment set
+      uint16_t* bd = (uint16_t*)(pkn + pack_off_b3(pi.C, pi.bands, which + 1));    // transposed + flipped (dgrad)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int e = e0 + q, kw = e % 3, kh = (e / 3) % 3, ci = (e / 9) & 63, co = e / 576;
-        pk[(((kh * 3 + kw) * 16 + (ci >> 2)) * 64 + co) * 4 + (ci & 3)] = pa[q];
-        pk[PACK_CONV + ((((2 - kh) * 3 + (2 - kw)) * 16 + (co >> 2)) * 64 + ci) * 4 + (co & 3)] = pa[q];
-        {                   // ... and as split-bf16 B fragments (conv3x3 tap loops)
-          uint32_t pcs[3];
-          b3_split(pa[q], pcs);
-          uint16_t* bf = (uint16_t*)(pkn + pack_off_b3(pi.C, pi.bands, which));
-          uint16_t* bd = (uint16_t*)(pkn + pack_off_b3(pi.C, pi.bands, which + 1));
+        uint32_t pcs[3];
+        b3_split(pa[q], pcs);
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
-            bf[conv_b3_index(kh * 3 + kw, ci, co, pc)] = (uint16_t)pcs[pc];
-            bd[conv_b3_index((2 - kh) * 3 + (2 - kw), co, ci, pc)] = (uint16_t)pcs[pc];
-          }
+        for (int pc = 0; pc < 3; ++pc) {
+          bf[conv_b3_index(kh * 3 + kw, ci, co, pc)] = (uint16_t)pcs[pc];
+          bd[conv_b3_index((2 - kh) * 3 + (2 - kw), co, ci, pc)] = (uint16_t)pcs[pc];
         }
-        if (which == 2) {   // conv2 also as 16x16x4 B fragments (fused tail / head kernels)
-          pkn[4 * PACK_CONV + conv2_frag_index(kh * 3 + kw, co, ci)] = pa[q];
-          pkn[5 * PACK_CONV + conv2_frag_index((2 - kh) * 3 + (2 - kw), ci, co)] = pa[q];
-        }
+        // conv2 also as 16x16x4 fp32 B fragments (forward tail of the fused kernel)
+        if (which == 2) pkn[pack_off_frag() + conv2_frag_index(kh * 3 + kw, co, ci)] = pa[q];
       }
     } else if (i4 >= pi.off_w0 && i4 < pi.off_w0 + 64LL * pi.C) {      // conv0.weight[co][c] -> w0T[c][co]
 #pragma unroll

@@ -32,6 +32,18 @@ WORKLOADS = {   # name: (C, H, W, bands, K)   -- SURVEY.md section 8d
     "B5": (48, 15, 15, 48, 20),     # Houston2018-shaped
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # same guide, "BF16/F16 ~2.5 PF dense"
+# The 3x3 convolutions compute fp32 products as six bf16 MFMAs (three exact bf16 pieces per operand, fp32 accumulate;
+# cmlpl_amd/csrc/conv3x3.hip): their ceiling in fp32-equivalent FLOP/s is the bf16 peak / 6.
+SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+
+
+def blended_peak(segments):
+    """fp32-equivalent MFMA peak of a kernel that mixes f32-input and split-bf16 MFMA segments:
+    total FLOPs / sum(FLOPs_i / peak_i).  segments: {"f32": flops, "split": flops}."""
+    tot = segments.get("f32", 0.0) + segments.get("split", 0.0)
+    floor_s = segments.get("f32", 0.0) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + segments.get("split", 0.0) / (SPLIT_PEAK_TFLOPS * 1e12)
+    return (tot / floor_s / 1e12) if floor_s > 0 else FP32_MFMA_PEAK_TFLOPS
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # written by scripts/pmc_summary.py --json
 CONV1_KERNELS = {
     "conv1_fwd": "conv3x3_kernel<FWD> (conv1 forward: 3x3 conv + bias + residual + ReLU + avgpool, both networks)",
@@ -276,40 +288,54 @@ def run_rank(args):
     n_local = bt + btu
     patches = n_local * world * args.steps
     dom_ms = ms[dom_id] / max(cnt[dom_id], 1)
-    kflops = {k: conv1_flops(shape, n_local) for k in CONV1_KERNELS}
+    wgrad_split = os.environ.get("CMLPL_WGRAD3_B3", "1") != "0"
+    c1 = conv1_flops(shape, n_local)
+    # per kernel: algorithmic FLOPs by MFMA kind ("split" = three-piece bf16 operands, "f32" = f32-input MFMA)
+    kseg = {"conv1_fwd": {"split": c1}, "conv1_dgrad": {"split": c1},
+            "conv1_wgrad": {"split": c1} if wgrad_split else {"f32": c1}}
     labels = dict(CONV1_KERNELS)
+    conv0_flops = 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64                # 2*nets*n*HW*C*64
     if fused_fwd:
-        kflops["conv1_fwd"] += 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64      # conv0: 2*nets*n*HW*C*64
+        kseg["conv1_fwd"]["f32"] = conv0_flops
         labels["conv1_fwd"] = ("conv3x3_kernel<FWD0> (conv0 1x1 + conv1 3x3 forward fused: conv + bias + residual + "
                                "ReLU + avgpool, both networks)")
     if fused_bwd:
-        kflops["conv1_dgrad"] += 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64
+        kseg["conv1_dgrad"]["f32"] = conv0_flops
         labels["conv1_dgrad"] = ("conv3x3_kernel<DGRAD0> (conv1 data gradient + conv0 weight gradient fused, "
                                  "both networks)")
     conv2_flops = 2.0 * 2 * n_local * (shape[1] // 2) * (shape[2] // 2) * 64 * 576    # dense 3x3 on the pooled map
     if tail_fwd:
-        kflops["conv1_fwd"] += conv2_flops
+        kseg["conv1_fwd"]["f32"] += conv2_flops                                         # 16x16x4 f32 MFMA in the tail
         labels["conv1_fwd"] = ("conv3x3_kernel<2,1,1> (per-sample fused forward: augmentation + conv0 1x1 + conv1 3x3 + "
                                "ReLU/pool + conv2 3x3 + ReLU/pool + concat/dropout/classifier/L2-norm, both networks)")
     if head_bwd:
-        kflops["conv1_dgrad"] += conv2_flops
+        kseg["conv1_dgrad"]["split"] += conv2_flops
         labels["conv1_dgrad"] = ("conv3x3_kernel<3,1,1> (per-sample fused backward: head + conv2 data gradient + conv1 "
                                  "data gradient + conv0 weight gradient, both networks)")
+    kflops = {k: sum(v.values()) for k, v in kseg.items()}
+    kpeak = {k: blended_peak(v) for k, v in kseg.items()}
     traffic, traffic_src = recorded_traffic(args.workload, n_local)
     flops = kflops[dom_name]
     achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     out = {
         "metric": "HSI patches/sec per training step", "value": patches / dt, "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32 (3x3 convolutions: f32 operands as 3 exact bf16 pieces on the bf16 MFMA, f32 accumulate; "
+                 "everything else f32 MFMA / f32 VALU)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic PaviaU-shaped patches {shape[1]}x{shape[2]}x{shape[0]}, "
                                f"spectrum {shape[3]}, {shape[4]} classes, {bt} labelled + {btu} unlabelled "
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
                                f"bank + Adam, epoch 1 (memory-bank smoothing active), Philox noise/dropout",
                    "global_batch": n_local * world, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": labels[dom_name],
-                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     "achieved": achieved, "peak": kpeak[dom_name], "unit": "TFLOP/s",
+                     "frac": achieved / kpeak[dom_name],
+                     "peak_note": "fp32-equivalent MFMA ceiling of this kernel's own instruction mix: algorithmic "
+                                  "FLOPs / (f32-segment FLOPs / 157.3 T + split-segment FLOPs / (2500 T / 6)); "
+                                  "a split-bf16 product costs six bf16 MFMAs",
+                     "flops_by_mfma_kind": kseg[dom_name],
+                     "frac_of_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": traffic.get(dom_name),
                      "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; recorded in "
                                      f"{traffic_src or 'profiles/'}, null when the kernel sources changed since)",
@@ -317,9 +343,9 @@ def run_rank(args):
         # the other two conv1 kernels (same algorithmic FLOPs), from the calibration window
         "roofline_others": [
             {"kernel": labels[k], "ms_per_launch": calib[k], "launches_timed": calib_steps,
-             "flops_per_launch": kflops[k],
+             "flops_per_launch": kflops[k], "flops_by_mfma_kind": kseg[k], "peak": kpeak[k],
              "achieved": kflops[k] / (calib[k] * 1e-3) / 1e12 if calib[k] > 0 else 0.0,
-             "frac": (kflops[k] / (calib[k] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if calib[k] > 0 else 0.0,
+             "frac": (kflops[k] / (calib[k] * 1e-3) / 1e12 / kpeak[k]) if calib[k] > 0 else 0.0,
              "traffic": traffic.get(k)}
             for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},

@@ -24,12 +24,17 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in d, k
     assert d["unit"] == "patches/s" and d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"].startswith("f32") and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 256 * 1000.0 / d["ms_per_step"]) <= 1e-6 * d["value"]      # whole-job patches / time
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
-    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    # peak: the MFMA ceiling of the kernel's own mix of f32-input and split-bf16 segments, between the two pure cases
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 157.3 <= rf["peak"] <= 2500.0 / 6 + 1e-6
+    seg = rf["flops_by_mfma_kind"]
+    assert abs(sum(seg.values()) - rf["flops_per_launch"]) < 1.0
+    want_peak = sum(seg.values()) / (seg.get("f32", 0.0) / 157.3 + seg.get("split", 0.0) / (2500.0 / 6))
+    assert abs(rf["peak"] - want_peak) < 1e-6 * want_peak
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
     assert rf["launches_timed"] == 12
     assert rf["traffic"] is None or rf["traffic"] > 1e6     # null when the kernels changed since the recorded PMC pass

@@ -70,10 +70,23 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
   } else if (e < pack_off_wst(pi.C)) {
     const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
     v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
-  } else {
+  } else if (e < pack_off_w0b3(pi.C, pi.bands)) {
     const long long i = e - pack_off_wst(pi.C);
     const int band = (int)(i >> 10), o = (int)(i & 1023);
     v = P[pi.off_ws + (long long)o * pi.bands + band];
+  } else {                                           // conv0 as split-bf16 fragments: conv_b3_index(0, k = band, n = co, piece)
+    const int i = (int)(e - pack_off_w0b3(pi.C, pi.bands)) * 2;
+    const int j = i & 7, l31 = (i >> 3) & 31, h = (i >> 8) & 1, nt = (i >> 9) & 1, rest = i >> 10;
+    const int pc = rest % 3, kq = rest / 3, n = nt * 32 + l31;
+    uint32_t out = 0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int k = kq * 16 + h * 8 + j + d;
+      uint32_t pcs[3];
+      b3_split(k < pi.C ? P[pi.off_w0 + (long long)n * pi.C + k] : 0.f, pcs);
+      out |= pcs[pc] << (16 * d);
+    }
+    v = __uint_as_float(out);
   }
   packed[(long long)net * pi.stride + e] = v;
 }
@@ -276,6 +289,7 @@ __device__ __forceinline__ f32x16 mfma_b3(const uint4& A1, const uint4& A2, cons
   return acc;
 }
 
+constexpr int CONV0_MAXKQ = 8;   // fused conv0: at most 128 input bands (k-steps of 16)
 constexpr int WBUF = 6144;      // floats: one tap's weight fragments (4 k-steps x 3 pieces x 2 n tiles x 1 KiB)
 constexpr int TAPW = WBUF / 4;  // float4 per tap
 // a thread's share of one tap's weights on their way global -> LDS (named members: an array member ends up in scratch)
@@ -449,58 +463,50 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     // here, written into the LDS image (the conv1 input) and to HBM (the backward pass reads it).  The image and
     // tap-weight regions are idle until then, so the sample's whole [C][HW] slab is copied into them linearly by
     // global_load_lds_dwordx4 -- every piece in flight at once, ONE wait -- and only afterwards is the region
-    // re-initialised as the zero-bordered image.  wave = M tile of 32 pixels; A[pixel][band] = slab[band][pixel]
-    // (ds_read_b32, consecutive lanes = consecutive pixels); B = the k-major w0T rows straight from L2, fetched
-    // 16 k-steps ahead.
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(1))) const void gbl_void;
-    const int C = a.C, Cp = (C + 1) & ~1, KK = Cp >> 1;
-    float* slab = smem;                                   // [Cp][HW] (+64), aliases img | wbuf | lut
-    float* w0l = smem + Cp * HW + 64;                     // [Cp][64] k-major conv0 weights (pad row is zero)
-    const float* w0 = a.w0t + (long long)net * a.w0t_ns;
+    // re-initialised as the zero-bordered image.
+    // The product runs on the split-bf16 MFMA: wave = (output-channel tile nt, pixel half mh: M tiles 2mh, 2mh+1);
+    // A[pixel][band] = slab[band][pixel] (eight ds_read_b32 per tile and k-step of 16 bands, consecutive lanes =
+    // consecutive pixels, split in registers); B = this wave's share of the conv0 weight fragments (kernels.hpp:
+    // pack_off_w0b3), requested from L2 at kernel start -- nothing is shared between the waves, so no LDS copy.
+    const int C = a.C, KQ0 = (C + 15) >> 4;
+    float* slab = smem;                                   // [16 KQ0][HW] (+64), aliases img | wbuf | lut
+    const int nt0 = wave & 1, mh = wave >> 1;
+    uint4 bw[CONV0_MAXKQ][3];
+    {
+      const uint4* wq = (const uint4*)(a.w0t + (long long)net * a.w0t_ns) + lane;
+#pragma unroll
+      for (int kq = 0; kq < CONV0_MAXKQ; ++kq)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          bw[kq][pc] = (kq < KQ0) ? wq[((kq * 3 + pc) * 2 + nt0) * 64] : make_uint4(0u, 0u, 0u, 0u);
+    }
     {
       const int nfl = C * HW;
-      const int wf4 = Cp * 16;                            // w0T is 16-B aligned and a multiple of 64 floats
-      for (int q = wave; q * 64 < wf4; q += 4) {
-        const int f = q * 64 + lane;
-        if (f < wf4) __builtin_amdgcn_global_load_lds((gbl_void*)(w0 + 4 * f), (lds_void*)(w0l + q * 256), 16, 0, 0);
-      }
-      // the pad band (odd C) meets a zero weight row, but must be finite; so must the tail a clamped lane reads
-      for (int i = nfl + tid; i < Cp * HW + 64; i += 256) slab[i] = 0.f;
+      // the bands beyond C meet zero weights, but must be finite; so must the tail a clamped lane reads
+      for (int i = nfl + tid; i < 16 * KQ0 * HW + 64; i += 256) slab[i] = 0.f;
       slab_issue(a.xs, net, s0, nfl, slab, wave, lane);
       slab_finish(a.xs, net, s0, nfl, slab, tid, wave, lane);
     }
-    f32x16 z0 = zero16(), z1 = zero16();
-    const int pixA = (wave * 32 + l31 < HW) ? wave * 32 + l31 : HW - 1;
-    __syncthreads();                                      // slab + weights complete (the barrier waits for the DMA)
+    f32x16 z0 = zero16(), z1 = zero16();                  // M tiles 2mh and 2mh + 1 of output-channel tile nt0
+    __syncthreads();                                      // slab complete (the barrier waits for the DMA)
     STAMP(0, 4);
     {
-      const float* ap = slab + hh * HW + pixA;
-      const float* bp = w0l + hh * 64 + l31;
-      // operands of the next 8 k-steps are fetched from LDS while the 16 MFMAs of the current 8 run
-      float av[8], b0v[8], b1v[8], an[8], b0n[8], b1n[8];
+      const int pix0 = ((2 * mh) * 32 + l31 < HW) ? (2 * mh) * 32 + l31 : HW - 1;
+      const int pix1 = ((2 * mh + 1) * 32 + l31 < HW) ? (2 * mh + 1) * 32 + l31 : HW - 1;
+      const float* ap0 = slab + hh * 8 * HW + pix0;
+      const float* ap1 = slab + hh * 8 * HW + pix1;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = (q < KK) ? q : 0;
-        av[q] = ap[2 * k * HW]; b0v[q] = bp[2 * k * 64]; b1v[q] = bp[2 * k * 64 + 32];
-      }
-      for (int k0 = 0; k0 < KK; k0 += 8) {
+      for (int kq = 0; kq < CONV0_MAXKQ; ++kq) {
+        if (kq < KQ0) {                                   // uniform
+          float r0[8], r1[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int k = (k0 + 8 + q < KK) ? k0 + 8 + q : 0;
-          an[q] = ap[2 * k * HW]; b0n[q] = bp[2 * k * 64]; b1n[q] = bp[2 * k * 64 + 32];
+          for (int j = 0; j < 8; ++j) { r0[j] = ap0[(kq * 16 + j) * HW]; r1[j] = ap1[(kq * 16 + j) * HW]; }
+          uint4 A1, A2, A3;
+          a_split(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r0[4], r0[5], r0[6], r0[7]), A1, A2, A3);
+          z0 = mfma_b3(A1, A2, A3, bw[kq][0], bw[kq][1], bw[kq][2], z0);
+          a_split(make_float4(r1[0], r1[1], r1[2], r1[3]), make_float4(r1[4], r1[5], r1[6], r1[7]), A1, A2, A3);
+          z1 = mfma_b3(A1, A2, A3, bw[kq][0], bw[kq][1], bw[kq][2], z1);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (k0 + q < KK) {                              // uniform
-            z0 = mfma32(av[q], b0v[q], z0);
-            z1 = mfma32(av[q], b1v[q], z1);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { av[q] = an[q]; b0v[q] = b0n[q]; b1v[q] = b1n[q]; }
       }
     }
     __syncthreads();                                      // every wave is done with the slab
@@ -524,16 +530,18 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     }
     STAMP(0, 6);
     const float* b0 = a.b0 + (long long)net * a.b0_ns;
-    const float bv0 = b0[l31], bv1 = b0[32 + l31];
+    const float bv = b0[nt0 * 32 + l31];
     const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for m < 128, W <= 128 (checked on the host)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      z0[r] += bv0; z1[r] += bv1;
-      const int m = wave * 32 + acc_row(r, lane);
-      if (m < HW) {
-        const int h = (m * magic) >> 16, w = m - h * W;
-        float* p = img + (size_t)((h + 1) * PW + w + 1) * CS;
-        p[l31] = z0[r]; p[32 + l31] = z1[r];
+      z0[r] += bv; z1[r] += bv;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int m = (2 * mh + t) * 32 + acc_row(r, lane);
+        if (m < HW) {
+          const int h = (m * magic) >> 16, w = m - h * W;
+          img[(size_t)((h + 1) * PW + w + 1) * CS + nt0 * 32 + l31] = t ? z1[r] : z0[r];
+        }
       }
     }
     c.z0 = z0; c.z1 = z1;
@@ -1025,16 +1033,19 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
   // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
   STAMP(MODE & 1, 14);
   if (MODE == 2) {
-    // MTW == 1 here.  Rows 2s, 2s+1 of this wave's a0 tile go to HBM while tap s runs.
+    // MTW == 1 here.  Rows 2s, 2s+1 of this wave's two a0 tiles (pixel tiles 2mh, 2mh+1 of channel tile nt0, see
+    // conv3_stage) go to HBM while tap s runs.
     const f32x16 z0 = c.z0, z1 = c.z1;
     float* a0g = c.a0g;
+    const int nt0 = wave & 1, mh = wave >> 1;
     auto side = [&](int s) {
       if (s < 8) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if ((r >> 1) == s) {                           // s is uniform: two of the sixteen rows per tap
-            const int m = wave * 32 + acc_row(r, lane);
-            if (m < HW) { a0g[(size_t)m * 64 + l31] = z0[r]; a0g[(size_t)m * 64 + 32 + l31] = z1[r]; }
+            const int m0 = (2 * mh) * 32 + acc_row(r, lane), m1 = m0 + 32;
+            if (m0 < HW) a0g[(size_t)m0 * 64 + nt0 * 32 + l31] = z0[r];
+            if (m1 < HW) a0g[(size_t)m1 * 64 + nt0 * 32 + l31] = z1[r];
           }
         }
       }
@@ -1355,8 +1366,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
 // with one pixel tile per wave (H*W <= 128) and two workgroups still fit a CU with the slab + conv0 weights in LDS.
 // LDS of the fused kernel: the plain forward's regions, or slab [Cp][HW] + 64 + weights [Cp][64] if that is larger
 static size_t conv3_fused_lds(int H, int W, int C, size_t plain) {
-  const size_t Cp = (size_t)((C + 1) & ~1);
-  const size_t need = (Cp * H * W + 64 + Cp * 64) * 4;
+  const size_t need = ((size_t)16 * ((C + 15) / 16) * H * W + 64) * 4;     // slab rows up to whole k-steps of 16
   return need > plain ? need : plain;
 }
 
@@ -1365,7 +1375,7 @@ bool conv3_fused_ok(int H, int W, int C, int rows) {
   if (off || C < 1) return false;
   Conv3Plan pl;
   if (!plan_conv3(0, H, W, rows, &pl)) return false;
-  if (pl.S != 1 || pl.MTW != 1 || H * W > 128 || C * H * W > 4 * SLAB_MAXQ * 256) return false;
+  if (pl.S != 1 || pl.MTW != 1 || H * W > 128 || C * H * W > 4 * SLAB_MAXQ * 256 || C > 16 * CONV0_MAXKQ) return false;
   for (int m = 0; m < 128; ++m)                       // the magic-number divide of the kernel
     if (((m * ((65536 + W - 1) / W)) >> 16) != m / W) return false;
   return 2 * conv3_fused_lds(H, W, C, pl.lds) <= LDS_MAX;

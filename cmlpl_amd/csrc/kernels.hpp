@@ -38,7 +38,10 @@ __host__ __device__ inline int conv2_frag_index(int tap, int n, int k) {
 }
 __host__ __device__ inline long long pack_off_w0t() { return PACK_PER_NET; }
 __host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET + (long long)((C + 1) & ~1) * 64; }
-__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_wst(C) + (long long)bands * 1024; }
+// ... and conv0.weight as split-bf16 B fragments [k16 step][piece][n tile][lane][8 bf16] (= conv_b3_index with tap 0,
+// k = band, n = co; bands beyond C are zero) for the conv0 stage of the fused forward
+__host__ __device__ inline long long pack_off_w0b3(int C, int bands) { return pack_off_wst(C) + (long long)bands * 1024; }
+__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_w0b3(C, bands) + (long long)((C + 15) / 16) * 1536; }
 struct PackInfo { long long stride, off_w0, off_w1, off_w2, off_ws; int C, bands; };
 constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci][co] + db[co]
 constexpr size_t LDS_MAX = 160 * 1024;

@@ -57,7 +57,15 @@ __global__ void adam_kernel(float* __restrict__ params, long long pstride, const
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const long long e = i4 + q - pi.off_w0;
-        if (e < 64LL * pi.C) { const int co = (int)(e / pi.C), c = (int)(e - (long long)co * pi.C); pkn[pack_off_w0t() + c * 64 + co] = pa[q]; }
+        if (e < 64LL * pi.C) {
+          const int co = (int)(e / pi.C), c = (int)(e - (long long)co * pi.C);
+          pkn[pack_off_w0t() + c * 64 + co] = pa[q];
+          uint32_t pcs[3];
+          b3_split(pa[q], pcs);
+          uint16_t* wb = (uint16_t*)(pkn + pack_off_w0b3(pi.C, pi.bands));
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) wb[conv_b3_index(0, c, co, pc)] = (uint16_t)pcs[pc];
+        }
       }
     } else if (i4 >= pi.off_ws && i4 < pi.off_ws + 1024LL * pi.bands) { // feat_spe.weight[o][band] -> wsT[band][o]
 #pragma unroll

@@ -296,7 +296,8 @@ def run_rank(args):
     labels = dict(CONV1_KERNELS)
     conv0_flops = 2.0 * 2 * n_local * shape[1] * shape[2] * shape[0] * 64                # 2*nets*n*HW*C*64
     if fused_fwd:
-        kseg["conv1_fwd"]["f32"] = conv0_flops
+        kseg["conv1_fwd"]["split"] += conv0_flops                                       # conv0 stage: split-bf16 too
+        kseg["conv1_fwd"]["f32"] = 0.0
         labels["conv1_fwd"] = ("conv3x3_kernel<FWD0> (conv0 1x1 + conv1 3x3 forward fused: conv + bias + residual + "
                                "ReLU + avgpool, both networks)")
     if fused_bwd:

@@ -68,8 +68,9 @@ typedef struct cmlpl_layout_t {
   int64_t param_numel[CMLPL_NUM_TENSORS];
   int64_t param_total;                    /* floats per net (all 16 tensors)             */
   int64_t param_live;                     /* floats per net covered by Adam (tensors 0-9) */
-  int64_t packed_total;                   /* floats per net of kernel-side re-packed weights (3x3 taps, k-major
-                                             copies of conv0 / feat_spe); written by cmlpl_pack_weights and Adam */
+  int64_t packed_total;                   /* floats per net of kernel-side re-packed weights (3x3 and conv0 weights as
+                                             split-bf16 MFMA fragments, k-major copies of conv0 / feat_spe); opaque to
+                                             the caller; written by cmlpl_pack_weights and by cmlpl_adam_step */
   int32_t cls_in;                         /* 64*(H/2/2)*(W/2/2) + 1024                    */
   int32_t reserved;
 } cmlpl_layout_t;

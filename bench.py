@@ -301,7 +301,7 @@ def run_rank(args):
         labels["conv1_fwd"] = ("conv3x3_kernel<FWD0> (conv0 1x1 + conv1 3x3 forward fused: conv + bias + residual + "
                                "ReLU + avgpool, both networks)")
     if fused_bwd:
-        kseg["conv1_dgrad"]["f32"] = conv0_flops
+        kseg["conv1_dgrad"]["split"] += conv0_flops                                     # conv0 weight gradient: split-bf16 too
         labels["conv1_dgrad"] = ("conv3x3_kernel<DGRAD0> (conv1 data gradient + conv0 weight gradient fused, "
                                  "both networks)")
     conv2_flops = 2.0 * 2 * n_local * (shape[1] // 2) * (shape[2] // 2) * 64 * 576    # dense 3x3 on the pooled map

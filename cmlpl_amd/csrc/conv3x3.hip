@@ -1132,37 +1132,37 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     slab_finish(a.xs, net, s0, C * HW, slab, tid, wave, lane);   // ... with the forward's noise regenerated
     STAMP(1, 13);
     __syncthreads();                                      // slab landed (the barrier waits for the DMA), da0 complete
+    // dW0 tile of this wave on the split-bf16 MFMA: k-steps of 16 pixels; lane (row = band c, half h) takes pixels
+    // 16 kq + 8h .. + 7 of its slab row, lane (col = co, half h) the same pixels of da0; both are split in registers
+    // (132 VALU instructions per 12 MFMAs).  Pixels >= HW of the last step read the zero row behind da0.
     f32x16 g0 = zero16(), g1 = zero16();
     float dbacc = 0.f;
     {
-      const int KP = (HW + 1) >> 1;                       // pixel pairs
       const int crow = wave * 32 + l31;                   // band of this lane (rows >= C: finite garbage, dropped by the reduce)
-      const float* ap = slab + (size_t)crow * HW + hh;
-      const float* bp = dal + hh * 64 + l31;
-      float av[8], b0v[8], b1v[8], an[8], b0n[8], b1n[8];
+      const float* ap = slab + (size_t)crow * HW + 8 * hh;
+      const float* bp = dal + l31;
+      const int NS = (HW + 15) >> 4;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = (q < KP) ? q : 0;
-        av[q] = ap[2 * k]; b0v[q] = bp[2 * k * 64]; b1v[q] = bp[2 * k * 64 + 32];
-      }
-      for (int k0 = 0; k0 < KP; k0 += 8) {
+      for (int kq = 0; kq < 8; ++kq) {                    // HW <= 128 (conv3_fused_bwd_ok)
+        if (kq < NS) {                                    // uniform
+          float ra[8], rb0[8], rb1[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int k = (k0 + 8 + q < KP) ? k0 + 8 + q : 0;
-          an[q] = ap[2 * k]; b0n[q] = bp[2 * k * 64]; b1n[q] = bp[2 * k * 64 + 32];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (k0 + q < KP) {                              // uniform
-            g0 = mfma32(av[q], b0v[q], g0);
-            g1 = mfma32(av[q], b1v[q], g1);
-            dbacc += (wave == 0) ? b0v[q] : b1v[q];       // waves 0 / 1 sum co tile 0 / 1 for the bias gradient
+          for (int j = 0; j < 8; ++j) {
+            const int k = kq * 16 + 8 * hh + j;
+            const int kc = k < HW ? k : HW;               // the zero row
+            ra[j] = ap[kq * 16 + j];
+            rb0[j] = bp[kc * 64]; rb1[j] = bp[kc * 64 + 32];
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+          uint4 A1, A2, A3, P1, P2, P3;
+          a_split(make_float4(ra[0], ra[1], ra[2], ra[3]), make_float4(ra[4], ra[5], ra[6], ra[7]), A1, A2, A3);
+          a_split(make_float4(rb0[0], rb0[1], rb0[2], rb0[3]), make_float4(rb0[4], rb0[5], rb0[6], rb0[7]), P1, P2, P3);
+          g0 = mfma_b3(A1, A2, A3, P1, P2, P3, g0);
+          a_split(make_float4(rb1[0], rb1[1], rb1[2], rb1[3]), make_float4(rb1[4], rb1[5], rb1[6], rb1[7]), P1, P2, P3);
+          g1 = mfma_b3(A1, A2, A3, P1, P2, P3, g1);
+          // waves 0 / 1 sum co tile 0 / 1 for the bias gradient (fixed order: j, then k-step, then the two halves)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { av[q] = an[q]; b0v[q] = b0n[q]; b1v[q] = b1n[q]; }
+          for (int j = 0; j < 8; ++j) dbacc += (wave == 0) ? rb0[j] : rb1[j];
+        }
       }
     }
     const int Ct = ((C + 31) >> 5) * 32;

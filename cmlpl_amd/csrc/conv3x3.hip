@@ -1971,10 +1971,20 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(Wgrad3Args a) {
   const int UPG = a.UPG;
   const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
   STAMP(2, 0);
-  {  // halo columns, rows outside the image and the k padding must read as zero: clear both buffers once
+  {  // What staging never writes must read as zero, in both buffers and all three pieces: the activation halo
+     // columns x = 0 and x >= W + 1, and the gradient rows of the k padding.  (Everything else is rewritten by every
+     // stage, rows outside the image as zeros.)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* p4 = (float4*)smem;
-    for (int i = tid; i < (2 * BUF) >> 4; i += NT) p4[i] = z;
+    const int tail0 = (W + 1) * R, ntail = APOS - tail0;          // positions of the right halo (and beyond)
+    const int nz = R + ntail + (KP - CO * R);                      // positions to clear per (buffer, piece)
+    for (int i = tid; i < 6 * nz * 8; i += NT) {                   // 8 float4 per position
+      const int f = i & 7, q = (i >> 3) % nz, bp = (i >> 3) / nz, buf = bp / 3, pc = bp - 3 * buf;
+      char* base = lds + buf * BUF;
+      char* dst = q < R ? base + pc * APL + q * 128
+                : q < R + ntail ? base + pc * APL + (tail0 + q - R) * 128
+                : base + 3 * APL + pc * BPL + (CO * R + q - R - ntail) * 128;
+      *(float4*)(dst + f * 16) = z;
+    }
   }
   const float* src = a.in + (long long)net * a.in_ns;
   const float* dp = a.dpool + (long long)net * a.dpool_ns;

@@ -27,6 +27,11 @@ def test_general_wgrad_fallback_passes_backward_parity():
     _run({"CMLPL_WGRAD3_R": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
 
 
+def test_f32_mfma_row_split_wgrad_passes_backward_parity():
+    """wgrad3r_kernel (f32-input MFMA, LDS-DMA staging) is the fallback for maps too wide for the split-bf16 planes"""
+    _run({"CMLPL_WGRAD3_B3": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
+
+
 def test_unfused_conv0_kernels_pass_on_a_fusable_shape():
     _run({"CMLPL_FUSE_CONV0": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward and B2"])
 

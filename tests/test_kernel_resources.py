@@ -1,5 +1,5 @@
 """CPU: the hot kernels must not spill.  hipcc cross-compiles conv3x3.hip for gfx950 with
--Rpass-analysis=kernel-resource-usage; every conv3x3_kernel / wgrad3r_kernel instantiation has to report
+-Rpass-analysis=kernel-resource-usage; every conv3x3_kernel / wgrad3b_kernel / wgrad3r_kernel instantiation has to report
 ScratchSize 0, and the fused per-sample kernels at least 2 waves per SIMD (they rely on two co-resident
 workgroups per CU).
 Guards against the register blow-ups that loop-unrolling experiments produced."""
@@ -24,7 +24,7 @@ def test_hot_kernels_have_no_scratch(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        if "conv3x3_kernel" not in name and "wgrad3r_kernel" not in name and "conv3x3_small_kernel" not in name:
+        if not any(k in name for k in ("conv3x3_kernel", "wgrad3r_kernel", "wgrad3b_kernel", "conv3x3_small_kernel")):
             continue
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
@@ -32,4 +32,4 @@ def test_hot_kernels_have_no_scratch(tmp_path):
         if "conv3x3_kernelILi2E" in name or "conv3x3_kernelILi3E" in name:   # the fused per-sample kernels
             assert occ >= 2, (name, occ)
         seen += 1
-    assert seen >= 10
+    assert seen >= 20

@@ -415,6 +415,102 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
   }
 }
 
+// Tap loop of the per-sample fused kernels (S = 1, at most four M tiles), WITHOUT weight staging and without
+// barriers: wave w = (pixel half mh = w >> 1, channel half kh = w & 1) multiplies k-steps 2kh, 2kh+1 of every tap
+// (32 of the 64 input channels) into M tiles 2mh, 2mh+1 x both N tiles.  A weight fragment is then needed by two
+// waves only, so each wave takes its twelve fragments per tap straight from L2 into registers, a tap ahead -- the
+// 24 KiB-per-tap LDS copy and its two workgroup barriers per tap (3.7 us / 4.9 us of the forward / backward tap
+// loops, CMLPL_ABL=20) are gone.  The two channel halves meet once, after the loop, through LDS: wave w keeps tile
+// w and hands the other tile of its pair to wave w ^ 1 (see conv3_ks_fold).
+// Unit = (tile t, k-step q): two ds_read_b128 of raw activations, their split, 12 MFMAs; units are pipelined as in
+// tap_step (raw reads two units ahead, split one unit ahead between the MFMAs).
+template <int I>
+__device__ __forceinline__ void ks_unit(const float* __restrict__ img, const int (&abase)[2], f32x16 (&acc)[2][2],
+                                        ASplit& cur, float4& rn0, float4& rn1, const uint4 (&bq)[2][6], int s,
+                                        int kh, int PW) {
+  constexpr int t = I & 1, q = I >> 1;
+  // raw reads of unit u + 2
+  float4 rnn0, rnn1;
+  {
+    constexpr int I2 = (I + 2) & 3;
+    constexpr int t2 = I2 & 1, q2 = I2 >> 1;
+    const int s2 = (I + 2 >= 4) ? (s + 1 < 9 ? s + 1 : 8) : s;
+    const int kh2 = s2 / 3, kw2 = s2 - kh2 * 3;
+    const float* p = img + abase[t2] + ((kh2 - 1) * PW + (kw2 - 1)) * CS + (2 * kh + q2) * 16;
+    rnn0 = *(const float4*)p; rnn1 = *(const float4*)(p + 4);
+  }
+  acc[t][0] = mfma_b3(cur.p1, cur.p2, cur.p3, bq[q][0], bq[q][2], bq[q][4], acc[t][0]);
+  acc[t][1] = mfma_b3(cur.p1, cur.p2, cur.p3, bq[q][1], bq[q][3], bq[q][5], acc[t][1]);
+  ASplit nxt;
+  a_split(rn0, rn1, nxt.p1, nxt.p2, nxt.p3);
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  SchedInterleave<8>::run();
+  cur = nxt; rn0 = rnn0; rn1 = rnn1;
+}
+
+template <class Side = NoSide>
+__device__ __forceinline__ void conv3_taps_ks(const float* __restrict__ img, const uint4* __restrict__ wq,
+                                              const int (&abase)[2], f32x16 (&acc)[2][2], int PW, int wave, bool active,
+                                              Side side = Side()) {
+  const int kh = wave & 1;
+  // this wave's fragments of a tap: [k-step q][piece * 2 + n tile]
+  uint4 bq[2][6], nb[2][6];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bq[q][i] = wq[(((2 * kh + q) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
+  ASplit cur;
+  float4 rn0, rn1;
+  {  // pipeline fill: units 0 and 1 of tap 0 (the staged image is complete: the caller's barrier)
+    const float* p0 = img + abase[0] + (-PW - 1) * CS + (2 * kh) * 16;
+    a_split(*(const float4*)p0, *(const float4*)(p0 + 4), cur.p1, cur.p2, cur.p3);
+    const float* p1 = img + abase[1] + (-PW - 1) * CS + (2 * kh) * 16;
+    rn0 = *(const float4*)p1; rn1 = *(const float4*)(p1 + 4);
+  }
+#pragma unroll 1
+  for (int s = 0; s < 9; ++s) {
+    if (s + 1 < 9) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          nb[q][i] = wq[(size_t)(s + 1) * TAPW + (((2 * kh + q) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
+    }
+    side(s);
+    if (active) {        // wave-uniform: a pixel half without real pixels (HW <= 64) only keeps the barriers' company
+      ks_unit<0>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+      ks_unit<1>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+      ks_unit<2>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+      ks_unit<3>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) bq[q][i] = nb[q][i];
+  }
+}
+
+// After conv3_taps_ks: fold the two channel halves.  Wave w keeps tile w = 2mh + kh (acc[kh]) and gives acc[kh ^ 1]
+// to its partner w ^ 1, one n tile at a time through `x` (16 KiB: [4 waves][16][64] floats).  The caller's barrier
+// before (every wave out of its tap loop) and the last barrier here (x free again) are part of the protocol.
+template <int MTW>
+__device__ __forceinline__ void conv3_ks_fold(f32x16 (&acc)[2][2], f32x16 (&out)[MTW][2], float* x, int wave, int lane) {
+  const int kh = wave & 1;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const f32x16 give = kh ? acc[0][nt] : acc[1][nt];
+    f32x16 own = kh ? acc[1][nt] : acc[0][nt];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[(wave * 16 + r) * 64 + lane] = give[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) own[r] += x[((wave ^ 1) * 16 + r) * 64 + lane];
+    out[0][nt] = own;
+    __syncthreads();
+  }
+}
+
 // Everything a 3x3 workgroup does before its tap loop: zero-bordered LDS image of S samples (FWD: the
 // activation; DGRAD: dz = mask * upsample(dpool) / 4 formed on the fly), output-pixel LUT, and the tap-0
 // weights requested early so their latency overlaps the staging.
@@ -455,7 +551,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   }
   const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
   // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
-  c.wp = tap_fetch(wg, 0, tid);
+  if (MODE < 2) c.wp = tap_fetch(wg, 0, tid);   // (the per-sample kernels fetch their fragments themselves)
   __syncthreads();
 
   if (MODE == 2) {
@@ -544,8 +640,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         }
       }
     }
-    c.z0 = z0; c.z1 = z1;
-    c.a0g = a.a0out + ((long long)net * a.n + s0) * (long long)HW * 64;
+
     __syncthreads();                                      // the LUT (and the image) are complete
   } else if (MODE == 0) {
     const float* src = a.in + (long long)net * a.in_ns;
@@ -1029,33 +1124,46 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     acc[t][0] = zero16();
     acc[t][1] = zero16();
   }
+  // per-sample fused kernels (S == 1, MTW == 1): the barrier-free tap loop, see conv3_taps_ks
+  constexpr bool KS = (MODE >= 2);
+  int ab2[2];
+  f32x16 acc2[2][2];
+  if (KS) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ab2[t] = lut[(2 * (wave >> 1) + t) * 32 + l31] * CS + 8 * hh;
+      acc2[t][0] = zero16();
+      acc2[t][1] = zero16();
+    }
+  }
+  const uint4* wq = (const uint4*)wg + lane;
+  const bool ks_active = (wave >> 1) * 64 < npx;
 
   // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
   STAMP(MODE & 1, 14);
   if (MODE == 2) {
-    // MTW == 1 here.  Rows 2s, 2s+1 of this wave's two a0 tiles (pixel tiles 2mh, 2mh+1 of channel tile nt0, see
-    // conv3_stage) go to HBM while tap s runs.
-    const f32x16 z0 = c.z0, z1 = c.z1;
-    float* a0g = c.a0g;
-    const int nt0 = wave & 1, mh = wave >> 1;
+    // a0 goes to HBM (the backward pass reads it) from the LDS image itself, which is read-only during the tap
+    // loop: tap s copies items 256 s + tid (pixel, 16-byte channel chunk) -- coalesced 16-byte stores, no registers
+    // held across the loop.
+    float* a0g = a.a0out + ((long long)net * a.n + s0) * (long long)HW * 64;
+    const int magicW = (65536 + c.W - 1) / c.W;          // m / W == (m * magic) >> 16 for m < 128 (checked on the host)
     auto side = [&](int s) {
-      if (s < 8) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if ((r >> 1) == s) {                           // s is uniform: two of the sixteen rows per tap
-            const int m0 = (2 * mh) * 32 + acc_row(r, lane), m1 = m0 + 32;
-            if (m0 < HW) a0g[(size_t)m0 * 64 + nt0 * 32 + l31] = z0[r];
-            if (m1 < HW) a0g[(size_t)m1 * 64 + nt0 * 32 + l31] = z1[r];
-          }
-        }
+      const int idx = s * 256 + tid, m = idx >> 4, c4 = idx & 15;
+      if (s < 8 && m < HW) {
+        const int h = (m * magicW) >> 16, w = m - h * c.W;
+        *(float4*)(a0g + (size_t)m * 64 + c4 * 4) = *(const float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4);
       }
     };
-    if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp, abase, acc, PW, tid, lane, side);
-    else                           conv3_taps<MTW, MTW - 1, decltype(side), CMLPL_UNR_F>(img, wbuf, wg, wp, abase, acc, PW, tid, lane, side);
-  } else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
+    conv3_taps_ks(img, wq, ab2, acc2, PW, wave, ks_active, side);
+  } else if constexpr (KS) {
+    __syncthreads();   // the staged image is complete (conv3_taps has this barrier in front of its first tap)
+    conv3_taps_ks(img, wq, ab2, acc2, PW, wave, ks_active);
+  }
+  else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   STAMP(MODE & 1, 15);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
+  if constexpr (KS) conv3_ks_fold<MTW>(acc2, acc, wbuf, wave, lane);
   STAMP(MODE & 1, 2);
 
   if (!(MODE & 1)) {

@@ -56,11 +56,24 @@ for s in range(steps):
         for i in range(2):
             assert float((eng.bank_feats[i] - ref.bank_feats[i]).abs().max()) < 1e-5
             assert float((eng.bank_probs[i] - ref.bank_probs[i]).abs().max()) < 1e-5
-# replicas hold identical parameters
-psum = eng.params.double().sum().reshape(1).cpu()
-lst = [torch.zeros_like(psum) for _ in range(W)]
-dist.all_gather(lst, psum)
-assert all(float(x) == float(lst[0]) for x in lst), lst
+    # replicas hold identical parameters after this step's update
+    psum = eng.params.double().sum().reshape(1).cpu()
+    lst = [torch.zeros_like(psum) for _ in range(W)]
+    dist.all_gather(lst, psum)
+    assert all(float(x) == float(lst[0]) for x in lst), lst
+    # every step is compared from EQUAL states (tests/test_gpu_distributed.py explains why): all ranks continue from
+    # the single-process engine's parameters, Adam moments and banks
+    for name in ("params", "m", "v"):
+        t = getattr(eng, name)
+        if rank == 0:
+            t.copy_(getattr(ref, name))
+        dist.broadcast(t, 0)
+    for i in range(2):
+        for bank in (eng.bank_feats, eng.bank_probs):
+            if rank == 0:
+                bank[i].copy_((ref.bank_feats if bank is eng.bank_feats else ref.bank_probs)[i])
+            dist.broadcast(bank[i], 0)
+    eng._packed_dirty = True
 if rank == 0:
     print(f"OK world={W} steps={steps} worst_grad_rel_err={worst:.2e}")
 dist.barrier()

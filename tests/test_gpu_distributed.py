@@ -107,15 +107,26 @@ def test_sharded_step_equals_single_gpu_step(W, shape_name, bt, btu, explicit):
                 report(f"bank{i} feats", e.bank_feats[i], ref.bank_feats[i], 1e-5, 5e-6)
                 report(f"bank{i} probs", e.bank_probs[i], ref.bank_probs[i], 1e-5, 5e-6)
         assert engines[0].ptr == ref.ptr
-    for net in range(2):
-        sd_ref = ref.state_dict(net)
+        # parameters after this step's Adam update (one update from equal states; an element whose gradient is ~eps
+        # may move by O(lr) on a rounding-level difference of the all-reduced sum, see report_params) ...
+        for net in range(2):
+            sd_ref = ref.state_dict(net)
+            for e in (engines[0], engines[-1]):
+                sd = e.state_dict(net)
+                for k in O.LIVE_KEYS:
+                    report_params(f"param[{net}] {k}", sd[k], sd_ref[k], 1, hp.lr)
+        # every replica holds the same parameters bit for bit (same all-reduced gradient, same Adam)
+        for e in engines[1:]:
+            assert torch.equal(e.params, engines[0].params)
+        # ... and every step is compared from EQUAL states: the sharded engines continue from the single-GPU
+        # engine's parameters, Adam moments and banks.  (Left to themselves the two trajectories drift apart like any
+        # two runs whose gradient sums differ in the last bit: by step 3 of B2 / 64+64 a near-zero-gradient weight of
+        # conv0 had moved, and a fifth of conv0's gradient elements differed by 1e-3 relative.)
         for e in engines:
-            sd = e.state_dict(net)
-            for k in O.LIVE_KEYS:
-                report(f"param[{net}] {k}", sd[k], sd_ref[k], 1e-4, 3e-5)
-    # every replica holds the same parameters bit for bit (same all-reduced gradient, same Adam)
-    for e in engines[1:]:
-        assert torch.equal(e.params, engines[0].params)
+            e.params.copy_(ref.params); e.m.copy_(ref.m); e.v.copy_(ref.v)
+            e._packed_dirty = True
+            for i in range(2):
+                e.bank_feats[i].copy_(ref.bank_feats[i]); e.bank_probs[i].copy_(ref.bank_probs[i])
 
 
 def _global_gates(engines, shape, bt_l, btu_l):

@@ -416,8 +416,11 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
                                d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,
                                (long long)n * conv0_partial_size(d.C), &hd, st))))) return rc;
-    if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
-    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
+    // conv1's and conv2's weight gradients: one launch where the pair kernel exists (timed as the conv1 kernel)
+    bool merged = false;
+    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3_pair(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, d.H2, d.W2,
+                                  w.p1, w.dp2, w.m2, w.part2, &merged, st))))) return rc;
+    (void)merged;
   } else {
   // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
   if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,

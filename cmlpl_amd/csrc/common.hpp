@@ -168,6 +168,50 @@ __device__ __forceinline__ void b3_split(float v, uint32_t (&hi16)[3]) {
   hi16[0] = u0 >> 16; hi16[1] = u1 >> 16; hi16[2] = __float_as_uint(r2) >> 16;
 }
 
+// ---- split-bf16 MFMA helpers (conv3x3.hip "fp32 on the bf16 MFMA"; shared with wgrad3x3.hip)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_b16(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// high halves of two dwords -> one dword (lo element in the low half)
+__device__ __forceinline__ uint32_t hi_pair(uint32_t lo_el, uint32_t hi_el) {
+  return __builtin_amdgcn_perm(hi_el, lo_el, 0x07060302u);
+}
+// eight consecutive fp32 A elements (k = 8h .. 8h+7 of this lane's row) -> the three bf16 A fragments
+__device__ __forceinline__ void a_split(const float4& x0, const float4& x1, uint4& A1, uint4& A2, uint4& A3) {
+#if defined(CMLPL_ABL) && CMLPL_ABL == 21         // ablation: no split arithmetic -- wrong results
+  A1 = make_uint4(__float_as_uint(x0.x), __float_as_uint(x0.y), __float_as_uint(x0.z), __float_as_uint(x0.w));
+  A2 = make_uint4(__float_as_uint(x1.x), __float_as_uint(x1.y), __float_as_uint(x1.z), __float_as_uint(x1.w));
+  A3 = A1;
+  return;
+#endif
+  const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  uint32_t u0[8], u1[8], u2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u0[j] = __float_as_uint(v[j]);
+    const float r1 = v[j] - __uint_as_float(u0[j] & 0xffff0000u);
+    u1[j] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1[j] & 0xffff0000u);
+    u2[j] = __float_as_uint(r2);
+  }
+  A1 = make_uint4(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]), hi_pair(u0[4], u0[5]), hi_pair(u0[6], u0[7]));
+  A2 = make_uint4(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]), hi_pair(u1[4], u1[5]), hi_pair(u1[6], u1[7]));
+  A3 = make_uint4(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]), hi_pair(u2[4], u2[5]), hi_pair(u2[6], u2[7]));
+}
+// one 32 x 32 x 16 step of the split product; b1..b3 = the weight pieces of this n tile
+__device__ __forceinline__ f32x16 mfma_b3(const uint4& A1, const uint4& A2, const uint4& A3, const uint4& b1,
+                                          const uint4& b2, const uint4& b3, f32x16 acc) {
+  acc = mfma_b16(A1, b3, acc);
+  acc = mfma_b16(A2, b2, acc);
+  acc = mfma_b16(A3, b1, acc);
+  acc = mfma_b16(A1, b2, acc);
+  acc = mfma_b16(A2, b1, acc);
+  acc = mfma_b16(A1, b1, acc);
+  return acc;
+}
+
+
 struct XSrc {
   const float* lab[2]; const float* unl[2];       // per network (the same pointer twice for raw inputs)
   const float* nz_lab[2]; const float* nz_unl[2]; // explicit N(0,1) draws per network, or null

@@ -114,6 +114,9 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st);
 int wgrad3_G(int nets, int n, int H, int W);
+hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1, const float* dpool1,
+                              const uint8_t* mask1, float* part1, int H2, int W2, const float* in2,
+                              const float* dpool2, const uint8_t* mask2, float* part2, bool* merged, hipStream_t st);
 
 // ---- conv0.hip
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w0t, long long w0t_ns,

@@ -5,7 +5,7 @@ set -e
 N=${1:-9}
 cd "$(dirname "$0")/../cmlpl_amd"
 mkdir -p build_abl$N
-for f in api augment conv0 conv3x3 dense head loss memobank ntxent optim; do
+for f in api augment conv0 conv3x3 dense head loss memobank ntxent optim wgrad3x3; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DCMLPL_ABL=$N -c csrc/$f.hip -o build_abl$N/$f.o &
 done
 wait

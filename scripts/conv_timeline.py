@@ -21,6 +21,10 @@ lib = _lib.load()
 buf = np.zeros((3, 2048, 16), dtype=np.uint64)
 rc = lib.cmlpl_abl_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
+wbuf = np.zeros((2048, 16), dtype=np.uint64)          # the weight-gradient kernels live in their own translation unit
+rc = lib.cmlpl_abl_read_wstamps(wbuf.ctypes.data_as(ctypes.c_void_p))
+assert rc == 0
+buf[2] = wbuf
 for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1, last launch)", 240)):
     t = buf[mode, :nwg, :4].astype(np.int64)
     full = buf[mode, :nwg, :].astype(np.int64)

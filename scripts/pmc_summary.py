@@ -36,7 +36,7 @@ def load(d, counter):
 
 # bench.py's names for the conv1 kernels <- substrings of the rocprof kernel names (template arguments included)
 BENCH_KEYS = (("conv1_fwd", ("conv3x3_kernel<2,", "conv3x3_kernel<0,")), ("conv1_dgrad", ("conv3x3_kernel<3,", "conv3x3_kernel<1,")),
-              ("conv1_wgrad", ("wgrad3b_kernel<5", "wgrad3b_kernel<10", "wgrad3r_kernel<5", "wgrad3r_kernel<10", "wgrad3_kernel")))
+              ("conv1_wgrad", ("wgrad3b_pair_kernel", "wgrad3b_kernel<5", "wgrad3b_kernel<10", "wgrad3r_kernel<5", "wgrad3r_kernel<10", "wgrad3_kernel")))
 
 
 def write_json(rows, path, workload, n_local, profile):

@@ -28,7 +28,8 @@ def test_general_wgrad_fallback_passes_backward_parity():
 
 
 def test_f32_mfma_row_split_wgrad_passes_backward_parity():
-    """wgrad3r_kernel (f32-input MFMA, LDS-DMA staging) is the fallback for maps too wide for the split-bf16 planes"""
+    """with the split-bf16 weight gradient switched off: wgrad3r_kernel (f32-input MFMA, LDS-DMA staging; kept for the
+    two maps of the headline shape as the reference point) and the general wgrad3_kernel for every other window"""
     _run({"CMLPL_WGRAD3_B3": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
 
 

@@ -874,7 +874,8 @@ hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1,
       *merged = true;                                                                                \
       return hipGetLastError();                                                                      \
     }
-    WG3P_CASE(5, 2) WG3P_CASE(10, 5) WG3P_CASE(7, 3)   // B2 / B4 (11 x 11), P (20 x 20), B5 (15 x 15)
+    // windows 8..21: (W / 2, W / 4); B2 / B4 = (5, 2), P = (10, 5), B5 = (7, 3)
+    WG3P_CASE(4, 2) WG3P_CASE(5, 2) WG3P_CASE(6, 3) WG3P_CASE(7, 3) WG3P_CASE(8, 4) WG3P_CASE(9, 4) WG3P_CASE(10, 5)
 #undef WG3P_CASE
   }
   hipError_t e = launch_wgrad3(nets, n, H2, W2, in2, dpool2, mask2, part2, st);

@@ -254,6 +254,40 @@ def test_adam_step_matches_torch_formula():
         assert torch.equal(dp[:, live:].cpu(), p[:, live:])          # dead tensors untouched
 
 
+@pytest.mark.parametrize("name", ["B2", "P", "B4"])
+def test_adam_refreshes_every_packed_weight_copy_like_pack_weights(name):
+    """The optimizer rewrites the kernel-side weight copies itself (split-bf16 fragment sets of the 3x3 and conv0
+    weights, conv2's f32 fragments, the k-major thin weights): after a step the packed buffer must equal, bit for
+    bit, what cmlpl_pack_weights makes of the updated parameters."""
+    from cmlpl_amd import _lib
+    lib = _lib.load()
+    shape = SHAPES[name]
+    cs = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+    L = _lib.layout(cs)
+    P, PK = int(L.param_total), int(L.packed_total)
+    hp = O.HyperParams()
+    chp = _lib.HParams(hp.lr, hp.beta1, hp.beta2, hp.eps, hp.temperature, hp.alpha, hp.noise, hp.dropout,
+                       hp.w_contrast, hp.w_mutual, hp.pos_thr, hp.neg_thr)
+    g = torch.Generator().manual_seed(11)
+    dp = (torch.randn(2, P, generator=g) * 0.05).to(DEV)
+    dm, dv = torch.zeros(2, P, device=DEV), torch.zeros(2, P, device=DEV)
+    packed = torch.full((2, PK), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    # as the engines do: one cmlpl_pack_weights when parameters are loaded (it also zeroes the pad rows, which the
+    # optimizer never touches), then the optimizer keeps the copies current
+    assert lib.cmlpl_pack_weights(C.byref(cs), 2, dp.data_ptr(), P, packed.data_ptr(), st) == 0
+    for t in range(1, 3):
+        gr = (torch.randn(2, P, generator=g) * 0.01).to(DEV)
+        assert lib.cmlpl_adam_step(C.byref(cs), 2, dp.data_ptr(), P, gr.data_ptr(), P, dm.data_ptr(), dv.data_ptr(), t,
+                                   C.byref(chp), packed.data_ptr(), st) == 0
+    want = torch.empty(2, PK, device=DEV)
+    assert lib.cmlpl_pack_weights(C.byref(cs), 2, dp.data_ptr(), P, want.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    a, b = packed.view(torch.int32).cpu(), want.view(torch.int32).cpu()
+    diff = (a != b)
+    assert not diff.any(), f"{int(diff.sum())} packed words differ, first at {diff.nonzero()[0].tolist()}"
+
+
 def test_whole_image_inference_matches_oracle():
     """tools.hyper_tools.test_whole (reference hyper_tools.py:416-437) over a 'wholeset'
     loader with a ragged last batch: same argmax as the oracle's eval forward for every pixel."""

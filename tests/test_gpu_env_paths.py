@@ -33,6 +33,10 @@ def test_f32_mfma_row_split_wgrad_passes_backward_parity():
     _run({"CMLPL_WGRAD3_B3": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
 
 
+def test_separate_weight_gradient_launches_pass_backward_parity():
+    _run({"CMLPL_WGRAD3_PAIR": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward and B2"])
+
+
 def test_unfused_conv0_kernels_pass_on_a_fusable_shape():
     _run({"CMLPL_FUSE_CONV0": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward and B2"])
 

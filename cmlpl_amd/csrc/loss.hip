@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
 // 128 local rows meet W x more columns).  One workgroup = up to 128 local rows x 32 columns; wave w owns rows
 // 32w..32w+31 over the WHOLE contraction, so there is no cross-wave reduction and the column tile is read once
 // instead of once per 32 rows.  K is walked in 32-float lines staged in LDS (whole 128-B lines per row, row stride
-// PT floats), double-buffered, one barrier per line, the next line's loads in flight in registers.
+// PT floats), double-buffered, one barrier per line, the next line's loads in flight in registers.  The products run
+// on the split-bf16 MFMA (common.hpp): both fragments of a k-step are split in registers, six bf16 MFMAs per product
+// (64.5 -> 57.7 us per launch at W = 8; the per-line barrier, not the matrix pipe, sets the pace now).
 __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2][(128 + 32) * PT];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -269,9 +271,6 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
   float4 wb = *(const float4*)(pb + 32);
   const int wo = lr * PT + c8 * 4;
   f32x16 acc = zero16();
-#define CMLPL_M4(PA, PB)                                                            \
-    acc = mfma32(PA.x, PB.x, acc); acc = mfma32(PA.y, PB.y, acc);                   \
-    acc = mfma32(PA.z, PB.z, acc); acc = mfma32(PA.w, PB.w, acc);
 #define CMLPL_LINE(LN, R0, R1, R2, R3, RB)                                          \
   {                                                                                 \
     float* buf = lds[(LN) & 1];                                                     \
@@ -285,13 +284,15 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
       RB = *(const float4*)(pb + o);                                                \
     }                                                                               \
     __syncthreads(); /* line staged; the other buffer (read during the previous line) is free */ \
-    const float* rA = buf + (wave * 32 + l31) * PT + hh * 16;                       \
-    const float* rB = buf + (128 + l31) * PT + hh * 16;                             \
-    const float4 x0 = *(const float4*)(rA), x1 = *(const float4*)(rA + 4), x2 = *(const float4*)(rA + 8), \
-                 x3 = *(const float4*)(rA + 12);                                    \
-    const float4 y0 = *(const float4*)(rB), y1 = *(const float4*)(rB + 4), y2 = *(const float4*)(rB + 8), \
-                 y3 = *(const float4*)(rB + 12);                                    \
-    CMLPL_M4(x0, y0) CMLPL_M4(x1, y1) CMLPL_M4(x2, y2) CMLPL_M4(x3, y3)             \
+    const float* rA = buf + (wave * 32 + l31) * PT + hh * 8;                        \
+    const float* rB = buf + (128 + l31) * PT + hh * 8;                              \
+    _Pragma("unroll")                                                               \
+    for (int s16 = 0; s16 < 2; ++s16) {   /* split-bf16 MFMA: k = 16 s16 + 8 hh .. + 7 of this lane's row */ \
+      uint4 A1, A2, A3, P1, P2, P3;                                                 \
+      a_split(*(const float4*)(rA + 16 * s16), *(const float4*)(rA + 16 * s16 + 4), A1, A2, A3);              \
+      a_split(*(const float4*)(rB + 16 * s16), *(const float4*)(rB + 16 * s16 + 4), P1, P2, P3);              \
+      acc = mfma_b3(A1, A2, A3, P1, P2, P3, acc);                                   \
+    }                                                                               \
   }
   // fully unrolled: across a loop back-edge hipcc loses count of the outstanding loads and waits vmcnt(0) before the
   // LDS writes, i.e. for the prefetch it has just issued
@@ -301,7 +302,6 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
     CMLPL_LINE(ln + 1, wa0, wa1, wa2, wa3, wb)
   }
 #undef CMLPL_LINE
-#undef CMLPL_M4
   // epilogue: this wave's 32 rows x 32 columns (lane = column jb, register r = row)
   const bool jv = jb < NB;
   const int rw = r0 + wave * 32;
@@ -628,9 +628,9 @@ hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
   // wide products (many column tiles): tall tiles; narrow ones: 32x32 tiles with the contraction split over the waves
   static const int force_tall = getenv("CMLPL_PAIR_TALL") ? atoi(getenv("CMLPL_PAIR_TALL")) : -1;
   const int ctiles = (maxc + 31) / 32;
-  // measured per rank (scripts/rank_cost.py, B2, 128 local rows): 32x32 tiles 25.6 / 39.2 / 55.5 / 89.4 us at
-  // W = 1 / 2 / 4 / 8 against 37.9 / 39.3 / 56.8 / 81.6 us for tall tiles
-  const bool tall = force_tall >= 0 ? force_tall != 0 : (ctiles >= 256 && a.nunl >= 64);
+  // measured per rank (scripts/rank_cost.py, B2, 128 local rows; pair_exp + row kernel): 32x32 tiles (f32-input MFMA)
+  // 27.4 / 42.0 / 60.0 / 89 us at W = 1 / 2 / 4 / 8 against 43.4 / 45.4 / 56.0 / 78 us for tall tiles (split-bf16)
+  const bool tall = force_tall >= 0 ? force_tall != 0 : (ctiles >= 128 && a.nunl >= 64);
   if (tall) {
     hipLaunchKernelGGL(pair_exp_tall_kernel, dim3(ctiles, (a.nunl + 127) / 128, 3), dim3(256), 0, st, a);
   } else {

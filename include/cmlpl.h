@@ -82,8 +82,9 @@ int cmlpl_layout(const cmlpl_shape* shape, cmlpl_layout_t* out);
  * (n = labelled + unlabelled), `nets` networks and a bank of `bank_rows` rows. */
 size_t cmlpl_workspace_bytes(const cmlpl_shape* shape, int nets, int n, int bank_rows);
 
-/* Re-pack conv1/conv2 weights of `nets` networks into the kernel-side layouts
- * (must be called after parameters change; cmlpl_adam_step does it itself). */
+/* Re-pack the weights of `nets` networks into the kernel-side layouts (every entry of d_packed, pad rows included).
+ * Call it once after parameters are set or loaded; cmlpl_adam_step then keeps every non-pad entry current itself
+ * (it never touches the zero pad rows this call writes, so a packed buffer must have been through this call once). */
 int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params, int64_t param_stride,
                        float* d_packed, void* stream);
 

@@ -328,8 +328,8 @@ def run_rank(args):
         "metric": "HSI patches/sec per training step", "value": patches / dt, "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32 (3x3 convolutions: f32 operands as 3 exact bf16 pieces on the bf16 MFMA, f32 accumulate; "
-                 "everything else f32 MFMA / f32 VALU)", "data": "synthetic",
+        "dtype": "f32 (convolutions: f32 operands as 3 exact bf16 pieces on the bf16 MFMA, f32 accumulate, results "
+                 "as accurate as f32 arithmetic; everything else f32 MFMA / f32 VALU)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic PaviaU-shaped patches {shape[1]}x{shape[2]}x{shape[0]}, "
                                f"spectrum {shape[3]}, {shape[4]} classes, {bt} labelled + {btu} unlabelled "
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "

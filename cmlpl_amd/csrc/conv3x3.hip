@@ -240,8 +240,9 @@ __device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int n
 // form a . b as the six products whose weight is >= 2^-16,
 //      a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
 // on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each bf16 x bf16 product is exact in fp32; what is dropped
-// (a2 b3 + a3 b2 + a3 b3) is < 3 * 2^-24 |a b| -- the size of the rounding error of ONE fp32 multiply -- and the
-// accumulator is rounded 6 times per 16 k (once per MFMA) where the f32-input MFMA rounds it 8 times.  Six bf16
+// (a2 b3 + a3 b2 + a3 b3, with |x2| < 2^-7 |x|, |x3| < 2^-15 |x|) is below 2^-21 |a b| in the worst case and
+// 0.7 * 2^-24 |a b| on average -- less than the rounding of one fp32 multiply (tests/test_split_bf16_math.py) -- and
+// the accumulator is rounded 6 times per 16 k (once per MFMA) where the f32-input MFMA rounds it 8 times.  Six bf16
 // MFMAs of 32 cycles replace eight f32 MFMAs of 64: 2.7x fewer matrix-pipe cycles for the same fp32-grade result
 // (tests/test_gpu_ops.py measures the error of both against an fp64 reference).
 // The weights are split once per step (Adam writes the fragment sets, kernels.hpp: conv_b3_index); activations are

@@ -30,6 +30,7 @@ EXPORTS = (
     "cmlpl_unsup_workspace_bytes", "cmlpl_unsup_loss", "cmlpl_memobank_select", "cmlpl_memobank_proto",
     "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
     "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g", "cmlpl_memobank_loss",
+    "cmlpl_source_hash",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -128,11 +129,17 @@ def load(path: str = LIB_PATH):
     except OSError as e:  # e.g. libamdhip64 missing
         raise CmlplLibraryError(f"cannot load {path}: {e}") from e
     missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    default_lib = os.path.abspath(path) == os.path.join(HERE, "libcmlpl_hip.so")
+    if not default_lib and missing == ["cmlpl_source_hash"]:
+        missing = []            # an older build named through CMLPL_LIB (A/B runs against a previous round's binary)
     if missing:
         raise CmlplLibraryError(f"{path} does not export {missing}")
     vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
     SP, HP = C.POINTER(Shape), C.POINTER(HParams)
     lib.cmlpl_abi_version.restype = i32
+    if hasattr(lib, "cmlpl_source_hash"):
+        lib.cmlpl_source_hash.restype = C.c_char_p
+        lib.cmlpl_source_hash.argtypes = []
     lib.cmlpl_layout.argtypes = [SP, C.POINTER(Layout)]
     lib.cmlpl_workspace_bytes.argtypes = [SP, i32, i32, i32]
     lib.cmlpl_workspace_bytes.restype = sz
@@ -177,11 +184,20 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_timing_begin.argtypes = [C.c_uint32, i32]
     lib.cmlpl_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(i64)]
     for s in EXPORTS[1:]:
-        if s not in ("cmlpl_workspace_bytes", "cmlpl_loss_workspace_bytes", "cmlpl_ntxent_workspace_bytes",
-                     "cmlpl_unsup_workspace_bytes"):
+        if hasattr(lib, s) and s not in ("cmlpl_workspace_bytes", "cmlpl_loss_workspace_bytes", "cmlpl_ntxent_workspace_bytes",
+                     "cmlpl_unsup_workspace_bytes", "cmlpl_source_hash"):
             getattr(lib, s).restype = i32
     if lib.cmlpl_abi_version() != ABI_VERSION:
         raise CmlplLibraryError(f"ABI version mismatch: library {lib.cmlpl_abi_version()}, binding {ABI_VERSION}")
+    # A binary that was not built from the sources next to it is refused (a stale .so pushed to a GPU box would
+    # otherwise be measured as if it were the code).  Another build named on purpose through CMLPL_LIB (A/B runs,
+    # ablation builds) is taken as it is.
+    if default_lib and not os.environ.get("CMLPL_ALLOW_STALE"):
+        from .build_ext import source_hash
+        built, now = lib.cmlpl_source_hash().decode(), source_hash()
+        if built != now:
+            raise CmlplLibraryError(f"{path} is stale: built from sources {built}, the sources here are {now}; "
+                                    "rebuild with `python -m cmlpl_amd.build_ext`")
     _lib = lib
     return lib
 

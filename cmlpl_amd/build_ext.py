@@ -30,12 +30,24 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+HASH_MARK = b"CMLPL_SOURCE_HASH="
+
+
+def embedded_hash(lib=None):
+    """The source hash a built library carries (api.hip is compiled with -DCMLPL_SOURCE_HASH, the string is also what
+    `cmlpl_source_hash()` returns); None for a binary without one.  Read from the file: no dlopen."""
+    try:
+        blob = open(lib or LIB, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(HASH_MARK)
+    return blob[i + len(HASH_MARK): i + len(HASH_MARK) + 16].decode("ascii", "replace") if i >= 0 else None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "cmlpl.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    """True when the library is absent or was not built from the sources as they are now: the hash embedded in the
+    binary is compared with the hash of the sources (mtimes lie after a checkout or a copy to another box)."""
+    return embedded_hash() != source_hash()
 
 
 def build(force=False, verbose=True, jobs=4):
@@ -43,12 +55,13 @@ def build(force=False, verbose=True, jobs=4):
         return LIB
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    shash = source_hash()
     procs = []
     objs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, f'-DCMLPL_SOURCE_HASH="{shash}"', "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         if len(procs) >= jobs:
             _drain(procs, verbose)

@@ -66,7 +66,7 @@ __global__ void augment_kernel(AugArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int e = base + q;
       if (e < per) {
-        const float v = need_noise ? x[q] + z[q] * a.sigma : x[q];
+        const float v = need_noise ? fmaf(z[q], a.sigma, x[q]) : x[q];
         dst[e] = v;
         if (t == 1 && a.snT != nullptr) a.snT[((long long)net * per + e) * (a.bt + a.btu) + s] = v;
       }

@@ -1,17 +1,24 @@
-// 3x3 / pad 1 / 64->64 convolutions of BaseNet2 (tools/models.py:104-107,134-140) as
-// LDS-staged implicit GEMMs on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// 3x3 / pad 1 / 64->64 convolutions of BaseNet2 (tools/models.py:104-107,134-140) and the per-sample fused
+// forward / backward kernels built around them, on the bf16 MFMA with fp32 operands taken as three exact bf16 pieces
+// ("fp32 on the bf16 MFMA", below: v_mfma_f32_32x32x16_bf16, six products per fp32 product, fp32 accumulate).
 //
-//   conv3x3_kernel<FWD>   : z = conv(in)+bias+in ; r = relu(z) ; out = avgpool2(r) ; mask = (r>0) nibble
-//                           (models.py:134-136 / 138-140, fused)
-//   conv3x3_kernel<DGRAD> : dz = mask * upsample(dpool)/4 (avgpool+relu backward, formed while staging)
+//   conv3x3_kernel<0>     : z = conv(in)+bias+in ; r = relu(z) ; out = avgpool2(r) ; mask = (r>0) nibble
+//                           (models.py:134-136 / 138-140, fused), S samples per workgroup, tap weights staged in LDS
+//   conv3x3_kernel<1>     : dz = mask * upsample(dpool)/4 (avgpool+relu backward, formed while staging)
 //                           out = conv_transpose(dz) + dz      (residual branch adds dz itself)
-//   wgrad3r_kernel        : dW[s][ci][co] = sum_pix in[pix+s][ci] * dz[pix][co], db[co] = sum dz  (row-split,
-//                           double-buffered, LDS-DMA staging; wgrad3_kernel is the general fallback)
+//   conv3x3_kernel<2,1,1> : the WHOLE forward of one sample in one workgroup: input slab in 16-band chunks global ->
+//                           registers -> + noise -> LDS, conv0 1x1 per chunk as it lands, conv1 (barrier-free tap
+//                           loop, weight fragments L2 -> registers), ReLU / pool, conv2 + pool + concat / dropout /
+//                           classifier / L2-norm (conv3_fwd_tail)
+//   conv3x3_kernel<3,1,1> : the whole data-gradient chain of one sample: head backward + conv2 data gradient
+//                           (conv3_bwd_head), conv1 data gradient, conv0 weight-gradient partial (band passes)
+//   conv3x3_small_kernel  : maps of at most 32 pixels (one M tile shared by the four waves)
+//   (the 3x3 weight gradients live in wgrad3x3.hip)
 //
-// Data layout: activations are pixel-major / channel-last  [net][sample][pixel][64] so that
-// the 64 channels of a pixel are one 256-B line; the padded image of S samples sits in LDS
-// with a zero border, so the 9 taps are pure address offsets.  Weights are re-packed once per
-// step (pack_weights_kernel) to [tap][ci/4][co][4] so that both MFMA operands are ds_read_b128.
+// Data layout: activations are pixel-major / channel-last  [net][sample][pixel][64] so that the 64 channels of a
+// pixel are one 256-B line; the padded image of S samples sits in LDS with a zero border (pixel stride 68 floats),
+// so the 9 taps are pure address offsets.  Weights are kept re-packed by the optimizer (kernels.hpp, PACK_*) as
+// ready-made split-bf16 B fragments [tap][k16][piece][n tile][lane][8 bf16]: a fragment is one 16-byte read.
 #include <stdlib.h>
 
 // Ablation / timeline builds (scripts/conv_timeline.py): -DCMLPL_ABL=n removes one ingredient
@@ -126,6 +133,8 @@ struct Conv3Args {
   // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup; the input
   // slab is re-formed from `xs` (same noise as the forward: counter-based)
   float* part0; long long part0_ns;
+  int bp;                                         // bands per pass of the fused conv0 weight gradient (>= C: one pass)
+  int pair;                                       // per-sample kernels: 1-D grid with the workgroup -> (net, sample) map of wg_decode
   XSrc xs;
   // TAIL (forward): conv2 + ReLU + avgpool + flatten/concat + dropout + classifier + L2-norm for the same sample
   // (tools/models.py:137-152), in the workgroup that has just pooled conv1's output
@@ -142,6 +151,23 @@ struct Conv3Args {
   float* dy; float* dp2out; float* dp1out;
 };
 
+// Workgroup -> (network, first sample).  The per-sample kernels launch nets * n workgroups, two per CU, dealt to the
+// XCDs round-robin in id order: with two networks and a.pair set, ids are grouped in blocks of 256 = 128 samples x
+// 2 networks with the network in bit 7, so that
+//   ids i and i + 256 (the two workgroups a CU holds when 512 are dealt out) belong to the SAME network: their
+//     weight-fragment streams (conv1 216 KB, conv2 147 / 216 KB, classifier 46 KB per workgroup) meet in the CU's L1;
+//   the two networks of one sample are 128 ids apart: same XCD, so the sample's slab is fetched into that L2 once.
+// (Placement is the hardware's business: this is for speed only, any map gives the same results.)
+__device__ __forceinline__ void wg_decode(const Conv3Args& a, int& net, int& s0) {
+  if (a.pair) {
+    const int id = (int)blockIdx.x, blk = id >> 8, r = id & 255, full = a.n >> 7;
+    if (blk < full) { net = r >> 7; s0 = (blk << 7) | (r & 127); }
+    else { const int m = a.n - (full << 7); net = r / m; s0 = (full << 7) + (r - net * m); }   // last, partial block
+  } else {
+    net = (int)blockIdx.y; s0 = (int)blockIdx.x * a.S;
+  }
+}
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32: A lane l holds A[i = l&15][k = l>>4]; B lane l holds B[k = l>>4][j = l&15];
 // D reg r of lane l is D[row = 4*(l>>4) + r][col = l&15].  Exact fp32, 32 cycles.
@@ -154,58 +180,68 @@ __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
 // LDS: while its pieces are in flight a lane forms the noise of exactly the elements it requested (Philox, or the
 // explicit draws in parity mode), then waits for ITS OWN pieces only (vmcnt) and adds it in place -- no augmented
 // copy of the input ever exists in HBM.  The caller's next __syncthreads() publishes the slab.
-constexpr int SLAB_MAXQ = 16;   // pieces per wave: C*HW <= 4 waves * 16 * 256 floats
+// (Fused data gradient, MODE 3.  A RANGE of the slab -- `nfl` floats from float4 offset `f4base` of the sample's
+// block, the whole block unless the bands take several passes -- lands at `slab`; the noise counters are those of the
+// whole block, so every pass, the forward and the augmentation kernel see the same draws.)
+constexpr int SLAB_MAXQ = 16;   // pieces per wave: range <= 4 waves * 16 * 256 floats
+constexpr int SLAB_RING = 7;    // forward: chunks (16 bands each) resident in LDS per pass
+constexpr int SLAB_WIN = 4;     // forward: chunks in flight global -> registers per wave
 typedef __attribute__((address_space(3))) void slab_lds_void;
 typedef __attribute__((address_space(1))) const void slab_gbl_void;
-__device__ __forceinline__ void slab_issue(const XSrc& x, int net, int s, int nfl, float* slab, int wave, int lane) {
-  const float* xs = xsrc_row(x, net, s, nfl);
-  const int nf4 = nfl >> 2;
+struct SlabRange { const float* xs; const float* nz; uint64_t gsample; int f4base, nfl; };
+__device__ __forceinline__ SlabRange slab_range(const XSrc& x, int net, int s, int per, int f4base, int nfl) {
+  SlabRange r;
+  r.xs = xsrc_row(x, net, s, per) + 4LL * f4base;
+  const float* nz = (x.sigma != 0.f) ? xsrc_noise_row(x, net, s, per) : nullptr;
+  r.nz = nz != nullptr ? nz + 4LL * f4base : nullptr;
+  r.gsample = xsrc_global_sample(x, s); r.f4base = f4base; r.nfl = nfl;
+  return r;
+}
+__device__ __forceinline__ void slab_issue(const SlabRange& r, float* slab, int wave, int lane) {
+  const int nf4 = r.nfl >> 2;
 #pragma unroll
   for (int k = 0; k < SLAB_MAXQ; ++k) {
     const int q = wave + 4 * k;                           // wave-uniform
     if (q * 64 < nf4) {
       const int f = q * 64 + lane;
-      if (f < nf4) __builtin_amdgcn_global_load_lds((slab_gbl_void*)(xs + 4 * f), (slab_lds_void*)(slab + q * 256), 16, 0, 0);
+      if (f < nf4) __builtin_amdgcn_global_load_lds((slab_gbl_void*)(r.xs + 4 * f), (slab_lds_void*)(slab + q * 256), 16, 0, 0);
     }
   }
 }
 // noise of this wave's piece k (elements 4f..4f+3, f = (wave + 4k) * 64 + lane) and of the last partial group
 struct SlabNoise { float4 z[SLAB_MAXQ]; float zt; };
-__device__ __forceinline__ float4 slab_noise_piece(const XSrc& x, int net, int s, int nfl, int k, int wave, int lane) {
-  const int nf4 = nfl >> 2, q = wave + 4 * k;
+__device__ __forceinline__ float4 slab_noise_piece(const XSrc& x, int net, const SlabRange& r, int k, int wave, int lane) {
+  const int nf4 = r.nfl >> 2, q = wave + 4 * k;
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   if (x.sigma != 0.f && q * 64 < nf4) {                   // wave-uniform
-    const float* nz = xsrc_noise_row(x, net, s, nfl);
-    if (nz != nullptr) {                                  // parity mode: the reference's own draws
+    if (r.nz != nullptr) {                                // parity mode: the reference's own draws
       const int f = q * 64 + lane, fc = f < nf4 ? f : 0;
-      z = make_float4(nz[4 * fc], nz[4 * fc + 1], nz[4 * fc + 2], nz[4 * fc + 3]);
+      z = make_float4(r.nz[4 * fc], r.nz[4 * fc + 1], r.nz[4 * fc + 2], r.nz[4 * fc + 3]);
     } else {
-      z = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(xsrc_global_sample(x, s), (uint32_t)(q * 64 + lane)));
+      z = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(r.gsample, (uint32_t)(r.f4base + q * 64 + lane)));
     }
   }
   return z;
 }
-__device__ __forceinline__ float slab_noise_tail(const XSrc& x, int net, int s, int nfl, int tid) {
-  const int nf4 = nfl >> 2, rem = nfl - 4 * nf4;
+__device__ __forceinline__ float slab_noise_tail(const XSrc& x, int net, const SlabRange& r, int tid) {
+  const int nf4 = r.nfl >> 2, rem = r.nfl - 4 * nf4;
   float zt = 0.f;
   if (x.sigma != 0.f && rem != 0 && tid < 64) {           // the last, partial group: one wave forms it
-    const float* nz = xsrc_noise_row(x, net, s, nfl);
-    if (nz != nullptr) {
-      if (tid < rem) zt = nz[4 * nf4 + tid];
+    if (r.nz != nullptr) {
+      if (tid < rem) zt = r.nz[4 * nf4 + tid];
     } else {
-      const float4 t = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(xsrc_global_sample(x, s), (uint32_t)nf4));
+      const float4 t = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(r.gsample, (uint32_t)(r.f4base + nf4)));
       zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
     }
   }
   return zt;
 }
 // wait for this wave's pieces, add the noise in place, write the tail elements
-__device__ __forceinline__ void slab_apply(const XSrc& x, int net, int s, int nfl, float* slab, int tid, int wave,
+__device__ __forceinline__ void slab_apply(const XSrc& x, const SlabRange& r, float* slab, int tid, int wave,
                                            int lane, const SlabNoise& nzv) {
-  const float* xs = xsrc_row(x, net, s, nfl);
-  const int nf4 = nfl >> 2, rem = nfl - 4 * nf4;
+  const int nf4 = r.nfl >> 2, rem = r.nfl - 4 * nf4;
   float tailv = 0.f;
-  if (tid < rem) tailv = xs[4 * nf4 + tid];
+  if (tid < rem) tailv = r.xs[4 * nf4 + tid];
   if (x.sigma != 0.f) {                                   // uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
 #pragma unroll
@@ -215,23 +251,23 @@ __device__ __forceinline__ void slab_apply(const XSrc& x, int net, int s, int nf
         const int f = q * 64 + lane;
         if (f < nf4) {
           float4 v = *(float4*)(slab + 4 * f);
-          v.x = v.x + nzv.z[k].x * x.sigma; v.y = v.y + nzv.z[k].y * x.sigma;
-          v.z = v.z + nzv.z[k].z * x.sigma; v.w = v.w + nzv.z[k].w * x.sigma;
+          v.x = fmaf(nzv.z[k].x, x.sigma, v.x); v.y = fmaf(nzv.z[k].y, x.sigma, v.y);
+          v.z = fmaf(nzv.z[k].z, x.sigma, v.z); v.w = fmaf(nzv.z[k].w, x.sigma, v.w);
           *(float4*)(slab + 4 * f) = v;
         }
       }
     }
-    if (tid < rem) tailv = tailv + nzv.zt * x.sigma;
+    if (tid < rem) tailv = fmaf(nzv.zt, x.sigma, tailv);
   }
   if (tid < rem) slab[4 * nf4 + tid] = tailv;
 }
-__device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int nfl, float* slab, int tid, int wave,
+__device__ __forceinline__ void slab_finish(const XSrc& x, int net, const SlabRange& r, float* slab, int tid, int wave,
                                             int lane) {
   SlabNoise nzv;
 #pragma unroll
-  for (int k = 0; k < SLAB_MAXQ; ++k) nzv.z[k] = slab_noise_piece(x, net, s, nfl, k, wave, lane);
-  nzv.zt = slab_noise_tail(x, net, s, nfl, tid);
-  slab_apply(x, net, s, nfl, slab, tid, wave, lane, nzv);
+  for (int k = 0; k < SLAB_MAXQ; ++k) nzv.z[k] = slab_noise_piece(x, net, r, k, wave, lane);
+  nzv.zt = slab_noise_tail(x, net, r, tid);
+  slab_apply(x, r, slab, tid, wave, lane, nzv);
 }
 
 // ---- "fp32 on the bf16 MFMA" ------------------------------------------------------------------------------------
@@ -248,7 +284,6 @@ __device__ __forceinline__ void slab_finish(const XSrc& x, int net, int s, int n
 // The weights are split once per step (Adam writes the fragment sets, kernels.hpp: conv_b3_index); activations are
 // split in registers right after their ds_read_b128 (the LDS image stays fp32: a split image would not leave room
 // for two workgroups per CU).
-constexpr int CONV0_MAXKQ = 8;   // fused conv0: at most 128 input bands (k-steps of 16)
 constexpr int WBUF = 6144;      // floats: one tap's weight fragments (4 k-steps x 3 pieces x 2 n tiles x 1 KiB)
 constexpr int TAPW = WBUF / 4;  // float4 per tap
 // a thread's share of one tap's weights on their way global -> LDS (named members: an array member ends up in scratch)
@@ -490,7 +525,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
                                             const float* dp_lds = nullptr, const uint32_t* mpre = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int net = blockIdx.y, s0 = blockIdx.x * a.S;
+  int net, s0;
+  wg_decode(a, net, s0);
   const int H = a.H, W = a.W, HW = H * W, PW = W + 2, IMG = (H + 2) * PW;
   const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
   const int RO = !(MODE & 1) ? 2 * H2 : H, CO = !(MODE & 1) ? 2 * W2 : W;
@@ -527,44 +563,129 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     // A[pixel][band] = slab[band][pixel] (eight ds_read_b32 per tile and k-step of 16 bands, consecutive lanes =
     // consecutive pixels, split in registers); B = this wave's share of the conv0 weight fragments (kernels.hpp:
     // pack_off_w0b3), requested from L2 at kernel start -- nothing is shared between the waves, so no LDS copy.
+    // The slab is walked in CHUNKS of 16 bands (= one k-step of the conv0 MFMA): a chunk goes global -> registers
+    // (SLAB_WIN chunks in flight per wave, 16-byte loads, 1 KiB per wave-instruction) -> + sigma * noise -> its own
+    // LDS slot, and as soon as a chunk is complete (one barrier) its twelve MFMAs per wave run while the later chunks
+    // are still landing -- round 2 landed the whole slab by LDS-DMA first (9 us with the noise) and only then
+    // multiplied (4 us); the conv0 work now hides under the arrival of the data.  (LDS-DMA would not do here: the
+    // compiler makes every LDS access behind an outstanding global_load_lds wait for ALL of them.)  The noise of
+    // every chunk of a pass is formed up front, while the first loads are in flight.  Up to SLAB_RING chunks are
+    // resident per pass; C > 16 * SLAB_RING (B4: 200 bands) takes further passes through the same slots, the
+    // accumulators carried.
     const int C = a.C, KQ0 = (C + 15) >> 4;
-    float* slab = smem;                                   // [16 KQ0][HW] (+64), aliases img | wbuf | lut
+    const int CH4 = 4 * HW;                               // float4 per chunk (16 bands x HW floats)
+    const int PPW = (CH4 + 255) >> 8;                     // float4 per lane and chunk: 1 (HW <= 64) or 2 (HW <= 128)
+    const int SLOT = PPW << 10;                           // floats per LDS slot (>= 16 * HW)
+    float* slab = smem;                                   // [SLAB_RING][SLOT], aliases img | wbuf | lut
     const int nt0 = wave & 1, mh = wave >> 1;
-    uint4 bw[CONV0_MAXKQ][3];
-    {
-      const uint4* wq = (const uint4*)(a.w0t + (long long)net * a.w0t_ns) + lane;
-#pragma unroll
-      for (int kq = 0; kq < CONV0_MAXKQ; ++kq)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          bw[kq][pc] = (kq < KQ0) ? wq[((kq * 3 + pc) * 2 + nt0) * 64] : make_uint4(0u, 0u, 0u, 0u);
-    }
-    {
-      const int nfl = C * HW;
-      // the bands beyond C meet zero weights, but must be finite; so must the tail a clamped lane reads
-      for (int i = nfl + tid; i < 16 * KQ0 * HW + 64; i += 256) slab[i] = 0.f;
-      slab_issue(a.xs, net, s0, nfl, slab, wave, lane);
-      slab_finish(a.xs, net, s0, nfl, slab, tid, wave, lane);
+    const int nfl = C * HW, nf4 = nfl >> 2, rem = nfl & 3;
+    const float* xrow = xsrc_row(a.xs, net, s0, nfl);
+    const float sigma = a.xs.sigma;
+    const float* nzrow = (sigma != 0.f) ? xsrc_noise_row(a.xs, net, s0, nfl) : nullptr;
+    const uint64_t gsample = xsrc_global_sample(a.xs, s0);
+    const uint4* wq0 = (const uint4*)(a.w0t + (long long)net * a.w0t_ns) + lane;
+    // the last, partial float4 group of the slab (C * HW need not be a multiple of 4): threads 0 .. rem-1
+    float tailv = 0.f;
+    if (tid < rem) {
+      tailv = xrow[4 * nf4 + tid];
+      if (sigma != 0.f) {
+        float zt;
+        if (nzrow != nullptr) zt = nzrow[4 * nf4 + tid];
+        else {
+          const float4 t = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)nf4));
+          zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
+        }
+        tailv = fmaf(zt, sigma, tailv);
+      }
     }
     f32x16 z0 = zero16(), z1 = zero16();                  // M tiles 2mh and 2mh + 1 of output-channel tile nt0
-    __syncthreads();                                      // slab complete (the barrier waits for the DMA)
-    STAMP(0, 4);
-    {
-      const int pix0 = ((2 * mh) * 32 + l31 < HW) ? (2 * mh) * 32 + l31 : HW - 1;
-      const int pix1 = ((2 * mh + 1) * 32 + l31 < HW) ? (2 * mh + 1) * 32 + l31 : HW - 1;
-      const float* ap0 = slab + hh * 8 * HW + pix0;
-      const float* ap1 = slab + hh * 8 * HW + pix1;
+    const int pix0 = ((2 * mh) * 32 + l31 < HW) ? (2 * mh) * 32 + l31 : HW - 1;
+    const int pix1 = ((2 * mh + 1) * 32 + l31 < HW) ? (2 * mh + 1) * 32 + l31 : HW - 1;
+    for (int c0 = 0; c0 < KQ0; c0 += SLAB_RING) {         // uniform; one pass up to 112 bands
+      const int nch = (KQ0 - c0 < SLAB_RING) ? KQ0 - c0 : SLAB_RING;
+      // (opaque copy: keeps the compiler from hoisting this pass body's per-lane offsets out of the loop and holding
+      // them in registers across it)
+      int CH4l = CH4;
+      asm volatile("" : "+s"(CH4l));
+      const int HWl = CH4l >> 2;
+      if (c0 > 0) __syncthreads();                        // every wave is done reading the previous pass's slots
+      uint4 bw[3][3];                                     // conv0 weight fragments of three chunks (window)
+      float4 dv[SLAB_WIN][2], nzv[SLAB_RING][2];
+      auto fetch_b = [&](int kq, uint4 (&b)[3]) {
 #pragma unroll
-      for (int kq = 0; kq < CONV0_MAXKQ; ++kq) {
-        if (kq < KQ0) {                                   // uniform
+        for (int pc = 0; pc < 3; ++pc) b[pc] = wq0[(((c0 + kq) * 3 + pc) * 2 + nt0) * 64];
+      };
+      // this lane's float4 k of chunk kq: local index g inside the chunk, global index gg inside the slab
+      auto fetch_d = [&](int kq, float4 (&d)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+          const bool ok = k < PPW && g < CH4l && gg < nf4;
+          const float4 v = *(const float4*)(xrow + 4 * (ok ? gg : 0));
+          d[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+#pragma unroll
+      for (int kq = 0; kq < 3; ++kq) if (kq < nch) fetch_b(kq, bw[kq]);
+#pragma unroll
+      for (int kq = 0; kq < SLAB_WIN; ++kq) if (kq < nch) fetch_d(kq, dv[kq]);
+      if (c0 + nch == KQ0) {
+        // the bands beyond C of the last chunk meet zero weights, but must be finite
+        const int used = nfl - (KQ0 - 1) * 16 * HWl;
+        float* sl = slab + (nch - 1) * SLOT;
+        for (int i = used + tid; i < 16 * HWl; i += 256) sl[i] = 0.f;
+      }
+      // the noise of this pass's chunks, formed while the first loads are in flight
+#pragma unroll
+      for (int kq = 0; kq < SLAB_RING; ++kq) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+          float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (sigma != 0.f && kq < nch && k < PPW && (wave + 4 * k) * 64 < CH4l) {   // uniform
+            if (nzrow != nullptr) {                       // parity mode: the reference's own draws
+              const int gc = (g < CH4l && gg < nf4) ? gg : 0;
+              z = *(const float4*)(nzrow + 4 * gc);
+            } else {
+              z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
+            }
+          }
+          nzv[kq][k] = z;
+        }
+      }
+      if (c0 == 0) STAMP(0, 4);
+#pragma unroll
+      for (int kq = 0; kq < SLAB_RING; ++kq) {
+        if (kq < nch) {                                   // uniform
+          float* sl = slab + kq * SLOT;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+            if (k < PPW && g < CH4l && gg < nf4) {
+              float4 v = dv[kq % SLAB_WIN][k];
+              if (sigma != 0.f) {
+                v.x = fmaf(nzv[kq][k].x, sigma, v.x); v.y = fmaf(nzv[kq][k].y, sigma, v.y);
+                v.z = fmaf(nzv[kq][k].z, sigma, v.z); v.w = fmaf(nzv[kq][k].w, sigma, v.w);
+              }
+              *(float4*)(sl + 4 * g) = v;
+            }
+          }
+          if (c0 + kq == KQ0 - 1 && tid < rem) sl[4 * nf4 - (KQ0 - 1) * 16 * HWl + tid] = tailv;
+          if (kq + SLAB_WIN < nch) fetch_d(kq + SLAB_WIN, dv[kq % SLAB_WIN]);
+          __syncthreads();                                // chunk kq complete in LDS
+          if (c0 == 0 && kq == 0) STAMP(0, 12);
+          if (c0 == 0 && kq == 3) STAMP(0, 13);
+          const float* ap0 = sl + hh * 8 * HWl + pix0;
+          const float* ap1 = sl + hh * 8 * HWl + pix1;
           float r0[8], r1[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { r0[j] = ap0[(kq * 16 + j) * HW]; r1[j] = ap1[(kq * 16 + j) * HW]; }
+          for (int j = 0; j < 8; ++j) { r0[j] = ap0[j * HWl]; r1[j] = ap1[j * HWl]; }
           uint4 A1, A2, A3;
           a_split(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r0[4], r0[5], r0[6], r0[7]), A1, A2, A3);
-          z0 = mfma_b3(A1, A2, A3, bw[kq][0], bw[kq][1], bw[kq][2], z0);
+          z0 = mfma_b3(A1, A2, A3, bw[kq % 3][0], bw[kq % 3][1], bw[kq % 3][2], z0);
           a_split(make_float4(r1[0], r1[1], r1[2], r1[3]), make_float4(r1[4], r1[5], r1[6], r1[7]), A1, A2, A3);
-          z1 = mfma_b3(A1, A2, A3, bw[kq][0], bw[kq][1], bw[kq][2], z1);
+          z1 = mfma_b3(A1, A2, A3, bw[kq % 3][0], bw[kq % 3][1], bw[kq % 3][2], z1);
+          if (kq + 3 < nch) fetch_b(kq + 3, bw[kq % 3]);
         }
       }
     }
@@ -733,6 +854,40 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   for (int st = 0; st < 16; ++st) bcur[st] = wq[st * 64];
   const float4 y4 = *(const float4*)(a.yin + rs * FD + 4 * tid);
   const float bias2 = (a.b2 + (long long)net * a.p_ns)[wave * 16 + j];
+  // ... and what the head will want after conv2, so that its L2 round trips run under conv2's: the classifier rows of
+  // the first 16 classes (wave w owns features [w F/4, (w+1) F/4) of the row, 5 per lane) and the dropout multipliers
+  // of this thread's two float4 of the row (counter-based: they depend on nothing computed here)
+  const float* wc = a.wc + (long long)net * a.p_ns;
+  const int F4 = F >> 2, fb = wave * F4;   // 320 features per wave = 5 per lane
+  float wv0[16][5];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float* wr = wc + (long long)(q < K ? q : K - 1) * F + fb + lane;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wv0[q][i] = wr[64 * i];
+  }
+  // 0 = none, 1 = explicit mask, 2 = generate (Philox) and record for the backward pass
+  const int dmode = (!a.train || a.dropout_p <= 0.f) ? 0 : (a.dropmask != nullptr ? 1 : 2);
+  const float keep_scale = 1.0f / (1.0f - a.dropout_p);
+  float4 dm4[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f0 = 1024 * q + 4 * tid;
+    dm4[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (f0 < F) {
+      if (dmode == 1) {
+        dm4[q] = *(const float4*)(a.dropmask + rs * F + f0);
+      } else if (dmode == 2) {
+        const unsigned long long gs = xsrc_global_sample(a.xs, sample);
+        const float4 u = philox_uniform4(a.xs.seed, a.xs.step, STREAM_DROPOUT + net, (gs * F + f0) >> 2);
+        float4 m4;
+        m4.x = (u.x >= a.dropout_p) ? keep_scale : 0.f; m4.y = (u.y >= a.dropout_p) ? keep_scale : 0.f;
+        m4.z = (u.z >= a.dropout_p) ? keep_scale : 0.f; m4.w = (u.w >= a.dropout_p) ? keep_scale : 0.f;
+        *(float4*)(a.dropgen + rs * F + f0) = m4;
+        dm4[q] = m4;
+      }
+    }
+  }
   __syncthreads();                           // img2 interior complete; every thread is done pooling from img
   *(float4*)(row + SF + 4 * tid) = y4;       // spectral part of the head row (pre-dropout); row aliases the dead img
   // ---- conv2: pixel i = lane & 15 = (oh, ow) = (i >> 2, i & 3)
@@ -797,43 +952,37 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
     o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
     *(float4*)(a.feat + rs * FD + 4 * tid) = o;
   }
-  // 0 = none, 1 = explicit mask, 2 = generate (Philox) and record for the backward pass
-  const int dmode = (!a.train || a.dropout_p <= 0.f) ? 0 : (a.dropmask != nullptr ? 1 : 2);
-  const float keep_scale = 1.0f / (1.0f - a.dropout_p);
   float* catd = a.catd + rs * F;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int f0 = 1024 * q + 4 * tid;
     if (f0 < F) {
       float4 x = *(const float4*)(row + f0);
-      if (dmode == 1) {
-        const float4 m4 = *(const float4*)(a.dropmask + rs * F + f0);
-        x.x *= m4.x; x.y *= m4.y; x.z *= m4.z; x.w *= m4.w;
-      } else if (dmode == 2) {
-        const unsigned long long gs = xsrc_global_sample(a.xs, sample);
-        const float4 u = philox_uniform4(a.xs.seed, a.xs.step, STREAM_DROPOUT + net, (gs * F + f0) >> 2);
-        float4 m4;
-        m4.x = (u.x >= a.dropout_p) ? keep_scale : 0.f; m4.y = (u.y >= a.dropout_p) ? keep_scale : 0.f;
-        m4.z = (u.z >= a.dropout_p) ? keep_scale : 0.f; m4.w = (u.w >= a.dropout_p) ? keep_scale : 0.f;
-        *(float4*)(a.dropgen + rs * F + f0) = m4;
-        x.x *= m4.x; x.y *= m4.y; x.z *= m4.z; x.w *= m4.w;
-      }
+      if (dmode != 0) { x.x *= dm4[q].x; x.y *= dm4[q].y; x.z *= dm4[q].z; x.w *= dm4[q].w; }
       *(float4*)(catd + f0) = x;
       *(float4*)(row + f0) = x;              // same thread re-writes what it read
     }
   }
   __syncthreads();
   STAMP(0, 9);
-  // logits: wave w takes the quarter [w*F4, (w+1)*F4) of the row for ALL classes (8 accumulators at a time),
-  // then the four partial dot products meet in LDS
-  const float* wc = a.wc + (long long)net * a.p_ns;
+  // logits: wave w takes the quarter [w*F4, (w+1)*F4) of the row for ALL classes (16 at a time), then the four
+  // partial dot products meet in LDS
   const float* bc = a.bc + (long long)net * a.p_ns;
   float* part = red + 4;                     // [4 waves][64 classes]
-  const int F4 = F >> 2, fb = wave * F4;   // 320 features per wave = 5 per lane
   float xr[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) xr[i] = row[fb + lane + 64 * i];
-  for (int kc = 0; kc < K; kc += 16) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if (q < K) {                             // uniform: no reduction for classes that do not exist
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc = fmaf(xr[i], wv0[q][i], acc);
+      const float t = wave_sum(acc);
+      if (lane == 0) part[wave * 64 + q] = t;
+    }
+  }
+  for (int kc = 16; kc < K; kc += 16) {      // more than 16 classes: further chunks
     // 16 classes x 5 features: all 80 weight loads are issued before the first is used (one L2 round trip per
     // chunk; a load -> fma -> load loop here cost ~7 us per workgroup)
     float wv[16][5];
@@ -870,7 +1019,8 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
 __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float* smem, uint32_t (&mpre)[2]) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int net = blockIdx.y, sample = blockIdx.x;
+  int net, sample;
+  wg_decode(a, net, sample);
   const int H2 = a.H >> 1, W2 = a.W >> 1, P2 = H2 * W2, PW2 = W2 + 2;
   const int SF = 256, F = SF + FD, K = a.K;
   float* img2 = smem + (size_t)(a.H + 2) * (a.W + 2) * CS;        // = wbuf: [(H2+2)*(W2+2)][CS] <= 4096 floats
@@ -1064,8 +1214,9 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   return dp1s;
 }
 
+// (the per-sample kernels, MODE >= 2, count on two workgroups per CU: two waves per SIMD, at most 256 registers)
 template <int MODE, int MTW, int TAIL = 0>
-__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
+__global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Conv3Ctx c;
   STAMP(MODE & 1, 0);
@@ -1168,14 +1319,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     STAMP(0, 7);
     if (TAIL) conv3_fwd_tail(a, c, smem);
   } else if (MODE == 3) {
-    // conv0 weight gradient fused in (S == 1, MTW == 1, C <= 128):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
+    // conv0 weight gradient fused in (S == 1, MTW == 1):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
     // This wave's da0 tile = accumulators + dz (the residual branch); it goes to LDS as the B operand [pix][64]
-    // next to the sample's [C][HW] input slab, which global_load_lds_dwordx4 copies linearly into the now dead
-    // image region.  wave = band tile (A rows c = 32 wave + l31, conflict-free: row stride HW is odd or the
-    // reads are b32 over consecutive c), both co tiles.  The partial has conv0_wgrad_kernel's layout.
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(1))) const void gbl_void;
-    const int C = a.C;
+    // next to the sample's input slab, which global_load_lds_dwordx4 copies linearly into the now dead image
+    // region.  wave = band tile (A rows c = 32 wave + l31, conflict-free: row stride HW is odd or the reads are b32
+    // over consecutive c), both co tiles.  The partial has conv0_wgrad_kernel's layout.  Up to a.bp bands fit beside
+    // da0 (two workgroups per CU): more bands (B4: 200) take further PASSES over [bp][HW] ranges of the slab through
+    // the same region, da0 staying where it is.
+    const int C = a.C, BP = a.bp;
     float v0[16], v1[16];
     {
       int pos[16];
@@ -1190,9 +1341,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
       for (int r = 0; r < 16; ++r) { v0[r] += acc[0][0][r]; v1[r] += acc[0][1][r]; }
     }
     __syncthreads();                                      // image and LUT are dead from here on
-    float* slab = smem;                                   // [C][HW]
-    float* dal = smem + C * HW;                           // [HW + 1][64]
-    slab_issue(a.xs, net, s0, C * HW, slab, wave, lane);   // the forward's input again
+    float* slab = smem;                                   // [min(C, BP)][HW]
+    float* dal = smem + (C < BP ? C : BP) * HW;           // [HW + 1][64]
+    const int Ct = ((C + 31) >> 5) * 32;
+    float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Ct * 64 + 64);
+    SlabRange rg = slab_range(a.xs, net, s0, C * HW, 0, (C < BP ? C : BP) * HW);
+    slab_issue(rg, slab, wave, lane);                     // the forward's input again (first pass)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = wave * 32 + acc_row(r, lane);
@@ -1200,55 +1354,70 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
     }
     if (tid < 64) dal[HW * 64 + tid] = 0.f;               // the pixel past the end of an odd map
     STAMP(1, 12);
-    slab_finish(a.xs, net, s0, C * HW, slab, tid, wave, lane);   // ... with the forward's noise regenerated
-    STAMP(1, 13);
-    __syncthreads();                                      // slab landed (the barrier waits for the DMA), da0 complete
-    // dW0 tile of this wave on the split-bf16 MFMA: k-steps of 16 pixels; lane (row = band c, half h) takes pixels
-    // 16 kq + 8h .. + 7 of its slab row, lane (col = co, half h) the same pixels of da0; both are split in registers
-    // (132 VALU instructions per 12 MFMAs).  Pixels >= HW of the last step read the zero row behind da0.
-    f32x16 g0 = zero16(), g1 = zero16();
-    float dbacc = 0.f;
-    {
-      const int crow = wave * 32 + l31;                   // band of this lane (rows >= C: finite garbage, dropped by the reduce)
-      const float* ap = slab + (size_t)crow * HW + 8 * hh;
-      const float* bp = dal + l31;
-      const int NS = (HW + 15) >> 4;
+#pragma unroll 1
+    for (int cb = 0; cb < C; cb += BP) {                  // uniform; one pass unless C > BP
+      const int nb = (C - cb < BP) ? C - cb : BP;
+      // (an opaque copy of HW: left alone, the compiler hoists the ~64 per-lane operand offsets of the MFMA block out
+      // of this loop and keeps them in registers across it -- the kernel then no longer fits two waves per SIMD)
+      int HWl = HW;
+      asm volatile("" : "+s"(HWl));
+      if (cb > 0) {
+        __syncthreads();                                  // every wave is done reading the previous pass's rows
+        rg = slab_range(a.xs, net, s0, C * HW, (cb * HW) >> 2, nb * HW);   // (BP * HW is a multiple of 4)
+        slab_issue(rg, slab, wave, lane);
+      }
+      slab_finish(a.xs, net, rg, slab, tid, wave, lane);  // ... with the forward's noise regenerated
+      if (cb == 0) STAMP(1, 13);
+      __syncthreads();                                    // range landed (the barrier waits for the DMA), da0 complete
+      // dW0 tile of this wave on the split-bf16 MFMA: k-steps of 16 pixels; lane (row = band c, half h) takes pixels
+      // 16 kq + 8h .. + 7 of its slab row, lane (col = co, half h) the same pixels of da0; both are split in registers
+      // (132 VALU instructions per 12 MFMAs).  Pixels >= HW of the last step read the zero row behind da0.
+      const bool has_tile = wave * 32 < nb;               // uniform: this wave's band tile exists in this pass
+      const bool has_db = cb == 0 && wave < 2;            // waves 0 / 1 also sum the bias gradient (first pass)
+      if (has_tile || has_db) {
+        f32x16 g0 = zero16(), g1 = zero16();
+        float dbacc = 0.f;
+        const int crow = wave * 32 + l31;                 // band cb + crow of this lane (rows >= nb: finite garbage, not stored)
+        const float* ap = slab + (size_t)crow * HWl + 8 * hh;
+        const float* bp = dal + l31;
+        const int NS = (HWl + 15) >> 4;
 #pragma unroll
-      for (int kq = 0; kq < 8; ++kq) {                    // HW <= 128 (conv3_fused_bwd_ok)
-        if (kq < NS) {                                    // uniform
-          float ra[8], rb0[8], rb1[8];
+        for (int kq = 0; kq < 8; ++kq) {                  // HW <= 128 (conv3_fused_bwd_ok)
+          if (kq < NS) {                                  // uniform
+            float ra[8], rb0[8], rb1[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int k = kq * 16 + 8 * hh + j;
-            const int kc = k < HW ? k : HW;               // the zero row
-            ra[j] = ap[kq * 16 + j];
-            rb0[j] = bp[kc * 64]; rb1[j] = bp[kc * 64 + 32];
+            for (int j = 0; j < 8; ++j) {
+              const int k = kq * 16 + 8 * hh + j;
+              const int kc = k < HWl ? k : HWl;           // the zero row
+              ra[j] = ap[kq * 16 + j];
+              rb0[j] = bp[kc * 64]; rb1[j] = bp[kc * 64 + 32];
+            }
+            uint4 A1, A2, A3, P1, P2, P3;
+            a_split(make_float4(ra[0], ra[1], ra[2], ra[3]), make_float4(ra[4], ra[5], ra[6], ra[7]), A1, A2, A3);
+            a_split(make_float4(rb0[0], rb0[1], rb0[2], rb0[3]), make_float4(rb0[4], rb0[5], rb0[6], rb0[7]), P1, P2, P3);
+            g0 = mfma_b3(A1, A2, A3, P1, P2, P3, g0);
+            a_split(make_float4(rb1[0], rb1[1], rb1[2], rb1[3]), make_float4(rb1[4], rb1[5], rb1[6], rb1[7]), P1, P2, P3);
+            g1 = mfma_b3(A1, A2, A3, P1, P2, P3, g1);
+            // waves 0 / 1 sum co tile 0 / 1 for the bias gradient (fixed order: j, then k-step, then the two halves)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dbacc += (wave == 0) ? rb0[j] : rb1[j];
           }
-          uint4 A1, A2, A3, P1, P2, P3;
-          a_split(make_float4(ra[0], ra[1], ra[2], ra[3]), make_float4(ra[4], ra[5], ra[6], ra[7]), A1, A2, A3);
-          a_split(make_float4(rb0[0], rb0[1], rb0[2], rb0[3]), make_float4(rb0[4], rb0[5], rb0[6], rb0[7]), P1, P2, P3);
-          g0 = mfma_b3(A1, A2, A3, P1, P2, P3, g0);
-          a_split(make_float4(rb1[0], rb1[1], rb1[2], rb1[3]), make_float4(rb1[4], rb1[5], rb1[6], rb1[7]), P1, P2, P3);
-          g1 = mfma_b3(A1, A2, A3, P1, P2, P3, g1);
-          // waves 0 / 1 sum co tile 0 / 1 for the bias gradient (fixed order: j, then k-step, then the two halves)
+        }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dbacc += (wave == 0) ? rb0[j] : rb1[j];
+        for (int r = 0; r < 16; ++r) {
+          const int cc = wave * 32 + acc_row(r, lane);
+          // single pass: whole band tiles as before (rows >= C are dropped by the reduce); several passes: only this
+          // pass's bands (the rows behind them belong to the next pass)
+          if (has_tile && (cc < nb || (C <= BP && cc < Ct))) {
+            pp[(size_t)(cb + cc) * 64 + l31] = g0[r];
+            pp[(size_t)(cb + cc) * 64 + 32 + l31] = g1[r];
+          }
+        }
+        if (has_db) {
+          const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
+          if (hh == 0) pp[(size_t)Ct * 64 + wave * 32 + l31] = tot;
         }
       }
-    }
-    const int Ct = ((C + 31) >> 5) * 32;
-    float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Ct * 64 + 64);
-    if (wave * 32 < Ct) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cc = wave * 32 + acc_row(r, lane);
-        pp[(size_t)cc * 64 + l31] = g0[r];
-        pp[(size_t)cc * 64 + 32 + l31] = g1[r];
-      }
-    }
-    if (wave < 2) {
-      const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
-      if (hh == 0) pp[(size_t)Ct * 64 + wave * 32 + l31] = tot;
     }
   } else {
     float* out = a.out + (long long)net * a.out_ns;
@@ -1413,7 +1582,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0;
-  a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0;
+  a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0; a.pair = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
@@ -1436,8 +1605,15 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
 // conv0 fused into the conv1 forward (MODE 2).  Possible when the plain forward plan is one sample per workgroup
 // with one pixel tile per wave (H*W <= 128) and two workgroups still fit a CU with the slab + conv0 weights in LDS.
 // LDS of the fused kernel: the plain forward's regions, or slab [Cp][HW] + 64 + weights [Cp][64] if that is larger
+// same-network pairing of the two workgroups of a CU (wg_decode); CMLPL_PAIR_NETS=0: plain (sample, net) grid
+static int conv3_pair_nets(int nets) {
+  static const bool off = getenv("CMLPL_PAIR_NETS") && atoi(getenv("CMLPL_PAIR_NETS")) == 0;
+  return (nets == 2 && !off) ? 1 : 0;
+}
 static size_t conv3_fused_lds(int H, int W, int C, size_t plain) {
-  const size_t need = ((size_t)16 * ((C + 15) / 16) * H * W + 64) * 4;     // slab rows up to whole k-steps of 16
+  const int KQ0 = (C + 15) / 16, ring = KQ0 < SLAB_RING ? KQ0 : SLAB_RING;
+  const size_t slot = (size_t)((4 * H * W + 255) / 256) * 1024;           // floats per chunk slot
+  const size_t need = ring * slot * 4;
   return need > plain ? need : plain;
 }
 
@@ -1446,7 +1622,7 @@ bool conv3_fused_ok(int H, int W, int C, int rows) {
   if (off || C < 1) return false;
   Conv3Plan pl;
   if (!plan_conv3(0, H, W, rows, &pl)) return false;
-  if (pl.S != 1 || pl.MTW != 1 || H * W > 128 || C * H * W > 4 * SLAB_MAXQ * 256 || C > 16 * CONV0_MAXKQ) return false;
+  if (pl.S != 1 || pl.MTW != 1 || H * W > 128) return false;
   for (int m = 0; m < 128; ++m)                       // the magic-number divide of the kernel
     if (((m * ((65536 + W - 1) / W)) >> 16) != m / W) return false;
   return 2 * conv3_fused_lds(H, W, C, pl.lds) <= LDS_MAX;
@@ -1472,7 +1648,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C;
-  a.xs = xs; a.part0 = nullptr; a.part0_ns = 0;
+  a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0; a.pair = conv3_pair_nets(nets);
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -1483,26 +1659,38 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
     static DevOnce attr_once;
     hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), dim3(n, nets), dim3(256), conv3_fused_lds(H, W, C, pl.lds), st, a);
+    hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), a.pair ? dim3(n * nets) : dim3(n, nets), dim3(256),
+                       conv3_fused_lds(H, W, C, pl.lds), st, a);
     return hipGetLastError();
   }
-  return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
+  return launch_conv3_t<2, 1>(a, a.pair ? dim3(n * nets) : dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
 }
 
-// conv0 weight gradient fused into the conv1 data gradient (MODE 3): same shape conditions as the fused forward,
-// at most four band tiles, and two workgroups per CU with slab [C][HW] + da0 [HW+1][64] in LDS.
+// conv0 weight gradient fused into the conv1 data gradient (MODE 3): same shape conditions as the fused forward, and
+// two workgroups per CU with slab [bp][HW] + da0 [HW+1][64] in LDS, bp = bands per pass (at most four band tiles).
+// All C bands in one pass when they fit (B2: 103), else the largest multiple of four that does (B4: 104 + 96).
+static int conv3_bwd_bp(int H, int W, int C) {
+  const int HW = H * W;
+  const long long avail = (long long)(LDS_MAX / 2 / 4) - (long long)(HW + 1) * 64;     // floats left for the slab rows
+  long long bp = avail / HW;
+  if (bp > 128) bp = 128;
+  if ((long long)bp * HW > 4 * SLAB_MAXQ * 256) bp = 4 * SLAB_MAXQ * 256 / HW;
+  if (C <= bp) return C;
+  return (int)(bp & ~3LL);
+}
 static size_t conv3_fused_bwd_lds(int H, int W, int C, size_t plain) {
-  const size_t need = ((size_t)C * H * W + (size_t)(H * W + 1) * 64) * 4;
+  const int bp = conv3_bwd_bp(H, W, C);
+  const size_t need = ((size_t)(bp > 0 ? bp : 0) * H * W + (size_t)(H * W + 1) * 64) * 4;
   return need > plain ? need : plain;
 }
 
 bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
   static const bool off = getenv("CMLPL_FUSE_CONV0") && atoi(getenv("CMLPL_FUSE_CONV0")) == 0;
   static const bool offb = getenv("CMLPL_FUSE_CONV0_BWD") && atoi(getenv("CMLPL_FUSE_CONV0_BWD")) == 0;
-  if (off || offb || C < 1 || C > 128) return false;
+  if (off || offb || C < 1 || C > 256) return false;
   Conv3Plan pl;
   if (!plan_conv3(1, H, W, rows, &pl)) return false;
-  if (pl.S != 1 || pl.MTW != 1 || H * W > 128) return false;
+  if (pl.S != 1 || pl.MTW != 1 || H * W > 128 || conv3_bwd_bp(H, W, C) < 32) return false;
   // band rows up to 127 are read (garbage rows are dropped later) and must stay inside the allocation
   const size_t lds = conv3_fused_bwd_lds(H, W, C, pl.lds);
   if ((size_t)128 * H * W * 4 > lds) return false;
@@ -1534,7 +1722,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C;
-  a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns;
+  a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = conv3_bwd_bp(H, W, C); a.pair = conv3_pair_nets(nets);
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
@@ -1543,10 +1731,11 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
     static DevOnce attr_once;
     hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), dim3(n, nets), dim3(256), conv3_fused_bwd_lds(H, W, C, pl.lds), st, a);
+    hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), a.pair ? dim3(n * nets) : dim3(n, nets), dim3(256),
+                       conv3_fused_bwd_lds(H, W, C, pl.lds), st, a);
     return hipGetLastError();
   }
-  return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
+  return launch_conv3_t<3, 1>(a, a.pair ? dim3(n * nets) : dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
 }
 
 }  // namespace cmlpl

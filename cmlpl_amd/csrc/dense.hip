@@ -76,7 +76,7 @@ hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const flo
 // workgroups also write sn (row-major) for the weight gradient.  Replaces the augmentation launch (+ its transposed
 // copy) and the GEMM launch.  (A first version staged the augmented rows in LDS and walked the contraction
 // serially per wave: slower than the two launches it replaced.)
-constexpr int SPE_MAXP = 16;    // k-pairs per wave: bands <= 4 * 2 * 16 = 128
+// SPE_MAXP = k-pairs per wave (template parameter): 16 covers bands <= 4 * 2 * 16 = 128, 32 covers 256 (B4: 200)
 
 struct SpeArgs {
   XSrc xs; const float* wsT; long long wsT_ns; const float* bias; long long p_ns;
@@ -84,6 +84,7 @@ struct SpeArgs {
   const long long* labels; float* labels_f; int bt;        // optional: labels as float for the exchange buffer
 };
 
+template <int SPE_MAXP>
 __global__ __launch_bounds__(256) void spe_fused_kernel(SpeArgs a) {
   __shared__ float red[3][16][64];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void spe_fused_kernel(SpeArgs a) {
   for (int q = 0; q < SPE_MAXP; ++q) {
     const int k = 2 * (t0 + q) + hh;
     const bool kv = (t0 + q < t1) && (k < bands);
-    const float v = (kv && iv) ? av[q] + zv[q] * a.xs.sigma : 0.f;
+    const float v = (kv && iv) ? fmaf(zv[q], a.xs.sigma, av[q]) : 0.f;
     if (nt == 0 && kv && iv) a.sn[((long long)net * a.n + i) * bands + k] = v;
     if (t0 + q < t1) acc = mfma32(v, bv[q], acc);            // uniform
   }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void spe_fused_kernel(SpeArgs a) {
 
 bool spe_fused_ok(int bands) {
   static const bool off = getenv("CMLPL_FUSE_SPE") && atoi(getenv("CMLPL_FUSE_SPE")) == 0;
-  return !off && bands <= 8 * SPE_MAXP;
+  return !off && bands <= 256;
 }
 
 hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const float* wsT, long long wsT_ns,
@@ -160,7 +161,8 @@ hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const fl
   SpeArgs a;
   a.labels = labels; a.labels_f = labels != nullptr ? labels_f : nullptr; a.bt = bt;
   a.xs = xs; a.wsT = wsT; a.wsT_ns = wsT_ns; a.bias = bias; a.p_ns = p_ns; a.y = y; a.sn = sn; a.n = n; a.bands = bands;
-  hipLaunchKernelGGL(spe_fused_kernel, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
+  if (bands <= 128) hipLaunchKernelGGL(spe_fused_kernel<16>, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
+  else              hipLaunchKernelGGL(spe_fused_kernel<32>, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

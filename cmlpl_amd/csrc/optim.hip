@@ -14,10 +14,7 @@ struct AdamArgs {
 };
 
 __device__ __forceinline__ float adam_update(float& mm, float& vv, float p, float g, const AdamArgs& a) {
-  mm = mm + a.w1 * (g - mm);                             // exp_avg.lerp_(grad, 1-beta1)
-  vv = vv * a.b2 + (a.w2 * g) * g;                       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
-  const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
-  return p - a.step_size * (mm / denom);                 // param.addcdiv_(exp_avg, denom, -step_size)
+  return adam_elem(mm, vv, p, g, a.w1, a.b2, a.w2, a.step_size, a.bc2_sqrt, a.eps);
 }
 
 // A 3x3 weight tensor, four output channels (4 x 576 consecutive elements) per workgroup: Adam on 9 elements per
@@ -119,6 +116,16 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
       }
     }
   }
+}
+
+AdamFuse make_adam_fuse(float* params, long long pstride, float* m, float* v, float* packed, const PackInfo& pi,
+                        long long t, float lr, float b1, float b2, float eps) {
+  const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+  AdamFuse a;
+  a.params = params; a.m = m; a.v = v; a.packed = packed; a.pstride = pstride; a.pi = pi;
+  a.w1 = (float)(1.0 - (double)b1); a.b2 = b2; a.w2 = (float)(1.0 - (double)b2);
+  a.step_size = (float)((double)lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = eps;
+  return a;
 }
 
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,

@@ -626,13 +626,15 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   for (int ub = ubeg; ub < uend; ub += U) {
     const bool more = ub + U < uend;            // workgroup-uniform
     const char* buf = lds + cur * BUF;
-    if (more) fetch(ub + U);                    // in flight across the MFMAs below
+    // (ablation builds: 30 = no global fetch after the first stage, 31 = no split / plane writes after the first stage,
+    //  32 = no MFMA loop -- wrong results on purpose, timeline only)
+    if (more && CMLPL_ABL != 30) fetch(ub + U); // in flight across the MFMAs below
     const char* pa_ = buf + a_lane;
     const char* pb_ = buf + b_lane;
 #pragma unroll
     for (int st = 0; st < (NST + 1) / 2; ++st) {
       const int step = 2 * st + kg;             // wave-uniform
-      if (step < NST) {
+      if (step < NST && CMLPL_ABL != 32) {
         const char* pbs = pb_ + step * 2048;
         const bf16x8 b1 = tr_frag(pbs), b2 = tr_frag(pbs + BPL), b3 = tr_frag(pbs + 2 * BPL);
 #pragma unroll
@@ -648,7 +650,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
         }
       }
     }
-    if (more) commit(lds + (cur ^ 1) * BUF);
+    if (more && CMLPL_ABL != 31) commit(lds + (cur ^ 1) * BUF);
     __syncthreads();   // stage g fully read by every wave, stage g+1 fully written
     cur ^= 1;
   }

@@ -14,6 +14,15 @@ from . import _lib
 NUM_QUERIES = 256          # loss_helper.py:60
 NUM_NEGATIVES = 50         # :61
 TEMP = 0.5                 # :59
+PENDING_MAX = 64           # one-pass calls whose enqueue logs may wait on the device before they are folded in
+
+
+def _draw_key():
+    """64-bit key of one call's in-kernel index draws (the reference's two torch.randint calls, :164/:179).  It comes
+    from torch's CPU generator, so it ADVANCES with every call in the process -- across MemoryBank objects (the
+    drop-in list path builds a new one per call), across resumed runs that restore the generator state -- and
+    torch.manual_seed() still makes a run reproducible.  No device sync."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 def _p(t):
@@ -49,13 +58,23 @@ class MemoryBank:
     def ptrs(self):
         """the reference's queue_ptr per class; one-pass calls log their enqueue counts on the device and the
         pointers are brought up to date here, when someone asks (one read-back for all pending calls)"""
+        self._fold_pending()
+        return self._ptrs
+
+    def _fold_pending(self):
         if self.pending:
-            logs = torch.stack(self.pending).cpu()
+            logs = torch.stack(self.pending).cpu().tolist()
             self.pending = []
             for log in logs:
                 for c in range(self.K):
-                    self.note_enqueued(c, int(log[c, 1]), int(log[c, 0]))
-        return self._ptrs
+                    self.note_enqueued(c, int(log[c][1]), int(log[c][0]))
+
+    def log_call(self, keys_log):
+        """remember one one-pass call's device log; the list is bounded (one small read-back every PENDING_MAX calls
+        when nobody asks for the pointers in between, instead of an ever-growing list of device tensors)"""
+        self.pending.append(keys_log)
+        if len(self.pending) >= PENDING_MAX:
+            self._fold_pending()
 
     # ---- reference-style views -------------------------------------------------------------
     def host_state(self):
@@ -152,7 +171,8 @@ def contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_m
     tensor [K] on this fast path (the reference's list of ints would need the read-back); with `as_tensors=False`
     -- or when `draws` are injected, which is the parity-test path -- it is the reference's list.
     `draws`, if given, is (anchor_idx, neg_idx): dicts loop position -> int64 index tensors replacing the two
-    torch.randint calls (:164, :179); otherwise the indices are drawn in-kernel (Philox)."""
+    torch.randint calls (:164, :179); otherwise the indices are drawn in-kernel (Philox,
+    keyed by a fresh 64-bit draw from torch's CPU generator per call: see _draw_key)."""
     lib = _lib.load()
     dev = rep.device
     if dev.type != "cuda":
@@ -187,7 +207,7 @@ def contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_m
         keep += [a_all, n_all]
         c.d_anchor_draw, c.d_neg_draw = a_all.data_ptr(), n_all.data_ptr()
     bank.calls += 1
-    c.seed, c.call = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, bank.calls
+    c.seed, c.call = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, _draw_key()
     prototype = None
     if momentum_prototype is not None:                    # :194-203
         mp = _f32(momentum_prototype, dev).reshape(K, Q, D)
@@ -202,7 +222,7 @@ def contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_m
     (c.d_lists, c.d_counts, c.d_proto, c.d_keys_log, c.d_lossq, c.d_ganchor, c.d_arow, c.d_drep,
      c.d_total) = [t.data_ptr() for t in (lists, counts, proto, keys_log, lossq, ganchor, arow, drep, total)]
     _lib.check("cmlpl_memobank_loss", lib.cmlpl_memobank_loss(C.byref(c), st))
-    bank.pending.append(keys_log)                         # pointer bookkeeping is resolved when someone asks
+    bank.log_call(keys_log)                               # pointer bookkeeping is resolved when someone asks
     loss = _Scaled.apply(rep, total[0], drep)
     if draws is not None:       # parity path: injected indices must have been in range (the kernel clamps them)
         cnt, (rows, _) = counts.cpu(), bank.host_state()

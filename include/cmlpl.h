@@ -76,6 +76,10 @@ typedef struct cmlpl_layout_t {
 } cmlpl_layout_t;
 
 int cmlpl_abi_version(void);
+/* 16-hex-digit hash of the kernel sources and this header the binary was built from ("unknown" for a build outside
+ * cmlpl_amd/build_ext.py).  The Python binding compares it with the hash of the sources next to it and refuses a
+ * stale binary (cmlpl_amd/_lib.py); the reference has no counterpart (it has no native code). */
+const char* cmlpl_source_hash(void);
 int cmlpl_layout(const cmlpl_shape* shape, cmlpl_layout_t* out);
 
 /* Bytes of device workspace needed by the calls below for up to `n` rows per network

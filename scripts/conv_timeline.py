@@ -32,7 +32,8 @@ for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1, la
     t = t[t[:, 0] > 0]
     if mode == 0 and full[:, 4].max() > 0:
         f = (full - full[:, :1]) / 100.0
-        print(f"fwd fused prologue (us from workgroup start): slab landed {f[:,4].mean():.2f}  conv0 MFMAs done {f[:,5].mean():.2f}  "
+        print(f"fwd fused prologue (us from workgroup start): loads issued + noise formed {f[:,4].mean():.2f}  chunk 0 in LDS "
+              f"{f[:,12].mean():.2f}  chunk 3 in LDS {f[:,13].mean():.2f}  conv0 MFMAs done {f[:,5].mean():.2f}  "
               f"image zeroed {f[:,6].mean():.2f}  a0 written / stage end {f[:,1].mean():.2f}")
     if mode == 0 and full[:, 9].max() > 0:
         f = (full - full[:, :1]) / 100.0

@@ -45,10 +45,10 @@ def blended_peak(segments):
     floor_s = segments.get("f32", 0.0) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + segments.get("split", 0.0) / (SPLIT_PEAK_TFLOPS * 1e12)
     return (tot / floor_s / 1e12) if floor_s > 0 else FP32_MFMA_PEAK_TFLOPS
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # written by scripts/pmc_summary.py --json
-CONV1_KERNELS = {
-    "conv1_fwd": "conv3x3_kernel<FWD> (conv1 forward: 3x3 conv + bias + residual + ReLU + avgpool, both networks)",
-    "conv1_dgrad": "conv3x3_kernel<DGRAD> (conv1 data gradient, both networks)",
-    "conv1_wgrad": "wgrad3r_kernel (conv1 weight gradient, both networks)",
+CONV1_KERNELS = {     # labels of the unfused launches; the fused ones are named where the calibration window finds them
+    "conv1_fwd": "conv3x3_kernel<0> (conv1 forward: 3x3 conv + bias + residual + ReLU + avgpool, both networks)",
+    "conv1_dgrad": "conv3x3_kernel<1> (conv1 data gradient, both networks)",
+    "conv1_wgrad": "wgrad3b_kernel (conv1 weight gradient, split-bf16, both networks)",
 }
 
 
@@ -63,6 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", default=None, metavar="BT+BTU",
                     help="fix the GLOBAL batch (labelled+unlabelled) and shard it over the GPUs: strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true",
+                    help="N > 1: every rank shards ONE common global batch; rank 0 then runs the same global batch "
+                         "through the single-GPU engine and the first step's logged scalars must agree (1e-4 relative) "
+                         "-- exits non-zero otherwise")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -132,7 +136,7 @@ def _host_cores():
     return min(cores, int(os.environ.get("CMLPL_CPU_THREADS", "32")))   # torch intra-op scaling flattens beyond this
 
 
-def cpu_baseline(shape, bt, btu, budget_s=14.0, budget_1t_s=8.0):
+def cpu_baseline(shape, bt, btu, budget_s=12.0, budget_1t_s=7.0, budget_b1_s=5.0):
     """The oracle (CPU restatement of the reference step, verified against the reference's own outputs)
     timed on this host's cores on the same workload; bounded sample.  All host cores, then one thread
     (SURVEY.md 8d asks for both figures)."""
@@ -166,11 +170,34 @@ def cpu_baseline(shape, bt, btu, budget_s=14.0, budget_1t_s=8.0):
     cores = _host_cores()
     med, k = sample(cores, budget_s, 2)
     med1, k1 = sample(1, budget_1t_s, 1)
-    return {"value": (bt + btu) / med, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"{k} steps of the same {bt}+{btu} workload after 2 warm-up steps, median "
-                      f"{med * 1e3:.1f} ms/step, PyTorch-CPU {torch.__version__}, {cores} threads",
-            "value_1thread": (bt + btu) / med1,
-            "sample_1thread": f"{k1} steps after 1 warm-up step, median {med1 * 1e3:.1f} ms/step, 1 thread"}
+    out = {"value": (bt + btu) / med, "unit": "patches/s", "cores": cores, "kind": "port",
+           "sample": f"{k} steps of the same {bt}+{btu} workload after 2 warm-up steps, median "
+                     f"{med * 1e3:.1f} ms/step, PyTorch-CPU {torch.__version__}, {cores} threads",
+           "value_1thread": (bt + btu) / med1,
+           "sample_1thread": f"{k1} steps after 1 warm-up step, median {med1 * 1e3:.1f} ms/step, 1 thread"}
+    # BASELINE.json configs[0] / BASELINE.md B1: the reference's own CPU-runnable case (its 60x20x20 shape, 32 + 32 rows)
+    sB = O.NetShape(60, 20, 20, 103, 9)
+    stB = O.StepState.create(sB, O.closed_form_params(sB, 1), O.closed_form_params(sB, 2), 32, hp)
+    bB = [O.synthetic_batch(sB, 32, 32, 2088 + i) for i in range(2)]
+    torch.set_num_threads(cores)
+    tB = []
+    t_start = time.perf_counter()
+    i = 0
+    while True:
+        b = bB[i % 2]
+        t0 = time.perf_counter()
+        noise = [torch.randn_like(t) for t in b["noise"]]
+        dm = [(torch.rand(64, sB.cls_in) < 1.0 - hp.dropout).float() / (1.0 - hp.dropout) for _ in range(2)]
+        O.train_step(stB, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], noise, dm, 1, i, hp)
+        tB.append(time.perf_counter() - t0)
+        i += 1
+        if i >= 3 and (time.perf_counter() - t_start > budget_b1_s or i >= 200):
+            break
+    medB = sorted(tB[2:])[len(tB[2:]) // 2]
+    out["b1"] = {"value": 64 / medB, "unit": "patches/s", "cores": cores,
+                 "sample": f"BASELINE configs[0] (reference shape 60x20x20, 32+32 rows): {len(tB) - 2} steps after 2 "
+                           f"warm-up steps, median {medB * 1e3:.1f} ms/step, {cores} threads"}
+    return out
 
 
 def launch_ranks(args, argv):
@@ -187,6 +214,43 @@ def launch_ranks(args, argv):
         sys.stdout.write(lines[-1] + "\n")
         sys.stdout.flush()
     return rc
+
+
+def check_against_single_rank(eng, shape, bt, btu, world, rank, device, hp):
+    """--check: ONE global batch (common seed), sharded by sample as the data-parallel engine expects (rank r takes
+    labelled rows [r bt, (r+1) bt) and unlabelled rows [r btu, (r+1) btu)); step 0 on all ranks, then the same global
+    batch through the single-GPU TrainEngine on rank 0 from the same parameters and seed (the in-kernel noise / dropout
+    streams are keyed by the GLOBAL sample index, so the two runs draw the same numbers).  The logged row and the
+    Base1 losses must agree to 1e-4 relative; a mismatch ends the job with a non-zero code."""
+    import torch
+    from cmlpl_amd import NetShape, TrainEngine
+    g = synth(shape, bt * world, btu * world, 4242, device)
+    sl = lambda t, k: t[rank * k:(rank + 1) * k].contiguous()
+    snap = [eng.params.clone(), eng.m.clone(), eng.v.clone(), eng.bank_feats.clone(), eng.bank_probs.clone()]
+    state = (list(eng.ptr), eng.adam_t, eng.step_count)
+    eng.step(sl(g["XPl"], bt), sl(g["Xl"], bt), sl(g["Y"], bt), sl(g["XPu"], btu), sl(g["Xu"], btu), epoch=1, batch_index=0)
+    got = eng.read_scalars()                      # all-reduced: every rank calls it
+    ok = True
+    if rank == 0:
+        ref = TrainEngine(NetShape(*shape), bt * world, btu * world, hp, device=device, seed=1088)
+        ref.params.copy_(snap[0])
+        ref._packed_dirty = True
+        ref.step(g["XPl"], g["Xl"], g["Y"], g["XPu"], g["Xu"], epoch=1, batch_index=0)
+        want = ref.read_scalars()
+        for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc", "total_w", "cls_w", "con_w"):
+            if not abs(got[k] - want[k]) <= 1e-4 * abs(want[k]) + 1e-6:
+                ok = False
+        print(f"bench.py --check: {world} ranks {['MISMATCH', 'ok'][ok]}: sharded {got} vs single-rank {want}", file=sys.stderr)
+        del ref
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    eng.comm.all_reduce(flag)                     # rank 0's verdict reaches every rank (the others contribute 1)
+    # restore the state the timed run starts from
+    for dst, src in zip((eng.params, eng.m, eng.v, eng.bank_feats, eng.bank_probs), snap):
+        dst.copy_(src)
+    eng.ptr, eng.adam_t, eng.step_count = list(state[0]), state[1], state[2]
+    eng._packed_dirty = True
+    if float(flag.item()) < world - 0.5:
+        raise SystemExit("bench.py --check: the sharded step does not reproduce the single-rank step")
 
 
 def run_rank(args):
@@ -215,18 +279,20 @@ def run_rank(args):
     hp = HyperParams()
     dist = None
     if world > 1 or os.environ.get("CMLPL_FORCE_DIST"):
-        import torch.distributed as dist
         if not os.environ.get("MASTER_ADDR"):
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29513", RANK="0", WORLD_SIZE="1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-        from cmlpl_amd.distributed import DistTrainEngine
+        from cmlpl_amd.distributed import DistStartupError, DistTrainEngine, init_distributed
+        try:     # checked start-up: one device per local rank, rendezvous and first collectives under a watchdog
+            dist = init_distributed(backend, device, timeout_s=float(os.environ.get("CMLPL_DIST_TIMEOUT", "180")),
+                                    one_gpu=one_gpu)
+        except DistStartupError as e:
+            raise SystemExit(f"bench.py: {e}")
         eng = DistTrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088)
     else:
         eng = TrainEngine(NetShape(*shape), bt, btu, hp, device=device, seed=1088)
     eng.init_params_default(1088)
+    if args.check and world > 1:
+        check_against_single_rank(eng, shape, bt, btu, world, rank, device, hp)
     batches = [synth(shape, bt, btu, 1088 + 7919 * rank + i, device) for i in range(4)]
     lib = _lib.load()
 
@@ -328,12 +394,13 @@ def run_rank(args):
         "metric": "HSI patches/sec per training step", "value": patches / dt, "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32 (convolutions: f32 operands as 3 exact bf16 pieces on the bf16 MFMA, f32 accumulate, results "
-                 "as accurate as f32 arithmetic; everything else f32 MFMA / f32 VALU)", "data": "synthetic",
+        "dtype": "f32 (convolutions: f32 operands as 3 exact bf16 pieces on the bf16 MFMA, 6 of 9 piece products, f32 "
+                 "accumulate: max-norm error measured at f32 level against f64, per-product worst case 2^-21; "
+                 "everything else f32 MFMA / f32 VALU)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic PaviaU-shaped patches {shape[1]}x{shape[2]}x{shape[0]}, "
                                f"spectrum {shape[3]}, {shape[4]} classes, {bt} labelled + {btu} unlabelled "
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
-                               f"bank + Adam, epoch 1 (memory-bank smoothing active), Philox noise/dropout",
+                               f"bank + Adam, epoch 1 (memory-bank smoothing active), in-kernel PCG4D noise / Philox dropout",
                    "global_batch": n_local * world, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": labels[dom_name],
                      "achieved": achieved, "peak": kpeak[dom_name], "unit": "TFLOP/s",

@@ -274,7 +274,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st, const AdamFuse* adam = nullptr);
+             int64_t grad_stride, const NetWs& w, hipStream_t st);
 }  // namespace
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
@@ -389,7 +389,7 @@ namespace {
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st, const AdamFuse* adam) {
+             int64_t grad_stride, const NetWs& w, hipStream_t st) {
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
   hipStream_t main_st = st;
@@ -411,8 +411,6 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     h.B = d_sn; h.b_bstride = (long long)n * d.bands; h.ldb = d.bands; h.N = d.bands;
     h.C = d_grads + L.param_off[6]; h.ldc = d.bands;
     h.bias = d_grads + L.param_off[7];
-    g.adam_c_off = L.param_off[8]; g.adam_bias_off = L.param_off[9]; g.adam_wst = 0;
-    h.adam_c_off = L.param_off[6]; h.adam_bias_off = L.param_off[7]; h.adam_wst = 1;
   }
   auto cls_spe_wgrad = [&](hipStream_t st) -> int {
     return TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn2(gw_cls, gw_spe, st)));
@@ -471,16 +469,12 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
   rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride;
-  reduce_table_add(rt, w.part1, wgrad3_G(nets, n, d.H, d.W), PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3],
-                   L.param_off[2], L.param_off[3], 1);
-  reduce_table_add(rt, w.part2, wgrad3_G(nets, n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5],
-                   L.param_off[4], L.param_off[5], 2);
+  reduce_table_add(rt, w.part1, wgrad3_G(nets, n, d.H, d.W), PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
+  reduce_table_add(rt, w.part2, wgrad3_G(nets, n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
   reduce_table_add(rt, w.part0, conv0_partials(d, nets, n), conv0_partial_size(d.C), 0, d.C,
-                   d_grads + L.param_off[0], d_grads + L.param_off[1], L.param_off[0], L.param_off[1], 0);
-  if (fused_head)   // the classifier / feat_spe weight-gradient GEMMs ride along (independent, short); on one GPU the
-                    // Adam update of every element follows in the block that has just formed its gradient
-    return TIMED(CMLPL_K_CONV1_WRED, chk(launch_reduce_gemm(nets, rt, gw_cls, gw_spe, st, adam)));
-  if (adam != nullptr) return CMLPL_E_ARG;   // (the caller asks for the fused update only where this launch exists)
+                   d_grads + L.param_off[0], d_grads + L.param_off[1]);
+  if (fused_head)   // the classifier / feat_spe weight-gradient GEMMs ride along (independent, short)
+    return TIMED(CMLPL_K_CONV1_WRED, chk(launch_reduce_gemm(nets, rt, gw_cls, gw_spe, st)));
   return TIMED(CMLPL_K_CONV1_WRED, chk(launch_partial_reduce(nets, rt, st)));
 }
 
@@ -536,13 +530,10 @@ int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
                   train, seed, step, shard, d_logits, d_feat, nw, st);
 }
 
-}  // extern "C"
-namespace {
-// cmlpl_backward, optionally with the Adam update folded into its last launch (cmlpl_train_step on one GPU)
-int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
-                  const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
-                  uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
-                  void* d_workspace, size_t workspace_bytes, void* stream, const AdamFuse* adam) {
+int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                   const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                   uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
+                   void* d_workspace, size_t workspace_bytes, void* stream) {
   Dims d;
   cmlpl_layout_t L;
   if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
@@ -556,17 +547,7 @@ int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
   const bool copy = need_xn_copy(d, 2 * n);
   return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
                   copy ? sw.xn : nullptr, sw.sn, d_dropmask, hp->dropout_p, train, d_dlogits, d_dfeat, d_grads,
-                  grad_stride, nw, (hipStream_t)stream, adam);
-}
-}  // namespace
-extern "C" {
-
-int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
-                   const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
-                   uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
-                   void* d_workspace, size_t workspace_bytes, void* stream) {
-  return backward_impl(shape, hp, batch, shard, d_params, d_packed, d_dropmask, train, seed, step, d_dlogits, d_dfeat,
-                       d_grads, grad_stride, d_workspace, workspace_bytes, stream, nullptr);
+                  grad_stride, nw, (hipStream_t)stream);
 }
 
 namespace {
@@ -760,19 +741,10 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
                                io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, sw.probs, sw.loss,
                                loss_ws_floats(n, n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream)))
     return rc;
-  // One GPU: nothing sits between a gradient element and its update, so Adam runs in the launch that forms the
-  // final gradients (weight-gradient reduce + classifier / feat_spe GEMMs) where that launch exists.  The gradients
-  // are still written (tests, inspection).  CMLPL_FUSE_ADAM=0: the separate adam_kernel launch.
-  static const bool fuse_off = getenv("CMLPL_FUSE_ADAM") && atoi(getenv("CMLPL_FUSE_ADAM")) == 0;
-  const bool fuse = io->apply_update && !fuse_off && io->adam_t >= 1 && conv3_fused_head_ok(d.H, d.W, d.C, 2 * n, d.K);
-  AdamFuse af;
-  if (fuse)
-    af = make_adam_fuse(io->d_params, L.param_total, io->d_m, io->d_v, io->d_packed, make_pack_info(d, L), io->adam_t,
-                        hp->lr, hp->beta1, hp->beta2, hp->eps);
-  if ((rc = backward_impl(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
-                          io->step, sw.dlogits, sw.dfeat, io->d_grads, L.param_total, io->d_workspace,
-                          io->workspace_bytes, stream, fuse ? &af : nullptr))) return rc;
-  if (io->apply_update && !fuse)
+  if ((rc = cmlpl_backward(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
+                           io->step, sw.dlogits, sw.dfeat, io->d_grads, L.param_total, io->d_workspace,
+                           io->workspace_bytes, stream))) return rc;
+  if (io->apply_update)
     return cmlpl_adam_step(shape, 2, io->d_params, L.param_total, io->d_grads, L.param_total, io->d_m, io->d_v,
                            io->adam_t, hp, io->d_packed, stream);
   return 0;

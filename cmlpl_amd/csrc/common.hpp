@@ -168,16 +168,6 @@ __device__ __forceinline__ void b3_split(float v, uint32_t (&hi16)[3]) {
   hi16[0] = u0 >> 16; hi16[1] = u1 >> 16; hi16[2] = __float_as_uint(r2) >> 16;
 }
 
-// piece `pc` (0..2) of b3_split(v), without an indexed array (a runtime index into a register array goes to scratch)
-__device__ __forceinline__ uint32_t b3_piece(float v, int pc) {
-  const uint32_t u0 = __float_as_uint(v);
-  const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
-  const uint32_t u1 = __float_as_uint(r1);
-  const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-  const uint32_t u = pc == 0 ? u0 : (pc == 1 ? u1 : __float_as_uint(r2));
-  return u >> 16;
-}
-
 // ---- split-bf16 MFMA helpers (conv3x3.hip "fp32 on the bf16 MFMA"; shared with wgrad3x3.hip)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_b16(const uint4& a, const uint4& b, f32x16 c) {
@@ -222,20 +212,10 @@ __device__ __forceinline__ f32x16 mfma_b3(const uint4& A1, const uint4& A2, cons
 }
 
 
-// torch.optim.Adam's element update (train.py:131-132,268,272; optim.hip), shared by adam_kernel and the fused
-// reduce + update launch: w1 = 1 - beta1, w2 = 1 - beta2, step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t)
-__device__ __forceinline__ float adam_elem(float& mm, float& vv, float p, float g, float w1, float b2, float w2,
-                                           float step_size, float bc2_sqrt, float eps) {
-  mm = mm + w1 * (g - mm);                               // exp_avg.lerp_(grad, 1-beta1)
-  vv = vv * b2 + (w2 * g) * g;                           // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
-  const float denom = sqrtf(vv) / bc2_sqrt + eps;
-  return p - step_size * (mm / denom);                   // param.addcdiv_(exp_avg, denom, -step_size)
-}
-
 struct XSrc {
   const float* lab[2]; const float* unl[2];       // per network (the same pointer twice for raw inputs)
   const float* nz_lab[2]; const float* nz_unl[2]; // explicit N(0,1) draws per network, or null
-  float sigma; int nlab, philox, lab0, unl_base;
+  float sigma; int nlab, philox /* 1 = in-kernel draws (PCG4D noise), 0 = explicit noise tensors */, lab0, unl_base;
   uint64_t seed, step;
 };
 __device__ __forceinline__ const float* xsrc_row(const XSrc& x, int net, int s, long long per) {

@@ -188,35 +188,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 // One block = 256 consecutive elements x 4 slices of g: a thread owns 4 consecutive elements (one 16-B load per
 // partial row, a wave reads 1 KiB of a row at a time -- the 4-B-per-lane version read 256-B pieces of rows that lie
 // tens of KB apart and reached 3.1 TB/s), 8 loads in flight, fixed summation order.
-// DEPTH loads in flight per thread: conv0's 256 partials per network are 64 rows per slice -- at 8 in flight that was
-// eight dependent memory round trips for the 66 conv0 blocks while every other block made one or two.
-template <int DEPTH>
-__device__ __forceinline__ void partial_rows_sum(const float* p, int G, int PS, int sl, float4& s0, float4& s1) {
-  for (int g0 = sl; g0 < G; g0 += 4 * DEPTH) {
-    float4 v[DEPTH];
-#pragma unroll
-    for (int q = 0; q < DEPTH; ++q) {
-      const int g = g0 + 4 * q;
-      const float4 x = *(const float4*)(p + (size_t)(g < G ? g : 0) * PS);
-      v[q] = (g < G) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // fixed summation order: pairs, then quads, then the two running sums (independent of DEPTH's grouping of the
-    // rows into batches only through the order below, which is the same for every element)
-#pragma unroll
-    for (int q = 0; q < DEPTH; q += 8) {
-#define CMLPL_ADD4(F) s0.F += (v[q].F + v[q + 1].F) + (v[q + 2].F + v[q + 3].F); s1.F += (v[q + 4].F + v[q + 5].F) + (v[q + 6].F + v[q + 7].F);
-      CMLPL_ADD4(x) CMLPL_ADD4(y) CMLPL_ADD4(z) CMLPL_ADD4(w)
-#undef CMLPL_ADD4
-    }
-  }
-}
-
-__device__ __forceinline__ void partial_reduce_block(const ReduceTable& t, int bx, int net, float (*red)[64],
-                                                     const AdamFuse& adf) {
-  // (fields are read through the reference into the kernel arguments: a pointer that may be null would make the
-  // compiler copy the struct to scratch)
-  const bool fuse = adf.params != nullptr;
-  const AdamFuse* ad = &adf;
+__device__ __forceinline__ void partial_reduce_block(const ReduceTable& t, int bx, int net, float (*red)[64]) {
   int pi = 0;
   if (t.count > 1 && bx >= t.p[1].blk0) pi = 1;
   if (t.count > 2 && bx >= t.p[2].blk0) pi = 2;
@@ -227,136 +199,73 @@ __device__ __forceinline__ void partial_reduce_block(const ReduceTable& t, int b
   const bool ev = e0 < PS;
   const float* p = pr.part + (long long)net * G * PS + (ev ? e0 : 0);
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  if (G > 64) partial_rows_sum<16>(p, G, PS, sl, s0, s1);
-  else        partial_rows_sum<8>(p, G, PS, sl, s0, s1);
+  for (int g0 = sl; g0 < G; g0 += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int g = g0 + 4 * q;
+      const float4 x = *(const float4*)(p + (size_t)(g < G ? g : 0) * PS);
+      v[q] = (g < G) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#define CMLPL_ADD4(F) s0.F += (v[0].F + v[1].F) + (v[2].F + v[3].F); s1.F += (v[4].F + v[5].F) + (v[6].F + v[7].F);
+    CMLPL_ADD4(x) CMLPL_ADD4(y) CMLPL_ADD4(z) CMLPL_ADD4(w)
+#undef CMLPL_ADD4
+  }
   float4* red4 = (float4*)&red[0][0];                  // [4 slices][64] float4 = 4 KB
   red4[sl * 64 + el] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
   __syncthreads();
-  float pn[4] = {0.f, 0.f, 0.f, 0.f};                  // updated parameters of this thread's elements (fused Adam)
-  const int body = PS - 64;
   if (sl == 0 && ev) {
     const float4 a = red4[el], b = red4[64 + el], c = red4[128 + el], d = red4[192 + el];
     const float sum[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
                           (a.w + b.w) + (c.w + d.w)};
+    const int body = PS - 64;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = e0 + j;
-      long long off = -1;                              // element of the flat per-net buffer, or -1 (padding row)
       if (e >= body) {
         pr.db[(long long)net * t.grad_ns + (e - body)] = sum[j];
-        off = pr.b_off + (e - body);
       } else if (pr.mode == 0) {
         const int c2 = e >> 6, co = e & 63;
-        if (c2 < pr.C) { pr.dW[(long long)net * t.grad_ns + co * pr.C + c2] = sum[j]; off = pr.w_off + co * pr.C + c2; }
+        if (c2 < pr.C) pr.dW[(long long)net * t.grad_ns + co * pr.C + c2] = sum[j];
       } else {
         const int s = e >> 12, ci = (e >> 6) & 63, co = e & 63;
         pr.dW[(long long)net * t.grad_ns + co * 576 + ci * 9 + s] = sum[j];
-        off = pr.w_off + co * 576 + ci * 9 + s;
-      }
-      if (fuse && off >= 0) {
-        const long long q = (long long)net * ad->pstride + off;
-        float mm = ad->m[q], vv = ad->v[q];
-        pn[j] = adam_elem(mm, vv, ad->params[q], sum[j], ad->w1, ad->b2, ad->w2, ad->step_size, ad->bc2_sqrt, ad->eps);
-        ad->m[q] = mm; ad->v[q] = vv; ad->params[q] = pn[j];
       }
     }
-  }
-  if (!fuse || ad->packed == nullptr) return;              // (uniform)
-  // ---- packed copies of the 256 weights this block has just updated (what adam_kernel / pack_weights_kernel write):
-  // a block holds 4 consecutive k rows x 64 outputs: (c .. c+3, co) of conv0, (tap, ci .. ci+3, co) of conv1 / conv2
-  if (e0 - 4 * el >= body) return;                        // the bias tail has no packed copy (block-uniform: 64-float tail)
-  __syncthreads();                                        // red4 is dead: it becomes the [4][64] tile of new values
-  float* nw = &red[0][0];
-  if (sl == 0 && ev) { nw[(el >> 4) * 64 + (el & 15) * 4] = pn[0]; nw[(el >> 4) * 64 + (el & 15) * 4 + 1] = pn[1];
-                       nw[(el >> 4) * 64 + (el & 15) * 4 + 2] = pn[2]; nw[(el >> 4) * 64 + (el & 15) * 4 + 3] = pn[3]; }
-  __syncthreads();
-  float* pkn = ad->packed + (long long)net * ad->pi.stride;
-  const int eb = (bx - pr.blk0) * 256;                    // first element of the block
-  if (pr.mode == 0) {
-    const int c0 = eb >> 6;                               // bands c0 .. c0+3 (rows >= C: zero weights, nothing to refresh)
-    // w0T [c][co]: the block's elements in order
-    if (tid < 64) {
-      const int c = c0 + (tid >> 4);
-      if (c < pr.C) *(float4*)(pkn + pack_off_w0t() + (long long)c * 64 + (tid & 15) * 4) = *(const float4*)(nw + tid * 4);
-    }
-    // split-bf16 fragments [k16][piece][n tile][lane][8]: (co, piece) -> bands c0..c0+3 = 4 consecutive bf16 (8 bytes)
-    if (tid < 192 && c0 < pr.C) {
-      const int co = tid & 63, pc = tid >> 6;
-      uint32_t h[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) h[k] = b3_piece((c0 + k < pr.C) ? nw[k * 64 + co] : 0.f, pc);
-      uint16_t* wb = (uint16_t*)(pkn + pack_off_w0b3(ad->pi.C, ad->pi.bands));
-      *(uint2*)(wb + conv_b3_index(0, c0, co, pc)) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    }
-    return;
-  }
-  const int tap = eb >> 12, ci0 = (eb >> 6) & 63;         // (tap, ci0 .. ci0+3, all co)
-  const int which = (pr.which == 1) ? 0 : 2;             // conv1: sets 0 / 1, conv2: sets 2 / 3
-  // forward set (k = ci, n = co): (co, piece) -> ci0..ci0+3 = 4 consecutive bf16
-  if (tid < 192) {
-    const int co = tid & 63, pc = tid >> 6;
-    uint32_t h[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) h[k] = b3_piece(nw[k * 64 + co], pc);
-    uint16_t* bf = (uint16_t*)(pkn + pack_off_b3(ad->pi.C, ad->pi.bands, which));
-    *(uint2*)(bf + conv_b3_index(tap, ci0, co, pc)) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-  }
-  // data-gradient set (k = co, n = ci, tap flipped): (ci, 8 co, piece) -> 8 consecutive bf16 (16 bytes)
-  if (tid < 96) {
-    const int pc = tid % 3, g8 = (tid / 3) & 7, k = tid / 24;
-    uint32_t h[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = b3_piece(nw[k * 64 + g8 * 8 + j], pc);
-    uint16_t* bd = (uint16_t*)(pkn + pack_off_b3(ad->pi.C, ad->pi.bands, which + 1));
-    *(uint4*)(bd + conv_b3_index(8 - tap, g8 * 8, ci0 + k, pc)) =
-        make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-  }
-  // conv2 also as fp32 B fragments of the 16x16x4 MFMA (forward tail of the fused kernel): (ci, 4 co) -> 16 bytes
-  if (which == 2 && tid >= 192) {
-    const int t2 = tid - 192, k = t2 >> 4, c4 = t2 & 15;
-    *(float4*)(pkn + pack_off_frag() + conv2_frag_index(tap, c4 * 4, ci0 + k)) = *(const float4*)(nw + k * 64 + c4 * 4);
   }
 }
 
-__global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t, AdamFuse ad) {
+__global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceTable t) {
   __shared__ __attribute__((aligned(16))) float red[16][64];
-  partial_reduce_block(t, (int)blockIdx.x, (int)blockIdx.y, red, ad);
+  partial_reduce_block(t, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
 // The weight-gradient reduce and the two small weight-gradient GEMMs (classifier, feat_spe) are independent and
 // both short: one launch, reduce blocks first, GEMM tiles after them.
-__global__ __launch_bounds__(256) void reduce_gemm_kernel(ReduceTable t, int reduce_blocks, GemmTN2 g, AdamFuse ad) {
+__global__ __launch_bounds__(256) void reduce_gemm_kernel(ReduceTable t, int reduce_blocks, GemmTN2 g) {
   __shared__ GemmTNShared sh;
   const int bid = (int)blockIdx.x;
-  if (bid < reduce_blocks) partial_reduce_block(t, bid % t.total_blocks, bid / t.total_blocks, (float (*)[64])&sh.red[0][0][0], ad);   // 4 KB of the 12 KB
-  else gemm_tn_block(g, bid - reduce_blocks, sh, ad);
+  if (bid < reduce_blocks) partial_reduce_block(t, bid % t.total_blocks, bid / t.total_blocks, (float (*)[64])&sh.red[0][0][0]);   // 4 KB of the 12 KB
+  else gemm_tn_block(g, bid - reduce_blocks, sh);
 }
 
-hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, const GemmTN& g1, hipStream_t st,
-                              const AdamFuse* adam) {
+hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, const GemmTN& g1, hipStream_t st) {
   GemmTN2 g;
   g.p[0] = g0; g.p[1] = g1; g.nblk0 = gemm_tn_blocks(g0);
   const int rb = t.total_blocks * nets, gb = g.nblk0 + gemm_tn_blocks(g1);
-  AdamFuse ad = AdamFuse();
-  ad.params = nullptr;
-  if (adam != nullptr) ad = *adam;
-  hipLaunchKernelGGL(reduce_gemm_kernel, dim3(rb + gb), dim3(256), 0, st, t, rb, g, ad);
+  hipLaunchKernelGGL(reduce_gemm_kernel, dim3(rb + gb), dim3(256), 0, st, t, rb, g);
   return hipGetLastError();
 }
 
-void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db,
-                      long long w_off, long long b_off, int which) {
+void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db) {
   ReduceProb& p = t.p[t.count++];
   p.part = part; p.dW = dW; p.db = db; p.G = G; p.PS = PS; p.mode = mode; p.C = C; p.blk0 = t.total_blocks;
-  p.w_off = w_off; p.b_off = b_off; p.which = which;
   p.el = 256;
   t.total_blocks += (PS + 255) / 256;
 }
 
 hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st) {
-  AdamFuse none = AdamFuse();
-  none.params = nullptr;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3(t.total_blocks, nets), dim3(256), 0, st, t, none);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(t.total_blocks, nets), dim3(256), 0, st, t);
   return hipGetLastError();
 }
 

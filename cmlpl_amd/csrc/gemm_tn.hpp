@@ -15,11 +15,7 @@ constexpr int GT_DEPTH = 16;
 struct GemmTN2 { GemmTN p[2]; int nblk0; };
 struct GemmTNShared { __attribute__((aligned(16))) float red[3][16][64]; float ared[4][64]; };
 
-// `ad` (reduce_gemm_kernel, one GPU): the tile's outputs are final weight-gradient elements; their Adam update and
-// the refresh of the packed copy follow right here (see AdamFuse, kernels.hpp).
-__device__ __forceinline__ void gemm_tn_block_impl(const GemmTN2& t, int bid, GemmTNShared& sh, const AdamFuse& adf, bool fuse_ok) {
-  const bool fuse = fuse_ok && adf.params != nullptr;
-  const AdamFuse* ad = &adf;
+__device__ __forceinline__ void gemm_tn_block(const GemmTN2& t, int bid, GemmTNShared& sh) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // linear block id -> (problem, nt, mt, batch)
@@ -81,43 +77,15 @@ __device__ __forceinline__ void gemm_tn_block_impl(const GemmTN2& t, int bid, Ge
         float v = (((acc[r] + sh.red[0][r][lane]) + sh.red[1][r][lane]) + sh.red[2][r][lane]) * g.scale;
         if (g.bias_in != nullptr) v += g.bias_in[(long long)bz * g.bias_in_bstride + j];
         if (g.relu) v = relu_nan(v);
-        if (row < g.M) {
-          C[(long long)row * g.ldc + j] = v;
-          if (fuse && g.adam_c_off >= 0) {
-            const long long e = (long long)bz * ad->pstride + g.adam_c_off + (long long)row * g.ldc + j;
-            float mm = ad->m[e], vv = ad->v[e];
-            const float pn = adam_elem(mm, vv, ad->params[e], v, ad->w1, ad->b2, ad->w2, ad->step_size, ad->bc2_sqrt, ad->eps);
-            ad->m[e] = mm; ad->v[e] = vv; ad->params[e] = pn;
-            if (g.adam_wst && ad->packed != nullptr)      // feat_spe.weight[o = row][band = j] -> wsT[band][o]
-              ad->packed[(long long)bz * ad->pi.stride + pack_off_wst(ad->pi.C) + (long long)j * 1024 + row] = pn;
-          }
-        }
+        if (row < g.M) C[(long long)row * g.ldc + j] = v;
       }
     }
     if (g.bias != nullptr && nt == 0) {
       float tot = (sh.ared[0][lane] + sh.ared[1][lane]) + (sh.ared[2][lane] + sh.ared[3][lane]);
       tot += __shfl_xor(tot, 32, 64);
-      if (hh == 0 && iv) {
-        const float gb = tot * g.scale;
-        g.bias[(long long)bz * g.bias_bstride + i] = gb;
-        if (fuse && g.adam_bias_off >= 0) {
-          const long long e = (long long)bz * ad->pstride + g.adam_bias_off + i;
-          float mm = ad->m[e], vv = ad->v[e];
-          const float pn = adam_elem(mm, vv, ad->params[e], gb, ad->w1, ad->b2, ad->w2, ad->step_size, ad->bc2_sqrt, ad->eps);
-          ad->m[e] = mm; ad->v[e] = vv; ad->params[e] = pn;
-        }
-      }
+      if (hh == 0 && iv) g.bias[(long long)bz * g.bias_bstride + i] = tot * g.scale;
     }
   }
-}
-
-__device__ __forceinline__ void gemm_tn_block(const GemmTN2& t, int bid, GemmTNShared& sh) {
-  AdamFuse none;
-  none.params = nullptr;
-  gemm_tn_block_impl(t, bid, sh, none, false);
-}
-__device__ __forceinline__ void gemm_tn_block(const GemmTN2& t, int bid, GemmTNShared& sh, const AdamFuse& ad) {
-  gemm_tn_block_impl(t, bid, sh, ad, true);
 }
 
 inline int gemm_tn_blocks(const GemmTN& g) { return ((g.M + 31) / 32) * ((g.N + 31) / 32) * g.batches; }

@@ -123,25 +123,12 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
                             const float* b, long long pstride, float* a0, hipStream_t st);
 int plan_conv0_wgrad_G(int n, int C, int HW);
 // deterministic sum of per-workgroup weight-gradient partials, up to 3 tensors in one launch
-struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C, blk0, el;
-                    long long w_off, b_off; int which; };   // offsets of the tensors in the flat buffer; which: 0 conv0, 1 conv1, 2 conv2
-// Adam folded into the launch that produces the final gradient elements (one GPU: nothing sits between the gradient
-// and the update).  Every block updates exactly the elements whose gradient it has just formed -- no block waits for
-// another -- and refreshes their packed copies (kernels.hpp: PACK_*), as adam_kernel does.
-struct AdamFuse {
-  float* params; float* m; float* v; float* packed;     // null params: no update (plain reduce / GEMM)
-  long long pstride; PackInfo pi;
-  float w1, b2, w2, step_size, bc2_sqrt, eps;
-};
-AdamFuse make_adam_fuse(float* params, long long pstride, float* m, float* v, float* packed, const PackInfo& pi,
-                        long long t, float lr, float b1, float b2, float eps);
+struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C, blk0, el; };
 struct ReduceTable { ReduceProb p[3]; int count, total_blocks; long long grad_ns; };
-void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db,
-                      long long w_off = 0, long long b_off = 0, int which = 0);
+void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db);
 hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st);
 struct GemmTN;
-hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, const GemmTN& g1, hipStream_t st,
-                              const AdamFuse* adam = nullptr);
+hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, const GemmTN& g1, hipStream_t st);
 int conv0_partial_size(int C);
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
                               hipStream_t st);
@@ -161,9 +148,6 @@ struct GemmTN {
   int lda, ldb, ldc, M, N, R, batches;
   float scale;
   int b_seg_rows = 0; long long b_seg_stride = 0;   // > 0: row r of B lives at (r / seg_rows) * seg_stride + (r % seg_rows) * ldb
-  // fused Adam (reduce_gemm_kernel only): offsets of C[0][0] / bias[0] in the flat parameter buffer, -1 = none;
-  // adam_wst: C is the feat_spe weight gradient [1024][bands], whose k-major packed copy wsT is refreshed too
-  long long adam_c_off = -1, adam_bias_off = -1; int adam_wst = 0;
 };
 hipError_t launch_gemm_tn(const GemmTN& g, hipStream_t st);
 hipError_t launch_gemm_tn2(const GemmTN& g0, const GemmTN& g1, hipStream_t st);   // two problems, one launch
@@ -248,6 +232,7 @@ struct MbLoss {
   float* prototype;                                            // out [K][Q][D] when momentum is given
   float temp;
   float* lossq; float* ganchor; int* arow; float* drep; float* total;
+  int keys_lds = 0;                                            // set by the launcher: the gathered keys stay in LDS
 };
 
 hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st);

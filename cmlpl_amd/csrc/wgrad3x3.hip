@@ -612,6 +612,10 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   for (int s = 0; s < 3; ++s) acc[s] = zero16();
   __syncthreads();                 // zero fill complete
   if (ubeg < uend) { fetch(ubeg); commit(lds); }
+  // (Measured, round 3: with all eight waves in lockstep a stage costs MFMAs 1.06 us + split / plane writes 0.85 us +
+  // global-load issue and wait 0.55 us, nothing overlapped -- and letting waves 4..7 do their staging BEFORE their
+  // MFMAs, with their loads one stage further ahead, made the launch 3 us slower: every wave's own chain is still
+  // MFMAs + staging, the order does not shorten it.)
   __syncthreads();
   STAMP(2, 1);
   // this lane's part of a transposed read: 16-lane group gq = lane >> 4 covers k half (gq >> 1) and channel block

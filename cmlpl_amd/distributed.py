@@ -34,22 +34,155 @@ from .config import FEAT_DIM, HyperParams, NetShape
 from .engine import SCALAR_NAMES, TrainEngine, _chk_f32
 
 
-class TorchDistComm:
-    """torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU)."""
+class DistStartupError(RuntimeError):
+    """the job's ranks cannot run as one process per GPU (raised before the first training step)"""
 
-    def __init__(self, group=None):
+
+def _fail_after(seconds: float, what: str):
+    """Watchdog for a start-up phase that may hang (rendezvous, RCCL communicator creation, first collective): if the
+    returned timer is not cancelled in time, say what was being waited for and end THIS process with code 3 -- a hung
+    rank would otherwise hang the whole job (the launcher stops the others when one exits non-zero)."""
+    import os
+    import sys
+    import threading
+
+    def boom():
+        sys.stderr.write(f"cmlpl_amd.distributed: rank {os.environ.get('RANK', '?')} gave up after {seconds:.0f} s "
+                         f"waiting for {what}\n")
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(seconds, boom)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def init_distributed(backend: str = "nccl", device: Optional[torch.device] = None, timeout_s: float = 180.0,
+                     one_gpu: bool = False):
+    """Create the process group of a one-process-per-GPU job and CHECK it before anything else runs on it.
+
+    Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run or cmlpl_amd.launch set them).  Raises
+    DistStartupError -- with a message that says what to fix -- when the node cannot give every local rank its own
+    GPU, or when the first collectives return wrong data; exits with code 3 (message on stderr) when rendezvous or the
+    first collective does not finish within `timeout_s`, instead of hanging.  Checks, in order:
+      1. backend "nccl" (= RCCL on ROCm): LOCAL_WORLD_SIZE visible devices at least, LOCAL_RANK < device count;
+      2. init_process_group under the watchdog (RCCL: bound to `device`, its timeout set to `timeout_s`);
+      3. an all-gather of (rank, device index, PCI bus id) -- every local rank must sit on a DIFFERENT device
+         (RCCL refuses two ranks on one GPU late and cryptically) -- and an all-reduce of rank + 1 whose sum must be
+         W (W + 1) / 2 on every rank.
+    `one_gpu`: rehearsal of the multi-process path on a one-GPU box (gloo over device buffers): check 1 / the
+    distinct-device part of 3 are skipped.  Returns torch.distributed."""
+    import datetime
+    import os
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if backend == "nccl" and not one_gpu:
+        ndev = torch.cuda.device_count()
+        if ndev < local_world or local_rank >= ndev:
+            raise DistStartupError(
+                f"rank {rank}: {local_world} ranks on this node but {ndev} visible GPU(s) (LOCAL_RANK {local_rank}): "
+                "one process per GPU needs one device per local rank -- check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES "
+                "and --nproc-per-node")
+    guard = _fail_after(timeout_s, "the process-group rendezvous (MASTER_ADDR/MASTER_PORT reachable? all ranks started?)")
+    try:
+        kw = dict(timeout=datetime.timedelta(seconds=timeout_s))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, **kw)
+        else:
+            dist.init_process_group(backend, **kw)
+    finally:
+        guard.cancel()
+    guard = _fail_after(timeout_s, f"the first {backend} collective (RCCL: HSA_ENABLE_IPC_MODE_LEGACY=0 set? xGMI peers visible?)")
+    try:
+        on = device if (backend == "nccl" and device is not None) else torch.device("cpu")
+        idx = -1 if device is None or device.index is None else int(device.index)
+        bus = 0
+        if device is not None and device.type == "cuda":
+            try:
+                bus = int(torch.cuda.get_device_properties(device).pci_bus_id)
+            except Exception:
+                bus = idx
+        mine = torch.tensor([rank, idx, bus, local_rank], dtype=torch.int64, device=on)
+        allr = torch.zeros(world * 4, dtype=torch.int64, device=on)
+        dist.all_gather_into_tensor(allr, mine)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=on)
+        dist.all_reduce(t)
+        if on.type == "cuda":
+            torch.cuda.synchronize(on)
+        rows = allr.view(world, 4).cpu().tolist()
+    finally:
+        guard.cancel()
+    if [r[0] for r in rows] != list(range(world)):
+        raise DistStartupError(f"rank {rank}: all-gather returned ranks {[r[0] for r in rows]}")
+    if abs(float(t.item()) - world * (world + 1) / 2) > 1e-9:
+        raise DistStartupError(f"rank {rank}: all-reduce of rank+1 gave {float(t.item())}, expected {world * (world + 1) / 2}")
+    if backend == "nccl" and not one_gpu and world == local_world:
+        seen = {}
+        for r, dev_i, bus_i, lr in rows:
+            key = (dev_i, bus_i)
+            if key in seen:
+                raise DistStartupError(f"ranks {seen[key]} and {r} share GPU {dev_i} (PCI bus {bus_i}): give every "
+                                       "local rank its own device (device = cuda:LOCAL_RANK)")
+            seen[key] = r
+    return dist
+
+
+class TorchDistComm:
+    """torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU).
+
+    Stream hand-off.  The HIP kernels of a stage are launched on torch's CURRENT stream of the engine's device.  A
+    torch.distributed collective called with async_op=False on a CUDA tensor is enqueued on ProcessGroupNCCL's own
+    stream behind an event recorded on the current stream, and the current stream is made to wait for the collective's
+    end event before the call returns: producer kernels -> collective -> consumer kernels are ordered on the device
+    without a host synchronisation.  `debug=True` (CMLPL_DIST_DEBUG=1) asserts it after every collective: the data
+    that must have arrived is checked on the host (own block of an all-gather bit-equal to the input; float64 sums
+    before / after a reduce-scatter and an all-reduce agree across ranks) -- slow, for bring-up on a new node."""
+
+    def __init__(self, group=None, debug: Optional[bool] = None):
+        import os
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.debug = bool(int(os.environ.get("CMLPL_DIST_DEBUG", "0"))) if debug is None else bool(debug)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         self.dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
+        if self.debug:
+            n = inp.numel()
+            got = out.view(-1)[self.rank * n:(self.rank + 1) * n]
+            if not torch.equal(got.cpu(), inp.view(-1).cpu()):
+                raise RuntimeError(f"rank {self.rank}: all_gather did not deliver this rank's own block (stream order?)")
+
+    def _check(self, name, before, after):
+        """debug: [sum, sum of |.|] over all ranks before and after a reduction must agree to fp32 summation error"""
+        self.dist.all_reduce(before, group=self.group)
+        self.dist.all_reduce(after, group=self.group)
+        b, a = before.tolist(), after.tolist()
+        if not abs(a[0] - b[0]) <= 1e-5 * b[1] + 1e-6:
+            raise RuntimeError(f"rank {self.rank}: {name} checksum {a[0]} != {b[0]} (stream order?)")
+
+    @staticmethod
+    def _sums(t):
+        d = t.detach().double()
+        return torch.stack([d.sum(), d.abs().sum()])
 
     def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor):
+        before = self._sums(inp) if self.debug else None
         self.dist.reduce_scatter_tensor(out.view(-1), inp.view(-1), op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.debug:      # sum over ranks of the inputs == sum over ranks of the scattered outputs
+            after = self._sums(out)
+            after[1] = before[1]
+            self._check("reduce_scatter", before, after)
 
     def all_reduce(self, t: torch.Tensor):
+        before = self._sums(t) if self.debug else None
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.debug:      # every rank now holds the sum: W x (sum over ranks of the inputs) after the second reduction
+            after = self._sums(t) / self.world
+            after[1] = before[1]
+            self._check("all_reduce", before, after)
 
 
 class SingleComm:

@@ -150,8 +150,8 @@ class TrainEngine:
         """One training step; asynchronous.  Results land in ``self.scalars`` (device),
         ``self.logits`` / ``self.feat`` ([2][n][..]) and ``self.grads``.
 
-        noise    : None -> in-kernel Philox; or the 8 draws in reference order (parity mode)
-        dropmask : None -> Philox (or no dropout when hp.dropout == 0); or [2][n][cls_in] multipliers
+        noise    : None -> in-kernel draws (PCG4D hash + Box-Muller); or the 8 draws in reference order (parity mode)
+        dropmask : None -> Philox4x32-10 mask (or no dropout when hp.dropout == 0); or [2][n][cls_in] multipliers
         """
         s = self.shape
         bt, btu = XPl.shape[0], XPu.shape[0]

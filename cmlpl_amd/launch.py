@@ -32,15 +32,36 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
+    # dmabuf IPC: the host driver of this pool supports no other kind, and without it RCCL (and any CUDA-tensor sharing
+    # across processes) fails with `hipIpcGetMemHandle: invalid argument`.  Only a default: an operator's own setting wins.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env
 
 
+DEFAULT_TIMEOUT_S = 3600.0      # a rank stuck in a collective must not hang the parent for ever
+RENDEZVOUS_RETRY_S = 20.0       # a job that dies this early is taken to have lost its port to another process
+
+
 def spawn_ranks(world: int, argv: Sequence[str], extra_env: Optional[Dict[str, str]] = None,
-                timeout: Optional[float] = None, poll_s: float = 0.05) -> Tuple[int, str]:
+                timeout: Optional[float] = DEFAULT_TIMEOUT_S, poll_s: float = 0.05, retries: int = 1) -> Tuple[int, str]:
     """Run ``argv`` as ``world`` ranks; returns (exit code, rank 0's stdout).  Ranks > 0 write their stdout to
     this process's stderr; every rank's stderr is inherited.  Exit code = first non-zero child code, else 0;
-    124 on timeout."""
+    124 on timeout (the children are stopped).  The rendezvous port is picked by bind-and-release, so another
+    process can take it before rank 0 binds it: a job that fails within RENDEZVOUS_RETRY_S seconds is started once
+    more, as fresh children on a new port (``retries``)."""
+    t_first = time.monotonic()
+    rc, out = _spawn_once(world, argv, extra_env, timeout, poll_s)
+    while rc not in (0, 124) and retries > 0 and world > 1 and time.monotonic() - t_first < RENDEZVOUS_RETRY_S:
+        retries -= 1
+        sys.stderr.write(f"cmlpl_amd.launch: job failed {time.monotonic() - t_first:.1f} s after start (rc {rc}); "
+                         "starting it once more on a new rendezvous port\n")
+        t_first = time.monotonic() - RENDEZVOUS_RETRY_S      # at most one quick retry
+        rc, out = _spawn_once(world, argv, extra_env, timeout, poll_s)
+    return rc, out
+
+
+def _spawn_once(world: int, argv: Sequence[str], extra_env: Optional[Dict[str, str]],
+                timeout: Optional[float], poll_s: float) -> Tuple[int, str]:
     if world < 1:
         raise ValueError("world must be >= 1")
     port = free_port()

@@ -11,7 +11,11 @@
  *   - every call takes a hipStream_t as `void* stream`, is asynchronous and re-entrant
  *     across streams (no implicit synchronisation, graph-capturable);
  *   - return 0 = ok, negative = argument error (CMLPL_E_*), positive = hipError_t;
- *   - all arithmetic is fp32; labels are int64 (torch.long).
+ *   - every tensor is fp32 and every result is fp32-grade; labels are int64 (torch.long).  The 3x3 / 1x1 convolutions
+ *     (forward, data and weight gradients) form each fp32 product from three exact bf16 pieces per operand, six of
+ *     the nine piece products (the dropped ones are below 2^-21 |a b| in the worst case, 0.7 * 2^-24 on average),
+ *     fp32 accumulation: measured against fp64 at the level of an fp32 fma chain.  An infinite
+ *     operand of such a product becomes NaN (a finite fp32 path would keep the infinity); NaN stays NaN.
  *   - the library expects ONE calling thread per process at a time (one process per GPU is the deployment
  *     model); the lazily-set kernel attributes are tracked per device, so engines on several devices of one
  *     process work, but cmlpl_timing_begin/_end state is process-global and not thread-safe.
@@ -94,7 +98,7 @@ int cmlpl_pack_weights(const cmlpl_shape* shape, int nets, const float* d_params
 
 /* Row shard of a data-parallel step: the global batch has bt_g labelled and
  * btu_g unlabelled rows; this rank owns labelled rows [lab0, lab0+nlab) and unlabelled rows
- * [unl0, unl0+nunl).  One GPU: {bt, btu, 0, bt, 0, btu} (or NULL where allowed).  In-kernel Philox
+ * [unl0, unl0+nunl).  One GPU: {bt, btu, 0, bt, 0, btu} (or NULL where allowed).  In-kernel random
  * streams are keyed by the GLOBAL sample index, so noise/dropout do not depend on the sharding. */
 typedef struct cmlpl_shard {
   int32_t bt_g, btu_g;
@@ -104,7 +108,7 @@ typedef struct cmlpl_shard {
 
 /* Input augmentation + batch concat: train.py:157-158,163-164,170-171,173-174,181-184.
  *   xn[net] = cat(XPl, XPu) + sigma * N(0,1),  sn[net] = cat(Xl, Xu) + sigma * N(0,1)
- * d_noise: NULL (in-kernel Philox, keyed by seed/step) or 8 device pointers in the
+ * d_noise: NULL (in-kernel counter-based draws -- PCG4D hash + Box-Muller, keyed by seed/step/stream/global sample) or 8 device pointers in the
  * reference's draw order [XPl/0, Xl/0, XPl/1, Xl/1, XPu/0, Xu/0, XPu/1, Xu/1].
  * With bt == 0 or sigma == 0 it is a plain (concatenating) copy. */
 int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu,
@@ -142,7 +146,7 @@ int cmlpl_basenet2_bwd(const cmlpl_shape* shape, int nets, int n,
 
 /* One training batch as the reference holds it (train.py:155-171): labelled and unlabelled rows in their own
  * buffers (the concat of train.py:173-174,183-184 is an index computation in the kernels, not a copy) and the
- * augmentation noise either drawn in-kernel (Philox, noise8 == NULL) or given as the 8 tensors of the
+ * augmentation noise either drawn in-kernel (PCG4D hash + Box-Muller, noise8 == NULL) or given as the 8 tensors of the
  * reference's draw order (see cmlpl_augment). */
 typedef struct cmlpl_batch {
   const float* d_xpl; const float* d_xl;   /* [bt][C][H][W], [bt][bands]   */
@@ -255,8 +259,8 @@ int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t
 typedef struct cmlpl_step_io {
   const float* d_xpl; const float* d_xl; const int64_t* d_labels;  /* labelled batch  */
   const float* d_xpu; const float* d_xu;                           /* unlabelled batch */
-  const float* const* noise8;   /* NULL = Philox                                        */
-  const float* d_dropmask;      /* NULL = Philox; else [2][n][cls_in]                   */
+  const float* const* noise8;   /* NULL = in-kernel draws (PCG4D hash + Box-Muller)     */
+  const float* d_dropmask;      /* NULL = Philox4x32-10 mask; else [2][n][cls_in]       */
   float* d_params; float* d_m; float* d_v; float* d_grads; float* d_packed;  /* [2][param_total] (packed: [2][packed_total]) */
   cmlpl_banks banks;
   float* d_scalars;             /* [16] as in cmlpl_loss_fwd_bwd                        */
@@ -265,7 +269,7 @@ typedef struct cmlpl_step_io {
   int32_t bt, btu;
   int32_t smooth; float adap_mask;
   int64_t adam_t;               /* 1-based                                               */
-  uint64_t seed, step;          /* Philox key / counter                                  */
+  uint64_t seed, step;          /* key / counter of the in-kernel random streams         */
   int32_t apply_update;         /* 0 = stop after the gradients                          */
   int32_t reserved;
 } cmlpl_step_io;

@@ -226,8 +226,24 @@ def round2(only=None):
             f()
 
 
+def round3(only=None):
+    """Fixtures added in round 3 (earlier files are left byte-identical)."""
+    B4 = O.NetShape(200, 11, 11, 200, 16)
+    cases = dict(
+        # BASELINE configs[3] at its stated batch (Indian-Pines-shaped 11x11x200, 16 classes, 128 + 128 rows): the
+        # shape that takes the chunked slab (two passes of the fused conv0 stages)
+        b4_b256=lambda: run_case("b4_b256", B4, 128, 128, steps=3, seed=41, epoch0=1, full_steps=(0, 2)),
+    )
+    for k, f in cases.items():
+        if only is None or k in only:
+            f()
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--round2":
         round2(sys.argv[2:] or None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "--round3":
+        round3(sys.argv[2:] or None)
     else:
         main()
+        round3()

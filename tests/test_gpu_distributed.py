@@ -129,6 +129,59 @@ def test_sharded_step_equals_single_gpu_step(W, shape_name, bt, btu, explicit):
                 e.bank_feats[i].copy_(ref.bank_feats[i]); e.bank_probs[i].copy_(ref.bank_probs[i])
 
 
+def test_sharded_trajectory_left_alone_stays_within_the_drift_bound():
+    """Eight steps, W = 2, WITHOUT putting the sharded engines back on the single-GPU engine's state: the two runs are
+    the same arithmetic up to the order in which fp32 gradient sums are formed (rank-local partial sums + all-reduce
+    against one sum), and Adam turns a last-bit difference of a near-zero gradient into an O(lr) parameter difference
+    (update ~ lr * sign(g)).  Stated bounds for this configuration (B2, 32 + 32 rows, explicit noise / dropout, lr 5e-4):
+      every parameter within 2 * lr * steps of the single-GPU run (the worst case of the sign argument),
+      at most 2 % of the elements of any tensor beyond 1e-4 + 1e-3 |w|,
+      the logged scalars within 1e-2 relative at every step,
+      the threshold / graph counts equal at step 0 (later steps may move a borderline sample);
+    the measured drift is printed per step."""
+    from cmlpl_amd import TrainEngine
+    from cmlpl_amd.distributed import DistTrainEngine
+    W, bt, btu, steps = 2, 32, 32, 8
+    shape = O.NetShape(103, 11, 11, 103, 9)
+    hp = O.HyperParams()
+    p0, p1 = O.closed_form_params(shape, 31), O.closed_form_params(shape, 32)
+    ref = TrainEngine(to_shape(shape), bt, btu, to_hp(hp), device=DEV, seed=99)
+    engines = [DistTrainEngine(to_shape(shape), bt // W, btu // W, to_hp(hp), device=DEV, seed=99, comm=FakeComm(W, r))
+               for r in range(W)]
+    for e in [ref] + engines:
+        e.load_state_dict(0, p0); e.load_state_dict(1, p1)
+    worst = 0.0
+    for s in range(steps):
+        b = O.synthetic_batch(shape, bt, btu, 1900 + s, separable=1.0 if s >= 2 else 0.0)
+        cb = cuda_batch(b)
+        ref.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], 1, s, noise=cb["noise"], dropmask=cb["dropmask"])
+        lockstep_step(engines, shard_inputs(cb, W, bt, btu, shape.cls_in, True), 1, s)
+        torch.cuda.synchronize()
+        want = ref.read_scalars()
+        got = dict(zip(want.keys(), sum(e.scalars for e in engines).tolist()))
+        rel = max(abs(got[k] - want[k]) / (abs(want[k]) + 1e-6) for k in ("ctr_s", "total_s", "cls_s", "total_w", "cls_w"))
+        pmax, frac = 0.0, 0.0
+        for net in range(2):
+            for k in O.LIVE_KEYS:
+                a, r_ = engines[0].view(engines[0].params, net, k), ref.view(ref.params, net, k)
+                d = (a - r_).abs()
+                pmax = max(pmax, float(d.max()))
+                frac = max(frac, float((d > 1e-4 + 1e-3 * r_.abs()).float().mean()))
+        print(f"step {s}: scalar drift {rel:.2e}  max |param diff| {pmax:.2e} (bound {2 * hp.lr * (s + 1):.1e})  "
+              f"worst tensor fraction outside 1e-4 + 1e-3|w|: {frac:.4f}")
+        worst = max(worst, rel)
+        assert rel <= 1e-2, (s, rel)
+        assert pmax <= 2 * hp.lr * (s + 1) + 1e-6, (s, pmax)
+        assert frac <= 0.02, (s, frac)
+        if s == 0:
+            assert [got[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")] == \
+                   [want[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")]
+        assert engines[0].ptr == ref.ptr
+        for e in engines[1:]:
+            assert torch.equal(e.params, engines[0].params)          # replicas never diverge from each other
+    print(f"worst scalar drift over {steps} steps without re-synchronisation: {worst:.2e}")
+
+
 def _global_gates(engines, shape, bt_l, btu_l):
     """ReLU decisions of all ranks in GLOBAL row order [labelled of all ranks ; unlabelled of all ranks]."""
     from tests.gpu_util import hip_relu_gates

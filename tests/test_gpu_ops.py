@@ -111,6 +111,69 @@ def test_split_bf16_convolutions_keep_fp32_accuracy(name, n):
     assert max(errs.values()) < 2e-6, errs
 
 
+@pytest.mark.parametrize("mixed", [False, True], ids=["unit-scale", "mixed-1e-6..1e3"])
+def test_split_bf16_conv1_error_bound_per_element(mixed):
+    """Per-ELEMENT accuracy of the split-bf16 3x3 convolution (forward, and the weight gradient), not just against the
+    tensor's maximum.  conv1's output and weight gradient are re-computed in fp64 FROM THE DEVICE'S OWN operands (the
+    saved a0, the saved pooled gradient and ReLU masks), so the only difference is conv1's arithmetic.  The bound is
+    the one an fp32 dot product obeys, |err_i| <= c * S_i with S_i = sum_k |a_k| |w_k| (+ |bias| + |residual|) the
+    absolute-value convolution of that element -- a bound relative to the element's own terms, with no floor borrowed
+    from larger elements.  A split product drops at most 2^-21 |a w| and the fp32 accumulation
+    adds its rounding; stated bounds: forward (K = 576 terms) c = 2^-18, weight gradient (K = n * 121 terms) c = 2^-16;
+    the measured maxima are printed.  `mixed`: the 64 channels of a0 span 1e-6 .. 1e3 (conv0 scaled per channel, conv1's
+    input channels scaled inversely): operands of very different magnitude meet in every sum, outputs of different
+    channels differ by nine orders of magnitude, and every element still has to meet its own bound."""
+    import torch.nn.functional as F
+    shape, n = SHAPES["B2"], 32
+    params = O.closed_form_params(shape, 9)
+    if mixed:
+        g0 = torch.Generator().manual_seed(5)
+        sc = 10.0 ** (torch.rand(64, generator=g0) * 9.0 - 6.0)
+        params["conv0.weight"] = params["conv0.weight"] * sc.view(64, 1, 1, 1)
+        params["conv0.bias"] = params["conv0.bias"] * sc
+        params["conv1.weight"] = params["conv1.weight"] / sc.view(1, 64, 1, 1)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, shape.C, shape.H, shape.W, generator=g)
+    y = torch.randn(n, shape.bands, generator=g)
+    dlog = torch.randn(n, shape.K, generator=g)
+    net = _module(shape, params, dropout=0.0)
+    net.train()
+    lo, fe = net(x.to(DEV), y.to(DEV))
+    reg = ModuleRegions(net, lo, n)
+    (lo * dlog.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    H, W, H2, W2 = shape.H, shape.W, shape.H // 2, shape.W // 2
+    a0 = reg.debug_region("a0").view(1, n, H * W, 64)[0].cpu().double().permute(0, 2, 1).reshape(n, 64, H, W)
+    p1 = reg.debug_region("p1").view(1, n, H2 * W2, 64)[0].cpu().double().permute(0, 2, 1).reshape(n, 64, H2, W2)
+    dp1 = reg.debug_region("dp1").view(1, n, H2 * W2, 64)[0].cpu().double().permute(0, 2, 1).reshape(n, 64, H2, W2)
+    gate = hip_relu_gates(reg, shape, n)[0]["z1"]                                   # [n, 64, H, W] bool
+    w1, b1 = params["conv1.weight"].double(), params["conv1.bias"].double()
+    # ---- forward: p1 = avgpool2(relu(conv1(a0) + b1 + a0)), the device's ReLU decisions
+    z1 = F.conv2d(a0, w1, b1, padding=1) + a0
+    s1 = F.conv2d(a0.abs(), w1.abs(), b1.abs(), padding=1) + a0.abs()
+    zero = torch.zeros((), dtype=torch.float64)
+    p1_ref = F.avg_pool2d(torch.where(gate, z1, zero), 2)
+    s_p1 = F.avg_pool2d(torch.where(gate, s1, zero), 2)
+    err = (p1 - p1_ref).abs()
+    ratio_f = float((err / s_p1.clamp_min(1e-300)).max())
+    # ---- weight gradient: dW1 = sum a0(shifted) * dz1, dz1 = mask * upsample(dp1) / 4 (avgpool + ReLU backward)
+    dz1 = torch.zeros(n, 64, H, W, dtype=torch.float64)
+    dz1[:, :, :2 * H2, :2 * W2] = dp1.repeat_interleave(2, 2).repeat_interleave(2, 3) / 4
+    dz1 = torch.where(gate, dz1, zero)
+    dz1[:, :, 2 * H2:, :] = 0
+    dz1[:, :, :, 2 * W2:] = 0
+    dw_ref = torch.nn.grad.conv2d_weight(a0, w1.shape, dz1, padding=1)
+    s_dw = torch.nn.grad.conv2d_weight(a0.abs(), w1.shape, dz1.abs(), padding=1)
+    dw = dict(net.named_parameters())["conv1.weight"].grad.cpu().double()
+    errw = (dw - dw_ref).abs()
+    ratio_w = float((errw / s_dw.clamp_min(1e-300)).max())
+    print(f"[{'mixed' if mixed else 'unit'}] forward: max err/S = {ratio_f:.3e} (2^{np.log2(max(ratio_f, 1e-300)):.1f}), "
+          f"|p1| from {float(p1_ref.abs()[p1_ref != 0].min()):.2e} to {float(p1_ref.abs().max()):.2e};  "
+          f"weight gradient: max err/S = {ratio_w:.3e} (2^{np.log2(max(ratio_w, 1e-300)):.1f})")
+    assert ratio_f <= 2.0 ** -18, ratio_f
+    assert ratio_w <= 2.0 ** -16, ratio_w
+
+
 def test_window_too_large_for_lds_fails_loudly():
     """a 22x22 window needs a 24x24x68-float LDS image (157 KB) + tap buffer: no silent fallback, a shape error"""
     from cmlpl_amd import _lib

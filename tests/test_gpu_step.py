@@ -96,6 +96,43 @@ def test_step_matches_golden_and_oracle(name):
         report(f"bank{i} probs", eng.bank_probs[i], st.bank_probs[i], 1e-4, 2e-4)   # softmax of |logits|~100 (peaky case)
 
 
+def test_b5_1to8_single_gpu_runs_on_with_modulo_bank_writes():
+    """BASELINE configs[4]'s batch split (64 labelled + 512 unlabelled, 15x15x48, 20 classes) on ONE GPU through
+    TrainEngine.  The reference runs exactly one step at this split (its second bank slice-assign raises):
+    step 0 is held to the reference's own numbers (fixture b5_1to8); the steps behind it write the banks modulo Q
+    (Q = 640 < 576 + 256: every write overlaps the previous step's rows and wraps) and are held to the oracle's
+    modulo write -- losses, counts, every gradient, pointers, banks."""
+    g = GoldenCase("b5_1to8")
+    eng, p0, p1 = _engine(g)
+    st = O.StepState.create(g.shape, p0, p1, g.bt, g.hp)
+    n, steps = g.bt + g.btu, 4
+    for s in range(steps):
+        b = g.batch(s)
+        epoch, bi = g.epoch_bi(s)
+        cb = cuda_batch(b)
+        eng.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], epoch, bi, noise=cb["noise"],
+                 dropmask=cb["dropmask"])
+        gates = hip_relu_gates(eng, g.shape, n)
+        ref = O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"],
+                           epoch, bi, g.hp, relu_gates=gates)
+        sc = eng.read_scalars()
+        row = [sc[k] for k in ("ctr_s", "total_s", "cls_s", "con_s", "acc")]
+        print(f"[b5_1to8 x{steps}] step {s}: hip={row} oracle={ref['hist']}")
+        if s == 0:
+            assert rel_err(row, g.z["hist"][0], 1e-7) < LOSS_RTOL, (row, g.z["hist"][0])     # the reference itself
+        assert rel_err(row, ref["hist"], 1e-7) < LOSS_RTOL, (s, row, ref["hist"])
+        assert eng.ptr == list(st.ptr), (s, eng.ptr, st.ptr)
+        relu_mask_audit(eng, ref["taps"], g.shape, n, ztol_y=2e-5 + 0.25 * g.hp.lr * s)
+        for net in range(2):
+            for k in O.LIVE_KEYS:
+                gr = ref["grads"][net][k]
+                report(f"grad[{net}] {k}", eng.grad(net, k), gr, 5e-4, 5e-5 * max(float(gr.abs().max()), 1e-4))
+    assert eng.Q == 640 and eng.ptr == [(steps * 256) % 640, (steps * 256 + 256) % 640]
+    for i in range(2):
+        report_after_updates(f"bank{i} feats", eng.bank_feats[i], st.bank_feats[i], 1e-5, 5e-6, steps, g.hp.lr)
+        report(f"bank{i} probs", eng.bank_probs[i], st.bank_probs[i], 1e-4, 2e-4)
+
+
 @pytest.mark.parametrize("name", NAN_CASES)
 def test_dead_relu_rows_propagate_nan_like_the_reference(name):
     """SURVEY.md section 4 regime (v): a sample whose spectral ReLU output is all zero makes Normalize
@@ -206,3 +243,32 @@ def test_philox_noise_statistics():
                              None, 0.5, 123, 7, None, xn2.data_ptr(), sn.data_ptr(), None, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(xn, xn2)                                          # counter-based: reproducible
+
+
+def test_device_noise_is_the_documented_generator():
+    """The augmentation noise of the kernels, value by value, against the numpy restatement of pcg4d + Box-Muller in
+    tests/test_noise_generator_math.py (counter = (global sample << 24) | element group, stream 0x100 + network for the
+    patches): zero inputs and sigma = 1 make cmlpl_augment return the noise itself.  Tolerance 2e-5 absolute: the
+    kernel takes log2 / sin / cos from the hardware's approximations."""
+    import ctypes as C
+    from cmlpl_amd import _lib
+    from tests.test_noise_generator_math import noise_normal4, _ctr
+    lib = _lib.load()
+    shape = O.NetShape(103, 11, 11, 103, 9)
+    cs = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+    bt = btu = 4
+    per = 103 * 121
+    xpl = torch.zeros(bt, 103, 11, 11, device=DEV); xpu = torch.zeros(btu, 103, 11, 11, device=DEV)
+    xl = torch.zeros(bt, 103, device=DEV); xu = torch.zeros(btu, 103, device=DEV)
+    xn = torch.empty(2, bt + btu, per, device=DEV); sn = torch.empty(2, bt + btu, 103, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    seed, step = 1088, 3
+    assert lib.cmlpl_augment(C.byref(cs), 2, bt, btu, xpl.data_ptr(), xl.data_ptr(), xpu.data_ptr(), xu.data_ptr(),
+                             None, 1.0, seed, step, None, xn.data_ptr(), sn.data_ptr(), None, st) == 0
+    torch.cuda.synchronize()
+    groups = np.arange((per + 3) // 4)
+    for net in range(2):
+        for row in (0, 3, 5):                      # rows 0..3 labelled (global sample = row), 4..7 unlabelled (bt + i)
+            want = noise_normal4(seed, step, 0x100 + net, _ctr(row, groups)).T.reshape(-1)[:per]
+            got = xn[net, row].cpu().numpy()
+            assert np.abs(got - want).max() < 2e-5, (net, row, np.abs(got - want).max())

@@ -146,6 +146,33 @@ def test_hip_contra_memobank_loss_matches_oracle(name, style):
 
 
 @pytest.mark.gpu
+def test_in_kernel_draws_advance_from_call_to_call():
+    """The drop-in list path builds a fresh MemoryBank on every call (loss_helper.compute_contra_memobank_loss with
+    the reference's list structure): the in-kernel anchor / negative draws must still differ from one training
+    iteration to the next (they are keyed by a 64-bit value drawn from torch's CPU generator per call), and a run
+    must stay reproducible under torch.manual_seed."""
+    import loss_helper as LH
+    cfg, inp, res, grad, _ = run_oracle_contra("k9")
+    args = [inp[k].cuda() for k in ("label_l", "label_u", "prob_l", "prob_u", "low_mask", "high_mask")]
+
+    def one_call():
+        rep = inp["rep"].cuda().requires_grad_(True)
+        memobank = [[b.clone().cuda()] for b in inp["bank"]]
+        ptrs = [torch.tensor([p], dtype=torch.long) for p in inp["ptrs"]]
+        out = LH.compute_contra_memobank_loss(rep, *args, memobank, ptrs, list(inp["sizes"]), inp["rep_teacher"].cuda())
+        out[-1].backward()
+        torch.cuda.synchronize()
+        return rep.grad.clone()
+
+    torch.manual_seed(123)
+    g1, g2 = one_call(), one_call()
+    assert not torch.equal(g1, g2)                  # consecutive iterations draw different anchors / negatives
+    torch.manual_seed(123)
+    h1, h2 = one_call(), one_call()
+    assert torch.equal(g1, h1) and torch.equal(g2, h2)      # same seed, same sequence of calls: same draws
+
+
+@pytest.mark.gpu
 def test_hip_enqueue_sliding_window():
     import loss_helper as LH
     rng = np.random.Generator(np.random.PCG64(9))

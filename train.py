@@ -6,7 +6,8 @@
 Differences from the reference that are deliberate, MI355X-first choices:
   * the labelled / unlabelled splits live in HBM for the whole run and batches are gathered there by
     index (the reference copies every batch over PCIe and draws noise on the CPU);
-  * noise and dropout come from in-kernel Philox streams seeded with the reference's seed 1088;
+  * noise and dropout come from in-kernel counter-based streams (PCG4D hash + Box-Muller for the augmentation noise,
+    Philox4x32-10 for the dropout masks) seeded with the reference's seed 1088;
   * the five logged scalars of every step (loss_hist, train.py:136,274-278) are written by the step into a
     device-side ring and read back once per ``print_per_batches`` steps, not five times a step; the printed line
     is the mean over that window, as in train.py:281-289.
@@ -99,9 +100,8 @@ def main(args, make_engine=None, device=None):
     if make_engine is not None:
         eng = make_engine(NetShape(*shape), bt // world, btu // world, hp, ppb)
     elif world > 1:
-        import torch.distributed as dist
-        from cmlpl_amd.distributed import DistTrainEngine
-        dist.init_process_group("nccl", device_id=device)
+        from cmlpl_amd.distributed import DistTrainEngine, init_distributed
+        dist = init_distributed("nccl", device)      # checked start-up: one device per local rank, no silent hang
         eng = DistTrainEngine(NetShape(*shape), bt // world, btu // world, hp, device=device, seed=1088, hist_rows=ppb)
     else:
         from cmlpl_amd import TrainEngine

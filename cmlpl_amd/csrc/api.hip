@@ -270,7 +270,8 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
              const float* d_packed, const XSrc& xs, const XSrc* xspec, float* d_sn_out, const long long* d_labels, float* d_labels_f, const float* d_xn,
              const float* d_sn, const float* d_snT,
              const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
-             const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st);
+             const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st,
+             float* xn_save = nullptr);
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
@@ -301,7 +302,8 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
              const float* d_packed, const XSrc& xs, const XSrc* xspec, float* d_sn_out, const long long* d_labels, float* d_labels_f, const float* d_xn,
              const float* d_sn, const float* d_snT,
              const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
-             const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st) {
+             const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st,
+             float* xn_save) {
   int rc;
   hipStream_t main_st = st;
   const long long pk_ns = L.packed_total;
@@ -340,7 +342,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     t.logits = d_logits; t.feat = d_feat; t.p2 = w.p2; t.m2 = w.m2; t.dropout_p = dropout_p; t.train = train; t.K = d.K;
     return TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0b3(d.C, d.bands),
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
-                               d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, main_st)));
+                               d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, main_st, xn_save)));
   }
   if (conv3_fused_ok(d.H, d.W, d.C, nets * n)) {
     // conv0 + conv1 in one launch, input rows taken where they lie and augmented in LDS: neither an augmented
@@ -348,7 +350,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // for the backward pass)
     if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0b3(d.C, d.bands),
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
-                               d_params + L.param_off[3], param_stride, w.p1, w.m1, nullptr, st))))) return rc;
+                               d_params + L.param_off[3], param_stride, w.p1, w.m1, nullptr, st, xn_save))))) return rc;
   } else {
     if (!d_xn) return CMLPL_E_ARG;
     if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
@@ -524,10 +526,13 @@ int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
     xspec.nz_lab[i] = batch->noise8 ? batch->noise8[2 * i + 1] : nullptr;
     xspec.nz_unl[i] = batch->noise8 ? batch->noise8[4 + 2 * i + 1] : nullptr;
   }
+  // (fused per-sample kernels, noise on: the forward leaves the augmented rows in sw.xn for cmlpl_backward, which lands
+  // them by DMA instead of regenerating the noise)
   return fwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
                   spe_fused ? &xspec : nullptr, sw.sn, (const long long*)batch->d_labels, d_labels_f,
                   copy ? sw.xn : nullptr, sw.sn, sw.snT, d_dropmask, hp->dropout_p,
-                  train, seed, step, shard, d_logits, d_feat, nw, st);
+                  train, seed, step, shard, d_logits, d_feat, nw, st,
+                  (!copy && hp->noise_sigma != 0.f) ? sw.xn : nullptr);
 }
 
 int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
@@ -545,7 +550,12 @@ int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlp
   carve_step(d, n, n, (char*)d_workspace + nw.bytes, &sw);
   if (nw.bytes + ((char*)sw.dlogits - ((char*)d_workspace + nw.bytes)) > workspace_bytes) return CMLPL_E_WORKSPACE;
   const bool copy = need_xn_copy(d, 2 * n);
-  return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
+  // the patches as the forward saw them: the augmented rows cmlpl_forward left in sw.xn (fused kernels with noise), or
+  // the raw rows when no noise is added
+  const XSrc xs = (!copy && hp->noise_sigma != 0.f)
+                      ? xsrc_plain(sw.xn, 2, n, (long long)d.C * d.HW, seed, step, shard)
+                      : xsrc_raw(batch, hp->noise_sigma, seed, step, shard);
+  return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xs,
                   copy ? sw.xn : nullptr, sw.sn, d_dropmask, hp->dropout_p, train, d_dlogits, d_dfeat, d_grads,
                   grad_stride, nw, (hipStream_t)stream);
 }

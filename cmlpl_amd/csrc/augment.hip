@@ -141,7 +141,7 @@ hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int
 // through LDS so that the cube is read along its contiguous channel axis and the band-major patch is
 // written along its contiguous pixel axis (odd LDS row stride: conflict-free transpose).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void extract_patches_kernel(const float* __restrict__ cube, int rows, int cols, int C,
+__global__ __launch_bounds__(512) void extract_patches_kernel(const float* __restrict__ cube, int rows, int cols, int C,
                                                               int w, const long long* __restrict__ idx, int n,
                                                               float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -152,15 +152,15 @@ __global__ __launch_bounds__(256) void extract_patches_kernel(const float* __res
   // gather: a wave takes whole pixels (its (i, j), the mirrored source pixel and its address are wave-uniform: scalar
   // arithmetic, no per-element division), lanes = channels: the cube is read along its contiguous channel axis, 256
   // consecutive bytes per wave-instruction.
-  // EIGHT pixels of a wave are in flight at once (16 loads per lane for C <= 128): one pixel at a time the gather
+  // (eight waves per workgroup) EIGHT pixels of a wave are in flight at once (16 loads per lane for C <= 128): one pixel at a time the gather
   // is a chain of ~30 dependent memory round trips per workgroup (measured: 1.5 TB/s written)
   constexpr int PB = 8;
-  for (int pix0 = wave; pix0 < ww; pix0 += 4 * PB) {
+  for (int pix0 = wave; pix0 < ww; pix0 += 8 * PB) {
     for (int ch0 = 0; ch0 < C; ch0 += 128) {
       float v[PB][2];
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
-        const int pix = pix0 + 4 * q, pc = pix < ww ? pix : 0;                      // wave-uniform
+        const int pix = pix0 + 8 * q, pc = pix < ww ? pix : 0;                      // wave-uniform
         const int i = pc / w, j = pc - i * w;
         int rr = r + i - hw, cc = c + j - hw;
         rr = rr < 0 ? -rr - 1 : (rr >= rows ? 2 * rows - 1 - rr : rr);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void extract_patches_kernel(const float* __res
       }
 #pragma unroll
       for (int q = 0; q < PB; ++q) {
-        const int pix = pix0 + 4 * q;
+        const int pix = pix0 + 8 * q;
         if (pix < ww) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) { const int ch = ch0 + 64 * h + lane; if (ch < C) tile[pix * CP + ch] = v[q][h]; }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void extract_patches_kernel(const float* __res
   // scatter: a wave takes whole bands, lanes = pixels: the band-major patch is written along its contiguous pixel axis
   // (256 consecutive bytes per wave-instruction; the LDS column reads are conflict-free, the row stride CP is odd)
   float* o = out + (long long)p * C * ww;
-  for (int ch = wave; ch < C; ch += 4) {
+  for (int ch = wave; ch < C; ch += 8) {
     float* orow = o + (long long)ch * ww;
     for (int px0 = 0; px0 < ww; px0 += 256) {
       float v[4];
@@ -204,7 +204,7 @@ hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, 
     hipError_t e = ensure_max_lds(attr_once, extract_patches_kernel);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(extract_patches_kernel, dim3(n), dim3(256), lds, st, cube, rows, cols, C, w, idx, n, out);
+  hipLaunchKernelGGL(extract_patches_kernel, dim3(n), dim3(512), lds, st, cube, rows, cols, C, w, idx, n, out);
   return hipGetLastError();
 }
 

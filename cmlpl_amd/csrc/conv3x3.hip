@@ -130,6 +130,7 @@ struct Conv3Args {
   const float* w0t; const float* b0; float* a0out;
   long long w0t_ns, b0_ns;
   int C;
+  float* xn_out;                                  // MODE 2, optional: the augmented rows [net][n][C*HW], kept for the backward pass
   // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup; the input
   // slab is re-formed from `xs` (same noise as the forward: counter-based)
   float* part0; long long part0_ns;
@@ -186,6 +187,8 @@ __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
 constexpr int SLAB_MAXQ = 16;   // pieces per wave: range <= 4 waves * 16 * 256 floats
 constexpr int SLAB_RING = 7;    // forward: chunks (16 bands each) resident in LDS per pass
 constexpr int SLAB_WIN = 4;     // forward: chunks in flight global -> registers per wave
+constexpr int SLAB_NUP = 7;     // forward: chunks whose noise is formed before the chunk loop starts (measured: all of
+                                // them -- forming the later chunks' noise inside the loop, beside the MFMAs, took 0.8 us longer)
 typedef __attribute__((address_space(3))) void slab_lds_void;
 typedef __attribute__((address_space(1))) const void slab_gbl_void;
 struct SlabRange { const float* xs; const float* nz; uint64_t gsample; int f4base, nfl; };
@@ -577,12 +580,17 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const int PPW = (CH4 + 255) >> 8;                     // float4 per lane and chunk: 1 (HW <= 64) or 2 (HW <= 128)
     const int SLOT = PPW << 10;                           // floats per LDS slot (>= 16 * HW)
     float* slab = smem;                                   // [SLAB_RING][SLOT], aliases img | wbuf | lut
-    const int nt0 = wave & 1, mh = wave >> 1;
+    // wave = pixel tile (32 pixels), BOTH output-channel tiles: the band values of a pixel are split into bf16 pieces
+    // once (not once per output-channel tile, as with wave = (channel tile, pixel half))
     const int nfl = C * HW, nf4 = nfl >> 2, rem = nfl & 3;
     const float* xrow = xsrc_row(a.xs, net, s0, nfl);
     const float sigma = a.xs.sigma;
     const float* nzrow = (sigma != 0.f) ? xsrc_noise_row(a.xs, net, s0, nfl) : nullptr;
     const uint64_t gsample = xsrc_global_sample(a.xs, s0);
+    // The augmented rows also go to HBM (16-byte stores from the registers that feed the LDS slots): the backward pass
+    // lands them by DMA instead of regenerating the noise -- forming 12,463 normals per sample-net costs ~5 us of vector
+    // work per workgroup, the longest single item of that kernel's second half, while these stores ride on an idle HBM.
+    float* xnrow = (a.xn_out != nullptr) ? a.xn_out + ((long long)net * a.n + s0) * (long long)nfl : nullptr;
     const uint4* wq0 = (const uint4*)(a.w0t + (long long)net * a.w0t_ns) + lane;
     // the last, partial float4 group of the slab (C * HW need not be a multiple of 4): threads 0 .. rem-1
     float tailv = 0.f;
@@ -598,9 +606,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         tailv = fmaf(zt, sigma, tailv);
       }
     }
-    f32x16 z0 = zero16(), z1 = zero16();                  // M tiles 2mh and 2mh + 1 of output-channel tile nt0
-    const int pix0 = ((2 * mh) * 32 + l31 < HW) ? (2 * mh) * 32 + l31 : HW - 1;
-    const int pix1 = ((2 * mh + 1) * 32 + l31 < HW) ? (2 * mh + 1) * 32 + l31 : HW - 1;
+    f32x16 z0 = zero16(), z1 = zero16();                  // output-channel tiles 0 / 1 of pixel tile `wave`
+    const int pix0 = (wave * 32 + l31 < HW) ? wave * 32 + l31 : HW - 1;
     for (int c0 = 0; c0 < KQ0; c0 += SLAB_RING) {         // uniform; one pass up to 112 bands
       const int nch = (KQ0 - c0 < SLAB_RING) ? KQ0 - c0 : SLAB_RING;
       // (opaque copy: keeps the compiler from hoisting this pass body's per-lane offsets out of the loop and holding
@@ -609,11 +616,13 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       asm volatile("" : "+s"(CH4l));
       const int HWl = CH4l >> 2;
       if (c0 > 0) __syncthreads();                        // every wave is done reading the previous pass's slots
-      uint4 bw[3][3];                                     // conv0 weight fragments of three chunks (window)
+      uint4 bw[2][6];                                     // conv0 weight fragments of two chunks (window): [n tile][piece]
       float4 dv[SLAB_WIN][2], nzv[SLAB_RING][2];
-      auto fetch_b = [&](int kq, uint4 (&b)[3]) {
+      auto fetch_b = [&](int kq, uint4 (&b)[6]) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) b[pc] = wq0[(((c0 + kq) * 3 + pc) * 2 + nt0) * 64];
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) b[3 * nt + pc] = wq0[(((c0 + kq) * 3 + pc) * 2 + nt) * 64];
       };
       // this lane's float4 k of chunk kq: local index g inside the chunk, global index gg inside the slab
       auto fetch_d = [&](int kq, float4 (&d)[2]) {
@@ -626,7 +635,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         }
       };
 #pragma unroll
-      for (int kq = 0; kq < 3; ++kq) if (kq < nch) fetch_b(kq, bw[kq]);
+      for (int kq = 0; kq < 2; ++kq) if (kq < nch) fetch_b(kq, bw[kq]);
 #pragma unroll
       for (int kq = 0; kq < SLAB_WIN; ++kq) if (kq < nch) fetch_d(kq, dv[kq]);
       if (c0 + nch == KQ0) {
@@ -635,9 +644,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         float* sl = slab + (nch - 1) * SLOT;
         for (int i = used + tid; i < 16 * HWl; i += 256) sl[i] = 0.f;
       }
-      // the noise of this pass's chunks, formed while the first loads are in flight
-#pragma unroll
-      for (int kq = 0; kq < SLAB_RING; ++kq) {
+      // The noise of a chunk's elements (pure vector work: a hash + Box-Muller per four normals, ~380 cycles per call and
+      // wave: 5 us per workgroup pair, the largest item of this prologue).  The first SLAB_NUP chunks' noise is formed
+      // up front, under the latency of the first loads; any further chunk's inside the chunk loop, one iteration ahead.
+      auto make_noise = [&](int kq, float4 (&zz)[2]) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
@@ -650,42 +660,64 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
               z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
             }
           }
-          nzv[kq][k] = z;
+          zz[k] = z;
         }
-      }
+      };
+#pragma unroll
+      for (int kq = 0; kq < SLAB_NUP; ++kq) make_noise(kq, nzv[kq]);
       if (c0 == 0) STAMP(0, 4);
+      // One chunk AHEAD: chunk kq + 1 is put into LDS (noise added) and published before the MFMAs of chunk kq are
+      // issued, and its operand reads go out in front of them -- the split of chunk kq + 1 then runs while the matrix
+      // pipe works on chunk kq (a chunk at a time, every wave walked read -> split -> MFMA -> barrier in series).
+      auto put_chunk = [&](int kq) {                      // registers -> (+ noise) -> LDS slot kq
+        float* sl = slab + kq * SLOT;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+          if (k < PPW && g < CH4l && gg < nf4) {
+            float4 v = dv[kq % SLAB_WIN][k];
+            if (sigma != 0.f) {
+              v.x = fmaf(nzv[kq][k].x, sigma, v.x); v.y = fmaf(nzv[kq][k].y, sigma, v.y);
+              v.z = fmaf(nzv[kq][k].z, sigma, v.z); v.w = fmaf(nzv[kq][k].w, sigma, v.w);
+            }
+            *(float4*)(sl + 4 * g) = v;
+            if (xnrow != nullptr) *(float4*)(xnrow + 4 * gg) = v;
+          }
+        }
+        if (c0 + kq == KQ0 - 1 && tid < rem) {
+          sl[4 * nf4 - (KQ0 - 1) * 16 * HWl + tid] = tailv;
+          if (xnrow != nullptr) xnrow[4 * nf4 + tid] = tailv;
+        }
+      };
+      float rn[8];                                        // raw operand values of the chunk ahead
+      auto read_chunk = [&](int kq) {
+        const float* ap0 = slab + kq * SLOT + hh * 8 * HWl + pix0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rn[j] = ap0[j * HWl];
+      };
+      uint4 A1, A2, A3;
+      put_chunk(0);
+      if (SLAB_WIN < nch) fetch_d(SLAB_WIN, dv[0]);
+      __syncthreads();                                    // chunk 0 complete in LDS
+      if (c0 == 0) STAMP(0, 12);
+      read_chunk(0);
+      a_split(make_float4(rn[0], rn[1], rn[2], rn[3]), make_float4(rn[4], rn[5], rn[6], rn[7]), A1, A2, A3);
 #pragma unroll
       for (int kq = 0; kq < SLAB_RING; ++kq) {
         if (kq < nch) {                                   // uniform
-          float* sl = slab + kq * SLOT;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
-            if (k < PPW && g < CH4l && gg < nf4) {
-              float4 v = dv[kq % SLAB_WIN][k];
-              if (sigma != 0.f) {
-                v.x = fmaf(nzv[kq][k].x, sigma, v.x); v.y = fmaf(nzv[kq][k].y, sigma, v.y);
-                v.z = fmaf(nzv[kq][k].z, sigma, v.z); v.w = fmaf(nzv[kq][k].w, sigma, v.w);
-              }
-              *(float4*)(sl + 4 * g) = v;
-            }
+          if (kq + 1 < nch) {
+            put_chunk(kq + 1);
+            if (kq + 1 + SLAB_WIN < nch) fetch_d(kq + 1 + SLAB_WIN, dv[(kq + 1) % SLAB_WIN]);
+            __syncthreads();                              // chunk kq + 1 complete in LDS
+            read_chunk(kq + 1);
           }
-          if (c0 + kq == KQ0 - 1 && tid < rem) sl[4 * nf4 - (KQ0 - 1) * 16 * HWl + tid] = tailv;
-          if (kq + SLAB_WIN < nch) fetch_d(kq + SLAB_WIN, dv[kq % SLAB_WIN]);
-          __syncthreads();                                // chunk kq complete in LDS
-          if (c0 == 0 && kq == 0) STAMP(0, 12);
           if (c0 == 0 && kq == 3) STAMP(0, 13);
-          const float* ap0 = sl + hh * 8 * HWl + pix0;
-          const float* ap1 = sl + hh * 8 * HWl + pix1;
-          float r0[8], r1[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { r0[j] = ap0[j * HWl]; r1[j] = ap1[j * HWl]; }
-          uint4 A1, A2, A3;
-          a_split(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r0[4], r0[5], r0[6], r0[7]), A1, A2, A3);
-          z0 = mfma_b3(A1, A2, A3, bw[kq % 3][0], bw[kq % 3][1], bw[kq % 3][2], z0);
-          a_split(make_float4(r1[0], r1[1], r1[2], r1[3]), make_float4(r1[4], r1[5], r1[6], r1[7]), A1, A2, A3);
-          z1 = mfma_b3(A1, A2, A3, bw[kq % 3][0], bw[kq % 3][1], bw[kq % 3][2], z1);
-          if (kq + 3 < nch) fetch_b(kq + 3, bw[kq % 3]);
+          z0 = mfma_b3(A1, A2, A3, bw[kq % 2][0], bw[kq % 2][1], bw[kq % 2][2], z0);
+          z1 = mfma_b3(A1, A2, A3, bw[kq % 2][3], bw[kq % 2][4], bw[kq % 2][5], z1);
+          if (kq + 2 < nch) fetch_b(kq + 2, bw[kq % 2]);
+          if (kq + SLAB_NUP < SLAB_RING) make_noise(kq + SLAB_NUP, nzv[kq + SLAB_NUP]);   // consumed by put_chunk(kq + 2) in the next iteration (zero beyond nch)
+          if (kq + 1 < nch)
+            a_split(make_float4(rn[0], rn[1], rn[2], rn[3]), make_float4(rn[4], rn[5], rn[6], rn[7]), A1, A2, A3);
         }
       }
     }
@@ -710,18 +742,15 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     }
     STAMP(0, 6);
     const float* b0 = a.b0 + (long long)net * a.b0_ns;
-    const float bv = b0[nt0 * 32 + l31];
+    const float bv0 = b0[l31], bv1 = b0[32 + l31];
     const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for m < 128, W <= 128 (checked on the host)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      z0[r] += bv; z1[r] += bv;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int m = (2 * mh + t) * 32 + acc_row(r, lane);
-        if (m < HW) {
-          const int h = (m * magic) >> 16, w = m - h * W;
-          img[(size_t)((h + 1) * PW + w + 1) * CS + nt0 * 32 + l31] = t ? z1[r] : z0[r];
-        }
+      const int m = wave * 32 + acc_row(r, lane);
+      if (m < HW) {
+        const int h = (m * magic) >> 16, w = m - h * W;
+        float* d = img + (size_t)((h + 1) * PW + w + 1) * CS + l31;
+        d[0] = z0[r] + bv0; d[32] = z1[r] + bv1;
       }
     }
 
@@ -1581,7 +1610,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   if (mode == 0) { a.in_ns = (long long)n * HW * 64; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns; a.mask_in_ns = 0; }
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0; a.pair = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
@@ -1638,7 +1667,7 @@ bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K) {
 hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
                               const float* bias, long long bias_ns, float* out, uint8_t* mask_out,
-                              const FwdTail* tail, hipStream_t st) {
+                              const FwdTail* tail, hipStream_t st, float* xn_out) {
   Conv3Plan pl;
   if (!conv3_fused_ok(H, W, C, nets * n) || !plan_conv3(0, H, W, nets * n, &pl)) return hipErrorInvalidValue;
   const int HW = H * W, P2 = (H / 2) * (W / 2);
@@ -1647,7 +1676,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   a.wpk_ns = wpk_ns; a.bias_ns = bias_ns;
   a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
   a.n = n; a.H = H; a.W = W; a.S = 1;
-  a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C;
+  a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0; a.pair = conv3_pair_nets(nets);
   (void)HW;
   if (tail != nullptr) {
@@ -1721,7 +1750,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.wpk_ns = wpk_ns; a.bias_ns = 0;
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = conv3_bwd_bp(H, W, C); a.pair = conv3_pair_nets(nets);
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;

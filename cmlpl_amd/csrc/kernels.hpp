@@ -97,7 +97,7 @@ bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
                               const float* bias, long long bias_ns, float* out, uint8_t* mask_out,
-                              const FwdTail* tail /* or null */, hipStream_t st);
+                              const FwdTail* tail /* or null */, hipStream_t st, float* xn_out = nullptr);
 bool conv3_fused_bwd_ok(int H, int W, int C, int rows);
 // the head / conv2 part of the backward in the same per-sample workgroup: see conv3_bwd_head
 struct BwdHead {

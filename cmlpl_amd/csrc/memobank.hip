@@ -655,10 +655,7 @@ hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st)
     MbLoss lb = la;
     const size_t keys_bytes = (size_t)(la.NN + 1) * la.D * 4;
     lb.keys_lds = (la.D % 4 == 0 && la.D <= 1024 && keys_bytes + (size_t)la.D * 4 <= 52 * 1024 + 2048) ? 1 : 0;
-    const size_t lds = (size_t)la.D * 4 + (lb.keys_lds ? keys_bytes : 0);
-    static DevOnce attr_once;
-    hipError_t e = ensure_max_lds(attr_once, mb_infonce_all_kernel);
-    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)la.D * 4 + (lb.keys_lds ? keys_bytes : 0);     // <= 55 KB: inside the default limit
     hipLaunchKernelGGL(mb_infonce_all_kernel, dim3(la.Q, la.K), dim3(256), lds, st, lb);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;

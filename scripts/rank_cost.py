@@ -1,7 +1,9 @@
 """Per-rank device cost of the data-parallel step at world size W, measured on ONE GPU: rank 0 of W is emulated
 (local 128+128 rows, global W x that, bank 10 x bt_global rows); the exchanges are faked by replicating the rank's
 own buffers, so collective time is NOT included -- this isolates how the per-rank kernels grow with W.
-    python scripts/rank_cost.py 8
+    python scripts/rank_cost.py 8                      weak scaling: B2, 128 + 128 rows per rank
+    python scripts/rank_cost.py 8 B3 64 64             strong scaling: BASELINE configs[2] (global 512 + 512 over 8 ranks)
+    python scripts/rank_cost.py 8 B5 8 64              strong scaling: BASELINE configs[4] (global 64 + 512 over 8 ranks)
 """
 import ctypes as C
 import os
@@ -38,10 +40,13 @@ def step(e, b, i):
 
 def main():
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    shape = WORKLOADS["B2"]
-    e = DistTrainEngine(NetShape(*shape), 128, 128, HyperParams(), device=DEV, seed=1088, comm=FakeComm(W, 0))
+    wl = sys.argv[2] if len(sys.argv) > 2 else "B2"
+    bt = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    btu = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+    shape = WORKLOADS[wl]
+    e = DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=DEV, seed=1088, comm=FakeComm(W, 0))
     e.init_params_default(1088)
-    b = synth(shape, 128, 128, 1, DEV)
+    b = synth(shape, bt, btu, 1, DEV)
     lib = _lib.load()
     for i in range(10):
         step(e, b, i)
@@ -54,9 +59,10 @@ def main():
     torch.cuda.synchronize()
     _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
     tot = sum(ms[i] for i in range(nk))
-    print(f"W={W}: Q={e.Q} bank rows, per-rank kernel time {tot / 30 * 1e3:.1f} us/step (hipEvent pairs, no collectives)")
+    print(f"W={W} {wl} {bt}+{btu} rows per rank ({2 * (bt + btu)} sample-net workgroups): Q={e.Q} bank rows, per-rank kernel "
+          f"time {tot / 30 * 1e3:.1f} us/step (hipEvent pairs, no collectives)")
     for i, nm in enumerate(_lib.KERNEL_NAMES):
-        if cnt[i] and ms[i] / 30 * 1e3 >= 5.0:
+        if cnt[i] and ms[i] / 30 * 1e3 >= 3.0:
             print(f"  {nm:12s} {ms[i] / cnt[i] * 1e3:9.1f} us/launch x{cnt[i] // 30}")
 
 

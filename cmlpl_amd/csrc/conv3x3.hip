@@ -135,7 +135,6 @@ struct Conv3Args {
   // slab is re-formed from `xs` (same noise as the forward: counter-based)
   float* part0; long long part0_ns;
   int bp;                                         // bands per pass of the fused conv0 weight gradient (>= C: one pass)
-  int pair;                                       // per-sample kernels: 1-D grid with the workgroup -> (net, sample) map of wg_decode
   XSrc xs;
   // TAIL (forward): conv2 + ReLU + avgpool + flatten/concat + dropout + classifier + L2-norm for the same sample
   // (tools/models.py:137-152), in the workgroup that has just pooled conv1's output
@@ -152,21 +151,10 @@ struct Conv3Args {
   float* dy; float* dp2out; float* dp1out;
 };
 
-// Workgroup -> (network, first sample).  The per-sample kernels launch nets * n workgroups, two per CU, dealt to the
-// XCDs round-robin in id order: with two networks and a.pair set, ids are grouped in blocks of 256 = 128 samples x
-// 2 networks with the network in bit 7, so that
-//   ids i and i + 256 (the two workgroups a CU holds when 512 are dealt out) belong to the SAME network: their
-//     weight-fragment streams (conv1 216 KB, conv2 147 / 216 KB, classifier 46 KB per workgroup) meet in the CU's L1;
-//   the two networks of one sample are 128 ids apart: same XCD, so the sample's slab is fetched into that L2 once.
-// (Placement is the hardware's business: this is for speed only, any map gives the same results.)
+// Workgroup -> (network, first sample).  (Measured, round 3: numbering the workgroups so that the two a CU holds belong
+// to the same network -- hoping their weight-fragment streams would meet in L1 -- changed nothing: 0.2129 vs 0.2128 ms.)
 __device__ __forceinline__ void wg_decode(const Conv3Args& a, int& net, int& s0) {
-  if (a.pair) {
-    const int id = (int)blockIdx.x, blk = id >> 8, r = id & 255, full = a.n >> 7;
-    if (blk < full) { net = r >> 7; s0 = (blk << 7) | (r & 127); }
-    else { const int m = a.n - (full << 7); net = r / m; s0 = (full << 7) + (r - net * m); }   // last, partial block
-  } else {
-    net = (int)blockIdx.y; s0 = (int)blockIdx.x * a.S;
-  }
+  net = (int)blockIdx.y; s0 = (int)blockIdx.x * a.S;
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -1611,7 +1599,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
-  a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0; a.pair = 0;
+  a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
@@ -1634,11 +1622,6 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
 // conv0 fused into the conv1 forward (MODE 2).  Possible when the plain forward plan is one sample per workgroup
 // with one pixel tile per wave (H*W <= 128) and two workgroups still fit a CU with the slab + conv0 weights in LDS.
 // LDS of the fused kernel: the plain forward's regions, or slab [Cp][HW] + 64 + weights [Cp][64] if that is larger
-// same-network pairing of the two workgroups of a CU (wg_decode); CMLPL_PAIR_NETS=0: plain (sample, net) grid
-static int conv3_pair_nets(int nets) {
-  static const bool off = getenv("CMLPL_PAIR_NETS") && atoi(getenv("CMLPL_PAIR_NETS")) == 0;
-  return (nets == 2 && !off) ? 1 : 0;
-}
 static size_t conv3_fused_lds(int H, int W, int C, size_t plain) {
   const int KQ0 = (C + 15) / 16, ring = KQ0 < SLAB_RING ? KQ0 : SLAB_RING;
   const size_t slot = (size_t)((4 * H * W + 255) / 256) * 1024;           // floats per chunk slot
@@ -1677,7 +1660,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
-  a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0; a.pair = conv3_pair_nets(nets);
+  a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -1688,11 +1671,11 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
     static DevOnce attr_once;
     hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), a.pair ? dim3(n * nets) : dim3(n, nets), dim3(256),
+    hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), dim3(n, nets), dim3(256),
                        conv3_fused_lds(H, W, C, pl.lds), st, a);
     return hipGetLastError();
   }
-  return launch_conv3_t<2, 1>(a, a.pair ? dim3(n * nets) : dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
+  return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
 }
 
 // conv0 weight gradient fused into the conv1 data gradient (MODE 3): same shape conditions as the fused forward, and
@@ -1751,7 +1734,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
-  a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = conv3_bwd_bp(H, W, C); a.pair = conv3_pair_nets(nets);
+  a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = conv3_bwd_bp(H, W, C);
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
@@ -1760,11 +1743,11 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
     static DevOnce attr_once;
     hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), a.pair ? dim3(n * nets) : dim3(n, nets), dim3(256),
+    hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), dim3(n, nets), dim3(256),
                        conv3_fused_bwd_lds(H, W, C, pl.lds), st, a);
     return hipGetLastError();
   }
-  return launch_conv3_t<3, 1>(a, a.pair ? dim3(n * nets) : dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
+  return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
 }
 
 }  // namespace cmlpl

@@ -76,7 +76,10 @@ hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const flo
 // workgroups also write sn (row-major) for the weight gradient.  Replaces the augmentation launch (+ its transposed
 // copy) and the GEMM launch.  (A first version staged the augmented rows in LDS and walked the contraction
 // serially per wave: slower than the two launches it replaced.)
-// SPE_MAXP = k-pairs per wave (template parameter): 16 covers bands <= 4 * 2 * 16 = 128, 32 covers 256 (B4: 200)
+// NW = waves per workgroup (template parameter); a wave takes at most 16 k-pairs: four waves cover bands <= 128,
+// eight waves 256 (B4: 200 -- with four waves of 32 k-pairs each the launch took 19.4 us against 9.9 for 103 bands)
+constexpr int SPE_MAXP = 16;   // MFMA steps (bands per lane half) of a wave
+constexpr int SPE_GPH = 4;     // groups of four bands per lane half
 
 struct SpeArgs {
   XSrc xs; const float* wsT; long long wsT_ns; const float* bias; long long p_ns;
@@ -84,17 +87,22 @@ struct SpeArgs {
   const long long* labels; float* labels_f; int bt;        // optional: labels as float for the exchange buffer
 };
 
-template <int SPE_MAXP>
-__global__ __launch_bounds__(256) void spe_fused_kernel(SpeArgs a) {
-  __shared__ float red[3][16][64];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
+  __shared__ float red[NW - 1][16][64];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x, mt = blockIdx.y, net = blockIdx.z;
   if (a.labels_f != nullptr && nt == 0 && mt == 0 && net == 0)
-    for (int q = tid; q < a.bt; q += 256) a.labels_f[q] = (float)a.labels[q];
-  // the waves split the bands by whole groups of four (= two k-steps), so a noise call is never shared across waves
-  const int bands = a.bands, pairs = (bands + 1) >> 1, ppw = 2 * ((((bands + 3) >> 2) + 3) >> 2);
-  const int t0 = wave * ppw, t1 = (t0 + ppw < pairs) ? t0 + ppw : pairs;
+    for (int q = tid; q < a.bt; q += 64 * NW) a.labels_f[q] = (float)a.labels[q];
+  // Band order of the contraction.  An MFMA step multiplies ONE band per lane half; which band is ours to choose, as
+  // long as both operands agree.  The bands are cut into groups of four (= one noise call, = one 16-byte load of the
+  // row); a wave takes 2 * SPE_GPH consecutive groups, its lower lane half the first SPE_GPH of them, the upper half
+  // the rest: a lane then walks CONSECUTIVE bands -- 16-byte loads of its row instead of one 4-byte load per band from
+  // 32 different rows per instruction, and every normal of a noise call is used by the lane that formed it.
+  const int bands = a.bands, G = (bands + 3) >> 2;
+  const int gpw = 2 * ((G + 2 * NW - 1) / (2 * NW));            // groups per wave (even), <= 2 * SPE_GPH
+  const int g0 = wave * gpw + hh * (gpw >> 1);                   // this lane half's first group
   const int i = mt * 32 + l31, j = nt * 32 + l31;
   const bool iv = i < a.n;
   const int ic = iv ? i : 0;
@@ -103,34 +111,61 @@ __global__ __launch_bounds__(256) void spe_fused_kernel(SpeArgs a) {
   const float* bp = a.wsT + (long long)net * a.wsT_ns + j;
   float av[SPE_MAXP], bv[SPE_MAXP], zv[SPE_MAXP];
 #pragma unroll
-  for (int q = 0; q < SPE_MAXP; ++q) {
-    const int k = 2 * (t0 + q) + hh;
-    const bool kv = (t0 + q < t1) && (k < bands);
-    const int kc = kv ? k : 0;
-    const float xa = x[kc], wb = bp[(long long)kc * FD];
-    av[q] = (kv && iv) ? xa : 0.f;
-    bv[q] = kv ? wb : 0.f;
-    zv[q] = (nz != nullptr && kv) ? nz[kc] : 0.f;          // parity mode: the reference's own draws
+  for (int gq = 0; gq < SPE_GPH; ++gq) {
+    const int g = g0 + gq, k0 = 4 * g;
+    const bool gv = gq < (gpw >> 1) && g < G;                    // (uniform per lane half)
+    // the row's four bands of this group: one 16-byte load where the whole group exists (rows are only 4-byte aligned:
+    // dword-aligned multi-dword loads are fine), band by band for the ragged last group
+    float xa[4] = {0.f, 0.f, 0.f, 0.f}, za[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gv && k0 + 3 < bands) {
+      const float4 v = *(const float4*)(x + k0);
+      xa[0] = v.x; xa[1] = v.y; xa[2] = v.z; xa[3] = v.w;
+      if (nz != nullptr) { const float4 z = *(const float4*)(nz + k0); za[0] = z.x; za[1] = z.y; za[2] = z.z; za[3] = z.w; }
+    } else if (gv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k0 + e < bands) { xa[e] = x[k0 + e]; if (nz != nullptr) za[e] = nz[k0 + e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      const bool kv = gv && k < bands;
+      const float wb = bp[(long long)(kv ? k : 0) * FD];
+      av[4 * gq + e] = (kv && iv) ? xa[e] : 0.f;
+      bv[4 * gq + e] = kv ? wb : 0.f;
+      zv[4 * gq + e] = za[e];                                     // parity mode: the reference's own draws
+    }
   }
-  if (a.xs.sigma != 0.f && nz == nullptr) {                 // in-kernel noise (uniform branch, pure ALU)
+  if (a.xs.sigma != 0.f && nz == nullptr) {                     // in-kernel noise (uniform branch, pure ALU)
     const uint64_t gs = xsrc_global_sample(a.xs, ic);
 #pragma unroll
-    for (int q = 0; q < SPE_MAXP; q += 2) {
-      // k-steps t0+q and t0+q+1 (t0 + q even): bands k = 4g + hh and k + 2 of the same group g
-      const int k = 2 * (t0 + q) + hh;
-      const float4 z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_X + net, noise_ctr(gs, (uint32_t)(k >> 2)));
-      zv[q] = hh ? z.y : z.x;
-      zv[q + 1] = hh ? z.w : z.z;
+    for (int gq = 0; gq < SPE_GPH; ++gq) {
+      const float4 z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_X + net, noise_ctr(gs, (uint32_t)(g0 + gq)));
+      zv[4 * gq] = z.x; zv[4 * gq + 1] = z.y; zv[4 * gq + 2] = z.z; zv[4 * gq + 3] = z.w;
     }
   }
   f32x16 acc = zero16();
+  float vq[SPE_MAXP];
 #pragma unroll
   for (int q = 0; q < SPE_MAXP; ++q) {
-    const int k = 2 * (t0 + q) + hh;
-    const bool kv = (t0 + q < t1) && (k < bands);
-    const float v = (kv && iv) ? fmaf(zv[q], a.xs.sigma, av[q]) : 0.f;
-    if (nt == 0 && kv && iv) a.sn[((long long)net * a.n + i) * bands + k] = v;
-    if (t0 + q < t1) acc = mfma32(v, bv[q], acc);            // uniform
+    const int k = 4 * g0 + q;
+    const bool kv = (q >> 2) < (gpw >> 1) && k < bands;
+    vq[q] = (kv && iv) ? fmaf(zv[q], a.xs.sigma, av[q]) : 0.f;
+    if (q < 2 * gpw) acc = mfma32(vq[q], bv[q], acc);             // uniform
+  }
+  if (nt == 0 && iv) {                                            // the augmented row, for the weight gradient
+    float* snr = a.sn + ((long long)net * a.n + i) * bands;
+#pragma unroll
+    for (int gq = 0; gq < SPE_GPH; ++gq) {
+      const int g = g0 + gq, k0 = 4 * g;
+      if (gq < (gpw >> 1) && g < G) {
+        if (k0 + 3 < bands) *(float4*)(snr + k0) = make_float4(vq[4 * gq], vq[4 * gq + 1], vq[4 * gq + 2], vq[4 * gq + 3]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k0 + e < bands) snr[k0 + e] = vq[4 * gq + e];
+        }
+      }
+    }
   }
   if (wave > 0) {
 #pragma unroll
@@ -143,7 +178,10 @@ __global__ __launch_bounds__(256) void spe_fused_kernel(SpeArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + acc_row(r, lane);
-      const float v = (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]) + bias;
+      float v = acc[r];
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];     // fixed order: waves 1, 2, ...
+      v += bias;
       if (row < a.n) Y[(long long)row * FD + j] = relu_nan(v);
     }
   }
@@ -161,8 +199,8 @@ hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const fl
   SpeArgs a;
   a.labels = labels; a.labels_f = labels != nullptr ? labels_f : nullptr; a.bt = bt;
   a.xs = xs; a.wsT = wsT; a.wsT_ns = wsT_ns; a.bias = bias; a.p_ns = p_ns; a.y = y; a.sn = sn; a.n = n; a.bands = bands;
-  if (bands <= 128) hipLaunchKernelGGL(spe_fused_kernel<16>, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
-  else              hipLaunchKernelGGL(spe_fused_kernel<32>, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
+  if (bands <= 128) hipLaunchKernelGGL(spe_fused_kernel<4>, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
+  else              hipLaunchKernelGGL(spe_fused_kernel<8>, dim3(FD / 32, (n + 31) / 32, nets), dim3(512), 0, st, a);
   return hipGetLastError();
 }
 

@@ -312,20 +312,11 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     if (xspec != nullptr) {
       // raw spectra: augmentation + GEMM + bias + ReLU in one launch (also writes the augmented rows for the
       // weight gradient)
-      if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fused(nets, n, d.bands, *xspec, d_packed + pack_off_wst(d.C), pk_ns,
+      if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fused(nets, n, d.bands, *xspec, d_params + L.param_off[6],
                                    d_params + L.param_off[7], param_stride, w.y, d_sn_out, d_labels, d_labels_f,
                                    xspec->nlab, st))))) return rc;
-    } else if (d_snT != nullptr) {
-      // y[row][o] = relu( sum_band snT[band][row] * wsT[band][o] + b[o] ): both operands k-major, K split over waves
-      GemmTN g;
-      g.A = d_snT; g.a_bstride = (long long)n * d.bands; g.lda = n; g.M = n;
-      g.B = d_packed + pack_off_wst(d.C); g.b_bstride = pk_ns; g.ldb = 1024; g.N = 1024;
-      g.C = w.y; g.c_bstride = (long long)n * 1024; g.ldc = 1024;
-      g.bias = nullptr; g.bias_bstride = 0;
-      g.bias_in = d_params + L.param_off[7]; g.bias_in_bstride = param_stride; g.relu = 1;
-      g.R = d.bands; g.batches = nets; g.scale = 1.f;
-      if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_gemm_tn(g, st))))) return rc;
     } else {
+      // pre-augmented spectra (the nn.Module path): y = relu(sn . W^T + b) from the canonical weight
       if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
                                    d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
     }

@@ -78,9 +78,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
     const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
     v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
   } else if (e < pack_off_w0b3(pi.C, pi.bands)) {
-    const long long i = e - pack_off_wst(pi.C);
-    const int band = (int)(i >> 10), o = (int)(i & 1023);
-    v = P[pi.off_ws + (long long)o * pi.bands + band];
+    v = 0.f;                                           // (former k-major copy of feat_spe.weight: unused region)
   } else {                                           // conv0 as split-bf16 fragments: conv_b3_index(0, k = band, n = co, piece)
     const int i = (int)(e - pack_off_w0b3(pi.C, pi.bands)) * 2;
     const int j = i & 7, l31 = (i >> 3) & 31, h = (i >> 8) & 1, nt = (i >> 9) & 1, rest = i >> 10;
@@ -881,7 +879,7 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   for (int q = 0; q < 16; ++q) {
     const float* wr = wc + (long long)(q < K ? q : K - 1) * F + fb + lane;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) wv0[q][i] = wr[64 * i];
+    for (int i = 0; i < 5; ++i) wv0[q][i] = wr[64 * i];     // (loading only the classes that exist, behind uniform branches, was 1 us slower)
   }
   // 0 = none, 1 = explicit mask, 2 = generate (Philox) and record for the backward pass
   const int dmode = (!a.train || a.dropout_p <= 0.f) ? 0 : (a.dropmask != nullptr ? 1 : 2);

@@ -82,7 +82,7 @@ constexpr int SPE_MAXP = 16;   // MFMA steps (bands per lane half) of a wave
 constexpr int SPE_GPH = 4;     // groups of four bands per lane half
 
 struct SpeArgs {
-  XSrc xs; const float* wsT; long long wsT_ns; const float* bias; long long p_ns;
+  XSrc xs; const float* w; const float* bias; long long p_ns;      // feat_spe.weight [1024][bands] / .bias, canonical
   float* y; float* sn; int n, bands;
   const long long* labels; float* labels_f; int bt;        // optional: labels as float for the exchange buffer
 };
@@ -108,7 +108,10 @@ __global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
   const int ic = iv ? i : 0;
   const float* x = xsrc_row(a.xs, net, ic, bands);
   const float* nz = (a.xs.sigma != 0.f) ? xsrc_noise_row(a.xs, net, ic, bands) : nullptr;
-  const float* bp = a.wsT + (long long)net * a.wsT_ns + j;
+  // this lane's output row of feat_spe.weight: walked along the bands like the input row, 16 bytes at a time (round 2
+  // kept a k-major copy wsT for 128-byte reads across the lanes; with consecutive bands per lane it is not needed, and
+  // the optimizer no longer scatters 2 x 105k four-byte stores into it every step)
+  const float* wrow = a.w + (long long)net * a.p_ns + (long long)j * bands;
   float av[SPE_MAXP], bv[SPE_MAXP], zv[SPE_MAXP];
 #pragma unroll
   for (int gq = 0; gq < SPE_GPH; ++gq) {
@@ -116,23 +119,22 @@ __global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
     const bool gv = gq < (gpw >> 1) && g < G;                    // (uniform per lane half)
     // the row's four bands of this group: one 16-byte load where the whole group exists (rows are only 4-byte aligned:
     // dword-aligned multi-dword loads are fine), band by band for the ragged last group
-    float xa[4] = {0.f, 0.f, 0.f, 0.f}, za[4] = {0.f, 0.f, 0.f, 0.f};
+    float xa[4] = {0.f, 0.f, 0.f, 0.f}, za[4] = {0.f, 0.f, 0.f, 0.f}, wa[4] = {0.f, 0.f, 0.f, 0.f};
     if (gv && k0 + 3 < bands) {
-      const float4 v = *(const float4*)(x + k0);
+      const float4 v = *(const float4*)(x + k0), w4 = *(const float4*)(wrow + k0);
       xa[0] = v.x; xa[1] = v.y; xa[2] = v.z; xa[3] = v.w;
+      wa[0] = w4.x; wa[1] = w4.y; wa[2] = w4.z; wa[3] = w4.w;
       if (nz != nullptr) { const float4 z = *(const float4*)(nz + k0); za[0] = z.x; za[1] = z.y; za[2] = z.z; za[3] = z.w; }
     } else if (gv) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (k0 + e < bands) { xa[e] = x[k0 + e]; if (nz != nullptr) za[e] = nz[k0 + e]; }
+        if (k0 + e < bands) { xa[e] = x[k0 + e]; wa[e] = wrow[k0 + e]; if (nz != nullptr) za[e] = nz[k0 + e]; }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int k = k0 + e;
-      const bool kv = gv && k < bands;
-      const float wb = bp[(long long)(kv ? k : 0) * FD];
+      const bool kv = gv && k0 + e < bands;
       av[4 * gq + e] = (kv && iv) ? xa[e] : 0.f;
-      bv[4 * gq + e] = kv ? wb : 0.f;
+      bv[4 * gq + e] = kv ? wa[e] : 0.f;
       zv[4 * gq + e] = za[e];                                     // parity mode: the reference's own draws
     }
   }
@@ -192,13 +194,13 @@ bool spe_fused_ok(int bands) {
   return !off && bands <= 256;
 }
 
-hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const float* wsT, long long wsT_ns,
+hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const float* w,
                             const float* bias, long long p_ns, float* y, float* sn, const long long* labels,
                             float* labels_f, int bt, hipStream_t st) {
   if (!spe_fused_ok(bands)) return hipErrorInvalidValue;
   SpeArgs a;
   a.labels = labels; a.labels_f = labels != nullptr ? labels_f : nullptr; a.bt = bt;
-  a.xs = xs; a.wsT = wsT; a.wsT_ns = wsT_ns; a.bias = bias; a.p_ns = p_ns; a.y = y; a.sn = sn; a.n = n; a.bands = bands;
+  a.xs = xs; a.w = w; a.bias = bias; a.p_ns = p_ns; a.y = y; a.sn = sn; a.n = n; a.bands = bands;
   if (bands <= 128) hipLaunchKernelGGL(spe_fused_kernel<4>, dim3(FD / 32, (n + 31) / 32, nets), dim3(256), 0, st, a);
   else              hipLaunchKernelGGL(spe_fused_kernel<8>, dim3(FD / 32, (n + 31) / 32, nets), dim3(512), 0, st, a);
   return hipGetLastError();

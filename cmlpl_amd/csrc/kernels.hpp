@@ -22,7 +22,8 @@ constexpr int PACK_CONV = 9 * 64 * 64;       // elements of one 3x3 weight set
 //   conv2_frag_index): the per-sample tail of the fused forward reads them straight from L2;
 //   k-major copies of the two "thin" weights, so that their MFMA B fragments (fixed k, 32 consecutive outputs) are
 //   coalesced 128-B global reads:   w0T [Cp][64] = conv0.weight^T (Cp = C rounded up to even, pad row zero),
-//                                   wsT [bands][1024] = feat_spe.weight^T
+//                                   (wsT [bands][1024] = feat_spe.weight^T: region kept, no longer written or read --
+//                                    the spectral kernels read the canonical tensor, see dense.hip)
 constexpr int PACK_B3 = PACK_CONV * 3 / 2;   // floats occupied by one split weight set
 constexpr int PACK_PER_NET = 4 * PACK_B3 + PACK_CONV;
 __host__ __device__ inline long long pack_off_b3(int /*C*/, int /*bands*/, int which) { return (long long)which * PACK_B3; }
@@ -135,7 +136,7 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
 
 // ---- dense.hip
 bool spe_fused_ok(int bands);
-hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const float* wsT, long long wsT_ns,
+hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const float* w /* feat_spe.weight, canonical */,
                             const float* bias, long long p_ns, float* y, float* sn, const long long* labels,
                             float* labels_f, int bt, hipStream_t st);
 hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const float* w, const float* b,

@@ -35,12 +35,20 @@ __device__ __forceinline__ void adam_conv_chunk(const AdamArgs& a, int chunk, in
   const float* g = a.grads + (long long)net * a.gstride + off;
   float* mm = a.m + (long long)net * a.pstride + off;
   float* vv = a.v + (long long)net * a.pstride + off;
+  // every load of the nine elements first: written load -> update -> store element by element, the stores to m / v / p
+  // may alias the next element's loads as far as the compiler can tell, and the nine become a chain of dependent
+  // memory round trips -- for the 64 chunk workgroups that chain WAS the kernel's duration
+  float gq[9], mq[9], vq[9], pq[9];
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     const int i = tid + 256 * q;
-    float m1 = mm[i], v1 = vv[i];
-    const float pn = adam_update(m1, v1, p[i], g[i], a);
-    mm[i] = m1; vv[i] = v1; p[i] = pn;
+    gq[q] = g[i]; mq[q] = mm[i]; vq[q] = vv[i]; pq[q] = p[i];
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int i = tid + 256 * q;
+    const float pn = adam_update(mq[q], vq[q], pq[q], gq[q], a);
+    mm[i] = mq[q]; vv[i] = vq[q]; p[i] = pn;
     lds[i] = pn;
   }
   if (a.packed == nullptr) return;
@@ -115,13 +123,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
           for (int pc = 0; pc < 3; ++pc) wb[conv_b3_index(0, c, co, pc)] = (uint16_t)pcs[pc];
         }
       }
-    } else if (i4 >= pi.off_ws && i4 < pi.off_ws + 1024LL * pi.bands) { // feat_spe.weight[o][band] -> wsT[band][o]
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long long e = i4 + q - pi.off_ws;
-        if (e < 1024LL * pi.bands) { const int o = (int)(e / pi.bands), band = (int)(e - (long long)o * pi.bands); pkn[pack_off_wst(pi.C) + (long long)band * 1024 + o] = pa[q]; }
-      }
     }
+    // (feat_spe.weight has no packed copy any more: the spectral kernels read the canonical tensor, dense.hip)
   }
 }
 

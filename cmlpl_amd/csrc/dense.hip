@@ -112,6 +112,7 @@ __global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
   // kept a k-major copy wsT for 128-byte reads across the lanes; with consecutive bands per lane it is not needed, and
   // the optimizer no longer scatters 2 x 105k four-byte stores into it every step)
   const float* wrow = a.w + (long long)net * a.p_ns + (long long)j * bands;
+  const float bias = a.bias[(long long)net * a.p_ns + j];      // requested with the rows, used after the fold
   float av[SPE_MAXP], bv[SPE_MAXP], zv[SPE_MAXP];
 #pragma unroll
   for (int gq = 0; gq < SPE_GPH; ++gq) {
@@ -175,7 +176,6 @@ __global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
   }
   __syncthreads();
   if (wave == 0) {
-    const float bias = a.bias[(long long)net * a.p_ns + j];
     float* Y = a.y + (long long)net * a.n * FD;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -388,21 +388,24 @@ __device__ __forceinline__ void bank_write_block(const LossArgs& a, int r) {
   if (r < btu) { s0 = feat_unl(a, 1, r); s1 = feat_unl(a, 0, r); }
   else         { s0 = feat_lab(a, 0, r - btu); s1 = feat_lab(a, 1, r - btu); }
   const float4 v0 = ((const float4*)s0)[tid], v1 = ((const float4*)s1)[tid];
+  const float NEG = -3.0e38f;
+  const bool kv = lane < K;
+  float zs = NEG, zw = NEG;
+  int yl = -1;
+  if (tid < 64) {                                          // requested before the feature stores, not behind them
+    if (r < btu) { if (kv) { zs = logit_unl(a, 0, r)[lane]; zw = logit_unl(a, 1, r)[lane]; } }
+    else yl = label_of(a, r - btu);
+  }
   ((float4*)(a.bank_fw[0] + (long long)d0 * FD))[tid] = v0;
   ((float4*)(a.bank_fw[1] + (long long)d1 * FD))[tid] = v1;
   if (tid < 64) {
-    const bool kv = lane < K;
     float q0, q1;
     if (r < btu) {
-      const float NEG = -3.0e38f;
-      const float zs = kv ? logit_unl(a, 0, r)[lane] : NEG;
-      const float zw = kv ? logit_unl(a, 1, r)[lane] : NEG;
       const float mxs = wave_max(zs), mxw = wave_max(zw);
       const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
       const float ses = wave_sum(es), sew = wave_sum(ew);
       q0 = ew / sew; q1 = es / ses;                      // "probs" (Base1) -> bank0, "probs1" (Base) -> bank1
     } else {
-      const int yl = label_of(a, r - btu);
       q0 = q1 = (lane == yl) ? 1.f : 0.f;
     }
     if (kv) {
@@ -426,9 +429,10 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   if (idx < nlab) {
     const int il = idx, ig = a.lab0 + il;                 // local / global labelled row
     const int yl = label_of(a, ig);
+    const float zin[2] = {kv ? logit_lab(a, 0, ig)[lane] : NEG, kv ? logit_lab(a, 1, ig)[lane] : NEG};   // both before any store
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
-      const float z = kv ? logit_lab(a, net, ig)[lane] : NEG;
+      const float z = zin[net];
       const float mx = wave_max(z);
       const float ez = kv ? expf(z - mx) : 0.f;
       const float se = wave_sum(ez);
@@ -454,6 +458,33 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const int i = idx - nlab, ig = a.unl0 + i;               // local / global unlabelled row
   const float zs = kv ? logit_unl(a, 0, ig)[lane] : NEG;
   const float zw = kv ? logit_unl(a, 1, ig)[lane] : NEG;
+  // The per-column-tile partials of pair_exp_kernel are requested BEFORE the softmax arithmetic (they do not depend on
+  // it; loaded after it, the row paid three memory round trips in a row: logits, row sums, E.p partials).  Lanes are
+  // split into 64/KP groups of KP >= K lanes; group gq takes tiles ct = gq, gq+G, ... for class (lane % KP), LRD loads
+  // of each product in flight at a time.
+  constexpr int LRD = 16;
+  const int CT = (a.Q + 31) >> 5;
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  const int G = 64 / KP, gq = lane / KP, kq = lane - gq * KP;
+  const bool kqv = kq < K;
+  const long long cstride = (long long)nunl * K;
+  const float* e0 = a.ep_part + ((long long)0 * CT * nunl + i) * K + (kqv ? kq : 0);
+  const float* e1 = a.ep_part + ((long long)1 * CT * nunl + i) * K + (kqv ? kq : 0);
+  float t0[LRD], t1[LRD], r0 = 0.f, r1 = 0.f;
+  if (a.smooth) {
+#pragma unroll
+    for (int q = 0; q < LRD; ++q) {
+      const int ct = gq + q * G;
+      const bool ok = ct < CT;
+      const float x0 = e0[(long long)(ok ? ct : 0) * cstride], x1 = e1[(long long)(ok ? ct : 0) * cstride];
+      t0[q] = ok ? x0 : 0.f; t1[q] = ok ? x1 : 0.f;
+    }
+    if (lane < CT) {
+      r0 = a.rs_part[((long long)0 * CT + lane) * nunl + i];
+      r1 = a.rs_part[((long long)1 * CT + lane) * nunl + i];
+    }
+  }
   const float mxs = wave_max(zs), mxw = wave_max(zw);
   const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
   const float ses = wave_sum(es), sew = wave_sum(ew);
@@ -461,34 +492,25 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const float lsms = zs - mxs - logf(ses), lsmw = zw - mxw - logf(sew);  // log_softmax
   float pw = smw, ps = sms;                              // "probs" (Base1) / "probs1" (Base)
   if (a.smooth) {
-    // sum the per-column-tile partials of pair_exp_kernel.  Lanes are split into 64/KP groups of KP >= K
-    // lanes; group gq takes tiles ct = gq, gq+G, ... for class (lane % KP), 8 loads in flight at a time.
-    const int CT = (a.Q + 31) >> 5;
-    float rsw = 0.f, rss = 0.f;
-    for (int ct = lane; ct < CT; ct += 64) {
+    float rsw = r0, rss = r1;
+    for (int ct = lane + 64; ct < CT; ct += 64) {
       rsw += a.rs_part[((long long)0 * CT + ct) * nunl + i];
       rss += a.rs_part[((long long)1 * CT + ct) * nunl + i];
     }
     rsw = wave_sum(rsw); rss = wave_sum(rss);
-    int KP = 1;
-    while (KP < K) KP <<= 1;
-    const int G = 64 / KP, gq = lane / KP, kq = lane - gq * KP;
-    const bool kqv = kq < K;
     float epw = 0.f, eps_ = 0.f;
-    const float* e0 = a.ep_part + ((long long)0 * CT * nunl + i) * K + (kqv ? kq : 0);
-    const float* e1 = a.ep_part + ((long long)1 * CT * nunl + i) * K + (kqv ? kq : 0);
-    const long long cstride = (long long)nunl * K;
-    for (int cb = gq; cb < CT; cb += 8 * G) {
-      float t0[8], t1[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < LRD; ++q) { epw += t0[q]; eps_ += t1[q]; }
+    for (int cb = gq + LRD * G; cb < CT; cb += LRD * G) {      // banks of more than LRD * G column tiles (data parallelism)
+#pragma unroll
+      for (int q = 0; q < LRD; ++q) {
         const int ct = cb + q * G;
         const bool ok = ct < CT;
         const float x0 = e0[(long long)(ok ? ct : 0) * cstride], x1 = e1[(long long)(ok ? ct : 0) * cstride];
         t0[q] = ok ? x0 : 0.f; t1[q] = ok ? x1 : 0.f;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { epw += t0[q]; eps_ += t1[q]; }
+      for (int q = 0; q < LRD; ++q) { epw += t0[q]; eps_ += t1[q]; }
     }
     for (int o = KP; o < 64; o <<= 1) { epw += __shfl_xor(epw, o, 64); eps_ += __shfl_xor(eps_, o, 64); }
     // lanes 0..K-1 (group 0) now hold the full sums for class = lane
@@ -525,12 +547,27 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// N sums at once: one pair of barriers instead of N (the same fold order as block_sum: lanes, then waves 0..3)
+template <int N>
+__device__ __forceinline__ void block_sum_n(float (&v)[N], float* red, int tid) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = wave_sum(v[q]);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) red[(tid >> 6) * N + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = red[q] + red[N + q] + red[2 * N + q] + red[3 * N + q];
+}
+
 // One workgroup per local unlabelled row (under data parallelism a row meets W x more columns; a single wavefront
 // walking them in three passes was 32 us at W = 8): the 256 threads stride the columns, sums are folded per wave
 // and then across the four waves in a fixed order.
 __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // gq[btu], pp[btu]
-  __shared__ float red[4];
+  __shared__ float red[32];
   const int tid = threadIdx.x;
   const int btu = a.btu, K = a.K, i = blockIdx.x;               // local row
   const int ig = a.unl0 + i;                                    // global row (diagonal position)
@@ -551,8 +588,11 @@ __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
     npos += isp ? 1.f : 0.f; nneg += isn ? 1.f : 0.f;
     gq[j] = pos; pp[j] = neg;
   }
-  sQ = block_sum(sQ, red, tid); sN = block_sum(sN, red, tid); R = block_sum(R, red, tid);
-  npos = block_sum(npos, red, tid); nneg = block_sum(nneg, red, tid);
+  {
+    float v5[5] = {sQ, sN, R, npos, nneg};
+    block_sum_n<5>(v5, red, tid);
+    sQ = v5[0]; sN = v5[1]; R = v5[2]; npos = v5[3]; nneg = v5[4];
+  }
   float lp = 0.f, ln = 0.f, gp = 0.f;
   const float inv_btu = 1.f / (float)btu;
   for (int j = tid; j < btu; j += 256) {            // each thread revisits exactly the columns it wrote
@@ -565,7 +605,11 @@ __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
     gp = fmaf(g, P, gp);
     gq[j] = g; pp[j] = P;
   }
-  lp = block_sum(lp, red, tid); ln = block_sum(ln, red, tid); gp = block_sum(gp, red, tid);
+  {
+    float v3[3] = {lp, ln, gp};
+    block_sum_n<3>(v3, red, tid);
+    lp = v3[0]; ln = v3[1]; gp = v3[2];
+  }
   const float scale = a.w_contrast / a.T;
   for (int j = tid; j < btu; j += 256) {
     const float Gij = pp[j] * (gq[j] - gp) * scale;   // softmax backward, then d(sim)/d(f.f/T)

@@ -24,57 +24,61 @@ __device__ __forceinline__ float adam_update(float& mm, float& vv, float p, floa
   return p - a.step_size * (mm / denom);                 // param.addcdiv_(exp_avg, denom, -step_size)
 }
 
-// A 3x3 weight tensor, four output channels (4 x 576 consecutive elements) per workgroup: Adam on 9 elements per
-// thread (coalesced), the updated values meet in LDS, and the split-bf16 fragment sets are written as whole 16-byte
-// (forward: 8 consecutive ci of one (co, tap)) and 8-byte (data gradient: these 4 co of one (ci, tap)) pieces
-// instead of 54 scattered 2-byte stores per thread -- same contents as pack_weights_kernel.
+// A 3x3 weight tensor in chunks of (four output channels) x (sixteen input channels) = 4 segments of 144 consecutive
+// elements per workgroup, 128 chunks per tensor pair and network: Adam on <= 3 elements per thread, the updated values
+// meet in LDS, and the split-bf16 fragment sets are written as whole 16-byte (forward: 8 consecutive ci of one (co, tap))
+// and 8-byte (data gradient: these 4 co of one (ci, tap)) pieces instead of scattered 2-byte stores -- same contents as
+// pack_weights_kernel.  (Round 3: chunks of 4 x 64 input channels, 32 workgroups per network, each with nine elements
+// per thread and three passes over the packing items, were the long pole of the launch: 10 us.)
+constexpr int ADAM_CHUNKS = 2 * 16 * 4;          // (conv1 | conv2) x output-channel quads x input-channel blocks
 __device__ __forceinline__ void adam_conv_chunk(const AdamArgs& a, int chunk, int net, float* lds) {
-  const int which = (chunk >= 16) ? 2 : 0, co0 = (chunk & 15) * 4, tid = threadIdx.x;
-  const long long off = (which == 0 ? a.pi.off_w1 : a.pi.off_w2) + (long long)co0 * 576;
+  const int which = (chunk >= 64) ? 2 : 0, co0 = ((chunk >> 2) & 15) * 4, ci0 = (chunk & 3) * 16, tid = threadIdx.x;
+  const long long off = (which == 0 ? a.pi.off_w1 : a.pi.off_w2) + (long long)co0 * 576 + ci0 * 9;
   float* p = a.params + (long long)net * a.pstride + off;
   const float* g = a.grads + (long long)net * a.gstride + off;
   float* mm = a.m + (long long)net * a.pstride + off;
   float* vv = a.v + (long long)net * a.pstride + off;
-  // every load of the nine elements first: written load -> update -> store element by element, the stores to m / v / p
-  // may alias the next element's loads as far as the compiler can tell, and the nine become a chain of dependent
-  // memory round trips -- for the 64 chunk workgroups that chain WAS the kernel's duration
-  float gq[9], mq[9], vq[9], pq[9];
+  // every load first: with load -> update -> store element by element the stores to m / v / p may alias the next
+  // element's loads as far as the compiler can tell, and the elements become a chain of dependent memory round trips
+  float gq[3], mq[3], vq[3], pq[3];
+  int gi[3];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int i = tid + 256 * q;
+  for (int q = 0; q < 3; ++q) {
+    const int e = tid + 256 * q, j = e / 144, r = e - j * 144;      // segment (output channel), element in it
+    gi[q] = (e < 576) ? j * 576 + r : -1;
+    const int i = gi[q] < 0 ? 0 : gi[q];
     gq[q] = g[i]; mq[q] = mm[i]; vq[q] = vv[i]; pq[q] = p[i];
   }
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int i = tid + 256 * q;
+  for (int q = 0; q < 3; ++q) {
+    if (gi[q] < 0) continue;
     const float pn = adam_update(mq[q], vq[q], pq[q], gq[q], a);
-    mm[i] = mq[q]; vv[i] = vq[q]; p[i] = pn;
-    lds[i] = pn;
+    mm[gi[q]] = mq[q]; vv[gi[q]] = vq[q]; p[gi[q]] = pn;
+    lds[tid + 256 * q] = pn;                                          // [4 co][16 ci][9 taps]
   }
   if (a.packed == nullptr) return;
   __syncthreads();
   float* pkn = a.packed + (long long)net * a.pi.stride;
-  uint4* bf = (uint4*)(pkn + pack_off_b3(a.pi.C, a.pi.bands, which));          // forward set, as 8-bf16 pieces
-  uint2* bd = (uint2*)(pkn + pack_off_b3(a.pi.C, a.pi.bands, which + 1));      // data-gradient set, as 4-bf16 pieces
-  // forward: item = (co, tap, k-step kq, half h) -> ci = 16 kq + 8 h .. + 7
-  for (int it = tid; it < 4 * 9 * 8; it += 256) {
-    const int kqh = it & 7, tap = (it >> 3) % 9, cl = it / 72, co = co0 + cl;
+  if (tid < 72) {
+    // forward set, as 8-bf16 pieces: item = (co, tap, half h) -> ci = ci0 + 8 h .. + 7
+    uint4* bf = (uint4*)(pkn + pack_off_b3(a.pi.C, a.pi.bands, which));
+    const int h = tid & 1, tap = (tid >> 1) % 9, cl = tid / 18, co = co0 + cl;
     uint32_t pc[8][3];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b3_split(lds[cl * 576 + (kqh * 8 + j) * 9 + tap], pc[j]);
+    for (int j = 0; j < 8; ++j) b3_split(lds[cl * 144 + (h * 8 + j) * 9 + tap], pc[j]);
 #pragma unroll
     for (int pcs = 0; pcs < 3; ++pcs)
-      bf[conv_b3_index(tap, kqh * 8, co, pcs) >> 3] =
+      bf[conv_b3_index(tap, ci0 + h * 8, co, pcs) >> 3] =
           make_uint4(pc[0][pcs] | (pc[1][pcs] << 16), pc[2][pcs] | (pc[3][pcs] << 16),
                      pc[4][pcs] | (pc[5][pcs] << 16), pc[6][pcs] | (pc[7][pcs] << 16));
-  }
-  // data gradient (k = co, n = ci, tap flipped): item = (ci, tap) -> these four co
-  for (int it = tid; it < 64 * 9; it += 256) {
-    const int tap = it % 9, ci = it / 9;
+  } else if (tid < 72 + 144) {
+    // data-gradient set (k = co, n = ci, tap flipped), as 4-bf16 pieces: item = (ci, tap) -> these four co
+    uint2* bd = (uint2*)(pkn + pack_off_b3(a.pi.C, a.pi.bands, which + 1));
+    const int it = tid - 72, tap = it % 9, cil = it / 9, ci = ci0 + cil;
     float w4[4];
     uint32_t pc[4][3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { w4[j] = lds[j * 576 + ci * 9 + tap]; b3_split(w4[j], pc[j]); }
+    for (int j = 0; j < 4; ++j) { w4[j] = lds[j * 144 + cil * 9 + tap]; b3_split(w4[j], pc[j]); }
 #pragma unroll
     for (int pcs = 0; pcs < 3; ++pcs)
       bd[conv_b3_index(8 - tap, co0, ci, pcs) >> 2] = make_uint2(pc[0][pcs] | (pc[1][pcs] << 16), pc[2][pcs] | (pc[3][pcs] << 16));
@@ -84,7 +88,7 @@ __device__ __forceinline__ void adam_conv_chunk(const AdamArgs& a, int chunk, in
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * 576];
+  __shared__ __attribute__((aligned(16))) float lds[768];
   const int net = blockIdx.y;
   if ((int)blockIdx.x >= a.nb_elem) { adam_conv_chunk(a, (int)blockIdx.x - a.nb_elem, net, lds); return; }
   const PackInfo& pi = a.pi;
@@ -139,7 +143,7 @@ hipError_t launch_adam(int nets, float* params, long long pstride, const float* 
   a.w1 = (float)(1.0 - (double)b1); a.b2 = b2; a.w2 = (float)(1.0 - (double)b2); a.step_size = step_size;
   a.bc2_sqrt = bc2_sqrt; a.eps = eps; a.packed = (CMLPL_ABL == 40) ? nullptr : packed; a.pi = pi;   // (40: timing of the update alone)
   a.nb_elem = (int)((n4 + 255) / 256);
-  dim3 grid((unsigned)(a.nb_elem + 32), nets);          // + 16 four-channel chunks of conv1.weight, 16 of conv2.weight
+  dim3 grid((unsigned)(a.nb_elem + ADAM_CHUNKS), nets);  // + the (4 co x 16 ci) chunks of conv1.weight and conv2.weight
   hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

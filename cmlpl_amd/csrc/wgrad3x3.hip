@@ -594,16 +594,37 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
     for (int q = 0; q < NRA; ++q)
       if (a_u[q] < (1 << 28)) plane_put(buf, APL, a_dst[q], pa[q]);
     if (d_u < (1 << 28)) {
+      // the four positions of a pooled item's 2x2 window carry the SAME value d / 4, each behind its own gate bit:
+      // split once, then gate the packed pieces (a 16-bit lane mask per channel) -- 4 x (gate, scale, split) before
+      const float q[4] = {pdd.x * 0.25f, pdd.y * 0.25f, pdd.z * 0.25f, pdd.w * 0.25f};
+      uint32_t u0[4], u1[4], u2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u0[j] = __float_as_uint(q[j]);
+        const float r1 = q[j] - __uint_as_float(u0[j] & 0xffff0000u);
+        u1[j] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[j] & 0xffff0000u);
+        u2[j] = __float_as_uint(r2);
+      }
+      const uint2 p0 = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
+      const uint2 p1 = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
+      const uint2 p2 = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
+      char* bpl = buf + 3 * APL;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
-        float4 v;
-        v.x = ((pdm >> sub) & 1u) ? pdd.x * 0.25f : 0.f;
-        v.y = ((pdm >> (8 + sub)) & 1u) ? pdd.y * 0.25f : 0.f;
-        v.z = ((pdm >> (16 + sub)) & 1u) ? pdd.z * 0.25f : 0.f;
-        v.w = ((pdm >> (24 + sub)) & 1u) ? pdd.w * 0.25f : 0.f;
-        plane_put(buf + 3 * APL, BPL, d_dst[sub], v);
-        dbsum.x += v.x; dbsum.y += v.y; dbsum.z += v.z; dbsum.w += v.w;
+        // gate bit of channel j and window position sub: bit 8 j + sub of the mask word -> all-ones / zero
+        const uint32_t s0 = (uint32_t)((int32_t)(pdm << (31 - sub)) >> 31), s1 = (uint32_t)((int32_t)(pdm << (23 - sub)) >> 31);
+        const uint32_t s2 = (uint32_t)((int32_t)(pdm << (15 - sub)) >> 31), s3 = (uint32_t)((int32_t)(pdm << (7 - sub)) >> 31);
+        const uint32_t m01 = (s0 & 0xffffu) | (s1 & 0xffff0000u), m23 = (s2 & 0xffffu) | (s3 & 0xffff0000u);
+        *(uint2*)(bpl + d_dst[sub]) = make_uint2(p0.x & m01, p0.y & m23);
+        *(uint2*)(bpl + BPL + d_dst[sub]) = make_uint2(p1.x & m01, p1.y & m23);
+        *(uint2*)(bpl + 2 * BPL + d_dst[sub]) = make_uint2(p2.x & m01, p2.y & m23);
       }
+      // bias gradient: the value times the number of open gates of its window
+      // (a closed window contributes 0 whatever its value, as the per-position gate did)
+      const uint32_t g0 = pdm & 0xfu, g1 = pdm & 0xf00u, g2 = pdm & 0xf0000u, g3 = pdm & 0xf000000u;
+      dbsum.x += g0 ? q[0] * (float)__popc(g0) : 0.f; dbsum.y += g1 ? q[1] * (float)__popc(g1) : 0.f;
+      dbsum.z += g2 ? q[2] * (float)__popc(g2) : 0.f; dbsum.w += g3 ? q[3] * (float)__popc(g3) : 0.f;
     }
   };
 

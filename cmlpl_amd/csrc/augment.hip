@@ -8,6 +8,10 @@
 //
 // dist_unpack_kernel: re-orders the all-gathered per-rank [logits | feat | labels] blocks into the
 // global row order [labelled of all ranks ; unlabelled of all ranks] the loss kernels expect.
+#ifndef CMLPL_ABL
+#define CMLPL_ABL 0
+#endif
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -139,65 +143,158 @@ hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int
 // out[p][ch][i][j] = cube[mirror(r+i-hw)][mirror(c+j-hw)][ch] for pixel k = idx[p] = r*cols + c, hw = w/2,
 // symmetric (edge-repeating) mirror.  Pure gather, exact.  One workgroup per patch; the w*w x C tile goes
 // through LDS so that the cube is read along its contiguous channel axis and the band-major patch is
-// written along its contiguous pixel axis (odd LDS row stride: conflict-free transpose).
+// written along its contiguous pixel axis.
+//   Gather.  A patch whose columns need no mirroring (all but a 2*hw-wide margin of the image) reads w SPANS of w*C
+// consecutive floats, one per patch row (row mirroring only picks another source row): 16-byte loads, each thread's
+// eight in flight together, i.e. the whole patch in one round trip.  (Round 3 measurements: stores alone run at
+// 5.1 TB/s; pixel by pixel with 4-byte loads -- two wave-instructions per 412-byte pixel, sixteen in flight per wave --
+// the gather alone took 149 of the launch's 167 us, however the patches were ordered.)  Patches on the column margin
+// keep the pixel-by-pixel path.
+//   LDS layout.  C odd: tile[i * RS + j * C + ch], RS = w*C rounded up to 4 floats, so that a span lands with aligned
+// 16-byte LDS writes; the scatter's column reads (lanes = consecutive pixels) see stride C (odd) inside a row.  C even:
+// tile[(i*w + j) * (C+1) + ch], the padded layout (odd pixel stride); span elements are placed one by one.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void extract_patches_kernel(const float* __restrict__ cube, int rows, int cols, int C,
                                                               int w, const long long* __restrict__ idx, int n,
                                                               float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long k = idx[p];
-  const int r = (int)(k / cols), c = (int)(k - (long long)r * cols), hw = w >> 1, ww = w * w, CP = C | 1;
-  // gather: a wave takes whole pixels (its (i, j), the mirrored source pixel and its address are wave-uniform: scalar
-  // arithmetic, no per-element division), lanes = channels: the cube is read along its contiguous channel axis, 256
-  // consecutive bytes per wave-instruction.
-  // (eight waves per workgroup) EIGHT pixels of a wave are in flight at once (16 loads per lane for C <= 128): one pixel at a time the gather
-  // is a chain of ~30 dependent memory round trips per workgroup (measured: 1.5 TB/s written)
-  constexpr int PB = 8;
-  for (int pix0 = wave; pix0 < ww; pix0 += 8 * PB) {
-    for (int ch0 = 0; ch0 < C; ch0 += 128) {
-      float v[PB][2];
+  const int hw = w >> 1, ww = w * w;
+  const bool codd = (C & 1) != 0;
+  const int NF = w * C;                               // floats of one patch row (span)
+  const int RS = codd ? ((NF + 3) & ~3) : w * (C + 1);   // LDS floats per patch row
+  const int CS = codd ? C : C + 1;                    // LDS floats per pixel
+  const int n4 = NF >> 2, NI = w * n4, rem = NF & 3;  // 16-byte items per row / per patch; floats beyond them per row
+  const float inv4 = 1.0f / (float)(n4 > 0 ? n4 : 1), invC = 1.0f / (float)C;
+  constexpr int GB = 8;                               // 16-byte items per thread in one batch (one batch covers w*C <= 16 K floats)
+  // (Gather alone and scatter alone take 84 and 80 us for the 8192-patch case -- each 408 MB at ~5 TB/s -- and the
+  // launch 139 us: reads + writes together are at the HBM rate.  Persistent workgroups that keep the NEXT patch's loads in
+  // flight across this patch's stores were slower, 149 us: two instead of three workgroups per CU for the registers.)
+  float4 v[GB];
+  float vt = 0.f;
+  int r = 0, c = 0;
+  bool interior = false;
+  // fetch(p): request patch p's spans (first batch and the row tails); margin patches are gathered in put()
+  auto fetch = [&](int p) {
+    const long long k = idx[p];
+    r = (int)(k / cols); c = (int)(k - (long long)r * cols);
+    interior = (c - hw >= 0) && (c - hw + w <= cols) && CMLPL_ABL != 50;      // workgroup-uniform
+    if (!interior) return;
 #pragma unroll
-      for (int q = 0; q < PB; ++q) {
-        const int pix = pix0 + 8 * q, pc = pix < ww ? pix : 0;                      // wave-uniform
-        const int i = pc / w, j = pc - i * w;
-        int rr = r + i - hw, cc = c + j - hw;
-        rr = rr < 0 ? -rr - 1 : (rr >= rows ? 2 * rows - 1 - rr : rr);
-        cc = cc < 0 ? -cc - 1 : (cc >= cols ? 2 * cols - 1 - cc : cc);
-        const float* src = cube + ((long long)rr * cols + cc) * C;
+    for (int q = 0; q < GB; ++q) {
+      const int t = tid + 512 * q, tc = t < NI ? t : 0;
+      // row of the item: exact for t < 2^22 / n4 (the quotient is at least 0.5 / n4 away from an integer)
+      const int i = (int)(((float)tc + 0.5f) * inv4), e4 = tc - i * n4;
+      int rr = r + i - hw;
+      rr = rr < 0 ? -rr - 1 : (rr >= rows ? 2 * rows - 1 - rr : rr);
+      v[q] = *(const float4*)(cube + ((long long)rr * cols + (c - hw)) * C + 4 * e4);
+    }
+    if (tid < w * rem) {
+      const int i = tid / rem, e = (NF & ~3) + (tid - i * rem);
+      int rr = r + i - hw;
+      rr = rr < 0 ? -rr - 1 : (rr >= rows ? 2 * rows - 1 - rr : rr);
+      vt = cube[((long long)rr * cols + (c - hw)) * C + e];
+    }
+  };
+  auto put_item = [&](int i, int e0, const float4& x4) {
+    if (codd) {
+      *(float4*)(tile + i * RS + e0) = x4;
+    } else {
+      int j = (int)(((float)e0 + 0.5f) * invC), ch = e0 - j * C;
+      const float x[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { const int ch = ch0 + 64 * h + lane; v[q][h] = src[ch < C ? ch : 0]; }
+      for (int e = 0; e < 4; ++e) {
+        tile[i * RS + j * CS + ch] = x[e];
+        if (++ch == C) { ch = 0; ++j; }
       }
+    }
+  };
+  // put(): the fetched patch -> LDS tile
+  auto put = [&]() {
+    if (interior) {
 #pragma unroll
-      for (int q = 0; q < PB; ++q) {
-        const int pix = pix0 + 8 * q;
-        if (pix < ww) {
+      for (int q = 0; q < GB; ++q) {
+        const int t = tid + 512 * q;
+        if (t < NI) { const int i = (int)(((float)t + 0.5f) * inv4); put_item(i, 4 * (t - i * n4), v[q]); }
+      }
+      for (int t = 512 * GB + tid; t < NI; t += 512) {            // rows beyond one batch (w*C > 16 K floats): not pipelined
+        const int i = (int)(((float)t + 0.5f) * inv4), e4 = t - i * n4;
+        int rr = r + i - hw;
+        rr = rr < 0 ? -rr - 1 : (rr >= rows ? 2 * rows - 1 - rr : rr);
+        put_item(i, 4 * e4, *(const float4*)(cube + ((long long)rr * cols + (c - hw)) * C + 4 * e4));
+      }
+      if (tid < w * rem) {
+        const int i = tid / rem, e = (NF & ~3) + (tid - i * rem);
+        const int j = e / C, ch = e - j * C;
+        tile[i * RS + j * CS + ch] = vt;
+      }
+    } else if (CMLPL_ABL != 50) {
+      // column margin: a wave takes whole pixels (its (i, j), the mirrored source pixel and its address are
+      // wave-uniform), lanes = channels, eight pixels of a wave in flight at once
+      constexpr int PB = 8;
+      for (int pix0 = wave; pix0 < ww; pix0 += 8 * PB) {
+        for (int ch0 = 0; ch0 < C; ch0 += 128) {
+          float x[PB][2];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) { const int ch = ch0 + 64 * h + lane; if (ch < C) tile[pix * CP + ch] = v[q][h]; }
+          for (int q = 0; q < PB; ++q) {
+            const int pix = pix0 + 8 * q, pc = pix < ww ? pix : 0;                      // wave-uniform
+            const int i = pc / w, j = pc - i * w;
+            int rr = r + i - hw, cc = c + j - hw;
+            rr = rr < 0 ? -rr - 1 : (rr >= rows ? 2 * rows - 1 - rr : rr);
+            cc = cc < 0 ? -cc - 1 : (cc >= cols ? 2 * cols - 1 - cc : cc);
+            const float* src = cube + ((long long)rr * cols + cc) * C;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const int ch = ch0 + 64 * h + lane; x[q][h] = src[ch < C ? ch : 0]; }
+          }
+#pragma unroll
+          for (int q = 0; q < PB; ++q) {
+            const int pix = pix0 + 8 * q;
+            if (pix < ww) {
+              const int i = pix / w, j = pix - i * w;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) { const int ch = ch0 + 64 * h + lane; if (ch < C) tile[i * RS + j * CS + ch] = x[q][h]; }
+            }
+          }
         }
       }
     }
-  }
+  };
+  // (Handing each XCD one contiguous eighth of a SORTED index list, so that the overlapping windows of its resident
+  // patches would be re-read from its own L2, changed nothing: 137 vs 140 us.  The cube is not what the launch waits for.)
+  const int p = blockIdx.x;
+  fetch(p);
+  put();
   __syncthreads();
-  // scatter: a wave takes whole bands, lanes = pixels: the band-major patch is written along its contiguous pixel axis
-  // (256 consecutive bytes per wave-instruction; the LDS column reads are conflict-free, the row stride CP is odd)
+  // scatter: a wave takes whole bands, lanes = pixels: the band-major patch is written along its contiguous pixel
+  // axis (256 consecutive bytes per wave-instruction)
   float* o = out + (long long)p * C * ww;
-  for (int ch = wave; ch < C; ch += 8) {
-    float* orow = o + (long long)ch * ww;
-    for (int px0 = 0; px0 < ww; px0 += 256) {
-      float v[4];
+  for (int px0 = 0; px0 < ww; px0 += 256) {
+    int po[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int pix = px0 + 64 * q + lane; v[q] = tile[(pix < ww ? pix : 0) * CP + ch]; }
+    for (int q = 0; q < 4; ++q) {
+      const int pix = px0 + 64 * q + lane, pc = pix < ww ? pix : 0, i = pc / w;
+      po[q] = i * RS + (pc - i * w) * CS;
+    }
+    for (int ch = wave; ch < C; ch += 8) {
+      float* orow = o + (long long)ch * ww;
+      float x[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int pix = px0 + 64 * q + lane; if (pix < ww) orow[pix] = v[q]; }
+      for (int q = 0; q < 4; ++q) x[q] = tile[po[q] + ch];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int pix = px0 + 64 * q + lane; if (pix < ww && (CMLPL_ABL != 51 || x[q] == 123.456f)) orow[pix] = x[q]; }
     }
   }
 }
 
+static size_t extract_lds(int C, int w) {
+  const size_t rs = (C & 1) ? (size_t)((w * C + 3) & ~3) : (size_t)w * (C + 1);
+  return (size_t)w * rs * 4;
+}
+
 hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, int w, const long long* idx, int n,
                                   float* out, hipStream_t st) {
-  const size_t lds = (size_t)w * w * (C | 1) * 4;
+  const size_t lds = extract_lds(C, w);
   if (lds > LDS_MAX) return hipErrorInvalidValue;
   static DevOnce attr_once;
   {

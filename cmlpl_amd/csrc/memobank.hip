@@ -8,6 +8,8 @@
 // Memory bank of one class: a physical ring [cap][D] with (rows, head); LOGICAL row i -- what the reference's
 // `queue[0][i]` holds after its cat + [-size:] -- is ring slot (head + i) % cap.  The reference copies the whole
 // bank on every call; the ring writes only the new keys.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -605,6 +607,178 @@ __global__ __launch_bounds__(256) void mb_infonce_all_kernel(MbLoss a) {
   }
 }
 
+// The same computation with the metadata in ONE round trip and the keys in REGISTERS (round 3; the default where it
+// fits: D a multiple of 4 and <= 1024, K <= 64, ceil(NK / 4) * ceil(D / 256) <= 16 -- the reference's 50 negatives of
+// 256 floats take 13 of the 16 slots).  The kernel above is a chain of ~8 dependent memory round trips per workgroup
+// (counts -> ring state -> anchor pool -> anchor row -> four batches of keys), and with the gathered keys kept in LDS
+// only three workgroups share a CU: 72 us for 120 MB of gathers.  Here every wave (a) reads the counts, ring states and
+// capacities of all classes at once (lane = class) and picks what it needs with a shuffle, (b) forms the addresses of
+// ITS keys j = wave, wave + 4, ... itself (lane t draws key t; no table in LDS, no barrier) and requests all of them --
+// one 16-byte load per lane and 256 floats of key -- before the anchor's pool entry and row are even known, (c) keeps
+// them in registers for the gradient pass: partial sum_j w_j k_j per wave, folded through 4 x D floats of LDS.  Same
+// draws (injected or Philox), same per-key dot products bit for bit; |a|^2 and the gradient sum fold in another order.
+template <int NCH>
+__global__ __launch_bounds__(256) void mb_infonce_fast_kernel(MbLoss a) {
+  constexpr int KW = 16 / NCH;                    // keys per wave
+  __shared__ float s_dot[MB_MAXKEYS], s_kn[MB_MAXKEYS];
+  extern __shared__ __attribute__((aligned(16))) float s_red[];   // [4][D]
+  const int q = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = a.D, D4 = D >> 2, NN = a.NN, NK = NN + 1, Q = a.Q, K = a.K;
+  const int slot = i * Q + q;
+  // (a) everything the draws depend on, one round trip
+  const bool cv = lane < K;
+  const int cnt0 = cv ? a.counts[lane * 3] : 0;
+  const int st_rows = cv ? a.state[lane * 2] : 0, st_head = cv ? a.state[lane * 2 + 1] : 0, st_cap = cv ? a.caps[lane] : 1;
+  const int pool_rows = a.counts[i * 3 + 1];         // position i's anchor pool (the reference's quirk, :158-168)
+  unsigned long long vm = __ballot(cv && cnt0 > 0);  // valid classes (loss_helper.py:139-145), in class order
+  const int nv = __popcll(vm);
+  if (nv <= 1 || i >= nv) {                          // no such loop position
+    if (tid == 0) { a.lossq[slot] = 0.f; a.arow[slot] = -1; }
+    return;
+  }
+  for (int s_ = 0; s_ < i; ++s_) vm &= vm - 1;
+  const int vc = __ffsll((long long)vm) - 1;
+  const int rows = __shfl(st_rows, vc, 64), head = __shfl(st_head, vc, 64), cap = __shfl(st_cap, vc, 64);
+  if (pool_rows == 0 || rows == 0) {                 // :158-172
+    if (tid == 0) { a.lossq[slot] = 0.f; a.arow[slot] = -1; }
+    return;
+  }
+  const float scale = 1.f / (float)nv;
+  const float* bank_c = a.bank + (size_t)vc * a.cap_stride * D;
+  // (b) this wave's keys: lane t owns key j = wave + 4 t
+  const int jt = wave + 4 * lane;
+  int krow = 0;
+  if (lane < KW && jt >= 1 && jt < NK) {
+    long long r;
+    if (a.neg_draw != nullptr) {
+      r = a.neg_draw[(size_t)i * Q * NN + (size_t)q * NN + (jt - 1)];
+      r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+    } else {
+      const int jj = jt - 1;
+      const float4 u = philox_uniform4(a.seed, a.call, 0x500 + i, (uint64_t)q * 64 + (jj >> 2));
+      const float uu = (jj & 3) == 0 ? u.x : (jj & 3) == 1 ? u.y : (jj & 3) == 2 ? u.z : u.w;
+      r = (long long)(uu * (float)rows);
+      if (r >= rows) r = rows - 1;
+    }
+    krow = (int)(((long long)head + r) % cap);
+  }
+  float4 kv[KW][NCH];
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    const int j = wave + 4 * t;                      // wave-uniform
+    const float4* k4 = (const float4*)(bank_c + (size_t)__builtin_amdgcn_readlane(krow, t) * D);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int d4 = lane + 64 * c;
+      kv[t][c] = (j >= 1 && j < NK && d4 < D4) ? k4[d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // the anchor (the draw is the same in every lane)
+  long long ad;
+  if (a.anchor_draw != nullptr) {                    // injected (the caller validates the range; clamp for safety)
+    ad = a.anchor_draw[(size_t)i * Q + q];
+    ad = ad < 0 ? 0 : (ad >= pool_rows ? pool_rows - 1 : ad);
+  } else {
+    const float4 u = philox_uniform4(a.seed, a.call, 0x400 + i, (uint64_t)q);
+    ad = (long long)(u.x * (float)pool_rows);
+    if (ad >= pool_rows) ad = pool_rows - 1;
+  }
+  const int arow = (a.lists + ((size_t)i * 3 + 1) * a.N)[ad];
+  const float4* av4 = (const float4*)(a.rep + (size_t)arow * D);
+  float4 a4[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { const int d4 = lane + 64 * c; a4[c] = d4 < D4 ? av4[d4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  // positive key (j = 0, wave 0): the class prototype of POSITION i (:186-192), blended with the momentum prototype (:194-203)
+  if (wave == 0) {
+    const float4* pr = (const float4*)(a.proto + (size_t)i * D);
+    const bool blend = a.momentum != nullptr && *a.momentum_on != 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int d4 = lane + 64 * c;
+      if (d4 < D4) {
+        float4 v = pr[d4];
+        if (blend) {
+          const float4 m = ((const float4*)(a.momentum + ((size_t)vc * Q + q) * D))[d4];
+          v.x = (1.f - a.ema) * v.x + a.ema * m.x; v.y = (1.f - a.ema) * v.y + a.ema * m.y;
+          v.z = (1.f - a.ema) * v.z + a.ema * m.z; v.w = (1.f - a.ema) * v.w + a.ema * m.w;
+        }
+        kv[0][c] = v;
+        if (a.prototype != nullptr) ((float4*)(a.prototype + ((size_t)vc * Q + q) * D))[d4] = v;
+      }
+    }
+  }
+  // a . k and |k|^2 of this wave's keys (lane t keeps key t's pair), |a|^2 (every wave forms it: no exchange)
+  float mydt = 0.f, mykn = 1.f;
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    const int j = wave + 4 * t;
+    if (j < NK) {                                    // wave-uniform
+      float dt = 0.f, kn = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float4 k = kv[t][c], x = a4[c];
+        dt += x.x * k.x; kn += k.x * k.x; dt += x.y * k.y; kn += k.y * k.y;
+        dt += x.z * k.z; kn += k.z * k.z; dt += x.w * k.w; kn += k.w * k.w;
+      }
+      dt = wave_sum(dt); kn = wave_sum(kn);
+      if (lane == t) { mydt = dt; mykn = fmaxf(sqrtf(kn), 1e-8f); }
+    }
+  }
+  if (lane < KW && jt < NK) { s_dot[jt] = mydt; s_kn[jt] = mykn; }
+  float an2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) an2 += (a4[c].x * a4[c].x + a4[c].y * a4[c].y) + (a4[c].z * a4[c].z + a4[c].w * a4[c].w);
+  const float an = sqrtf(wave_sum(an2));
+  const float anc = fmaxf(an, 1e-8f);
+  __syncthreads();
+  // softmax over the NK logits (NK <= 128: two per lane), formed by every wave for itself
+  float l0 = -3.0e38f, l1 = -3.0e38f, c0 = 0.f, c1 = 0.f, kn0 = 1.f, kn1 = 1.f;
+  if (lane < NK) { kn0 = s_kn[lane]; c0 = s_dot[lane] / (anc * kn0); l0 = c0 / a.temp; }
+  if (lane + 64 < NK) { kn1 = s_kn[lane + 64]; c1 = s_dot[lane + 64] / (anc * kn1); l1 = c1 / a.temp; }
+  const float mx = wave_max(fmaxf(l0, l1));
+  const float e0 = lane < NK ? expf(l0 - mx) : 0.f, e1 = lane + 64 < NK ? expf(l1 - mx) : 0.f;
+  const float se = wave_sum(e0 + e1);
+  const float first = __shfl(l0, 0, 64);
+  const float g = scale / ((float)Q * a.temp);
+  const float w0 = (e0 / se - (lane == 0 ? 1.f : 0.f)) * g, w1 = (e1 / se) * g;
+  float wc = 0.f, sw0 = 0.f, sw1 = 0.f;
+  if (lane < NK) { sw0 = w0 / (anc * kn0); wc += w0 * c0; }
+  if (lane + 64 < NK) { sw1 = w1 / (anc * kn1); wc += w1 * c1; }
+  wc = wave_sum(wc);
+  if (tid == 0) {
+    a.lossq[slot] = (mx + logf(se) - first) * scale / (float)Q;
+    a.arow[slot] = arow;
+  }
+  const float selfc = (wc / (anc * anc)) * ((an >= 1e-8f) ? 1.f : 0.f);
+  // (c) gradient wrt the anchor: this wave's keys from registers, the four partial sums through LDS
+  float4 gs[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) gs[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    const int j = wave + 4 * t;
+    if (j < NK) {
+      const float w = (j < 64) ? __shfl(sw0, j, 64) : __shfl(sw1, j - 64, 64);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        gs[c].x += w * kv[t][c].x; gs[c].y += w * kv[t][c].y; gs[c].z += w * kv[t][c].z; gs[c].w += w * kv[t][c].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { const int d4 = lane + 64 * c; if (d4 < D4) ((float4*)(s_red + (size_t)wave * D))[d4] = gs[c]; }
+  __syncthreads();
+  float4* go = (float4*)(a.ganchor + (size_t)slot * D);
+  for (int d4 = tid; d4 < D4; d4 += 256) {
+    const float4 r0 = ((const float4*)s_red)[d4], r1 = ((const float4*)(s_red + D))[d4];
+    const float4 r2 = ((const float4*)(s_red + 2 * (size_t)D))[d4], r3 = ((const float4*)(s_red + 3 * (size_t)D))[d4];
+    const float4 x = av4[d4];
+    go[d4] = make_float4(((r0.x + r1.x) + (r2.x + r3.x)) - selfc * x.x, ((r0.y + r1.y) + (r2.y + r3.y)) - selfc * x.y,
+                         ((r0.z + r1.z) + (r2.z + r3.z)) - selfc * x.z, ((r0.w + r1.w) + (r2.w + r3.w)) - selfc * x.w);
+  }
+}
+
 // d rep[row] = sum of the anchor gradients of ALL (position, query) slots that drew that row, in slot order
 // (deterministic).  One workgroup per ROW of rep: it collects the slots that drew its row by an ordered compaction
 // of the slot -> row table and writes its row of drep in full (zeros when nobody drew it).  The extra last
@@ -613,12 +787,17 @@ __global__ __launch_bounds__(256) void mb_scatter_all_kernel(MbLoss a, int slots
   extern __shared__ int s_hit[];                  // ordered list of the slots that drew this row
   __shared__ int wtot[4], s_n;
   const int r = blockIdx.x, tid = threadIdx.x, D = a.D, lane = tid & 63, wave = tid >> 6;
-  if (r == a.N) {                                 // total loss
-    if (tid == 0) {
-      float t = 0.f;
-      for (int i = 0; i < slots; ++i) t += a.lossq[i];
-      a.total[0] = t;
+  if (r == a.N) {                                 // total loss, in a fixed order: thread t takes slots t, t + 256, ...,
+    __shared__ float s_tot[256];                  // then the 256 partial sums fold as a tree.  (One thread adding all
+    float t = 0.f;                                // K * Q values one load after the other WAS the launch: 93 us.)
+    for (int i = tid; i < slots; i += 256) t += a.lossq[i];
+    s_tot[tid] = t;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+      if (tid < h) s_tot[tid] += s_tot[tid + h];
+      __syncthreads();
     }
+    if (tid == 0) a.total[0] = s_tot[0];
     return;
   }
   if (tid == 0) s_n = 0;
@@ -640,7 +819,15 @@ __global__ __launch_bounds__(256) void mb_scatter_all_kernel(MbLoss a, int slots
   const int nh = s_n;
   for (int d = tid; d < D; d += 256) {
     float sum = 0.f;
-    for (int k = 0; k < nh; ++k) sum += a.ganchor[(size_t)s_hit[k] * D + d];
+    int k = 0;
+    for (; k + 8 <= nh; k += 8) {                 // eight rows in flight, added in slot order
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = a.ganchor[(size_t)s_hit[k + e] * D + d];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[e];
+    }
+    for (; k < nh; ++k) sum += a.ganchor[(size_t)s_hit[k] * D + d];
     a.drep[(size_t)r * D + d] = sum;
   }
 }
@@ -651,12 +838,20 @@ hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   {
-    // gathered keys in LDS when they fit beside the positive key with three workgroups per CU
-    MbLoss lb = la;
-    const size_t keys_bytes = (size_t)(la.NN + 1) * la.D * 4;
-    lb.keys_lds = (la.D % 4 == 0 && la.D <= 1024 && keys_bytes + (size_t)la.D * 4 <= 52 * 1024 + 2048) ? 1 : 0;
-    const size_t lds = (size_t)la.D * 4 + (lb.keys_lds ? keys_bytes : 0);     // <= 55 KB: inside the default limit
-    hipLaunchKernelGGL(mb_infonce_all_kernel, dim3(la.Q, la.K), dim3(256), lds, st, lb);
+    // keys in registers where they fit (mb_infonce_fast_kernel), else the general kernel (keys re-read from L2)
+    const int NK = la.NN + 1, nch = (la.D / 4 + 63) / 64;
+    const bool fast = la.D % 4 == 0 && la.D >= 4 && la.D <= 1024 && la.K <= 64 && ((NK + 3) / 4) * nch <= 16 &&
+                      !(getenv("CMLPL_MB_FAST") && atoi(getenv("CMLPL_MB_FAST")) == 0);
+    const size_t lds = (size_t)4 * la.D * 4;
+    if (fast && nch == 1) hipLaunchKernelGGL(mb_infonce_fast_kernel<1>, dim3(la.Q, la.K), dim3(256), lds, st, la);
+    else if (fast && nch == 2) hipLaunchKernelGGL(mb_infonce_fast_kernel<2>, dim3(la.Q, la.K), dim3(256), lds, st, la);
+    else if (fast && nch == 3) hipLaunchKernelGGL(mb_infonce_fast_kernel<3>, dim3(la.Q, la.K), dim3(256), lds, st, la);
+    else if (fast && nch == 4) hipLaunchKernelGGL(mb_infonce_fast_kernel<4>, dim3(la.Q, la.K), dim3(256), lds, st, la);
+    else {
+      MbLoss lb = la;
+      lb.keys_lds = 0;
+      hipLaunchKernelGGL(mb_infonce_all_kernel, dim3(la.Q, la.K), dim3(256), (size_t)la.D * 4, st, lb);
+    }
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
   const int slots = la.K * la.Q;

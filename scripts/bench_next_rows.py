@@ -48,6 +48,10 @@ def n3():
     gb = out.numel() * 4 / 1e9
     print(f"N3 patch extraction, 8192 patches of {w}x{w}x{C} from a {H}x{W}x{C} cube: {dt * 1e6:.1f} us = "
           f"{gb / dt:.0f} GB/s written (HBM roofline ~8000 GB/s; reads are cached gathers)")
+    if os.environ.get("N3_SORTED"):           # what locality is worth: the same patches in raster order
+        ids = torch.sort(idx).values
+        dt = timeit(lambda: extract_patches(cube, ids, w, out=out))
+        print(f"N3 (indices sorted by the caller): {dt * 1e6:.1f} us = {gb / dt:.0f} GB/s written")
 
 
 def n4():
@@ -105,5 +109,7 @@ def n2():
 
 
 if __name__ == "__main__":
+    want = sys.argv[1:]                       # e.g. `bench_next_rows.py n2 n3`; default: all
     for f in (n1, n3, n4, n2):
-        f()
+        if not want or f.__name__ in want:
+            f()

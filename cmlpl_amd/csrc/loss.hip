@@ -232,6 +232,144 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   }
 }
 
+// 16-row variant of pair_exp_kernel for K <= 32 (the default): one workgroup per 16 x 32 tile on v_mfma_f32_16x16x4_f32
+// (two column blocks), same K split over the four waves, same per-column-tile partials.  At B2 the 32 x 32 tiling makes
+// 336 equal workgroups for 256 CUs -- 80 CUs get two and set the pace; 672 half-size workgroups spread as 3 / 2 per CU.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void pair_exp16_kernel(LossArgs a) {
+  constexpr int WT = 48 * PT;                                        // per-wave staging: A [16][PT] + B [32][PT]
+  __shared__ __attribute__((aligned(16))) float lds[4 * WT];         // later reused as red[4][8][64], then E / p tiles
+  float (*red)[8][64] = (float (*)[8][64])lds;
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prob = blockIdx.z;
+  if (prob < 2 && !a.smooth) return;
+  const int btu = a.btu, nunl = a.nunl, K = a.K;
+  const float* A = feat_unl(a, prob == 0 ? 1 : 0, a.unl0);        // local rows (one rank's block: contiguous)
+  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : nullptr;   // prob 2: fU_w, all rows
+  const int NB = (prob < 2) ? a.Q : btu;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 32;
+  if (c0 >= NB || r0 >= nunl) return;
+  float* tA = lds + wave * WT;
+  float* tB = tA + 16 * PT;
+  // the bank-probability tile [32 columns][K] of the epilogue, requested now (K <= 32: at most 4 values per thread)
+  float pq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (prob < 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 256 * q, c = i / K;
+      if (i < 32 * K && c0 + c < NB) pq[q] = a.bank_p[prob][(long long)(c0 + c) * K + (i - c * K)];
+    }
+  }
+  // loader role: lane -> (row group r8 = lane>>3, 16-byte chunk c8 = lane&7); load j covers rows 8j + r8
+  const int r8 = lane >> 3, c8 = lane & 7;
+  const long long ko = wave * 256 + c8 * 4;
+#define CMLPL_ROWPTR(base, r, lim) ((base) + (long long)((r) < (lim) ? (r) : 0) * FD + ko)
+#define CMLPL_BROW(r) ((B != nullptr ? B + (long long)((r) < NB ? (r) : 0) * FD : feat_unl(a, 1, (r) < NB ? (r) : 0)) + ko)
+  const float* la0 = CMLPL_ROWPTR(A, r0 + r8, nunl);
+  const float* la1 = CMLPL_ROWPTR(A, r0 + 8 + r8, nunl);
+  const float* lb0 = CMLPL_BROW(c0 + r8);
+  const float* lb1 = CMLPL_BROW(c0 + 8 + r8);
+  const float* lb2 = CMLPL_BROW(c0 + 16 + r8);
+  const float* lb3 = CMLPL_BROW(c0 + 24 + r8);
+#undef CMLPL_BROW
+#undef CMLPL_ROWPTR
+  // lines are requested THREE ahead (a ring of four register sets, the loop fully unrolled so that the compiler counts
+  // the outstanding loads): a line is only 16 MFMAs per wave, a bank row comes from HBM / the Infinity Cache, and one
+  // line of look-ahead made every line wait out most of a memory round trip (8 round trips per workgroup)
+  // (named register sets, pasted by macro: arrays indexed by the line number end up in scratch even when unrolled)
+#define CMLPL_DECL(S) float4 a0##S, a1##S, b0##S, b1##S, b2##S, b3##S;
+  CMLPL_DECL(_p) CMLPL_DECL(_q) CMLPL_DECL(_r) CMLPL_DECL(_s)
+#undef CMLPL_DECL
+#define CMLPL_LOADLINE(S, LN)                                                                              \
+  { const int o_ = (LN) * 32;                                                                              \
+    a0##S = *(const float4*)(la0 + o_); a1##S = *(const float4*)(la1 + o_);                                \
+    b0##S = *(const float4*)(lb0 + o_); b1##S = *(const float4*)(lb1 + o_);                                \
+    b2##S = *(const float4*)(lb2 + o_); b3##S = *(const float4*)(lb3 + o_); }
+  CMLPL_LOADLINE(_p, 0) CMLPL_LOADLINE(_q, 1) CMLPL_LOADLINE(_r, 2)
+  __builtin_amdgcn_sched_barrier(0);
+  float* wA = tA + r8 * PT + c8 * 4;
+  float* wB = tB + r8 * PT + c8 * 4;
+  const float* rA = tA + l16 * PT + kq * 8;      // lane group kq owns floats [8kq, 8kq+8) of the line
+  const float* rB = tB + l16 * PT + kq * 8;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#define CMLPL_M2(XA, YB, ZB)                                                                 \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA, YB, acc0, 0, 0, 0);                      \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA, ZB, acc1, 0, 0, 0);
+  // one line: request line LN + 3 into set N (free since line LN - 1), stage set C, multiply
+#define CMLPL_LINE(LN, C, N)                                                                 \
+  {                                                                                          \
+    if ((LN) + 3 < 8) CMLPL_LOADLINE(N, (LN) + 3)                                            \
+    __builtin_amdgcn_sched_barrier(0);   /* the scheduler would sink the loads to save registers */ \
+    *(float4*)(wA) = a0##C; *(float4*)(wA + 8 * PT) = a1##C;                                 \
+    *(float4*)(wB) = b0##C; *(float4*)(wB + 8 * PT) = b1##C;                                 \
+    *(float4*)(wB + 16 * PT) = b2##C; *(float4*)(wB + 24 * PT) = b3##C;                      \
+    const float4 x0 = *(const float4*)(rA), x1 = *(const float4*)(rA + 4);                   \
+    const float4 y0 = *(const float4*)(rB), y1 = *(const float4*)(rB + 4);                   \
+    const float4 z0 = *(const float4*)(rB + 16 * PT), z1 = *(const float4*)(rB + 16 * PT + 4); \
+    CMLPL_M2(x0.x, y0.x, z0.x) CMLPL_M2(x0.y, y0.y, z0.y) CMLPL_M2(x0.z, y0.z, z0.z) CMLPL_M2(x0.w, y0.w, z0.w) \
+    CMLPL_M2(x1.x, y1.x, z1.x) CMLPL_M2(x1.y, y1.y, z1.y) CMLPL_M2(x1.z, y1.z, z1.z) CMLPL_M2(x1.w, y1.w, z1.w) \
+  }
+  CMLPL_LINE(0, _p, _s) CMLPL_LINE(1, _q, _p) CMLPL_LINE(2, _r, _q) CMLPL_LINE(3, _s, _r)
+  CMLPL_LINE(4, _p, _s) CMLPL_LINE(5, _q, _p) CMLPL_LINE(6, _r, _q) CMLPL_LINE(7, _s, _r)
+#undef CMLPL_LINE
+#undef CMLPL_M2
+#undef CMLPL_LOADLINE
+  __syncthreads();                               // every wave is done with its staging tile: reuse as `red`
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { red[wave][r][lane] = acc0[r]; red[wave][4 + r][lane] = acc1[r]; }
+  __syncthreads();
+  // wave w finishes accumulator registers 2w, 2w+1: register g -> column block g >> 2, row 4 * kq + (g & 3)
+  float e[2];
+  int irow[2], col[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = wave * 2 + q;
+    const float u = ((red[0][g][lane] + red[1][g][lane]) + red[2][g][lane]) + red[3][g][lane];
+    col[q] = 16 * (g >> 2) + l16;
+    irow[q] = 4 * kq + (g & 3);
+    e[q] = (c0 + col[q] < NB) ? expf(u / a.T) : 0.f;
+  }
+  if (prob == 2) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (c0 + col[q] < NB && r0 + irow[q] < nunl) a.Smat[(long long)(r0 + irow[q]) * btu + c0 + col[q]] = e[q];
+    return;
+  }
+  const int CT = (a.Q + 31) >> 5, ctile = c0 >> 5;
+  float* rs = a.rs_part + ((long long)prob * CT + ctile) * nunl;
+  float* ep = a.ep_part + ((long long)prob * CT + ctile) * nunl * K;
+  // row sums and E . bank_probs as a small LDS product: the tile E [16][33] and the probability tile [32 cols][33] go
+  // to LDS (`red` is dead after the barrier), each thread then forms whole outputs, columns summed in index order
+  __syncthreads();                                   // all reads of `red` are done
+  float* ew = lds;                                   // [16][33]
+  float* pw = lds + 16 * 33;                         // [32][33]
+#pragma unroll
+  for (int q = 0; q < 2; ++q) ew[irow[q] * 33 + col[q]] = e[q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + 256 * q, c = i / K;
+    if (i < 32 * K) pw[c * 33 + (i - c * K)] = pq[q];
+  }
+  __syncthreads();
+  for (int o = tid; o < 16 * (K + 1); o += 256) {
+    const int row = o & 15, kk = o >> 4;             // kk == K: the plain row sum
+    const float* er = ew + row * 33;
+    float sum = 0.f;
+    if (kk < K) {
+#pragma unroll 8
+      for (int c = 0; c < 32; ++c) sum += er[c] * pw[c * 33 + kk];
+    } else {
+#pragma unroll 8
+      for (int c = 0; c < 32; ++c) sum += er[c];
+    }
+    const int ir = r0 + row;
+    if (ir < nunl) {
+      if (kk < K) ep[(long long)ir * K + kk] = sum; else rs[ir] = sum;
+    }
+  }
+}
+
 // Tall-tile variant for wide products (data parallelism: the banks hold 10 x the GLOBAL labelled batch, so a rank's
 // 128 local rows meet W x more columns).  One workgroup = up to 128 local rows x 32 columns; wave w owns rows
 // 32w..32w+31 over the WHOLE contraction, so there is no cross-wave reduction and the column tile is read once
@@ -675,8 +813,11 @@ hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
   // measured per rank (scripts/rank_cost.py, B2, 128 local rows; pair_exp + row kernel): 32x32 tiles (f32-input MFMA)
   // 27.4 / 42.0 / 60.0 / 89 us at W = 1 / 2 / 4 / 8 against 43.4 / 45.4 / 56.0 / 78 us for tall tiles (split-bf16)
   const bool tall = force_tall >= 0 ? force_tall != 0 : (ctiles >= 128 && a.nunl >= 64);
+  static const bool pair16 = !(getenv("CMLPL_PAIR16") && atoi(getenv("CMLPL_PAIR16")) == 0);
   if (tall) {
     hipLaunchKernelGGL(pair_exp_tall_kernel, dim3(ctiles, (a.nunl + 127) / 128, 3), dim3(256), 0, st, a);
+  } else if (a.K <= 32 && pair16) {
+    hipLaunchKernelGGL(pair_exp16_kernel, dim3(ctiles, (a.nunl + 15) / 16, 3), dim3(256), 0, st, a);
   } else {
     dim3 g1(ctiles, (a.nunl + 31) / 32, 3);
     hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 
   for (int s = sbeg; s < send; ++s) {
     const float* brow = da0 + ((long long)net * n + s) * HW * 64 + ct * 32 + l31;
-    float bc[C0_PB], bn[C0_PB];
+    float bq[4][C0_PB];             // ring of four batches: three requested ahead of the one being multiplied
     auto fetch = [&](float (&buf)[C0_PB], int t0) {
 #pragma unroll
       for (int q = 0; q < C0_PB; ++q) {
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
         buf[q] = brow[(long long)(p < HW ? p : 0) * 64];   // raw (masked at use): a select here would wait for the load
       }
     };
-    fetch(bc, 0);   // in flight while the slab is staged
+    // in flight while the slab is staged (three batches ahead of the one being multiplied)
+    fetch(bq[0], 0); fetch(bq[1], C0_PB); fetch(bq[2], 2 * C0_PB);
     __syncthreads();
     const float* xs = xn + ((long long)net * n + s) * C * HW;
     if (DMA) {
@@ -142,27 +143,53 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
       const int rem = C * HW - 4 * nf4;
       if (tid < rem) smem[4 * nf4 + tid] = xs[4 * nf4 + tid];
     } else {
-      staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
-                             [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
+      if ((HW & 3) == 0) {
+        // rows of whole 16-byte pieces (e.g. the reference's 20 x 20 window): one load, one divide per FOUR elements
+        const int H4 = HW >> 2;
+        staged_copy<8, float4>(C * H4, tid, [&](int i) { return ((const float4*)xs)[i]; },
+                               [&](int i, float4 v) {
+                                 const int c = i / H4, p = 4 * (i - c * H4);
+                                 float* d = smem + c * HWp + p;
+                                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                               });
+      } else {
+        staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
+                               [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
+      }
     }
     __syncthreads();
-    for (int t0 = 0; t0 < pairs; t0 += C0_PB) {
-      if (t0 + C0_PB < pairs) fetch(bn, t0 + C0_PB);
+    for (int t1 = 0; t1 < pairs; t1 += 4 * C0_PB) {
 #pragma unroll
-      for (int q = 0; q < C0_PB; ++q) {
-        if (t0 + q < pairs) {   // uniform
-          const int p = 2 * (t0 + q) + hh;
-          const float bq = (p < HW) ? bc[q] : 0.f;
-          dbacc += bq;
+      for (int u = 0; u < 4; ++u) {
+        const int t0 = t1 + u * C0_PB;                       // workgroup-uniform
+        if (t0 + 3 * C0_PB < pairs) fetch(bq[(u + 3) & 3], t0 + 3 * C0_PB);
+        if (t0 < pairs) {
+          // the batch's gradient values (zero past the last pixel: the tail batch multiplies zeros instead of branching
+          // per pixel pair), then per band tile ALL its activation reads before its MFMAs: with a branch in front of
+          // every MFMA each one waited out its own LDS read (~190 cycles per 64-cycle MFMA; 74 -> 52 us per launch at
+          // 60 x 20 x 20.  Requesting the NEXT batch's reads before this batch's MFMAs as well gained nothing more.)
+          float bv[C0_PB];
+#pragma unroll
+          for (int q = 0; q < C0_PB; ++q) {
+            const int p = 2 * (t0 + q) + hh;
+            bv[q] = (t0 + q < pairs && p < HW) ? bq[u][q] : 0.f;
+            dbacc += bv[q];
+          }
 #pragma unroll
           for (int k = 0; k < C0_MAXT; ++k) {
             const int tile = it0 + 2 * k;
-            if (tile < NT) acc[k] = mfma32(smem[(tile * 32 + l31) * HWp + p], bq, acc[k]);
+            if (tile < NT) {                                 // wave-uniform, the same for the whole kernel
+              const float* xr = smem + (tile * 32 + l31) * HWp + 2 * t0 + hh;   // (reads past the row end stay inside the slab + tail)
+              float av[C0_PB];
+#pragma unroll
+              for (int q = 0; q < C0_PB; ++q) av[q] = xr[2 * q];
+              __builtin_amdgcn_sched_barrier(0);             // (else the reads are sunk to their MFMAs again)
+#pragma unroll
+              for (int q = 0; q < C0_PB; ++q) acc[k] = mfma32(av[q], bv[q], acc[k]);
+            }
           }
         }
       }
-#pragma unroll
-      for (int q = 0; q < C0_PB; ++q) bc[q] = bn[q];
     }
   }
   // partial layout [c][co] (+ 64 db)

@@ -23,6 +23,17 @@ def test_tall_pair_exp_kernel_passes_loss_parity():
     _run({"CMLPL_PAIR_TALL": "1"}, ["tests/test_gpu_ops.py", "-k", "loss_block", "tests/test_gpu_distributed.py"])
 
 
+def test_32_row_pair_exp_kernel_passes_loss_parity():
+    """pair_exp_kernel (32 x 32 tiles, the round-2 default; still what K > 32 classes take) instead of pair_exp16_kernel"""
+    _run({"CMLPL_PAIR16": "0"}, ["tests/test_gpu_ops.py", "tests/test_gpu_step.py", "-k", "loss_block or b2_64"])
+
+
+def test_general_memobank_infonce_kernel_passes_losshelper_parity():
+    """mb_infonce_all_kernel (keys re-read from L2; what D > 1024, K > 64 or more than 16 key slots per wave take) instead
+    of the keys-in-registers kernel"""
+    _run({"CMLPL_MB_FAST": "0"}, ["tests/test_losshelper.py"])
+
+
 def test_general_wgrad_fallback_passes_backward_parity():
     _run({"CMLPL_WGRAD3_R": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
 

@@ -47,7 +47,9 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up256(bytes); return p; };
   const size_t N = (size_t)nets * n;
   Wgrad3Plan w1, w2;
-  if (!plan_wgrad3(nets, n, d.H, d.W, &w1) || !plan_wgrad3(nets, n, d.H2, d.W2, &w2)) return false;
+  bool wpair = false;
+  if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, conv3_fused_head_ok(d.H, d.W, d.C, nets * n, d.K), &w1, &w2, &wpair))
+    return false;
   Conv3Plan c;
   if (!plan_conv3(0, d.H, d.W, nets * n, &c) || !plan_conv3(1, d.H, d.W, nets * n, &c) ||
       !plan_conv3(0, d.H2, d.W2, nets * n, &c) || !plan_conv3(1, d.H2, d.W2, nets * n, &c)) return false;
@@ -462,8 +464,11 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
   rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride;
-  reduce_table_add(rt, w.part1, wgrad3_G(nets, n, d.H, d.W), PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
-  reduce_table_add(rt, w.part2, wgrad3_G(nets, n, d.H2, d.W2), PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
+  Wgrad3Plan wp1, wp2;
+  bool wpair = false;
+  if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, fused_head, &wp1, &wp2, &wpair)) return CMLPL_E_SHAPE;
+  reduce_table_add(rt, w.part1, wp1.G, PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
+  reduce_table_add(rt, w.part2, wp2.G, PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
   reduce_table_add(rt, w.part0, conv0_partials(d, nets, n), conv0_partial_size(d.C), 0, d.C,
                    d_grads + L.param_off[0], d_grads + L.param_off[1]);
   if (fused_head)   // the classifier / feat_spe weight-gradient GEMMs ride along (independent, short)

@@ -173,8 +173,9 @@ __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
 constexpr int SLAB_MAXQ = 16;   // pieces per wave: range <= 4 waves * 16 * 256 floats
 constexpr int SLAB_RING = 7;    // forward: chunks (16 bands each) resident in LDS per pass
 constexpr int SLAB_WIN = 4;     // forward: chunks in flight global -> registers per wave
-constexpr int SLAB_NUP = 7;     // forward: chunks whose noise is formed before the chunk loop starts (measured: all of
-                                // them -- forming the later chunks' noise inside the loop, beside the MFMAs, took 0.8 us longer)
+constexpr int SLAB_NUP = 7;     // forward: chunks whose noise is formed before the chunk loop starts = SLAB_RING, all of them
+                                // (measured: forming the later chunks' noise inside the loop, beside the MFMAs, took 0.8 us longer)
+static_assert(SLAB_NUP == SLAB_RING, "the forward forms the noise of every chunk of a pass up front");
 typedef __attribute__((address_space(3))) void slab_lds_void;
 typedef __attribute__((address_space(1))) const void slab_gbl_void;
 struct SlabRange { const float* xs; const float* nz; uint64_t gsample; int f4base, nfl; };
@@ -632,25 +633,32 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       }
       // The noise of a chunk's elements (pure vector work: a hash + Box-Muller per four normals, ~380 cycles per call and
       // wave: 5 us per workgroup pair, the largest item of this prologue).  The first SLAB_NUP chunks' noise is formed
-      // up front, under the latency of the first loads; any further chunk's inside the chunk loop, one iteration ahead.
-      auto make_noise = [&](int kq, float4 (&zz)[2]) {
+      // up front, under the latency of the first loads (SLAB_NUP == SLAB_RING: all of a pass's chunks).
+      // (Two bodies behind ONE uniform branch, not a branch per piece: with "load the reference's draw OR generate" inside
+      // one lambda both paths write the same registers, and the compiler guards the generated values' write with a
+      // vmcnt(0) against the possibly outstanding load -- which also waits for every chunk load in flight, 14 times.)
+      auto noise_live = [&](int kq, int k) { return sigma != 0.f && kq < nch && k < PPW && (wave + 4 * k) * 64 < CH4l; };   // uniform
+      if (nzrow != nullptr) {                             // parity mode: the reference's own draws
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
-          float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (sigma != 0.f && kq < nch && k < PPW && (wave + 4 * k) * 64 < CH4l) {   // uniform
-            if (nzrow != nullptr) {                       // parity mode: the reference's own draws
-              const int gc = (g < CH4l && gg < nf4) ? gg : 0;
-              z = *(const float4*)(nzrow + 4 * gc);
-            } else {
-              z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
-            }
+        for (int kq = 0; kq < SLAB_NUP; ++kq)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (noise_live(kq, k)) z = *(const float4*)(nzrow + 4 * ((g < CH4l && gg < nf4) ? gg : 0));
+            nzv[kq][k] = z;
           }
-          zz[k] = z;
-        }
-      };
+      } else {
 #pragma unroll
-      for (int kq = 0; kq < SLAB_NUP; ++kq) make_noise(kq, nzv[kq]);
+        for (int kq = 0; kq < SLAB_NUP; ++kq)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (noise_live(kq, k)) z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
+            nzv[kq][k] = z;
+          }
+      }
       if (c0 == 0) STAMP(0, 4);
       // One chunk AHEAD: chunk kq + 1 is put into LDS (noise added) and published before the MFMAs of chunk kq are
       // issued, and its operand reads go out in front of them -- the split of chunk kq + 1 then runs while the matrix
@@ -701,7 +709,6 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           z0 = mfma_b3(A1, A2, A3, bw[kq % 2][0], bw[kq % 2][1], bw[kq % 2][2], z0);
           z1 = mfma_b3(A1, A2, A3, bw[kq % 2][3], bw[kq % 2][4], bw[kq % 2][5], z1);
           if (kq + 2 < nch) fetch_b(kq + 2, bw[kq % 2]);
-          if (kq + SLAB_NUP < SLAB_RING) make_noise(kq + SLAB_NUP, nzv[kq + SLAB_NUP]);   // consumed by put_chunk(kq + 2) in the next iteration (zero beyond nch)
           if (kq + 1 < nch)
             a_split(make_float4(rn[0], rn[1], rn[2], rn[3]), make_float4(rn[4], rn[5], rn[6], rn[7]), A1, A2, A3);
         }

@@ -111,10 +111,11 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
                                   const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,
                                   const BwdHead* head /* or null */, hipStream_t st);
 struct Wgrad3Plan { int RU, U, G, cspl, rsplit, UPG, b3; size_t lds; };   // rsplit > 0: row-split kernel with CPR = rsplit, UPG units per workgroup
-bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p);
+bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role = 0);   // role: 0 alone, 1 / 2 first / second map of a pair launch
+bool plan_wgrad3_both(int nets, int n, int H1, int W1, int H2, int W2, bool want_pair, Wgrad3Plan* p1, Wgrad3Plan* p2,
+                      bool* pair);
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st);
-int wgrad3_G(int nets, int n, int H, int W);
 hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1, const float* dpool1,
                               const uint8_t* mask1, float* part1, int H2, int W2, const float* in2,
                               const float* dpool2, const uint8_t* mask2, float* part2, bool* merged, hipStream_t st);

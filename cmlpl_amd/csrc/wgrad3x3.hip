@@ -739,7 +739,7 @@ static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
   return ((size_t)U * (RU + 2) * PW * 64 + D * (64 / cspl)) * 4;
 }
 
-bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
+bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
   const int RO = 2 * (H / 2);
   if (RO <= 0) return false;
   // rows per unit: the largest even divisor-friendly RU that fits with U = 1
@@ -780,6 +780,22 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
     const int PW = W + 2, cpr = CO / 2;
     const long long NUr = (long long)n * (H / 2);
     long long Gt = 256 / (3 * nets);                          // one workgroup per CU over (chunks, nets, 3 rows)
+    // In the pair launch (wgrad3b_pair_kernel) a workgroup of either map fills a CU, so the first map's workgroups
+    // must not take ALL the CUs: with 240 of them the second map's 192 short ones ran almost entirely AFTER the first
+    // map's had finished (25 us + 10 us).  The first map gets 3/4 of the CUs (192 workgroups of ten stages instead of
+    // 240 of eight at B2), the second map fewer, longer workgroups (their ~4 us of prologue + epilogue weighs less) on
+    // the CUs left over, and both end together.  Measured (B2, launch + reduce): (40, 32) groups per network and kernel
+    // row 36.5 + 13.3 us, (36, 16) 38.2 + 12.4, (32, 16) 33.8 + 12.2, (32, 12) 33.5 + 12.1, (28, 12) 37.9 + 11.9.
+    static const int force_pg1 = getenv("CMLPL_WGRAD3_PG1") ? atoi(getenv("CMLPL_WGRAD3_PG1")) : 0;
+    static const int force_pg2 = getenv("CMLPL_WGRAD3_PG2") ? atoi(getenv("CMLPL_WGRAD3_PG2")) : 0;
+    if (role == 1) { Gt = (256 * 3 / 4) / (3 * nets); if (force_pg1 > 0) Gt = force_pg1; }
+    if (role == 2) {
+      long long g1 = (256 * 3 / 4) / (3 * nets);
+      if (force_pg1 > 0) g1 = force_pg1;
+      const long long spare = 256 - 3 * nets * g1;
+      Gt = (spare + spare / 8) / (3 * nets);
+      if (force_pg2 > 0) Gt = force_pg2;
+    }
     if (force_rg > 0) Gt = force_rg;
     if (Gt < 1) Gt = 1;
     const size_t red = (size_t)(4 * 48 * 64 + 512 * 4) * 4;   // fold area + per-thread bias sums
@@ -822,7 +838,7 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p) {
 hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const float* dpool, const uint8_t* mask,
                          float* part, hipStream_t st) {
   Wgrad3Plan pl;
-  if (!plan_wgrad3(nets, n, H, W, &pl)) return hipErrorInvalidValue;
+  if (!plan_wgrad3(nets, n, H, W, &pl, 0)) return hipErrorInvalidValue;
   static DevOnce attr_once;
   {
     hipError_t e = ensure_max_lds(attr_once, wgrad3_kernel<1>, wgrad3_kernel<2>);
@@ -879,14 +895,37 @@ static void wgrad3_args(Wgrad3Args& a, const Wgrad3Plan& pl, int n, int H, int W
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G; a.UPG = pl.UPG;
 }
 
+// Plans of both 3x3 weight gradients of a backward pass.  *pair: one launch (wgrad3b_pair_kernel) -- then the two plans
+// share the CUs between them (roles 1 / 2 above); otherwise each map is planned for a launch of its own.  want_pair:
+// the caller would use the pair launch (the fused backward does; the general path launches the two on side streams).
+// Every user of the group counts (workspace carving, the reduce table, the launch) goes through here.
+static bool wgrad3_pair_instantiated(int ca, int cb) {
+  return (ca == 4 && cb == 2) || (ca == 5 && cb == 2) || (ca == 6 && cb == 3) || (ca == 7 && cb == 3) ||
+         (ca == 8 && cb == 4) || (ca == 9 && cb == 4) || (ca == 10 && cb == 5);
+}
+bool plan_wgrad3_both(int nets, int n, int H1, int W1, int H2, int W2, bool want_pair, Wgrad3Plan* p1, Wgrad3Plan* p2,
+                      bool* pair) {
+  static const bool off = getenv("CMLPL_WGRAD3_PAIR") && atoi(getenv("CMLPL_WGRAD3_PAIR")) == 0;
+  *pair = false;
+  if (!plan_wgrad3(nets, n, H1, W1, p1, 0) || !plan_wgrad3(nets, n, H2, W2, p2, 0)) return false;
+  if (want_pair && !off && p1->b3 && p2->b3 && wgrad3_pair_instantiated(p1->rsplit, p2->rsplit)) {
+    Wgrad3Plan q1, q2;
+    if (plan_wgrad3(nets, n, H1, W1, &q1, 1) && plan_wgrad3(nets, n, H2, W2, &q2, 2) && q1.b3 && q2.b3) {
+      *p1 = q1; *p2 = q2; *pair = true;
+    }
+  }
+  return true;
+}
+
 // both 3x3 weight gradients of a backward pass: one launch where a pair kernel exists, else two
 hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1, const float* dpool1,
                               const uint8_t* mask1, float* part1, int H2, int W2, const float* in2,
                               const float* dpool2, const uint8_t* mask2, float* part2, bool* merged, hipStream_t st) {
-  static const bool off = getenv("CMLPL_WGRAD3_PAIR") && atoi(getenv("CMLPL_WGRAD3_PAIR")) == 0;
   Wgrad3Plan p1, p2;
   *merged = false;
-  if (!off && plan_wgrad3(nets, n, H1, W1, &p1) && plan_wgrad3(nets, n, H2, W2, &p2) && p1.b3 && p2.b3) {
+  bool pair = false;
+  if (!plan_wgrad3_both(nets, n, H1, W1, H2, W2, true, &p1, &p2, &pair)) return hipErrorInvalidValue;
+  if (pair) {
     Wgrad3Args a, b;
     wgrad3_args(a, p1, n, H1, W1, in1, dpool1, mask1, part1);
     wgrad3_args(b, p2, n, H2, W2, in2, dpool2, mask2, part2);
@@ -908,11 +947,6 @@ hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1,
   hipError_t e = launch_wgrad3(nets, n, H2, W2, in2, dpool2, mask2, part2, st);
   if (e != hipSuccess) return e;
   return launch_wgrad3(nets, n, H1, W1, in1, dpool1, mask1, part1, st);
-}
-
-int wgrad3_G(int nets, int n, int H, int W) {
-  Wgrad3Plan pl;
-  return plan_wgrad3(nets, n, H, W, &pl) ? pl.G : 0;
 }
 
 }  // namespace cmlpl

@@ -539,53 +539,59 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   const uint8_t* mk = a.mask + (long long)net * a.dpool_ns;
   const int ct = wave & 1, it = (wave >> 1) & 1, kg = wave >> 2;
 
-  // staging items of this thread (stage-invariant decode; the (sample, unit-in-sample) pair is carried)
+  // staging items of this thread (stage-invariant decode).  What is carried from stage to stage is each item's element
+  // OFFSET and image row, advanced by constants (a stage = U pooled rows = qU samples + rU rows; a row index that runs
+  // past its sample wraps into the next one): ~13 vector instructions per item and stage where carrying (sample, row)
+  // and re-forming the address cost ~25 -- on a SIMD these add to the MFMA time, they do not hide under it.
   const int qU = U / UPS, rU = U - qU * UPS;
-  int a_u[NRA], a_ir[NRA], a_src[NRA], a_dst[NRA], a_smp[NRA], a_j[NRA];
+  const int dStep = (qU * HW + 2 * rU * W) * 64, dWrap = (HW - 2 * UPS * W) * 64;
+  int a_u[NRA], a_dst[NRA], a_off[NRA], a_row[NRA], a_lim[NRA];
 #pragma unroll
   for (int q = 0; q < NRA; ++q) {
     const int t = tid + NT * q;
     const int c4 = t & 15, pr = t >> 4;
     const int rho = pr / W, px = pr - rho * W;
     const bool ex = rho < R;
-    a_u[q] = ex ? (rho >> 1) : (1 << 28); a_ir[q] = (rho & 1) + kh - 1;
-    a_src[q] = px * 64 + c4 * 4;
+    const int ir = (rho & 1) + kh - 1;
+    a_u[q] = ex ? (rho >> 1) : (1 << 28);
     a_dst[q] = plane_byte((px + 1) * R + (ex ? rho : 0), c4 * 4);
-    a_smp[q] = (ubeg + (rho >> 1)) / UPS; a_j[q] = (ubeg + (rho >> 1)) - a_smp[q] * UPS;
+    const int smp = (ubeg + (rho >> 1)) / UPS, j = (ubeg + (rho >> 1)) - smp * UPS;
+    a_row[q] = 2 * j + ir;                                 // image row of the item (-1 .. H: outside rows read as zero)
+    a_lim[q] = 2 * UPS + ir;
+    a_off[q] = (smp * HW + a_row[q] * W) * 64 + px * 64 + c4 * 4;
   }
-  int d_u, d_g, d_smp, d_j, d_dst[4];
+  int d_u, d_off, d_dst[4];
   {
     const bool ex = tid < U * W2 * 16;
     const int id = ex ? tid : 0;
     const int c4 = id & 15, p = id >> 4;
     const int u = p / W2, pw = p - u * W2;
-    d_u = ex ? u : (1 << 28); d_g = pw * 64 + c4 * 4;
+    d_u = ex ? u : (1 << 28);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) d_dst[sub] = plane_byte((2 * pw + (sub & 1)) * R + 2 * u + (sub >> 1), c4 * 4);
-    d_smp = (ubeg + u) / UPS; d_j = (ubeg + u) - d_smp * UPS;
+    d_off = (ubeg + u) * (W2 * 64) + pw * 64 + c4 * 4;    // pooled rows of consecutive samples are consecutive: linear
   }
   float4 pa[NRA];
   float4 pdd = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t pdm = 0u;
   float4 dbsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of channels 4*(tid&15)..+3 (kernel row 0 only)
-  // fetch(ub): the global loads of the stage that begins at unit ub (in order: it advances the carried indices)
+  // fetch(ub): the global loads of the stage that begins at unit ub (in order: it advances the carried offsets)
   auto fetch = [&](int ub) {
+    const int left = uend - ub;                          // units of this workgroup from ub on (uniform)
 #pragma unroll
     for (int q = 0; q < NRA; ++q) {
-      const int row = a_j[q] * 2 + a_ir[q];
-      const bool ok = a_u[q] < (1 << 28) && (ub + a_u[q] < uend) && row >= 0 && row < H;
-      const float4 v = *(const float4*)(src + (ok ? ((a_smp[q] * HW + row * W) << 6) + a_src[q] : 0));
+      const bool ok = a_u[q] < left && (unsigned)a_row[q] < (unsigned)H;      // (a_u of an item that does not exist is huge)
+      const float4 v = *(const float4*)(src + (ok ? a_off[q] : 0));
       pa[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-      a_smp[q] += qU; a_j[q] += rU;
-      if (a_j[q] >= UPS) { a_j[q] -= UPS; ++a_smp[q]; }
+      a_row[q] += 2 * rU; a_off[q] += dStep;
+      if (a_row[q] >= a_lim[q]) { a_row[q] -= 2 * UPS; a_off[q] += dWrap; }
     }
     {
-      const bool ok = d_u < (1 << 28) && ub + d_u < uend;
-      const int gi = ok ? ((d_smp * P2 + d_j * W2) << 6) + d_g : 0;
+      const bool ok = d_u < left;
+      const int gi = ok ? d_off : 0;
       pdd = *(const float4*)(dp + gi);
       pdm = ok ? *(const uint32_t*)(mk + gi) : 0u;
-      d_smp += qU; d_j += rU;
-      if (d_j >= UPS) { d_j -= UPS; ++d_smp; }
+      d_off += U * (W2 * 64);
     }
   };
   // commit(buf): split what fetch() loaded and write the planes of one stage buffer

@@ -791,7 +791,9 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
     // map's had finished (25 us + 10 us).  The first map gets 3/4 of the CUs (192 workgroups of ten stages instead of
     // 240 of eight at B2), the second map fewer, longer workgroups (their ~4 us of prologue + epilogue weighs less) on
     // the CUs left over, and both end together.  Measured (B2, launch + reduce): (40, 32) groups per network and kernel
-    // row 36.5 + 13.3 us, (36, 16) 38.2 + 12.4, (32, 16) 33.8 + 12.2, (32, 12) 33.5 + 12.1, (28, 12) 37.9 + 11.9.
+    // row 36.5 + 13.3 us, (36, 16) 38.2 + 12.4, (32, 16) 33.8 + 12.2, (32, 12) 33.5 + 12.1, (28, 12) 37.9 + 11.9.  The
+    // second map's workgroup count must not exceed the CUs left over: stragglers of a second round run on after the first
+    // map has finished (512 + 512 rows on one GPU: 0.680 -> 0.703 ms with 72 workgroups for 64 CUs).
     static const int force_pg1 = getenv("CMLPL_WGRAD3_PG1") ? atoi(getenv("CMLPL_WGRAD3_PG1")) : 0;
     static const int force_pg2 = getenv("CMLPL_WGRAD3_PG2") ? atoi(getenv("CMLPL_WGRAD3_PG2")) : 0;
     if (role == 1) { Gt = (256 * 3 / 4) / (3 * nets); if (force_pg1 > 0) Gt = force_pg1; }
@@ -799,7 +801,7 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
       long long g1 = (256 * 3 / 4) / (3 * nets);
       if (force_pg1 > 0) g1 = force_pg1;
       const long long spare = 256 - 3 * nets * g1;
-      Gt = (spare + spare / 8) / (3 * nets);
+      Gt = spare / (3 * nets);                                  // ONE round on the CUs left over, at every batch size
       if (force_pg2 > 0) Gt = force_pg2;
     }
     if (force_rg > 0) Gt = force_rg;

@@ -234,7 +234,6 @@ struct MbLoss {
   float* prototype;                                            // out [K][Q][D] when momentum is given
   float temp;
   float* lossq; float* ganchor; int* arow; float* drep; float* total;
-  int keys_lds = 0;                                            // set by the launcher: the gathered keys stay in LDS
 };
 
 hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st);

@@ -555,7 +555,7 @@ __device__ __forceinline__ void bank_write_block(const LossArgs& a, int r) {
 
 __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bt = a.bt, btu = a.btu, n = bt + btu, K = a.K;
+  const int bt = a.bt, btu = a.btu, K = a.K;
   const int nlab = a.nlab, nunl = a.nunl, nl = nlab + nunl;
   const int row_blocks = (nl + 3) >> 2;
   if ((int)blockIdx.x >= row_blocks) { bank_write_block(a, (int)blockIdx.x - row_blocks); return; }

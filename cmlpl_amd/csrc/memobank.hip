@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void mb_infonce_all_kernel(MbLoss a) {
   __shared__ const float* s_key[MB_MAXKEYS];
   __shared__ float s_an2[4], s_misc[2];
   __shared__ int s_valid[1024], s_nv;
-  extern __shared__ __attribute__((aligned(16))) float s_pos[];   // [D]: this query's positive key (+ [NK][D] gathered keys)
+  extern __shared__ __attribute__((aligned(16))) float s_pos[];   // [D]: this query's positive key
   const int q = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = a.D, NN = a.NN, NK = NN + 1, Q = a.Q;
   const int nv = mb_valid_list(a.counts, a.K, s_valid, &s_nv, tid);
@@ -526,53 +526,14 @@ __global__ __launch_bounds__(256) void mb_infonce_all_kernel(MbLoss a) {
   __syncthreads();
   const float an = sqrtf((s_an2[0] + s_an2[1]) + (s_an2[2] + s_an2[3]));
   const float anc = fmaxf(an, 1e-8f);
-  // Keys cross HBM ONCE: where the NK gathered rows fit in LDS (a.keys_lds; D a multiple of 4) a wave takes four keys
-  // at a time, every 16-byte load of them in flight together (a key of D = 256 is one load per lane), forms a . k and
-  // |k|^2 from the registers and leaves the row in LDS for the gradient pass below.  (One key at a time and a second
-  // pass over global memory was a chain of ~13 + 51 dependent round trips per workgroup: 1.36 TB/s of gathers.)
-  float* s_keys = s_pos + D;                     // [NK][D] when a.keys_lds
-  if (a.keys_lds) {
-    const int D4 = D >> 2, NCH = (D4 + 63) >> 6;    // float4 chunks per lane and key (<= 4: D <= 1024, host-checked)
-    for (int j0 = wave; j0 < NK; j0 += 16) {
-      float4 kv[4][4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = j0 + 4 * t;
-        const float4* k4 = (const float4*)s_key[j < NK ? j : 0];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int d4 = lane + 64 * c;
-          kv[t][c] = (c < NCH && d4 < D4) ? k4[d4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = j0 + 4 * t;
-        if (j < NK) {                              // wave-uniform
-          float dt = 0.f, kn = 0.f;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int d4 = lane + 64 * c;
-            if (c < NCH && d4 < D4) {
-              const float4 a4 = ((const float4*)av)[d4], k = kv[t][c];
-              dt += a4.x * k.x; kn += k.x * k.x; dt += a4.y * k.y; kn += k.y * k.y;
-              dt += a4.z * k.z; kn += k.z * k.z; dt += a4.w * k.w; kn += k.w * k.w;
-              ((float4*)(s_keys + (size_t)j * D))[d4] = k;
-            }
-          }
-          dt = wave_sum(dt); kn = wave_sum(kn);
-          if (lane == 0) { s_dot[j] = dt; s_kn[j] = fmaxf(sqrtf(kn), 1e-8f); }
-        }
-      }
-    }
-  } else {
-    for (int j = wave; j < NK; j += 4) {           // one wave per key: a . k and |k|^2
-      const float* k = s_key[j];
-      float dt = 0.f, kn = 0.f;
-      for (int d = lane; d < D; d += 64) { const float kv = k[d]; dt += av[d] * kv; kn += kv * kv; }
-      dt = wave_sum(dt); kn = wave_sum(kn);
-      if (lane == 0) { s_dot[j] = dt; s_kn[j] = fmaxf(sqrtf(kn), 1e-8f); }
-    }
+  // (general kernel: one wave per key, the keys re-read from L2 for the gradient pass; the default where it fits is
+  // mb_infonce_fast_kernel below, which keeps them in registers)
+  for (int j = wave; j < NK; j += 4) {           // a . k and |k|^2
+    const float* k = s_key[j];
+    float dt = 0.f, kn = 0.f;
+    for (int d = lane; d < D; d += 64) { const float kv = k[d]; dt += av[d] * kv; kn += kv * kv; }
+    dt = wave_sum(dt); kn = wave_sum(kn);
+    if (lane == 0) { s_dot[j] = dt; s_kn[j] = fmaxf(sqrtf(kn), 1e-8f); }
   }
   __syncthreads();
   if (wave == 0) {                               // softmax over the NK logits (NK <= 128: two per lane)
@@ -601,8 +562,7 @@ __global__ __launch_bounds__(256) void mb_infonce_all_kernel(MbLoss a) {
   float* go = a.ganchor + (size_t)slot * D;
   for (int d = tid; d < D; d += 256) {
     float s = 0.f;
-    if (a.keys_lds) { for (int j = 0; j < NK; ++j) s += s_w[j] * s_keys[(size_t)j * D + d]; }
-    else            { for (int j = 0; j < NK; ++j) s += s_w[j] * s_key[j][d]; }
+    for (int j = 0; j < NK; ++j) s += s_w[j] * s_key[j][d];
     go[d] = s - selfc * av[d];
   }
 }
@@ -848,9 +808,7 @@ hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st)
     else if (fast && nch == 3) hipLaunchKernelGGL(mb_infonce_fast_kernel<3>, dim3(la.Q, la.K), dim3(256), lds, st, la);
     else if (fast && nch == 4) hipLaunchKernelGGL(mb_infonce_fast_kernel<4>, dim3(la.Q, la.K), dim3(256), lds, st, la);
     else {
-      MbLoss lb = la;
-      lb.keys_lds = 0;
-      hipLaunchKernelGGL(mb_infonce_all_kernel, dim3(la.Q, la.K), dim3(256), (size_t)la.D * 4, st, lb);
+      hipLaunchKernelGGL(mb_infonce_all_kernel, dim3(la.Q, la.K), dim3(256), (size_t)la.D * 4, st, la);
     }
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -513,7 +513,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, W = a.W, HW = H * W;
-  const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
+  const int H2 = H >> 1, W2 = W >> 1;
   const int UPS = H2;                       // units (pooled rows) per sample
   const int NU = a.n * UPS;
   const int UPG = a.UPG;

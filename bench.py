@@ -374,7 +374,7 @@ def run_rank(args):
                                  "both networks)")
     conv2_flops = 2.0 * 2 * n_local * (shape[1] // 2) * (shape[2] // 2) * 64 * 576    # dense 3x3 on the pooled map
     if tail_fwd:
-        kseg["conv1_fwd"]["f32"] += conv2_flops                                         # 16x16x4 f32 MFMA in the tail
+        kseg["conv1_fwd"]["split"] += conv2_flops                                       # tail: split-bf16 too (16x16x32 MFMA)
         labels["conv1_fwd"] = ("conv3x3_kernel<2,1,1> (per-sample fused forward: augmentation + conv0 1x1 + conv1 3x3 + "
                                "ReLU/pool + conv2 3x3 + ReLU/pool + concat/dropout/classifier/L2-norm, both networks)")
     if head_bwd:

@@ -329,7 +329,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // concat / dropout / classifier / L2-norm.  Needs the spectral branch output (launched above, same stream).
     join_from(main_st, 0, 1);
     FwdTail t;
-    t.w2f = d_packed + pack_off_frag(); t.w2f_ns = pk_ns; t.b2 = d_params + L.param_off[5];
+    t.w2f = d_packed + pack_off_b3(d.C, d.bands, 2); t.w2f_ns = pk_ns; t.b2 = d_params + L.param_off[5];
     t.wc = d_params + L.param_off[8]; t.bc = d_params + L.param_off[9]; t.p_ns = param_stride;
     t.y = w.y; t.dropmask = d_dropmask; t.dropgen = w.dropgen; t.catd = w.catd; t.ynorm = w.ynorm;
     t.logits = d_logits; t.feat = d_feat; t.p2 = w.p2; t.m2 = w.m2; t.dropout_p = dropout_p; t.train = train; t.K = d.K;

@@ -68,12 +68,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
       out |= pcs[pc] << (16 * d);
     }
     v = __uint_as_float(out);
-  } else if (e < PACK_PER_NET) {                     // conv2 forward as 16x16x4 B fragments (inverse of conv2_frag_index)
-    const int i = (int)(e - pack_off_frag());
-    const int lane = i & 63, st = (i >> 6) & 15, nq = (i >> 10) & 3, tap = i >> 12;
-    const int nn = nq * 16 + (lane & 15), k = (lane >> 4) * 16 + st;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    v = P[pi.off_w2 + ((nn * 64 + k) * 3 + kh) * 3 + kw];                              // co=n, ci=k
+  } else if (e < PACK_PER_NET) {
+    v = 0.f;                                           // (former fp32 16x16x4 fragments of conv2: unused region)
   } else if (e < pack_off_wst(pi.C)) {
     const int i = (int)(e - pack_off_w0t()), c = i >> 6, co = i & 63;
     v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
@@ -136,7 +132,7 @@ struct Conv3Args {
   XSrc xs;
   // TAIL (forward): conv2 + ReLU + avgpool + flatten/concat + dropout + classifier + L2-norm for the same sample
   // (tools/models.py:137-152), in the workgroup that has just pooled conv1's output
-  const float* w2f; long long w2f_ns;            // conv2 forward weights as 16x16x4 B fragments (kernels.hpp)
+  const float* w2f; long long w2f_ns;            // conv2 forward split-bf16 fragment set (kernels.hpp: pack_off_b3(.., 2))
   const float* b2; const float* wc; const float* bc; long long p_ns;   // conv2.bias, classifier.weight / .bias
   const float* yin;                               // spectral branch output relu(feat_spe(x)) [net][n][1024]
   const float* dropmask; float* dropgen; float* catd; float* ynorm; float* logits; float* feat;
@@ -853,10 +849,13 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
 
 // The rest of BaseNet2.forward for this workgroup's sample (S == 1), entered right after conv1's pooled map p1 has
 // been written to HBM (backward needs it) and, zero-bordered, to img2 (LDS, in the dead tap-weight buffer):
-//   conv2 3x3 + bias + residual + ReLU + avgpool (models.py:137-140) on the 16x16x4 fp32 MFMA: the 4x4 output pixels
-//   that the floor-pooling keeps are ONE 16-row tile; wave w owns output channels 16w..16w+15.  A fragments are
-//   ds_read_b128 from img2, B fragments ready-made in L2 (conv2_frag_index): one coalesced 256-B load per MFMA, the
-//   next tap's sixteen in flight while this tap's MFMAs run.  No LDS weight staging, no block barrier in the loop.
+//   conv2 3x3 + bias + residual + ReLU + avgpool (models.py:137-140) on the split-bf16 MFMA, 16x16x32 shape: the 4x4
+//   output pixels that the floor-pooling keeps are ONE 16-row tile; wave w owns output channels 16w..16w+15.  The
+//   pooled map is split ONCE into three bf16 planes [pixel][64 ch] in LDS (all four waves need the same A operand);
+//   A fragments are ds_read_b128 from the planes, B fragments 16-byte loads of the conv2 forward split set in L2
+//   (conv_b3_index: a lane's 8 consecutive ci of one co are contiguous there too), the next tap's six in flight while
+//   this tap's twelve MFMAs run.  108 MFMAs of 16 cycles per wave where the f32-input 16x16x4 took 144 of 32.
+//   No LDS weight staging, no block barrier in the loop.
 //   flatten (NCHW order) + concat with the spectral branch + dropout + classifier, and the L2-normalised spectral
 //   feature (models.py:141-152) -- head_fwd_kernel's math on the row this workgroup already holds.
 // Requires H4 == W4 == 2 and (H2+2)*(W2+2)*CS <= 4096 floats (windows 8..11).
@@ -870,10 +869,15 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   const long long rs = (long long)net * a.n + sample;
   // ---- loads issued up front: tap-0 B fragments, this thread's slice of the spectral row
   const int j = lane & 15, kg = lane >> 4;
-  const float* wq = a.w2f + (long long)net * a.w2f_ns + (size_t)wave * 1024 + lane;
-  float bcur[16], bnxt[16];
+  // B fragment (tap, k-step ks of 32 ci, piece p) of this wave's 16 output channels: uint4 index
+  //   (((tap*4 + 2 ks + (kg >> 1)) * 3 + p) * 2 + (wave >> 1)) * 64 + (kg & 1) * 32 + 16 (wave & 1) + j
+  const uint4* wq = (const uint4*)(a.w2f + (long long)net * a.w2f_ns) + ((kg >> 1) * 6 + (wave >> 1)) * 64 + (kg & 1) * 32 +
+                    16 * (wave & 1) + j;
+  uint4 bcur[6], bnxt[6];                    // [ks][piece]
 #pragma unroll
-  for (int st = 0; st < 16; ++st) bcur[st] = wq[st * 64];
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) bcur[3 * ks + pc] = wq[((0 * 4 + 2 * ks) * 3 + pc) * 128];
   const float4 y4 = *(const float4*)(a.yin + rs * FD + 4 * tid);
   const float bias2 = (a.b2 + (long long)net * a.p_ns)[wave * 16 + j];
   // ... and what the head will want after conv2, so that its L2 round trips run under conv2's: the classifier rows of
@@ -912,29 +916,56 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   }
   __syncthreads();                           // img2 interior complete; every thread is done pooling from img
   *(float4*)(row + SF + 4 * tid) = y4;       // spectral part of the head row (pre-dropout); row aliases the dead img
-  // ---- conv2: pixel i = lane & 15 = (oh, ow) = (i >> 2, i & 3)
-  const float* ap0 = img2 + (size_t)(((j >> 2) + 1) * PW2 + (j & 3) + 1) * CS + 16 * kg;
+  // ---- the pooled map as three bf16 planes [pixel][64 ch] (pixel stride 36 dwords: the 16-byte reads of the 16 output
+  // pixels land two-way on the banks at worst), behind the head row in the dead image region
+  constexpr int PS2 = 36;
+  const int NPX2 = (c.H2 + 2) * PW2, PLN = NPX2 * PS2;
+  uint32_t* pl = (uint32_t*)(smem + 2048);
+  for (int it = tid; it < NPX2 * 16; it += 256) {
+    const int px = it >> 4, c4 = it & 15;
+    const float4 v = *(const float4*)(img2 + (size_t)px * CS + 4 * c4);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t u0[4], u1[4], u2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u0[q] = __float_as_uint(x[q]);
+      const float r1 = x[q] - __uint_as_float(u0[q] & 0xffff0000u);
+      u1[q] = __float_as_uint(r1);
+      const float r2 = r1 - __uint_as_float(u1[q] & 0xffff0000u);
+      u2[q] = __float_as_uint(r2);
+    }
+    uint32_t* d = pl + px * PS2 + 2 * c4;
+    *(uint2*)(d) = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
+    *(uint2*)(d + PLN) = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
+    *(uint2*)(d + 2 * PLN) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
+  }
+  __syncthreads();
+  // ---- conv2: pixel i = lane & 15 = (oh, ow) = (i >> 2, i & 3); lane group kg holds ci 8 kg .. 8 kg + 7 of a k-step
+  const uint32_t* ap0 = pl + (size_t)(((j >> 2) + 1) * PW2 + (j & 3) + 1) * PS2 + 4 * kg;
   f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  auto mm = [](const uint4& x, const uint4& y, f32x4v cc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), cc, 0, 0, 0);
+  };
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     if (tap + 1 < 9) {
 #pragma unroll
-      for (int st = 0; st < 16; ++st) bnxt[st] = wq[(size_t)(tap + 1) * 4096 + st * 64];
-    }
-    const float* ap = ap0 + ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * CS;
-    const float4 a0 = *(const float4*)(ap), a1 = *(const float4*)(ap + 4), a2 = *(const float4*)(ap + 8),
-                 a3 = *(const float4*)(ap + 12);
-    // two accumulator chains: a dependent 16x16x4 has 40 cycles of latency against 32 of issue
-    acc0 = mfma16(a0.x, bcur[0], acc0);  acc1 = mfma16(a0.y, bcur[1], acc1);
-    acc0 = mfma16(a0.z, bcur[2], acc0);  acc1 = mfma16(a0.w, bcur[3], acc1);
-    acc0 = mfma16(a1.x, bcur[4], acc0);  acc1 = mfma16(a1.y, bcur[5], acc1);
-    acc0 = mfma16(a1.z, bcur[6], acc0);  acc1 = mfma16(a1.w, bcur[7], acc1);
-    acc0 = mfma16(a2.x, bcur[8], acc0);  acc1 = mfma16(a2.y, bcur[9], acc1);
-    acc0 = mfma16(a2.z, bcur[10], acc0); acc1 = mfma16(a2.w, bcur[11], acc1);
-    acc0 = mfma16(a3.x, bcur[12], acc0); acc1 = mfma16(a3.y, bcur[13], acc1);
-    acc0 = mfma16(a3.z, bcur[14], acc0); acc1 = mfma16(a3.w, bcur[15], acc1);
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int st = 0; st < 16; ++st) bcur[st] = bnxt[st];
+        for (int pc = 0; pc < 3; ++pc) bnxt[3 * ks + pc] = wq[(((tap + 1) * 4 + 2 * ks) * 3 + pc) * 128];
+    }
+    const uint32_t* ap = ap0 + ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * PS2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 a1 = *(const uint4*)(ap + 16 * ks), a2 = *(const uint4*)(ap + PLN + 16 * ks),
+                  a3 = *(const uint4*)(ap + 2 * PLN + 16 * ks);
+      const uint4 b1 = bcur[3 * ks], b2 = bcur[3 * ks + 1], b3 = bcur[3 * ks + 2];
+      // the six products of weight >= 2^-16, two accumulator chains (a dependent MFMA waits for its predecessor)
+      acc0 = mm(a1, b3, acc0); acc1 = mm(a2, b2, acc1); acc0 = mm(a3, b1, acc0);
+      acc1 = mm(a1, b2, acc1); acc0 = mm(a2, b1, acc0); acc1 = mm(a1, b1, acc1);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) bcur[q] = bnxt[q];
   }
   STAMP(0, 8);
   // ---- conv2 epilogue: lane (co = 16 wave + j, output row oh = kg) holds the 4 pixels ow = 0..3 of that row

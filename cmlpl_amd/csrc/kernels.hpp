@@ -18,8 +18,9 @@ constexpr int PACK_CONV = 9 * 64 * 64;       // elements of one 3x3 weight set
 //     [tap][k16 step (4)][piece (3)][n tile (2)][lane (64)][8 bf16]   lane = (n & 31) + 32 * ((k >> 3) & 1), j = k & 7
 //   so a tap is one linear 24 KiB copy into LDS and a fragment one conflict-free ds_read_b128
 //     forward: k = ci, n = co            dgrad: k = co, n = ci, tap flipped (transposed convolution);
-//   conv2 forward once more as fp32 B fragments of the 16x16x4 MFMA ([tap][n-quarter][k-step][lane], see
-//   conv2_frag_index): the per-sample tail of the fused forward reads them straight from L2;
+//   (the fused forward's tail reads the conv2 forward set too, as 16x16x32 fragments: a lane's 8 consecutive k of one n
+//   are contiguous in this layout whatever the MFMA shape; the fp32 16x16x4 fragment copy it used through round 3a is
+//   gone, its region of PACK_CONV floats is kept and zero);
 //   k-major copies of the two "thin" weights, so that their MFMA B fragments (fixed k, 32 consecutive outputs) are
 //   coalesced 128-B global reads:   w0T [Cp][64] = conv0.weight^T (Cp = C rounded up to even, pad row zero),
 //                                   (wsT [bands][1024] = feat_spe.weight^T: region kept, no longer written or read --
@@ -31,11 +32,6 @@ __host__ __device__ inline long long pack_off_frag() { return 4LL * PACK_B3; }
 // bf16 element index of (tap, k, n, piece) inside one split weight set
 __host__ __device__ inline int conv_b3_index(int tap, int k, int n, int p) {
   return ((((tap * 4 + (k >> 4)) * 3 + p) * 2 + (n >> 5)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7);
-}
-// element of conv2.weight[co][ci][kh][kw] in the 16x16x4 fragment pack.  An MFMA step consumes k = 16*kg + s
-// (kg = lane >> 4, s = step 0..15) and produces the 16 outputs of one n-quarter (j = lane & 15); k = ci, n = co.
-__host__ __device__ inline int conv2_frag_index(int tap, int n, int k) {
-  return (((tap * 4 + (n >> 4)) * 16 + (k & 15)) * 64) + ((k >> 4) << 4) + (n & 15);
 }
 __host__ __device__ inline long long pack_off_w0t() { return PACK_PER_NET; }
 __host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET + (long long)((C + 1) & ~1) * 64; }

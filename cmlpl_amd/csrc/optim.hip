@@ -75,15 +75,12 @@ __device__ __forceinline__ void adam_conv_chunk(const AdamArgs& a, int chunk, in
     // data-gradient set (k = co, n = ci, tap flipped), as 4-bf16 pieces: item = (ci, tap) -> these four co
     uint2* bd = (uint2*)(pkn + pack_off_b3(a.pi.C, a.pi.bands, which + 1));
     const int it = tid - 72, tap = it % 9, cil = it / 9, ci = ci0 + cil;
-    float w4[4];
     uint32_t pc[4][3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { w4[j] = lds[j * 144 + cil * 9 + tap]; b3_split(w4[j], pc[j]); }
+    for (int j = 0; j < 4; ++j) b3_split(lds[j * 144 + cil * 9 + tap], pc[j]);
 #pragma unroll
     for (int pcs = 0; pcs < 3; ++pcs)
       bd[conv_b3_index(8 - tap, co0, ci, pcs) >> 2] = make_uint2(pc[0][pcs] | (pc[1][pcs] << 16), pc[2][pcs] | (pc[3][pcs] << 16));
-    // conv2 also as 16x16x4 fp32 B fragments (forward tail of the fused kernel): n = co, k = ci
-    if (which == 2) *(float4*)(pkn + pack_off_frag() + conv2_frag_index(tap, co0, ci)) = make_float4(w4[0], w4[1], w4[2], w4[3]);
   }
 }
 

@@ -6,18 +6,23 @@ import numpy as np
 import torch
 from cmlpl_amd import TrainEngine, NetShape, HyperParams, _lib
 
-shape = NetShape(103, 11, 11, 103, 9)
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 103          # bands: 103 = B2, 200 = B4
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+shape = NetShape(C, 11, 11, C, K)
 eng = TrainEngine(shape, 128, 128, HyperParams(), device="cuda:0", seed=1)
 g = torch.Generator(device="cuda:0").manual_seed(0)
-XPl = torch.randn(128, 103, 11, 11, device="cuda:0", generator=g)
-XPu = torch.randn(128, 103, 11, 11, device="cuda:0", generator=g)
-Xl = torch.randn(128, 103, device="cuda:0", generator=g)
-Xu = torch.randn(128, 103, device="cuda:0", generator=g)
-Y = torch.randint(0, 9, (128,), device="cuda:0", generator=g)
+XPl = torch.randn(128, C, 11, 11, device="cuda:0", generator=g)
+XPu = torch.randn(128, C, 11, 11, device="cuda:0", generator=g)
+Xl = torch.randn(128, C, device="cuda:0", generator=g)
+Xu = torch.randn(128, C, device="cuda:0", generator=g)
+Y = torch.randint(0, K, (128,), device="cuda:0", generator=g)
 for i in range(20):
     eng.step(XPl, Xl, Y, XPu, Xu, 1, i)
 torch.cuda.synchronize()
 lib = _lib.load()
+from cmlpl_amd.build_ext import embedded_hash, source_hash
+_h = embedded_hash(os.environ.get("CMLPL_LIB"))
+print(f"timeline library built from sources {_h}; sources here {source_hash()}" + ("" if _h == source_hash() else "   ** STALE BUILD: run scripts/build_abl.sh 9 **"))
 buf = np.zeros((3, 2048, 16), dtype=np.uint64)
 rc = lib.cmlpl_abl_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
@@ -25,7 +30,7 @@ wbuf = np.zeros((2048, 16), dtype=np.uint64)          # the weight-gradient kern
 rc = lib.cmlpl_abl_read_wstamps(wbuf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 buf[2] = wbuf
-for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1, last launch)", 240)):
+for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1 workgroups of the pair launch)", 192)):
     t = buf[mode, :nwg, :4].astype(np.int64)
     full = buf[mode, :nwg, :].astype(np.int64)
     full = full[t[:, 0] > 0]

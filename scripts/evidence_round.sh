@@ -7,7 +7,8 @@ python3 bench.py --steps 200 > $OUT/${TAG}_bench.json 2> /dev/null
 python3 scripts/bench_next_rows.py > $OUT/${TAG}_next_rows.txt 2>&1
 for w in 1 2 4 8; do python3 scripts/rank_cost.py $w 2>&1 | grep -av amdgpu.ids | tail -14; done > $OUT/${TAG}_rank_cost.txt
 python3 scripts/dist_overhead.py > $OUT/${TAG}_dist_overhead.txt 2>&1
-bash scripts/build_abl.sh 9 > /dev/null 2>&1
+# (the timeline library is built BEFORE the run, where hipcc is known to work: bash scripts/build_abl.sh 9; conv_timeline.py
+#  prints the source hash the library carries, so a stale one shows)
 CMLPL_LIB=cmlpl_amd/libabl9.so python3 scripts/conv_timeline.py 2>&1 | grep -av amdgpu.ids > $OUT/${TAG}_timeline.txt
 for wl in P B4 B5; do python3 bench.py --workload $wl --steps 100 --no-cpu-baseline 2> /dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$wl', '%.4f ms/step' % d['ms_per_step'], '%.0f patches/s' % d['value'])"; done > $OUT/${TAG}_other_shapes.txt
 python3 bench.py --workload B3 --gpus 1 --steps 100 --no-cpu-baseline 2> /dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B3 (512+512 on one GPU)', '%.4f ms/step' % d['ms_per_step'], '%.0f patches/s' % d['value'])" >> $OUT/${TAG}_other_shapes.txt

@@ -64,7 +64,7 @@ def n4():
         def step():
             ei.grad = ej.grad = None
             crit(ei, ej).backward()
-        dt = timeit(step)
+        dt = min(timeit(step) for _ in range(3))
         print(f"N4 NT-Xent forward+backward, B={B}, D={D}: {dt * 1e6:.1f} us")
 
 
@@ -114,4 +114,6 @@ if __name__ == "__main__":
     want = sys.argv[1:]                       # e.g. `bench_next_rows.py n2 n3`; default: all
     for f in (n1, n3, n4, n2):
         if not want or f.__name__ in want:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()          # a section's big buffers must not shape the next one's allocations
             f()

@@ -96,6 +96,46 @@ def test_step_matches_golden_and_oracle(name):
         report(f"bank{i} probs", eng.bank_probs[i], st.bank_probs[i], 1e-4, 2e-4)   # softmax of |logits|~100 (peaky case)
 
 
+def test_first_step_gradients_with_the_oracles_own_relu_decisions():
+    """The step test above hands the DEVICE's ReLU decisions to the oracle.  Here the oracle keeps its OWN sign(z)
+    decisions for every element except those whose pre-activation lies within 2e-5 of zero (where fp32 summation order
+    decides, and only there the device's decision is taken): every gradient tensor of the first step of a reference
+    fixture must still meet the tight elementwise bound.  The number of such boundary elements is printed."""
+    g = GoldenCase("b2_64")
+    eng, p0, p1 = _engine(g)
+    st = O.StepState.create(g.shape, p0, p1, g.bt, g.hp)
+    n = g.bt + g.btu
+    b = g.batch(0)
+    epoch, bi = g.epoch_bi(0)
+    cb = cuda_batch(b)
+    eng.step(cb["XPl"], cb["Xl"], cb["Y"], cb["XPu"], cb["Xu"], epoch, bi, noise=cb["noise"], dropmask=cb["dropmask"])
+    dev_gates = hip_relu_gates(eng, g.shape, n)
+    import copy
+    probe = O.train_step(copy.deepcopy(st), b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"],
+                         epoch, bi, g.hp)                                   # own decisions: only its pre-activations are used
+    gates, nbound, ndiff = [], 0, 0
+    for net in range(2):
+        gn = {}
+        for key in ("z1", "z2", "zy"):
+            zo = probe["taps"][net][key]
+            own = zo > 0
+            dev = dev_gates[net][key].reshape(own.shape)
+            boundary = zo.abs() < 2e-5
+            nbound += int(boundary.sum())
+            ndiff += int((own != dev)[~boundary].sum()) if key == "zy" else 0
+            gn[key] = torch.where(boundary, dev, own)
+        gates.append(gn)
+    print(f"elements within 2e-5 of a ReLU boundary: {nbound}; spectral decisions differing elsewhere: {ndiff}")
+    assert ndiff == 0
+    ref = O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"], epoch, bi, g.hp,
+                       relu_gates=gates)
+    for net in range(2):
+        for k in O.LIVE_KEYS:
+            gr = ref["grads"][net][k]
+            mx = max(float(gr.abs().max()), 1e-4)
+            report(f"grad[{net}] {k}", eng.grad(net, k), gr, 5e-4, 5e-5 * mx)
+
+
 def test_b5_1to8_single_gpu_runs_on_with_modulo_bank_writes():
     """BASELINE configs[4]'s batch split (64 labelled + 512 unlabelled, 15x15x48, 20 classes) on ONE GPU through
     TrainEngine.  The reference runs exactly one step at this split (its second bank slice-assign raises):

@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMLPL_LIB") or os.path.join(HERE, "libcmlpl_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_TENSORS = 16
 NUM_LIVE = 10
 
@@ -30,7 +30,8 @@ EXPORTS = (
     "cmlpl_unsup_workspace_bytes", "cmlpl_unsup_loss", "cmlpl_memobank_select", "cmlpl_memobank_proto",
     "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
     "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g", "cmlpl_memobank_loss",
-    "cmlpl_source_hash",
+    "cmlpl_source_hash", "cmlpl_dyn_adam", "cmlpl_step_graph_create", "cmlpl_step_graph_launch",
+    "cmlpl_step_graph_destroy",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -72,7 +73,20 @@ class Shard(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("d_xpl", C.c_void_p), ("d_xl", C.c_void_p), ("d_xpu", C.c_void_p), ("d_xu", C.c_void_p),
-                ("d_labels", C.c_void_p), ("noise8", C.POINTER(C.c_void_p)), ("bt", C.c_int32), ("btu", C.c_int32)]
+                ("d_labels", C.c_void_p), ("noise8", C.POINTER(C.c_void_p)), ("bt", C.c_int32), ("btu", C.c_int32),
+                ("d_lab_idx", C.c_void_p), ("d_unl_idx", C.c_void_p)]
+
+
+class Dyn(C.Structure):
+    """cmlpl_dyn: one step's scalars in device memory (graph replay); DYN_DTYPE is the same row as a numpy record"""
+    _fields_ = [("step", C.c_uint64), ("adam_t", C.c_int64), ("lab_off", C.c_int64), ("unl_off", C.c_int64),
+                ("ptr", C.c_int32 * 2), ("smooth", C.c_int32), ("adap_mask", C.c_float), ("hist_row", C.c_int32),
+                ("adam_step_size", C.c_float), ("adam_bc2_sqrt", C.c_float), ("reserved", C.c_int32)]
+
+
+DYN_DTYPE = [("step", "<u8"), ("adam_t", "<i8"), ("lab_off", "<i8"), ("unl_off", "<i8"), ("ptr", "<i4", (2,)),
+             ("smooth", "<i4"), ("adap_mask", "<f4"), ("hist_row", "<i4"), ("adam_step_size", "<f4"),
+             ("adam_bc2_sqrt", "<f4"), ("reserved", "<i4")]
 
 
 class MemobankCall(C.Structure):
@@ -109,6 +123,7 @@ class StepIO(C.Structure):
         ("bt", C.c_int32), ("btu", C.c_int32), ("smooth", C.c_int32), ("adap_mask", C.c_float),
         ("adam_t", C.c_int64), ("seed", C.c_uint64), ("step", C.c_uint64),
         ("apply_update", C.c_int32), ("reserved", C.c_int32),
+        ("d_lab_idx", C.c_void_p), ("d_unl_idx", C.c_void_p), ("d_dyn_table", C.c_void_p), ("d_dyn_cursor", C.c_void_p),
     ]
 
 
@@ -180,6 +195,10 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_memobank_loss.argtypes = [C.POINTER(MemobankCall), vp]
     lib.cmlpl_adam_step.argtypes = [SP, i32, vp, i64, vp, i64, vp, vp, i64, HP, vp, vp]
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
+    lib.cmlpl_dyn_adam.argtypes = [HP, i64, C.POINTER(f32), C.POINTER(f32)]
+    lib.cmlpl_step_graph_create.argtypes = [SP, HP, C.POINTER(StepIO), vp, C.POINTER(vp)]
+    lib.cmlpl_step_graph_launch.argtypes = [vp, vp]
+    lib.cmlpl_step_graph_destroy.argtypes = [vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]
     lib.cmlpl_timing_begin.argtypes = [C.c_uint32, i32]
     lib.cmlpl_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(i64)]
@@ -194,10 +213,17 @@ def load(path: str = LIB_PATH):
     # ablation builds) is taken as it is.
     if default_lib and not os.environ.get("CMLPL_ALLOW_STALE"):
         from .build_ext import source_hash
-        built, now = lib.cmlpl_source_hash().decode(), source_hash()
-        if built != now:
+        try:
+            now = source_hash()
+        except OSError as e:        # a deployment that ships the library without csrc/ and include/: nothing to compare
+            import warnings
+            warnings.warn(f"cmlpl_amd: kernel sources not found next to {path} ({e}); stale-binary check skipped")
+            now = None
+        built = lib.cmlpl_source_hash().decode()
+        if now is not None and built != now:
             raise CmlplLibraryError(f"{path} is stale: built from sources {built}, the sources here are {now}; "
-                                    "rebuild with `python -m cmlpl_amd.build_ext`")
+                                    "rebuild with `python -m cmlpl_amd.build_ext` (or set CMLPL_ALLOW_STALE=1 to "
+                                    "load it as it is)")
     _lib = lib
     return lib
 

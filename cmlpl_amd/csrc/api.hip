@@ -243,8 +243,9 @@ int cmlpl_augment(const cmlpl_shape* shape, int nets, int bt, int btu, const flo
 namespace {
 // patch rows that are already augmented: [nets][n][C*HW]
 XSrc xsrc_plain(const float* d_xn, int nets, int n, long long per, uint64_t seed, uint64_t step,
-                const cmlpl_shard* sh) {
+                const cmlpl_shard* sh, DynRef dyn = DynRef()) {
   XSrc x = XSrc();
+  x.sel.dyn = dyn;
   const int nlab = sh ? sh->nlab : n;
   for (int i = 0; i < 2; ++i) {
     x.lab[i] = d_xn + (long long)(i < nets ? i : 0) * n * per;
@@ -256,8 +257,15 @@ XSrc xsrc_plain(const float* d_xn, int nets, int n, long long per, uint64_t seed
   return x;
 }
 // raw labelled / unlabelled rows + noise formed in the kernels
-XSrc xsrc_raw(const cmlpl_batch* b, float sigma, uint64_t seed, uint64_t step, const cmlpl_shard* sh) {
+RowSel batch_sel(const cmlpl_batch* b, DynRef dyn) {
+  RowSel s = RowSel();
+  s.lab_idx = (const long long*)b->d_lab_idx; s.unl_idx = (const long long*)b->d_unl_idx; s.dyn = dyn;
+  return s;
+}
+XSrc xsrc_raw(const cmlpl_batch* b, float sigma, uint64_t seed, uint64_t step, const cmlpl_shard* sh,
+              DynRef dyn = DynRef()) {
   XSrc x = XSrc();
+  x.sel = batch_sel(b, dyn);
   for (int i = 0; i < 2; ++i) {
     x.lab[i] = b->d_xpl; x.unl[i] = b->d_xpu;
     x.nz_lab[i] = b->noise8 ? b->noise8[2 * i] : nullptr;          // reference draw order, see cmlpl_augment
@@ -277,7 +285,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st);
+             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor = nullptr);
 }  // namespace
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
@@ -359,7 +367,8 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   const int unl_base = shard ? shard->bt_g + shard->unl0 : n;
   return TIMED(CMLPL_K_HEAD_FWD, chk(launch_head_fwd(nets, n, d.P4, d.K, w.p2, w.y, d_dropmask, w.dropgen, dropout_p,
                              train, seed, step, nlab, lab0, unl_base, d_params + L.param_off[8],
-                             d_params + L.param_off[9], param_stride, w.catd, w.ynorm, d_logits, d_feat, st)));
+                             d_params + L.param_off[9], param_stride, w.catd, w.ynorm, d_logits, d_feat, st,
+                             xs.sel.dyn)));
 }
 }  // namespace
 
@@ -384,7 +393,7 @@ namespace {
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st) {
+             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor) {
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
   hipStream_t main_st = st;
@@ -463,7 +472,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   }
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
-  rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride;
+  rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride; rt.dyn_cursor = dyn_cursor;
   Wgrad3Plan wp1, wp2;
   bool wpair = false;
   if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, fused_head, &wp1, &wp2, &wpair)) return CMLPL_E_SHAPE;
@@ -485,10 +494,12 @@ bool check_batch(const cmlpl_batch* b) {
 }
 }  // namespace
 
-int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
-                  const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
-                  uint64_t step, float* d_logits, float* d_feat, float* d_labels_f, void* d_workspace,
-                  size_t workspace_bytes, void* stream) {
+}  // extern "C"
+namespace {
+int forward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                 const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                 uint64_t step, float* d_logits, float* d_feat, float* d_labels_f, void* d_workspace,
+                 size_t workspace_bytes, void* stream, DynRef dyn) {
   Dims d;
   cmlpl_layout_t L;
   if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
@@ -511,30 +522,56 @@ int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
   // conversion for the data-parallel exchange buffer
   const bool spe_fused = spe_fused_ok(d.bands);
   const int which = (copy ? 1 : 0) | (spe_fused ? 0 : 2);
+  const RowSel sel = batch_sel(batch, dyn);
   if (which &&
       (rc = TIMED(CMLPL_K_AUGMENT, chk(launch_augment(which, 2, batch->bt, batch->btu, d.C * d.HW, d.bands, lab0,
                                 unl_base, batch->d_xpl, batch->d_xl, batch->d_xpu, batch->d_xu, batch->noise8,
-                                hp->noise_sigma, seed, step, sw.xn, sw.sn, sw.snT, st,
-                                (const long long*)batch->d_labels, d_labels_f))))) return rc;
-  XSrc xspec = xsrc_raw(batch, hp->noise_sigma, seed, step, shard);
+                                hp->noise_sigma, seed, step, sw.xn, sw.sn, nullptr, st,
+                                (const long long*)batch->d_labels, d_labels_f, &sel))))) return rc;
+  XSrc xspec = xsrc_raw(batch, hp->noise_sigma, seed, step, shard, dyn);
   for (int i = 0; i < 2; ++i) {       // the spectral rows and their draws (reference order, see cmlpl_augment)
     xspec.lab[i] = batch->d_xl; xspec.unl[i] = batch->d_xu;
     xspec.nz_lab[i] = batch->noise8 ? batch->noise8[2 * i + 1] : nullptr;
     xspec.nz_unl[i] = batch->noise8 ? batch->noise8[4 + 2 * i + 1] : nullptr;
   }
-  // (fused per-sample kernels, noise on: the forward leaves the augmented rows in sw.xn for cmlpl_backward, which lands
-  // them by DMA instead of regenerating the noise)
-  return fwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard),
+  // (fused per-sample kernels: the forward leaves the rows it saw in sw.xn for cmlpl_backward, which lands them by DMA)
+  return fwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard, dyn),
                   spe_fused ? &xspec : nullptr, sw.sn, (const long long*)batch->d_labels, d_labels_f,
-                  copy ? sw.xn : nullptr, sw.sn, sw.snT, d_dropmask, hp->dropout_p,
+                  copy ? sw.xn : nullptr, sw.sn, nullptr, d_dropmask, hp->dropout_p,
                   train, seed, step, shard, d_logits, d_feat, nw, st,
-                  (!copy && hp->noise_sigma != 0.f) ? sw.xn : nullptr);
+                  !copy ? sw.xn : nullptr);
 }
+}  // namespace
+extern "C" {
+int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                  const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                  uint64_t step, float* d_logits, float* d_feat, float* d_labels_f, void* d_workspace,
+                  size_t workspace_bytes, void* stream) {
+  return forward_impl(shape, hp, batch, shard, d_params, d_packed, d_dropmask, train, seed, step, d_logits, d_feat,
+                      d_labels_f, d_workspace, workspace_bytes, stream, DynRef());
+}
+}  // extern "C"
+namespace {
+int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                  const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                  uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
+                  void* d_workspace, size_t workspace_bytes, void* stream, DynRef dyn, int* dyn_cursor);
+}  // namespace
+extern "C" {
 
 int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
                    const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
                    uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
                    void* d_workspace, size_t workspace_bytes, void* stream) {
+  return backward_impl(shape, hp, batch, shard, d_params, d_packed, d_dropmask, train, seed, step, d_dlogits, d_dfeat,
+                       d_grads, grad_stride, d_workspace, workspace_bytes, stream, DynRef(), nullptr);
+}
+}  // extern "C"
+namespace {
+int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                  const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                  uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
+                  void* d_workspace, size_t workspace_bytes, void* stream, DynRef dyn, int* dyn_cursor) {
   Dims d;
   cmlpl_layout_t L;
   if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
@@ -546,21 +583,22 @@ int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlp
   carve_step(d, n, n, (char*)d_workspace + nw.bytes, &sw);
   if (nw.bytes + ((char*)sw.dlogits - ((char*)d_workspace + nw.bytes)) > workspace_bytes) return CMLPL_E_WORKSPACE;
   const bool copy = need_xn_copy(d, 2 * n);
-  // the patches as the forward saw them: the augmented rows cmlpl_forward left in sw.xn (fused kernels with noise), or
-  // the raw rows when no noise is added
-  const XSrc xs = (!copy && hp->noise_sigma != 0.f)
-                      ? xsrc_plain(sw.xn, 2, n, (long long)d.C * d.HW, seed, step, shard)
-                      : xsrc_raw(batch, hp->noise_sigma, seed, step, shard);
+  // the patches as the forward saw them: the rows cmlpl_forward left in sw.xn (fused kernels: augmented, or plain copies
+  // when no noise is added -- the data gradient reads plain rows by batch row, it knows neither noise nor index lists)
+  const XSrc xs = !copy ? xsrc_plain(sw.xn, 2, n, (long long)d.C * d.HW, seed, step, shard, dyn)
+                        : xsrc_raw(batch, hp->noise_sigma, seed, step, shard, dyn);
   return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xs,
                   copy ? sw.xn : nullptr, sw.sn, d_dropmask, hp->dropout_p, train, d_dlogits, d_dfeat, d_grads,
-                  grad_stride, nw, (hipStream_t)stream);
+                  grad_stride, nw, (hipStream_t)stream, dyn_cursor);
 }
+}  // namespace
+extern "C" {
 
 namespace {
 int fill_loss_args(const Dims& d, const cmlpl_shard* sh, const float* d_logits, const float* d_feat,
                    const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
                    const cmlpl_hparams* hp, void* ws, size_t ws_bytes, LossArgs* out,
-                   const cmlpl_gathered* gth = nullptr) {
+                   const cmlpl_gathered* gth = nullptr, const RowSel* sel = nullptr) {
   if (!sh || !banks || !hp || !ws) return CMLPL_E_ARG;
   if (gth == nullptr && (!d_logits || !d_feat || !d_labels)) return CMLPL_E_ARG;
   if (gth != nullptr && (!gth->d_recv || gth->world < 1 || gth->bt_local < 1 || gth->btu_local < 1 ||
@@ -578,6 +616,7 @@ int fill_loss_args(const Dims& d, const cmlpl_shard* sh, const float* d_logits, 
   LossArgs a;
   memset(&a, 0, sizeof(a));
   a.logits = d_logits; a.feat = d_feat; a.labels = d_labels;
+  if (sel != nullptr) a.sel = *sel;
   if (gth != nullptr) {
     const long long n_l = gth->bt_local + gth->btu_local;
     a.recv = gth->d_recv; a.bt_l = gth->bt_local; a.btu_l = gth->btu_local;
@@ -682,19 +721,38 @@ int cmlpl_loss_phase2_g(const cmlpl_shape* shape, const cmlpl_shard* shard, cons
   return TIMED(CMLPL_K_LOSS_DFEAT, chk(launch_loss_dfeat(a, st)));
 }
 
+}  // extern "C"
+namespace {
+// the whole loss block on one GPU (both phases back to back); sel: labels by index / device-side step scalars
+int loss_both(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
+              const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
+              const cmlpl_hparams* hp, float* d_scalars, float* d_dlogits, float* d_dfeat,
+              float* d_probs, void* d_workspace, size_t workspace_bytes, void* stream, const RowSel* sel) {
+  Dims d;
+  if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
+  if (!d_probs || !d_dfeat || !d_dlogits || !d_scalars) return CMLPL_E_ARG;
+  const cmlpl_shard sh = {bt, btu, 0, bt, 0, btu};
+  LossArgs a;
+  int rc = fill_loss_args(d, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_workspace,
+                          workspace_bytes, &a, nullptr, sel);
+  if (rc) return rc;
+  a.dlogits = d_dlogits; a.dfeat = d_dfeat; a.probs_l = d_probs;
+  // one GPU: the probabilities are already global, and the column-side gradient goes straight to dfeat[1]
+  a.probs_g = d_probs; a.pshard = btu; a.scalars = d_scalars;
+  a.dfw_part = d_dfeat + ((size_t)(bt + btu) + bt) * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = TIMED(CMLPL_K_LOSS, chk(launch_loss_phase1(a, st))))) return rc;
+  if ((rc = TIMED(CMLPL_K_LOSS2, chk(launch_loss_graph(a, st))))) return rc;
+  return TIMED(CMLPL_K_LOSS_DFEAT, chk(launch_loss_dfeat(a, st)));
+}
+}  // namespace
+extern "C" {
 int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d_logits, const float* d_feat,
                        const int64_t* d_labels, const cmlpl_banks* banks, int smooth, float adap_mask,
                        const cmlpl_hparams* hp, float* d_scalars, float* d_dlogits, float* d_dfeat,
                        float* d_probs, void* d_workspace, size_t workspace_bytes, void* stream) {
-  if (!d_probs || !d_dfeat) return CMLPL_E_ARG;
-  cmlpl_shard sh = {bt, btu, 0, bt, 0, btu};
-  int rc = cmlpl_loss_phase1(shape, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_dlogits, d_dfeat,
-                             d_probs, d_workspace, workspace_bytes, stream);
-  if (rc) return rc;
-  // one GPU: the probabilities are already global, and the column-side gradient goes straight to dfeat[1]
-  return cmlpl_loss_phase2(shape, &sh, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_probs, btu,
-                           d_scalars, d_dfeat, d_dfeat + ((size_t)(bt + btu) + bt) * 1024, d_workspace,
-                           workspace_bytes, stream);
+  return loss_both(shape, bt, btu, d_logits, d_feat, d_labels, banks, smooth, adap_mask, hp, d_scalars, d_dlogits,
+                   d_dfeat, d_probs, d_workspace, workspace_bytes, stream, nullptr);
 }
 
 int cmlpl_dist_unpack(const cmlpl_shape* shape, int world, int bt_local, int btu_local, const float* d_gathered,
@@ -707,9 +765,17 @@ int cmlpl_dist_unpack(const cmlpl_shape* shape, int world, int bt_local, int btu
                                 (long long*)d_labels_g, (hipStream_t)stream));
 }
 
-int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t param_stride,
-                    const float* d_grads, int64_t grad_stride, float* d_m, float* d_v, int64_t t,
-                    const cmlpl_hparams* hp, float* d_packed, void* stream) {
+int cmlpl_dyn_adam(const cmlpl_hparams* hp, int64_t adam_t, float* step_size, float* bc2_sqrt) {
+  if (!hp || adam_t < 1 || !step_size || !bc2_sqrt) return CMLPL_E_ARG;
+  adam_bias_scalars(hp->lr, hp->beta1, hp->beta2, adam_t, step_size, bc2_sqrt);
+  return 0;
+}
+
+}  // extern "C"
+namespace {
+int adam_impl(const cmlpl_shape* shape, int nets, float* d_params, int64_t param_stride,
+              const float* d_grads, int64_t grad_stride, float* d_m, float* d_v, int64_t t,
+              const cmlpl_hparams* hp, float* d_packed, void* stream, DynRef dyn) {
   cmlpl_layout_t L;
   Dims d;
   int rc = cmlpl_layout(shape, &L);
@@ -719,7 +785,14 @@ int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t
   hipStream_t st = (hipStream_t)stream;
   return TIMED(CMLPL_K_ADAM, chk(launch_adam(nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v,
                             L.param_live, t, hp->lr, hp->beta1, hp->beta2, hp->eps, d_packed,
-                            make_pack_info(d, L), st)));
+                            make_pack_info(d, L), st, dyn)));
+}
+}  // namespace
+extern "C" {
+int cmlpl_adam_step(const cmlpl_shape* shape, int nets, float* d_params, int64_t param_stride,
+                    const float* d_grads, int64_t grad_stride, float* d_m, float* d_v, int64_t t,
+                    const cmlpl_hparams* hp, float* d_packed, void* stream) {
+  return adam_impl(shape, nets, d_params, param_stride, d_grads, grad_stride, d_m, d_v, t, hp, d_packed, stream, DynRef());
 }
 
 int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io, void* stream) {
@@ -738,21 +811,63 @@ int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cm
   if (nw.bytes + sw.bytes > io->workspace_bytes) return CMLPL_E_WORKSPACE;
   const int train = 1;
   int rc;
+  if ((io->d_dyn_table == nullptr) != (io->d_dyn_cursor == nullptr)) return CMLPL_E_ARG;
+  DynRef dyn;
+  dyn.table = io->d_dyn_table; dyn.cursor = io->d_dyn_cursor;
   const cmlpl_shard sh = {io->bt, io->btu, 0, io->bt, 0, io->btu};
-  const cmlpl_batch batch = {io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->d_labels, io->noise8, io->bt, io->btu};
-  if ((rc = cmlpl_forward(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
-                          io->step, io->d_logits, io->d_feat, nullptr, io->d_workspace, io->workspace_bytes, stream)))
+  const cmlpl_batch batch = {io->d_xpl, io->d_xl, io->d_xpu, io->d_xu, io->d_labels, io->noise8, io->bt, io->btu,
+                             io->d_lab_idx, io->d_unl_idx};
+  if ((rc = forward_impl(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
+                         io->step, io->d_logits, io->d_feat, nullptr, io->d_workspace, io->workspace_bytes, stream, dyn)))
     return rc;
-  if ((rc = cmlpl_loss_fwd_bwd(shape, io->bt, io->btu, io->d_logits, io->d_feat, io->d_labels, &io->banks,
-                               io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, sw.probs, sw.loss,
-                               loss_ws_floats(n, n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream)))
+  const RowSel sel = batch_sel(&batch, dyn);
+  if ((rc = loss_both(shape, io->bt, io->btu, io->d_logits, io->d_feat, io->d_labels, &io->banks,
+                      io->smooth, io->adap_mask, hp, io->d_scalars, sw.dlogits, sw.dfeat, sw.probs, sw.loss,
+                      loss_ws_floats(n, n, n, d.K, io->banks.Q > n ? io->banks.Q : n) * 4, stream, &sel)))
     return rc;
-  if ((rc = cmlpl_backward(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
-                           io->step, sw.dlogits, sw.dfeat, io->d_grads, L.param_total, io->d_workspace,
-                           io->workspace_bytes, stream))) return rc;
-  if (io->apply_update)
-    return cmlpl_adam_step(shape, 2, io->d_params, L.param_total, io->d_grads, L.param_total, io->d_m, io->d_v,
-                           io->adam_t, hp, io->d_packed, stream);
+  if ((rc = backward_impl(shape, hp, &batch, &sh, io->d_params, io->d_packed, io->d_dropmask, train, io->seed,
+                          io->step, sw.dlogits, sw.dfeat, io->d_grads, L.param_total, io->d_workspace,
+                          io->workspace_bytes, stream, dyn, io->d_dyn_cursor))) return rc;
+  if (io->apply_update)   // (device-side scalars: the by-value step count is not used, any valid one will do)
+    return adam_impl(shape, 2, io->d_params, L.param_total, io->d_grads, L.param_total, io->d_m, io->d_v,
+                     (dyn.table != nullptr && io->adam_t < 1) ? 1 : io->adam_t, hp, io->d_packed, stream, dyn);
+  return 0;
+}
+
+// ---- the step as a replayable hipGraph
+struct StepGraph { hipGraph_t graph; hipGraphExec_t exec; };
+
+int cmlpl_step_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io, void* stream,
+                            void** graph_out) {
+  if (!io || !graph_out || !io->d_dyn_table || !io->d_dyn_cursor) return CMLPL_E_ARG;
+  if (g_timing.on) return CMLPL_E_ARG;                     // (event pairs are not part of the product's graph)
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return (int)e;
+  const int rc = cmlpl_train_step(shape, hp, io, stream);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(st, &g);                          // always end the capture, also after a failed launch
+  if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return (int)e;
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); return (int)e; }
+  StepGraph* sg = new StepGraph{g, ex};
+  *graph_out = sg;
+  return 0;
+}
+
+int cmlpl_step_graph_launch(void* graph, void* stream) {
+  if (!graph) return CMLPL_E_ARG;
+  return chk(hipGraphLaunch(((StepGraph*)graph)->exec, (hipStream_t)stream));
+}
+
+int cmlpl_step_graph_destroy(void* graph) {
+  if (!graph) return CMLPL_E_ARG;
+  StepGraph* sg = (StepGraph*)graph;
+  (void)hipGraphExecDestroy(sg->exec);
+  (void)hipGraphDestroy(sg->graph);
+  delete sg;
   return 0;
 }
 

@@ -27,6 +27,7 @@ struct AugArgs {
   float sigma; int nets; int explicit_noise; uint64_t seed, step;
   int t0;                                         // first tensor handled by this launch (blockIdx.z = 0)
   const long long* labels; float* labels_f;       // optional: labels as float, for the packed exchange buffer
+  RowSel sel;                                     // batches by index / device-side step scalars (common.hpp)
 };
 
 __global__ void augment_kernel(AugArgs a) {
@@ -38,11 +39,14 @@ __global__ void augment_kernel(AugArgs a) {
   // once per network, each network with its own Philox stream.
   const int base = blockIdx.x * 1024 + 4 * threadIdx.x;
   if (a.labels_f != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-    for (int i = threadIdx.x; i < a.bt; i += 256) a.labels_f[i] = (float)a.labels[i];
+    for (int i = threadIdx.x; i < a.bt; i += 256) a.labels_f[i] = (float)a.labels[rowsel_index(a.sel, true, i)];
   if (blockIdx.x * 1024 >= per) return;
   const bool lab = s < a.bt;
   const int sl = lab ? s : s - a.bt;
-  const float* src = (lab ? a.srcl[t] : a.srcu[t]) + (long long)sl * per;
+  const float* src = (lab ? a.srcl[t] : a.srcu[t]) + rowsel_index(a.sel, lab, sl) * per;
+  uint64_t rstep = a.step;
+  const cmlpl_dyn* dynr = dyn_row(a.sel.dyn);
+  if (dynr != nullptr) rstep = (uint64_t)uni64((long long)dynr->step);
   const bool need_noise = a.sigma != 0.f;
   float x[4];
 #pragma unroll
@@ -55,7 +59,7 @@ __global__ void augment_kernel(AugArgs a) {
     float* dst = a.dst[t] + ((long long)net * (a.bt + a.btu) + s) * per;
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (need_noise && !a.explicit_noise) {
-      const float4 nz = noise_normal4(a.seed, a.step, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
+      const float4 nz = noise_normal4(a.seed, rstep, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
                                        noise_ctr(gs, (uint32_t)(base >> 2)));
       z[0] = nz.x; z[1] = nz.y; z[2] = nz.z; z[3] = nz.w;
     } else if (need_noise) {
@@ -81,8 +85,10 @@ __global__ void augment_kernel(AugArgs a) {
 hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int per_x, int lab0, int unl_base,
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
-                          float* xn, float* sn, float* snT, hipStream_t st, const long long* labels, float* labels_f) {
+                          float* xn, float* sn, float* snT, hipStream_t st, const long long* labels, float* labels_f,
+                          const RowSel* sel) {
   AugArgs a;
+  a.sel = sel != nullptr ? *sel : RowSel();
   a.snT = snT; a.labels = labels; a.labels_f = (labels != nullptr) ? labels_f : nullptr;
   a.srcl[0] = xpl; a.srcl[1] = xl; a.srcu[0] = xpu; a.srcu[1] = xu;
   for (int i = 0; i < 8; ++i) a.noise[i] = noise8 ? noise8[i] : nullptr;

@@ -3,7 +3,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/cmlpl.h"
+
 namespace cmlpl {
+
+// Per-step scalars in device memory (cmlpl_dyn, include/cmlpl.h): a step captured in a hipGraph reads what changes
+// from step to step -- random-stream counter, Adam step, bank pointers, gates, batch offsets, logging row -- from
+// table[*cursor (+ bias)] instead of from its launch arguments.  table == null: the by-value arguments are used.
+// The cursor is advanced once per step by the weight-gradient reduce launch (conv0.hip); launches behind it (Adam)
+// read the row with bias -1.
+struct DynRef { const cmlpl_dyn* table; const int* cursor; };
+// (by VALUE: a reference to a member of a kernel-argument struct makes hipcc copy the whole struct to scratch --
+//  pair_exp16_kernel went from 0 to 352 bytes of scratch per lane and from 15 to 30 us that way)
+__device__ __forceinline__ const cmlpl_dyn* dyn_row(DynRef d, int bias = 0) {
+  return d.table != nullptr ? d.table + (__builtin_amdgcn_readfirstlane(*d.cursor) + bias) : nullptr;
+}
+// values read through a row are the same for every lane: say so (they then live in scalar registers whatever kind of
+// load fetched them -- without this hipcc 7.2 dies in the backend on "illegal VGPR to SGPR copy" in conv3x3.hip)
+__device__ __forceinline__ int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -212,14 +234,42 @@ __device__ __forceinline__ f32x16 mfma_b3(const uint4& A1, const uint4& A2, cons
 }
 
 
+// Batches by index (cmlpl_batch.d_lab_idx / d_unl_idx): labelled (unlabelled) batch row r is row idx[off + r] of the
+// resident split; idx == null: row r.  The offsets come from the device-side row when one is given (graph replay).
+struct RowSel {
+  const long long* lab_idx; const long long* unl_idx;
+  long long lab_off, unl_off;
+  DynRef dyn;
+};
+__device__ __forceinline__ long long rowsel_index(RowSel s, bool lab, int r) {
+  const long long* idx = lab ? s.lab_idx : s.unl_idx;
+  if (idx == nullptr) return r;
+  const cmlpl_dyn* d = dyn_row(s.dyn);
+  long long loff = s.lab_off, uoff = s.unl_off;
+  if (d != nullptr) { loff = uni64(d->lab_off); uoff = uni64(d->unl_off); }   // (`lab` may differ between lanes)
+  return idx[(lab ? loff : uoff) + r];
+}
+
 struct XSrc {
   const float* lab[2]; const float* unl[2];       // per network (the same pointer twice for raw inputs)
   const float* nz_lab[2]; const float* nz_unl[2]; // explicit N(0,1) draws per network, or null
   float sigma; int nlab, philox /* 1 = in-kernel draws (PCG4D noise), 0 = explicit noise tensors */, lab0, unl_base;
   uint64_t seed, step;
+  RowSel sel;                                      // batches by index + device-side step scalars (all null: plain rows)
 };
+// row of the source buffers that batch row s stands for
+__device__ __forceinline__ long long xsrc_index(const XSrc& x, int s) {
+  const bool lab = s < x.nlab;
+  return rowsel_index(x.sel, lab, lab ? s : s - x.nlab);
+}
+__device__ __forceinline__ uint64_t xsrc_step(const XSrc& x) {
+  const cmlpl_dyn* d = dyn_row(x.sel.dyn);
+  uint64_t v = x.step;
+  if (d != nullptr) v = (uint64_t)uni64((long long)d->step);
+  return v;
+}
 __device__ __forceinline__ const float* xsrc_row(const XSrc& x, int net, int s, long long per) {
-  return s < x.nlab ? x.lab[net] + (long long)s * per : x.unl[net] + (long long)(s - x.nlab) * per;
+  return (s < x.nlab ? x.lab[net] : x.unl[net]) + xsrc_index(x, s) * per;
 }
 __device__ __forceinline__ const float* xsrc_noise_row(const XSrc& x, int net, int s, long long per) {
   const float* b = s < x.nlab ? x.nz_lab[net] : x.nz_unl[net];

@@ -221,6 +221,9 @@ __device__ __forceinline__ void partial_reduce_block(const ReduceTable& t, int b
   if (t.count > 2 && bx >= t.p[2].blk0) pi = 2;
   const ReduceProb pr = t.p[pi];
   const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
+  // graph replay: this launch is where the device-side step cursor advances (no workgroup of this launch reads it;
+  // the launches before it took their row at the old value, Adam behind it takes the row before the new one)
+  if (t.dyn_cursor != nullptr && bx == 0 && net == 0 && tid == 0) *t.dyn_cursor += 1;
   const int G = pr.G, PS = pr.PS;                      // PS is a multiple of 4 (64-float tail, 4096-float taps)
   const int e0 = ((bx - pr.blk0) * 64 + el) * 4;
   const bool ev = e0 < PS;

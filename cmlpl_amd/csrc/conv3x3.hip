@@ -125,6 +125,7 @@ struct Conv3Args {
   long long w0t_ns, b0_ns;
   int C;
   float* xn_out;                                  // MODE 2, optional: the augmented rows [net][n][C*HW], kept for the backward pass
+  int rev1;                                       // MODE 2: network 1 walks the slab's band chunks downwards (both networks read the same raw rows)
   // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup; the input
   // slab is re-formed from `xs` (same noise as the forward: counter-based)
   float* part0; long long part0_ns;
@@ -158,14 +159,13 @@ __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// The sample's [C][HW] input slab -> LDS as a LINEAR copy by global_load_lds_dwordx4 (1 KiB per wave-instruction,
-// every piece in flight at once), with the augmentation x + sigma * N(0,1) (train.py:157,163,170,181) applied in
-// LDS: while its pieces are in flight a lane forms the noise of exactly the elements it requested (Philox, or the
-// explicit draws in parity mode), then waits for ITS OWN pieces only (vmcnt) and adds it in place -- no augmented
-// copy of the input ever exists in HBM.  The caller's next __syncthreads() publishes the slab.
-// (Fused data gradient, MODE 3.  A RANGE of the slab -- `nfl` floats from float4 offset `f4base` of the sample's
-// block, the whole block unless the bands take several passes -- lands at `slab`; the noise counters are those of the
-// whole block, so every pass, the forward and the augmentation kernel see the same draws.)
+// Fused data gradient (MODE 3): the sample's [C][HW] rows AS THE FORWARD SAW THEM -- the augmented rows the fused
+// forward left in the workspace (cmlpl_forward: xn_save), or a caller's pre-augmented tensor -- go to LDS as a LINEAR
+// copy by global_load_lds_dwordx4 (1 KiB per wave-instruction, every piece in flight at once).  A RANGE of the slab --
+// `nfl` floats from float4 offset `f4base` of the sample's block, the whole block unless the bands take several
+// passes -- lands at `slab`; the caller's next __syncthreads() publishes it (the barrier waits for the DMA).
+// (Rounds 2-3 could also re-form the forward's noise here from the raw rows; since the forward stores the augmented
+// rows that path was dead, and it is gone: this kernel reads plain rows only, by batch row -- no index lists.)
 constexpr int SLAB_MAXQ = 16;   // pieces per wave: range <= 4 waves * 16 * 256 floats
 constexpr int SLAB_RING = 7;    // forward: chunks (16 bands each) resident in LDS per pass
 constexpr int SLAB_WIN = 4;     // forward: chunks in flight global -> registers per wave
@@ -174,13 +174,11 @@ constexpr int SLAB_NUP = 7;     // forward: chunks whose noise is formed before 
 static_assert(SLAB_NUP == SLAB_RING, "the forward forms the noise of every chunk of a pass up front");
 typedef __attribute__((address_space(3))) void slab_lds_void;
 typedef __attribute__((address_space(1))) const void slab_gbl_void;
-struct SlabRange { const float* xs; const float* nz; uint64_t gsample; int f4base, nfl; };
+struct SlabRange { const float* xs; int nfl; };
 __device__ __forceinline__ SlabRange slab_range(const XSrc& x, int net, int s, int per, int f4base, int nfl) {
   SlabRange r;
-  r.xs = xsrc_row(x, net, s, per) + 4LL * f4base;
-  const float* nz = (x.sigma != 0.f) ? xsrc_noise_row(x, net, s, per) : nullptr;
-  r.nz = nz != nullptr ? nz + 4LL * f4base : nullptr;
-  r.gsample = xsrc_global_sample(x, s); r.f4base = f4base; r.nfl = nfl;
+  r.xs = (s < x.nlab ? x.lab[net] + (long long)s * per : x.unl[net] + (long long)(s - x.nlab) * per) + 4LL * f4base;
+  r.nfl = nfl;
   return r;
 }
 __device__ __forceinline__ void slab_issue(const SlabRange& r, float* slab, int wave, int lane) {
@@ -194,66 +192,10 @@ __device__ __forceinline__ void slab_issue(const SlabRange& r, float* slab, int 
     }
   }
 }
-// noise of this wave's piece k (elements 4f..4f+3, f = (wave + 4k) * 64 + lane) and of the last partial group
-struct SlabNoise { float4 z[SLAB_MAXQ]; float zt; };
-__device__ __forceinline__ float4 slab_noise_piece(const XSrc& x, int net, const SlabRange& r, int k, int wave, int lane) {
-  const int nf4 = r.nfl >> 2, q = wave + 4 * k;
-  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (x.sigma != 0.f && q * 64 < nf4) {                   // wave-uniform
-    if (r.nz != nullptr) {                                // parity mode: the reference's own draws
-      const int f = q * 64 + lane, fc = f < nf4 ? f : 0;
-      z = make_float4(r.nz[4 * fc], r.nz[4 * fc + 1], r.nz[4 * fc + 2], r.nz[4 * fc + 3]);
-    } else {
-      z = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(r.gsample, (uint32_t)(r.f4base + q * 64 + lane)));
-    }
-  }
-  return z;
-}
-__device__ __forceinline__ float slab_noise_tail(const XSrc& x, int net, const SlabRange& r, int tid) {
+// the last, partial float4 group of the range (C * HW need not be a multiple of 4)
+__device__ __forceinline__ void slab_tail(const SlabRange& r, float* slab, int tid) {
   const int nf4 = r.nfl >> 2, rem = r.nfl - 4 * nf4;
-  float zt = 0.f;
-  if (x.sigma != 0.f && rem != 0 && tid < 64) {           // the last, partial group: one wave forms it
-    if (r.nz != nullptr) {
-      if (tid < rem) zt = r.nz[4 * nf4 + tid];
-    } else {
-      const float4 t = noise_normal4(x.seed, x.step, STREAM_NOISE_XP + net, noise_ctr(r.gsample, (uint32_t)(r.f4base + nf4)));
-      zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
-    }
-  }
-  return zt;
-}
-// wait for this wave's pieces, add the noise in place, write the tail elements
-__device__ __forceinline__ void slab_apply(const XSrc& x, const SlabRange& r, float* slab, int tid, int wave,
-                                           int lane, const SlabNoise& nzv) {
-  const int nf4 = r.nfl >> 2, rem = r.nfl - 4 * nf4;
-  float tailv = 0.f;
-  if (tid < rem) tailv = r.xs[4 * nf4 + tid];
-  if (x.sigma != 0.f) {                                   // uniform
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
-#pragma unroll
-    for (int k = 0; k < SLAB_MAXQ; ++k) {
-      const int q = wave + 4 * k;
-      if (q * 64 < nf4) {
-        const int f = q * 64 + lane;
-        if (f < nf4) {
-          float4 v = *(float4*)(slab + 4 * f);
-          v.x = fmaf(nzv.z[k].x, x.sigma, v.x); v.y = fmaf(nzv.z[k].y, x.sigma, v.y);
-          v.z = fmaf(nzv.z[k].z, x.sigma, v.z); v.w = fmaf(nzv.z[k].w, x.sigma, v.w);
-          *(float4*)(slab + 4 * f) = v;
-        }
-      }
-    }
-    if (tid < rem) tailv = fmaf(nzv.zt, x.sigma, tailv);
-  }
-  if (tid < rem) slab[4 * nf4 + tid] = tailv;
-}
-__device__ __forceinline__ void slab_finish(const XSrc& x, int net, const SlabRange& r, float* slab, int tid, int wave,
-                                            int lane) {
-  SlabNoise nzv;
-#pragma unroll
-  for (int k = 0; k < SLAB_MAXQ; ++k) nzv.z[k] = slab_noise_piece(x, net, r, k, wave, lane);
-  nzv.zt = slab_noise_tail(x, net, r, tid);
-  slab_apply(x, r, slab, tid, wave, lane, nzv);
+  if (tid < rem) slab[4 * nf4 + tid] = r.xs[4 * nf4 + tid];
 }
 
 // ---- "fp32 on the bf16 MFMA" ------------------------------------------------------------------------------------
@@ -570,6 +512,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const float sigma = a.xs.sigma;
     const float* nzrow = (sigma != 0.f) ? xsrc_noise_row(a.xs, net, s0, nfl) : nullptr;
     const uint64_t gsample = xsrc_global_sample(a.xs, s0);
+    const uint64_t rstep = xsrc_step(a.xs);               // counter of the random streams (launch argument, or the device-side row)
+    const bool rev = (net & 1) && a.rev1;                 // uniform: network 1 walks the bands downwards (see pch)
     // The augmented rows also go to HBM (16-byte stores from the registers that feed the LDS slots): the backward pass
     // lands them by DMA instead of regenerating the noise -- forming 12,463 normals per sample-net costs ~5 us of vector
     // work per workgroup, the longest single item of that kernel's second half, while these stores ride on an idle HBM.
@@ -583,7 +527,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         float zt;
         if (nzrow != nullptr) zt = nzrow[4 * nf4 + tid];
         else {
-          const float4 t = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)nf4));
+          const float4 t = noise_normal4(a.xs.seed, rstep, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)nf4));
           zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
         }
         tailv = fmaf(zt, sigma, tailv);
@@ -601,17 +545,25 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       if (c0 > 0) __syncthreads();                        // every wave is done reading the previous pass's slots
       uint4 bw[2][6];                                     // conv0 weight fragments of two chunks (window): [n tile][piece]
       float4 dv[SLAB_WIN][2], nzv[SLAB_RING][2];
+      // Which chunk of the slab the kq-th step of this pass takes.  Network 0 walks the bands upwards, network 1
+      // DOWNWARDS: both networks of a sample read the same raw rows (their workgroups are 256 block ids apart, i.e. on
+      // the same XCD) and start together -- walking the same way, both miss on every chunk and the slab crosses the
+      // fabric twice (FETCH 22.9 MB for 12.9 MB of patches, round 3); walking in opposite directions each finds the
+      // other's first half in L2 by the time it gets there.  (Only the order of conv0's k-steps differs between the
+      // networks: same products, another summation order.)
+      auto pch = [&](int kq) { return rev ? KQ0 - 1 - (c0 + kq) : c0 + kq; };
       auto fetch_b = [&](int kq, uint4 (&b)[6]) {
+        const int kp = pch(kq);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) b[3 * nt + pc] = wq0[(((c0 + kq) * 3 + pc) * 2 + nt) * 64];
+          for (int pc = 0; pc < 3; ++pc) b[3 * nt + pc] = wq0[((kp * 3 + pc) * 2 + nt) * 64];
       };
       // this lane's float4 k of chunk kq: local index g inside the chunk, global index gg inside the slab
       auto fetch_d = [&](int kq, float4 (&d)[2]) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+          const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
           const bool ok = k < PPW && g < CH4l && gg < nf4;
           const float4 v = *(const float4*)(xrow + 4 * (ok ? gg : 0));
           d[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -621,10 +573,11 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       for (int kq = 0; kq < 2; ++kq) if (kq < nch) fetch_b(kq, bw[kq]);
 #pragma unroll
       for (int kq = 0; kq < SLAB_WIN; ++kq) if (kq < nch) fetch_d(kq, dv[kq]);
-      if (c0 + nch == KQ0) {
-        // the bands beyond C of the last chunk meet zero weights, but must be finite
+      if (rev ? c0 == 0 : c0 + nch == KQ0) {
+        // the bands beyond C of the last chunk (this pass's slot nch - 1, or slot 0 when walking downwards) meet zero
+        // weights, but must be finite
         const int used = nfl - (KQ0 - 1) * 16 * HWl;
-        float* sl = slab + (nch - 1) * SLOT;
+        float* sl = slab + (rev ? 0 : nch - 1) * SLOT;
         for (int i = used + tid; i < 16 * HWl; i += 256) sl[i] = 0.f;
       }
       // The noise of a chunk's elements (pure vector work: a hash + Box-Muller per four normals, ~380 cycles per call and
@@ -639,7 +592,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         for (int kq = 0; kq < SLAB_NUP; ++kq)
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+            const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
             float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             if (noise_live(kq, k)) z = *(const float4*)(nzrow + 4 * ((g < CH4l && gg < nf4) ? gg : 0));
             nzv[kq][k] = z;
@@ -649,9 +602,9 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         for (int kq = 0; kq < SLAB_NUP; ++kq)
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+            const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
             float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (noise_live(kq, k)) z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
+            if (noise_live(kq, k)) z = noise_normal4(a.xs.seed, rstep, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
             nzv[kq][k] = z;
           }
       }
@@ -663,7 +616,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         float* sl = slab + kq * SLOT;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int g = (wave + 4 * k) * 64 + lane, gg = (c0 + kq) * CH4l + g;
+          const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
           if (k < PPW && g < CH4l && gg < nf4) {
             float4 v = dv[kq % SLAB_WIN][k];
             if (sigma != 0.f) {
@@ -674,7 +627,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             if (xnrow != nullptr) *(float4*)(xnrow + 4 * gg) = v;
           }
         }
-        if (c0 + kq == KQ0 - 1 && tid < rem) {
+        if (pch(kq) == KQ0 - 1 && tid < rem) {
           sl[4 * nf4 - (KQ0 - 1) * 16 * HWl + tid] = tailv;
           if (xnrow != nullptr) xnrow[4 * nf4 + tid] = tailv;
         }
@@ -905,7 +858,7 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
         dm4[q] = *(const float4*)(a.dropmask + rs * F + f0);
       } else if (dmode == 2) {
         const unsigned long long gs = xsrc_global_sample(a.xs, sample);
-        const float4 u = philox_uniform4(a.xs.seed, a.xs.step, STREAM_DROPOUT + net, (gs * F + f0) >> 2);
+        const float4 u = philox_uniform4(a.xs.seed, xsrc_step(a.xs), STREAM_DROPOUT + net, (gs * F + f0) >> 2);
         float4 m4;
         m4.x = (u.x >= a.dropout_p) ? keep_scale : 0.f; m4.y = (u.y >= a.dropout_p) ? keep_scale : 0.f;
         m4.z = (u.z >= a.dropout_p) ? keep_scale : 0.f; m4.w = (u.w >= a.dropout_p) ? keep_scale : 0.f;
@@ -1419,7 +1372,7 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
         rg = slab_range(a.xs, net, s0, C * HW, (cb * HW) >> 2, nb * HW);   // (BP * HW is a multiple of 4)
         slab_issue(rg, slab, wave, lane);
       }
-      slab_finish(a.xs, net, rg, slab, tid, wave, lane);  // ... with the forward's noise regenerated
+      slab_tail(rg, slab, tid);
       if (cb == 0) STAMP(1, 13);
       __syncthreads();                                    // range landed (the barrier waits for the DMA), da0 complete
       // dW0 tile of this wave on the split-bf16 MFMA: k-steps of 16 pixels; lane (row = band c, half h) takes pixels
@@ -1634,7 +1587,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   if (mode == 0) { a.in_ns = (long long)n * HW * 64; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns; a.mask_in_ns = 0; }
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr; a.rev1 = 0;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
@@ -1697,6 +1650,8 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
+  static const bool rev_off = getenv("CMLPL_FWD_REV") && atoi(getenv("CMLPL_FWD_REV")) == 0;
+  a.rev1 = (!rev_off && nets == 2 && xs.lab[0] == xs.lab[1] && xs.unl[0] == xs.unl[1]) ? 1 : 0;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -1769,7 +1724,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.wpk_ns = wpk_ns; a.bias_ns = 0;
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr; a.rev1 = 0;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = conv3_bwd_bp(H, W, C);
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;

@@ -84,7 +84,7 @@ constexpr int SPE_GPH = 4;     // groups of four bands per lane half
 struct SpeArgs {
   XSrc xs; const float* w; const float* bias; long long p_ns;      // feat_spe.weight [1024][bands] / .bias, canonical
   float* y; float* sn; int n, bands;
-  const long long* labels; float* labels_f; int bt;        // optional: labels as float for the exchange buffer
+  const long long* labels; float* labels_f; int bt;        // optional: labels as float for the exchange buffer (labels by xs.lab_idx)
 };
 
 template <int NW>
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x, mt = blockIdx.y, net = blockIdx.z;
   if (a.labels_f != nullptr && nt == 0 && mt == 0 && net == 0)
-    for (int q = tid; q < a.bt; q += 64 * NW) a.labels_f[q] = (float)a.labels[q];
+    for (int q = tid; q < a.bt; q += 64 * NW) a.labels_f[q] = (float)a.labels[xsrc_index(a.xs, q)];
   // Band order of the contraction.  An MFMA step multiplies ONE band per lane half; which band is ours to choose, as
   // long as both operands agree.  The bands are cut into groups of four (= one noise call, = one 16-byte load of the
   // row); a wave takes 2 * SPE_GPH consecutive groups, its lower lane half the first SPE_GPH of them, the upper half
@@ -141,9 +141,10 @@ __global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
   }
   if (a.xs.sigma != 0.f && nz == nullptr) {                     // in-kernel noise (uniform branch, pure ALU)
     const uint64_t gs = xsrc_global_sample(a.xs, ic);
+    const uint64_t rstep = xsrc_step(a.xs);
 #pragma unroll
     for (int gq = 0; gq < SPE_GPH; ++gq) {
-      const float4 z = noise_normal4(a.xs.seed, a.xs.step, STREAM_NOISE_X + net, noise_ctr(gs, (uint32_t)(g0 + gq)));
+      const float4 z = noise_normal4(a.xs.seed, rstep, STREAM_NOISE_X + net, noise_ctr(gs, (uint32_t)(g0 + gq)));
       zv[4 * gq] = z.x; zv[4 * gq + 1] = z.y; zv[4 * gq + 2] = z.z; zv[4 * gq + 3] = z.w;
     }
   }

@@ -15,6 +15,7 @@ struct HeadFwdArgs {
   float dropout_p; int train; uint64_t seed, step;
   int n, HW4, K;
   int nlab, lab0, unl_base;   // local row -> GLOBAL sample index (Philox key independent of sharding)
+  DynRef dyn;                 // the step counter from device memory (graph replay), or null
 };
 
 constexpr int HEAD_MAXQ4 = 3;   // ceil(F / 1024) <= 3  (F <= 3072)
@@ -70,7 +71,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
         x.x *= m4.x; x.y *= m4.y; x.z *= m4.z; x.w *= m4.w;
       } else if (dmode == 2) {
         const unsigned long long gs = (sample < a.nlab) ? a.lab0 + sample : a.unl_base + (sample - a.nlab);
-        const float4 u = philox_uniform4(a.seed, a.step, STREAM_DROPOUT + net, (gs * F + f0) >> 2);
+        uint64_t rstep = a.step;
+        const cmlpl_dyn* dynr = dyn_row(a.dyn);
+        if (dynr != nullptr) rstep = (uint64_t)uni64((long long)dynr->step);
+        const float4 u = philox_uniform4(a.seed, rstep, STREAM_DROPOUT + net, (gs * F + f0) >> 2);
         float4 m4;
         m4.x = (u.x >= a.dropout_p) ? keep_scale : 0.f; m4.y = (u.y >= a.dropout_p) ? keep_scale : 0.f;
         m4.z = (u.z >= a.dropout_p) ? keep_scale : 0.f; m4.w = (u.w >= a.dropout_p) ? keep_scale : 0.f;
@@ -130,8 +134,9 @@ hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, con
                            float* dropgen, float dropout_p, int train, uint64_t seed, uint64_t step,
                            int nlab, int lab0, int unl_base,
                            const float* wc, const float* bc, long long pstride,
-                           float* catd, float* ynorm, float* logits, float* feat, hipStream_t st) {
+                           float* catd, float* ynorm, float* logits, float* feat, hipStream_t st, DynRef dyn) {
   HeadFwdArgs a;
+  a.dyn = dyn;
   a.p2 = p2; a.y = y; a.dropmask = dropmask; a.dropgen = dropgen; a.wc = wc; a.bc = bc; a.pstride = pstride;
   a.catd = catd; a.ynorm = ynorm; a.logits = logits; a.feat = feat;
   a.dropout_p = dropout_p; a.train = train; a.seed = seed; a.step = step; a.n = n; a.HW4 = HW4; a.K = K;

@@ -66,7 +66,7 @@ hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int 
                           const float* xpl, const float* xl, const float* xpu, const float* xu,
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
                           float* xn, float* sn, float* snT, hipStream_t st,
-                          const long long* labels = nullptr, float* labels_f = nullptr);
+                          const long long* labels = nullptr, float* labels_f = nullptr, const RowSel* sel = nullptr);
 hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
                               long long* labels_g, hipStream_t st);
 
@@ -122,7 +122,7 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
 int plan_conv0_wgrad_G(int n, int C, int HW);
 // deterministic sum of per-workgroup weight-gradient partials, up to 3 tensors in one launch
 struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C, blk0, el; };
-struct ReduceTable { ReduceProb p[3]; int count, total_blocks; long long grad_ns; };
+struct ReduceTable { ReduceProb p[3]; int count, total_blocks; long long grad_ns; int* dyn_cursor /* advanced by 1, or null */; };
 void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db);
 hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st);
 struct GemmTN;
@@ -155,7 +155,8 @@ hipError_t launch_head_fwd(int nets, int n, int HW4, int K, const float* p2, con
                            float* dropgen, float dropout_p, int train, uint64_t seed, uint64_t step,
                            int nlab, int lab0, int unl_base,
                            const float* wc, const float* bc, long long pstride,
-                           float* catd, float* ynorm, float* logits, float* feat, hipStream_t st);
+                           float* catd, float* ynorm, float* logits, float* feat, hipStream_t st,
+                           DynRef dyn = DynRef());
 hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits, const float* dfeat,
                            const float* dropmask, const float* wc, long long pstride,
                            const float* y, const float* ynorm,
@@ -175,6 +176,8 @@ struct LossArgs {
   int pshard;                             // rows per shard in probs_g (= btu on one GPU)
   float adap_mask, T, alpha, w_contrast, w_mutual, pos_thr, neg_thr;
   float* scalars; float* dlogits; float* dfeat;   // local layouts: [2][nlab+nunl][K], [2][nlab+nunl][1024]
+  RowSel sel;                             // labels by index (plain mode) + device-side step scalars: ptr0 / ptr1 / smooth /
+                                          // adap_mask / logging row are then read from the row, `scalars` is the ring base
   float* probs_l;                         // [4][nunl][K] written by phase 1
   const float* probs_g;                   // shard-major [btu/pshard][4][pshard][K] read by phase 2
   float* dfw_part;                        // [btu][1024] partial of dfeat_w over this shard's rows
@@ -195,7 +198,8 @@ hipError_t launch_ntxent(const float* ei, const float* ej, int B, int D, float T
 // ---- optim.hip
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
-                       float* packed, const PackInfo& pi, hipStream_t st);
+                       float* packed, const PackInfo& pi, hipStream_t st, DynRef dyn = DynRef());
+void adam_bias_scalars(float lr, float b1, float b2, long long t, float* step_size, float* bc2_sqrt);
 
 
 // ---- memobank.hip  (loss_helper.py)

@@ -85,9 +85,20 @@ __device__ __forceinline__ const float* logit_unl(const LossArgs& a, int net, in
   return a.recv + r * a.pack + ((long long)net * n_l + a.bt_l + i) * a.K;
 }
 __device__ __forceinline__ int label_of(const LossArgs& a, int g) {
-  if (a.recv == nullptr) return (int)a.labels[g];
+  if (a.recv == nullptr) return (int)a.labels[rowsel_index(a.sel, true, g)];
   const int r = g / a.bt_l, i = g - r * a.bt_l, n_l = a.bt_l + a.btu_l;
   return (int)(a.recv[r * a.pack + 2LL * n_l * a.K + 2LL * n_l * FD + i] + 0.5f);
+}
+
+// the step scalars of the loss block: launch arguments, or the device-side row (graph replay)
+// (value first, then the override: written as `d ? d->smooth : a.smooth` the compiler selects between the two
+//  ADDRESSES, the kernel-argument struct escapes into a generic pointer and is copied to scratch -- 352 bytes per lane
+//  and 15 -> 30 us for pair_exp16_kernel)
+__device__ __forceinline__ int loss_smooth(const LossArgs& a) {
+  int v = a.smooth;
+  const cmlpl_dyn* d = dyn_row(a.sel.dyn);
+  if (d != nullptr) v = uni32(d->smooth);
+  return v;
 }
 
 // One workgroup per 32x32 tile of one product; the 1024-long contraction is split over the 4 waves (256
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(256) void pair_exp_kernel(LossArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
-  if (prob < 2 && !a.smooth) return;
+  if (prob < 2 && !loss_smooth(a)) return;
   const int btu = a.btu, nunl = a.nunl, K = a.K;
   const float* A = feat_unl(a, prob == 0 ? 1 : 0, a.unl0);        // local rows (one rank's block: contiguous)
   const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : nullptr;   // prob 2: fU_w, all rows
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(256) void pair_exp16_kernel(LossArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
-  if (prob < 2 && !a.smooth) return;
+  if (prob < 2 && !loss_smooth(a)) return;
   const int btu = a.btu, nunl = a.nunl, K = a.K;
   const float* A = feat_unl(a, prob == 0 ? 1 : 0, a.unl0);        // local rows (one rank's block: contiguous)
   const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : nullptr;   // prob 2: fU_w, all rows
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int prob = blockIdx.z;
-  if (prob < 2 && !a.smooth) return;
+  if (prob < 2 && !loss_smooth(a)) return;
   const int btu = a.btu, nunl = a.nunl, K = a.K;
   const float* A = feat_unl(a, prob == 0 ? 1 : 0, a.unl0);
   const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : nullptr;
@@ -521,7 +532,10 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
 __device__ __forceinline__ void bank_write_block(const LossArgs& a, int r) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int btu = a.btu, K = a.K, Q = a.Q;
-  const int d0 = (a.ptr0 + r) % Q, d1 = (a.ptr1 + r) % Q;
+  int p0 = a.ptr0, p1 = a.ptr1;
+  const cmlpl_dyn* dynr = dyn_row(a.sel.dyn);
+  if (dynr != nullptr) { p0 = uni32(dynr->ptr[0]); p1 = uni32(dynr->ptr[1]); }
+  const int d0 = (p0 + r) % Q, d1 = (p1 + r) % Q;
   const float *s0, *s1;
   if (r < btu) { s0 = feat_unl(a, 1, r); s1 = feat_unl(a, 0, r); }
   else         { s0 = feat_lab(a, 0, r - btu); s1 = feat_lab(a, 1, r - btu); }
@@ -564,6 +578,10 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const int RL = nlab > nunl ? nlab : nunl;
   const bool kv = lane < K;
   const float NEG = -3.0e38f;
+  int smooth = a.smooth;
+  float adap_mask = a.adap_mask;
+  const cmlpl_dyn* dynr = dyn_row(a.sel.dyn);
+  if (dynr != nullptr) { smooth = uni32(dynr->smooth); adap_mask = __int_as_float(uni32(__float_as_int(dynr->adap_mask))); }
   if (idx < nlab) {
     const int il = idx, ig = a.lab0 + il;                 // local / global labelled row
     const int yl = label_of(a, ig);
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const float* e0 = a.ep_part + ((long long)0 * CT * nunl + i) * K + (kqv ? kq : 0);
   const float* e1 = a.ep_part + ((long long)1 * CT * nunl + i) * K + (kqv ? kq : 0);
   float t0[LRD], t1[LRD], r0 = 0.f, r1 = 0.f;
-  if (a.smooth) {
+  if (smooth) {
 #pragma unroll
     for (int q = 0; q < LRD; ++q) {
       const int ct = gq + q * G;
@@ -629,7 +647,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   const float sms = es / ses, smw = ew / sew;            // softmax
   const float lsms = zs - mxs - logf(ses), lsmw = zw - mxw - logf(sew);  // log_softmax
   float pw = smw, ps = sms;                              // "probs" (Base1) / "probs1" (Base)
-  if (a.smooth) {
+  if (smooth) {
     float rsw = r0, rss = r1;
     for (int ct = lane + 64; ct < CT; ct += 64) {
       rsw += a.rs_part[((long long)0 * CT + ct) * nunl + i];
@@ -655,8 +673,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     pw = a.alpha * smw + (1.f - a.alpha) * (epw / rsw);
     ps = a.alpha * sms + (1.f - a.alpha) * (eps_ / rss);
   }
-  const float mw = (wave_max(kv ? pw : NEG) >= a.adap_mask) ? 1.f : 0.f;   // "mask"  (train.py:222)
-  const float ms = (wave_max(kv ? ps : NEG) >= a.adap_mask) ? 1.f : 0.f;   // "masks" (train.py:228)
+  const float mw = (wave_max(kv ? pw : NEG) >= adap_mask) ? 1.f : 0.f;   // "mask"  (train.py:222)
+  const float ms = (wave_max(kv ? ps : NEG) >= adap_mask) ? 1.f : 0.f;   // "masks" (train.py:228)
   const float spw = wave_sum(kv ? pw : 0.f), sps = wave_sum(kv ? ps : 0.f);
   const float cs = -wave_sum(kv ? lsms * pw : 0.f) * mw;   // train.py:239
   const float cw = -wave_sum(kv ? lsmw * ps : 0.f) * ms;   // train.py:240
@@ -768,22 +786,28 @@ __device__ __forceinline__ void loss_scalars_block(const LossArgs& a, float* red
   const int tid = threadIdx.x;
   const int bt = a.bt, btu = a.btu;
   const int RL = a.nlab > a.nunl ? a.nlab : a.nunl;
-  float v[RL_COUNT];
+  // every per-thread partial first (ten independent strided loads, one memory round trip), then ONE folded block sum
+  // (round 3 ran ten load -> two-barrier sums in a row: this single workgroup was the long pole of its launch)
+  float v[RL_COUNT + 2];
 #pragma unroll
   for (int q = 0; q < RL_COUNT; ++q) {
     const int cnt = (q <= RL_ACC) ? a.nlab : a.nunl;
     float s = 0.f;
     for (int i = tid; i < cnt; i += 256) s += a.rowloss[q * RL + i];
-    v[q] = block_sum(s, red, tid);
+    v[q] = s;
   }
   float mws = 0.f, mss = 0.f;
   for (int i = tid; i < a.nunl; i += 256) { mws += a.masks[i]; mss += a.masks[a.nunl + i]; }
-  mws = block_sum(mws, red, tid);
-  mss = block_sum(mss, red, tid);
+  v[RL_COUNT] = mws; v[RL_COUNT + 1] = mss;
+  block_sum_n<RL_COUNT + 2>(v, red, tid);
+  mws = v[RL_COUNT]; mss = v[RL_COUNT + 1];
   if (tid == 0) {
     const float cls_s = v[RL_CLS_S] / bt, cls_w = v[RL_CLS_W] / bt, acc = v[RL_ACC] / bt;
     const float con_s = v[RL_CON_S] / btu, con_w = v[RL_CON_W] / btu, ctr = v[RL_CTR] / btu;
-    float* o = a.scalars;
+    int hrow = 0;
+    const cmlpl_dyn* dynr = dyn_row(a.sel.dyn);
+    if (dynr != nullptr) hrow = dynr->hist_row;
+    float* o = a.scalars + 16 * hrow;
     o[0] = ctr;                                              // loss_contrast  (train.py:274)
     o[1] = cls_s + a.w_contrast * ctr + a.w_mutual * con_s;  // total_loss     (:266,275)
     o[2] = cls_s;                                            // (:276)
@@ -806,7 +830,8 @@ __global__ __launch_bounds__(256) void loss_dfeat_kernel(GemmTN2 t, int gemm_blo
 hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
   hipError_t e;
   const int nl = a.nlab + a.nunl;
-  const int maxc = (a.smooth && a.Q > a.btu) ? a.Q : a.btu;
+  // (device-side step scalars: whether the banks are read is decided in the kernels, the grid covers them)
+  const int maxc = ((a.smooth || a.sel.dyn.table != nullptr) && a.Q > a.btu) ? a.Q : a.btu;
   // wide products (many column tiles): tall tiles; narrow ones: 32x32 tiles with the contraction split over the waves
   static const int force_tall = getenv("CMLPL_PAIR_TALL") ? atoi(getenv("CMLPL_PAIR_TALL")) : -1;
   const int ctiles = (maxc + 31) / 32;

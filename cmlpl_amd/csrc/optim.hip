@@ -15,6 +15,7 @@ struct AdamArgs {
   float w1, b2, w2, step_size, bc2_sqrt, eps;
   float* packed; PackInfo pi;
   int nb_elem;                     // blocks of the elementwise part; the 3x3 weight chunks follow
+  DynRef dyn;                      // the two bias-correction scalars from device memory (graph replay), or null
 };
 
 __device__ __forceinline__ float adam_update(float& mm, float& vv, float p, float g, const AdamArgs& a) {
@@ -22,6 +23,14 @@ __device__ __forceinline__ float adam_update(float& mm, float& vv, float p, floa
   vv = vv * a.b2 + (a.w2 * g) * g;                       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
   const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
   return p - a.step_size * (mm / denom);                 // param.addcdiv_(exp_avg, denom, -step_size)
+}
+// (this launch runs behind the cursor's advance: its row is the one before the cursor)
+__device__ __forceinline__ void adam_dyn(AdamArgs& a) {
+  const cmlpl_dyn* d = dyn_row(a.dyn, -1);
+  if (d != nullptr) {
+    a.step_size = __int_as_float(uni32(__float_as_int(d->adam_step_size)));
+    a.bc2_sqrt = __int_as_float(uni32(__float_as_int(d->adam_bc2_sqrt)));
+  }
 }
 
 // A 3x3 weight tensor in chunks of (four output channels) x (sixteen input channels) = 4 segments of 144 consecutive
@@ -87,6 +96,7 @@ __device__ __forceinline__ void adam_conv_chunk(const AdamArgs& a, int chunk, in
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[768];
   const int net = blockIdx.y;
+  adam_dyn(a);
   if ((int)blockIdx.x >= a.nb_elem) { adam_conv_chunk(a, (int)blockIdx.x - a.nb_elem, net, lds); return; }
   const PackInfo& pi = a.pi;
   float* packed = a.packed;
@@ -129,13 +139,19 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
+void adam_bias_scalars(float lr, float b1, float b2, long long t, float* step_size, float* bc2_sqrt) {
+  const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+  *step_size = (float)((double)lr / bc1); *bc2_sqrt = (float)sqrt(bc2);
+}
+
 hipError_t launch_adam(int nets, float* params, long long pstride, const float* grads, long long gstride,
                        float* m, float* v, long long live, long long t, float lr, float b1, float b2, float eps,
-                       float* packed, const PackInfo& pi, hipStream_t st) {
-  const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
-  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+                       float* packed, const PackInfo& pi, hipStream_t st, DynRef dyn) {
+  float step_size, bc2_sqrt;
+  adam_bias_scalars(lr, b1, b2, t, &step_size, &bc2_sqrt);
   const long long n4 = (live + 3) / 4;
   AdamArgs a;
+  a.dyn = dyn;
   a.params = params; a.pstride = pstride; a.grads = grads; a.gstride = gstride; a.m = m; a.v = v; a.live = live;
   a.w1 = (float)(1.0 - (double)b1); a.b2 = b2; a.w2 = (float)(1.0 - (double)b2); a.step_size = step_size;
   a.bc2_sqrt = bc2_sqrt; a.eps = eps; a.packed = (CMLPL_ABL == 40) ? nullptr : packed; a.pi = pi;   // (40: timing of the update alone)

@@ -92,6 +92,14 @@ def init_distributed(backend: str = "nccl", device: Optional[torch.device] = Non
             dist.init_process_group("nccl", device_id=device, **kw)
         else:
             dist.init_process_group(backend, **kw)
+    except Exception as e:
+        from .launch import EXIT_PORT_TAKEN, port_taken
+        if port_taken(e):          # lost the port between the launcher's probe and this bind: the launcher starts over
+            import sys
+            sys.stderr.write(f"cmlpl_amd.distributed: rank {rank}: rendezvous port already in use ({e})\n")
+            sys.stderr.flush()
+            os._exit(EXIT_PORT_TAKEN)
+        raise
     finally:
         guard.cancel()
     guard = _fail_after(timeout_s, f"the first {backend} collective (RCCL: HSA_ENABLE_IPC_MODE_LEGACY=0 set? xGMI peers visible?)")
@@ -312,19 +320,17 @@ class DistTrainEngine(TrainEngine):
         return b
 
     # ------------------------------------------------------------------ stages (no communication inside)
-    def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True):
+    def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True,
+                      lab_idx=None, unl_idx=None):
         s, lib = self.shape, self.lib
-        bt_l, btu_l = int(XPl.shape[0]), int(XPu.shape[0])
-        if bt_l < 1 or btu_l < 1 or bt_l > self.bt_max or btu_l > self.btu_max:
+        # (lab_idx / unl_idx: THIS rank's rows as indices into the resident splits, see TrainEngine.step)
+        bt_l, btu_l = self._check_rows(XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
+        if btu_l > self.btu_max:
             raise ValueError(f"shard {bt_l}+{btu_l} outside the engine's capacity {self.bt_max}+{self.btu_max} per rank")
         if self.Q < (bt_l + btu_l) * self.world:
             raise ValueError("bank smaller than the global batch")
         self._bind(bt_l, btu_l)
         n_l = bt_l + btu_l
-        _chk_f32(XPl, (bt_l, s.C, s.H, s.W), "XPl"); _chk_f32(Xl, (bt_l, s.bands), "Xl")
-        _chk_f32(XPu, (btu_l, s.C, s.H, s.W), "XPu"); _chk_f32(Xu, (btu_l, s.bands), "Xu")
-        if Y.dtype != torch.int64 or tuple(Y.shape) != (bt_l,) or not Y.is_cuda:
-            raise ValueError("Y: need int64 cuda tensor [bt]")
         st = self._stream()
         self._ensure_packed(st)
         keep = None
@@ -335,11 +341,12 @@ class DistTrainEngine(TrainEngine):
         if dropmask is not None:
             _chk_f32(dropmask, (2, n_l, s.cls_in), "dropmask")
         self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
-        batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), Y.data_ptr(), noise8, bt_l, btu_l)
+        batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), Y.data_ptr(), noise8, bt_l, btu_l,
+                           None if lab_idx is None else lab_idx.data_ptr(), None if unl_idx is None else unl_idx.data_ptr())
         self._ctx = dict(epoch=epoch, batch_index=batch_index, apply_update=apply_update, dropmask=dropmask,
                          smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
-                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)), keep=(keep, XPl, Xl, Y, XPu, Xu, noise),
-                         batch=batch)
+                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)),
+                         keep=(keep, XPl, Xl, Y, XPu, Xu, noise, lab_idx, unl_idx), batch=batch)
         # augmentation + both forwards; the raw rows are handed over as they are (no augmented copy in HBM)
         _lib.check("cmlpl_forward", lib.cmlpl_forward(
             C.byref(self.cshape), C.byref(self._chp), C.byref(batch), C.byref(self.cshard), self.params.data_ptr(),
@@ -405,10 +412,14 @@ class DistTrainEngine(TrainEngine):
 
     # ------------------------------------------------------------------ the step
     def step(self, XPl, Xl, Y, XPu, Xu, epoch: int, batch_index: int, noise: Optional[Sequence[torch.Tensor]] = None,
-             dropmask: Optional[torch.Tensor] = None, apply_update: bool = True) -> None:
+             dropmask: Optional[torch.Tensor] = None, apply_update: bool = True, lab_idx=None, unl_idx=None) -> None:
         """Per-rank inputs: this rank's bt/W labelled and btu/W unlabelled rows (noise / dropmask, when given,
-        are this rank's slices too)."""
-        drive_step(self, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update)
+        are this rank's slices too) -- or, with lab_idx / unl_idx, the resident splits and this rank's row indices."""
+        drive_step(self, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update,
+                   lab_idx=lab_idx, unl_idx=unl_idx)
+
+    def capture(self, *a, **k):
+        raise NotImplementedError("the sharded step is not captured: its collectives run between the launches")
 
     def outputs(self):
         """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..], in global row order [labelled of all

@@ -39,6 +39,7 @@ class TrainEngine:
     size where the reference's slice-assign would raise; the pointer advance is the
     reference literal 256 (``hp.bank_step``) -- see DESIGN.md "memory bank".
     """
+    takes_indices = True      # step(..., lab_idx=, unl_idx=): batches as row indices into the resident splits
 
     def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
                  hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, bank_labeled: int = 0,
@@ -144,32 +145,78 @@ class TrainEngine:
             self._packed_dirty = False
 
     # ------------------------------------------------------------------ the step
+    def _check_rows(self, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx):
+        """Shapes of a batch: the rows themselves, or (lab_idx / unl_idx given) the resident splits the int64 index
+        lists point into (hsi_loader.py:109-133 hands rows out by index; here the kernels follow the index)."""
+        s = self.shape
+        if (lab_idx is None) != (unl_idx is None):
+            raise ValueError("lab_idx and unl_idx come together")
+        for name, t in (("lab_idx", lab_idx), ("unl_idx", unl_idx)):
+            if t is not None and (t.dtype != torch.int64 or t.dim() != 1 or not t.is_cuda or not t.is_contiguous()):
+                raise ValueError(f"{name}: need a contiguous int64 cuda vector")
+        bt = XPl.shape[0] if lab_idx is None else lab_idx.shape[0]
+        btu = XPu.shape[0] if unl_idx is None else unl_idx.shape[0]
+        n = bt + btu
+        if bt < 1 or btu < 1 or bt > self.bt_max or n > self.n_max:
+            raise ValueError(f"batch {bt}+{btu} outside the engine's capacity {self.bt_max}+{self.btu_max}")
+        nl, nu = XPl.shape[0], XPu.shape[0]
+        _chk_f32(XPl, (nl, s.C, s.H, s.W), "XPl"); _chk_f32(Xl, (nl, s.bands), "Xl")
+        _chk_f32(XPu, (nu, s.C, s.H, s.W), "XPu"); _chk_f32(Xu, (nu, s.bands), "Xu")
+        if Y.dtype != torch.int64 or tuple(Y.shape) != (nl,) or not Y.is_cuda:
+            raise ValueError("Y: need int64 cuda tensor, one label per labelled row")
+        return bt, btu
+
+    def _fill_io(self, io, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu):
+        io.d_xpl, io.d_xl, io.d_labels = XPl.data_ptr(), Xl.data_ptr(), Y.data_ptr()
+        io.d_xpu, io.d_xu = XPu.data_ptr(), Xu.data_ptr()
+        if lab_idx is not None:
+            io.d_lab_idx, io.d_unl_idx = lab_idx.data_ptr(), unl_idx.data_ptr()
+        io.d_params, io.d_m, io.d_v = self.params.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
+        io.d_grads, io.d_packed = self.grads.data_ptr(), self.packed.data_ptr()
+        for i in range(2):
+            io.banks.d_feats[i] = self.bank_feats[i].data_ptr()
+            io.banks.d_probs[i] = self.bank_probs[i].data_ptr()
+        io.banks.Q = self.Q
+        # outputs are laid out [2][n][..] for THIS n (views of the max-size buffers)
+        io.d_logits, io.d_feat = self.logits.data_ptr(), self.feat.data_ptr()
+        io.d_workspace, io.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
+        io.bt, io.btu = bt, btu
+        io.seed = self.seed
+
+    def _advance(self, n, apply_update=True):
+        """host copy of the step bookkeeping: bank pointers (train.py:234,237 -- ptr1 follows ptr0, reference quirk
+        kept), Adam step, step counter"""
+        p0 = (self.ptr[0] + self.hp.bank_step) % self.Q
+        self.ptr = [p0, (p0 + self.hp.bank_step) % self.Q]
+        if apply_update:
+            self.adam_t += 1
+        self.step_count += 1
+        self._last_n = n
+
     def step(self, XPl: torch.Tensor, Xl: torch.Tensor, Y: torch.Tensor, XPu: torch.Tensor, Xu: torch.Tensor,
              epoch: int, batch_index: int, noise: Optional[Sequence[torch.Tensor]] = None,
-             dropmask: Optional[torch.Tensor] = None, apply_update: bool = True) -> None:
+             dropmask: Optional[torch.Tensor] = None, apply_update: bool = True,
+             lab_idx: Optional[torch.Tensor] = None, unl_idx: Optional[torch.Tensor] = None) -> None:
         """One training step; asynchronous.  Results land in ``self.scalars`` (device),
         ``self.logits`` / ``self.feat`` ([2][n][..]) and ``self.grads``.
 
         noise    : None -> in-kernel draws (PCG4D hash + Box-Muller); or the 8 draws in reference order (parity mode)
         dropmask : None -> Philox4x32-10 mask (or no dropout when hp.dropout == 0); or [2][n][cls_in] multipliers
+        lab_idx / unl_idx : None -> XPl .. Xu ARE the batch; or int64 row numbers: XPl / Xl / Y (XPu / Xu) are then the
+                   whole resident labelled (unlabelled) split and batch row s is its row lab_idx[s] (unl_idx[s]) --
+                   no gathered copy of the batch is made (noise / dropmask stay indexed by batch row)
         """
         s = self.shape
-        bt, btu = XPl.shape[0], XPu.shape[0]
+        bt, btu = self._check_rows(XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
         n = bt + btu
-        if bt < 1 or btu < 1 or bt > self.bt_max or n > self.n_max:
-            raise ValueError(f"batch {bt}+{btu} outside the engine's capacity {self.bt_max}+{self.btu_max}")
-        _chk_f32(XPl, (bt, s.C, s.H, s.W), "XPl"); _chk_f32(Xl, (bt, s.bands), "Xl")
-        _chk_f32(XPu, (btu, s.C, s.H, s.W), "XPu"); _chk_f32(Xu, (btu, s.bands), "Xu")
-        if Y.dtype != torch.int64 or tuple(Y.shape) != (bt,) or not Y.is_cuda:
-            raise ValueError("Y: need int64 cuda tensor [bt]")
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._ensure_packed(stream)
         io = _lib.StepIO()
-        io.d_xpl, io.d_xl, io.d_labels = XPl.data_ptr(), Xl.data_ptr(), Y.data_ptr()
-        io.d_xpu, io.d_xu = XPu.data_ptr(), Xu.data_ptr()
+        self._fill_io(io, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu)
         keep = None
         if noise is not None:
-            shp = [XPl.shape, Xl.shape, XPl.shape, Xl.shape, XPu.shape, Xu.shape, XPu.shape, Xu.shape]
+            xpl, xl, xpu, xu = (bt, s.C, s.H, s.W), (bt, s.bands), (btu, s.C, s.H, s.W), (btu, s.bands)
+            shp = [xpl, xl, xpl, xl, xpu, xu, xpu, xu]
             for t, sh in zip(noise, shp):
                 _chk_f32(t, sh, "noise")
             keep = (C.c_void_p * 8)(*[t.data_ptr() for t in noise])
@@ -177,33 +224,23 @@ class TrainEngine:
         if dropmask is not None:
             _chk_f32(dropmask, (2, n, s.cls_in), "dropmask")
             io.d_dropmask = dropmask.data_ptr()
-        io.d_params, io.d_m, io.d_v = self.params.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
-        io.d_grads, io.d_packed = self.grads.data_ptr(), self.packed.data_ptr()
         for i in range(2):
-            io.banks.d_feats[i] = self.bank_feats[i].data_ptr()
-            io.banks.d_probs[i] = self.bank_probs[i].data_ptr()
             io.banks.ptr[i] = self.ptr[i]
-        io.banks.Q = self.Q
         self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
         io.d_scalars = self.scalars.data_ptr()
-        # outputs are laid out [2][n][..] for THIS n (views of the max-size buffers)
-        io.d_logits, io.d_feat = self.logits.data_ptr(), self.feat.data_ptr()
-        io.d_workspace, io.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
-        io.bt, io.btu = bt, btu
         io.smooth = 1 if self.hp.smooth_gate(epoch, batch_index) else 0
         io.adap_mask = float(self.hp.thr * self.hp.adap_thr(epoch))        # train.py:221
         io.adam_t = self.adam_t + 1
-        io.seed, io.step = self.seed, self.step_count
+        io.step = self.step_count
         io.apply_update = 1 if apply_update else 0
         _lib.check("cmlpl_train_step",
                    self.lib.cmlpl_train_step(C.byref(self.cshape), C.byref(self._chp), C.byref(io), stream))
-        # bank pointers, train.py:234,237 (ptr1 follows ptr0 -- reference quirk kept)
-        p0 = (self.ptr[0] + self.hp.bank_step) % self.Q
-        self.ptr = [p0, (p0 + self.hp.bank_step) % self.Q]
-        if apply_update:
-            self.adam_t += 1
-        self.step_count += 1
-        self._last_n = n
+        self._advance(n, apply_update)
+
+    def capture(self, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt: int, btu: int, capacity: int = 1024) -> "StepGraph":
+        """The step captured ONCE as a hipGraph over the resident splits and two index buffers (lab_idx / unl_idx: the
+        epoch's permutations, re-filled in place by the caller); see StepGraph."""
+        return StepGraph(self, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu, capacity)
 
     def outputs(self):
         """(logits [2][n][K], feat [2][n][1024]) of the last step."""
@@ -241,3 +278,108 @@ class TrainEngine:
 
     def _reduce_rows(self, rows: torch.Tensor) -> torch.Tensor:
         return rows
+
+
+class StepGraph:
+    """The training step as a replayable hipGraph (SURVEY.md section 7 stage 6; ``cmlpl_step_graph_create``).
+
+    Everything that changes from step to step -- random-stream counter, Adam step, bank pointers, the train.py:212 /
+    :221 gates, the offsets of the batch inside the index buffers, the row of the logging ring -- lives in a device
+    table of ``cmlpl_dyn`` rows that ``program()`` fills for a run of steps ahead of time (an epoch, say); a device
+    cursor walks it, advanced by the step itself.  ``launch()`` is then ONE hipGraphLaunch per step: no arguments to
+    marshal, nothing else enqueued.  The engine's host-side bookkeeping advances exactly as in ``TrainEngine.step``,
+    so eager steps and replays can be mixed (an epoch's short last batch runs eagerly: its shape is not the graph's).
+    """
+
+    def __init__(self, eng: TrainEngine, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt: int, btu: int, capacity: int = 1024):
+        import numpy as np
+        self.eng, self.bt, self.btu, self.capacity = eng, int(bt), int(btu), int(capacity)
+        if lab_idx is None or unl_idx is None:
+            raise ValueError("a captured step reads its rows through index buffers")
+        if lab_idx.shape[0] < bt or unl_idx.shape[0] < btu:
+            raise ValueError("index buffers shorter than one batch")
+        eng._check_rows(XPl, Xl, Y, XPu, Xu, lab_idx[:bt], unl_idx[:btu])
+        self._keep = (XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
+        self.n_lab_idx, self.n_unl_idx = int(lab_idx.shape[0]), int(unl_idx.shape[0])
+        dev = eng.device
+        self.table = torch.zeros(self.capacity * 64, dtype=torch.uint8, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.host = torch.zeros(self.capacity * 64, dtype=torch.uint8).pin_memory()
+        self.rows = self.host.numpy().view(np.dtype(_lib.DYN_DTYPE))
+        self.pending = 0
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        eng._ensure_packed(stream)
+        io = _lib.StepIO()
+        eng._fill_io(io, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, self.bt, self.btu)
+        io.d_scalars = eng.scalar_hist.data_ptr()          # ring base: the row comes from the table
+        io.apply_update = 1
+        io.d_dyn_table, io.d_dyn_cursor = self.table.data_ptr(), self.cursor.data_ptr()
+        self._io = io
+        # the launchers set their kernels' LDS attributes on first use, which must not happen inside a capture
+        if eng.step_count == 0:
+            raise RuntimeError("run one eager TrainEngine.step() before capturing (kernel attributes are set lazily)")
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        handle = C.c_void_p()
+        with torch.cuda.stream(cap):
+            _lib.check("cmlpl_step_graph_create", eng.lib.cmlpl_step_graph_create(
+                C.byref(eng.cshape), C.byref(eng._chp), C.byref(io), C.c_void_p(cap.cuda_stream), C.byref(handle)))
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        self.handle = handle
+
+    def program(self, steps) -> None:
+        """``steps``: (epoch, batch_index, lab_off, unl_off) of the next replays, in order.  Fills the table from the
+        engine's current state and rewinds the cursor (stream-ordered: behind every replay enqueued so far)."""
+        eng, hp = self.eng, self.eng.hp
+        steps = list(steps)
+        if self.pending:
+            raise RuntimeError(f"{self.pending} programmed steps have not been launched")
+        if not 1 <= len(steps) <= self.capacity:
+            raise ValueError(f"1..{self.capacity} steps per program")
+        ptr, adam_t, count = list(eng.ptr), eng.adam_t, eng.step_count
+        a, b = C.c_float(), C.c_float()
+        for j, (epoch, batch_index, lab_off, unl_off) in enumerate(steps):
+            if lab_off < 0 or unl_off < 0 or lab_off + self.bt > self.n_lab_idx or unl_off + self.btu > self.n_unl_idx:
+                raise ValueError("batch offsets outside the index buffers")
+            r = self.rows[j]
+            r["step"], r["adam_t"] = count + j, adam_t + 1 + j
+            r["lab_off"], r["unl_off"] = lab_off, unl_off
+            r["ptr"][0], r["ptr"][1] = ptr
+            r["smooth"] = 1 if hp.smooth_gate(epoch, batch_index) else 0
+            r["adap_mask"] = float(hp.thr * hp.adap_thr(epoch))
+            r["hist_row"] = (count + j) % eng.hist_rows
+            _lib.check("cmlpl_dyn_adam", eng.lib.cmlpl_dyn_adam(C.byref(eng._chp), adam_t + 1 + j, C.byref(a), C.byref(b)))
+            r["adam_step_size"], r["adam_bc2_sqrt"] = a.value, b.value
+            p0 = (ptr[0] + hp.bank_step) % eng.Q
+            ptr = [p0, (p0 + hp.bank_step) % eng.Q]
+        k = len(steps) * 64
+        self.table[:k].copy_(self.host[:k], non_blocking=True)
+        self.cursor.zero_()
+        self.pending = len(steps)
+        # (the pinned staging rows may be rewritten only after that copy has run)
+        self._copied = torch.cuda.Event()
+        self._copied.record(torch.cuda.current_stream(eng.device))
+
+    def launch(self) -> None:
+        """one replay = one training step (asynchronous)"""
+        eng = self.eng
+        if self.pending < 1:
+            raise RuntimeError("no programmed step left: call program() first")
+        stream = C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+        _lib.check("cmlpl_step_graph_launch", eng.lib.cmlpl_step_graph_launch(self.handle, stream))
+        eng.scalars = eng.scalar_hist[eng.step_count % eng.hist_rows]
+        eng._advance(self.bt + self.btu, True)
+        self.pending -= 1
+        if self.pending == 0:
+            self._copied.synchronize()        # cheap: that copy ran long ago
+
+    def close(self) -> None:
+        if self.handle:
+            self.eng.lib.cmlpl_step_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

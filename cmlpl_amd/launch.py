@@ -39,7 +39,17 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
 
 
 DEFAULT_TIMEOUT_S = 3600.0      # a rank stuck in a collective must not hang the parent for ever
-RENDEZVOUS_RETRY_S = 20.0       # a job that dies this early is taken to have lost its port to another process
+# Exit code of a rank whose rendezvous store could not bind MASTER_PORT (another process took the port between
+# free_port()'s release and rank 0's bind): the ONLY failure a job is started again for.  A deterministic early failure
+# (too few GPUs, bad arguments, a --check mismatch) exits with its own code and is reported as it is, once.
+EXIT_PORT_TAKEN = 98
+
+
+def port_taken(exc: BaseException) -> bool:
+    """does this exception say that the rendezvous port was already bound? (cmlpl_amd.distributed.init_distributed
+    turns it into EXIT_PORT_TAKEN)"""
+    s = f"{type(exc).__name__}: {exc}".lower()
+    return "address already in use" in s or "eaddrinuse" in s or "errno: 98" in s
 
 
 def spawn_ranks(world: int, argv: Sequence[str], extra_env: Optional[Dict[str, str]] = None,
@@ -47,15 +57,13 @@ def spawn_ranks(world: int, argv: Sequence[str], extra_env: Optional[Dict[str, s
     """Run ``argv`` as ``world`` ranks; returns (exit code, rank 0's stdout).  Ranks > 0 write their stdout to
     this process's stderr; every rank's stderr is inherited.  Exit code = first non-zero child code, else 0;
     124 on timeout (the children are stopped).  The rendezvous port is picked by bind-and-release, so another
-    process can take it before rank 0 binds it: a job that fails within RENDEZVOUS_RETRY_S seconds is started once
-    more, as fresh children on a new port (``retries``)."""
-    t_first = time.monotonic()
+    process can take it before rank 0 binds it: a job whose rank reports exactly that (EXIT_PORT_TAKEN) is started
+    again, as fresh children on a new port, at most ``retries`` times; any other failure is returned as it is."""
     rc, out = _spawn_once(world, argv, extra_env, timeout, poll_s)
-    while rc not in (0, 124) and retries > 0 and world > 1 and time.monotonic() - t_first < RENDEZVOUS_RETRY_S:
+    while rc == EXIT_PORT_TAKEN and retries > 0 and world > 1:
         retries -= 1
-        sys.stderr.write(f"cmlpl_amd.launch: job failed {time.monotonic() - t_first:.1f} s after start (rc {rc}); "
-                         "starting it once more on a new rendezvous port\n")
-        t_first = time.monotonic() - RENDEZVOUS_RETRY_S      # at most one quick retry
+        sys.stderr.write("cmlpl_amd.launch: the rendezvous port was taken by another process; starting the job once "
+                         "more on a new port\n")
         rc, out = _spawn_once(world, argv, extra_env, timeout, poll_s)
     return rc, out
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CMLPL_ABI_VERSION 2
+#define CMLPL_ABI_VERSION 3
 #define CMLPL_FEAT_DIM 1024 /* tools/models.py:119 */
 #define CMLPL_CONV_CH 64    /* tools/models.py:102-107 */
 
@@ -154,13 +154,42 @@ typedef struct cmlpl_batch {
   const int64_t* d_labels;                 /* [bt] (may be NULL where no entry point reads it) */
   const float* const* noise8;
   int32_t bt, btu;
+  /* ABI 3 -- batches BY INDEX (hsi_loader.py:109-133 hands out rows of XP.npy / X.npy / Y.npy by index; the reference's
+   * DataLoader then copies them into a batch tensor): when given, labelled row s of the batch is row d_lab_idx[s] of
+   * d_xpl / d_xl / d_labels and unlabelled row s is row d_unl_idx[s] of d_xpu / d_xu -- the kernels read the rows where
+   * the resident split lies, no gathered copy of the batch exists.  NULL = rows 0 .. bt-1 / 0 .. btu-1 as before.
+   * (The explicit noise tensors and dropout masks of parity mode stay indexed by batch row.) */
+  const int64_t* d_lab_idx; const int64_t* d_unl_idx;
 } cmlpl_batch;
 
+/* One step's scalars in DEVICE memory (ABI 3): what changes from step to step, for a step captured ONCE in a hipGraph
+ * and replayed (SURVEY.md section 7 stage 6; the reference's loop passes them as Python scalars, train.py:146-150,
+ * 212,221,234-237).  The caller fills a table of rows ahead of time (e.g. one epoch) and passes it with a device
+ * cursor: a launch of cmlpl_train_step with d_dyn_table != NULL takes these values from d_dyn_table[*d_dyn_cursor]
+ * instead of from cmlpl_step_io, and advances the cursor itself (in its weight-gradient reduce launch), so that
+ * replaying the captured launch sequence walks the table with no host work per step. */
+typedef struct cmlpl_dyn {
+  uint64_t step;            /* counter of the in-kernel random streams (cmlpl_step_io.step)            */
+  int64_t adam_t;           /* 1-based Adam step                                                       */
+  int64_t lab_off, unl_off; /* offsets added to the row number before d_lab_idx / d_unl_idx are read   */
+  int32_t ptr[2];           /* bank write pointers BEFORE the step (train.py:234,237)                  */
+  int32_t smooth;           /* train.py:212 gate                                                       */
+  float adap_mask;          /* train.py:221                                                            */
+  int32_t hist_row;         /* the step's scalars go to d_scalars + 16 * hist_row                      */
+  float adam_step_size;     /* lr / (1 - beta1^adam_t)   } torch.optim.Adam's bias corrections, formed in double  */
+  float adam_bc2_sqrt;      /* sqrt(1 - beta2^adam_t)    } on the host: cmlpl_dyn_adam() fills both               */
+  int32_t reserved;
+} cmlpl_dyn;
+/* the two Adam scalars of a table row, exactly as cmlpl_adam_step forms them from (hp, t) */
+int cmlpl_dyn_adam(const cmlpl_hparams* hp, int64_t adam_t, float* step_size, float* bc2_sqrt);
+
 /* Both networks' forward on one batch (train.py:157-189): augmentation + BaseNet2.forward for Base and Base1.
- * Where the window fits (H*W <= 128, C <= 128) the patches are augmented inside the fused conv0+conv1 kernel and
- * no augmented copy exists in HBM; cmlpl_backward re-forms the same noise (counter-based) for conv0's weight
- * gradient, so it must be given the same batch / seed / step / shard and the SAME workspace (sized by
- * cmlpl_workspace_bytes(shape, 2, bt + btu, bank_rows)), which holds the saved activations in between.
+ * Where the window fits the per-sample kernels (H*W <= 128) the patches are augmented inside the fused forward, which
+ * also stores the augmented rows in the workspace (2 * n * C * H * W floats written per step); cmlpl_backward lands
+ * them for conv0's weight gradient.  It must therefore be given the same batch / seed / step / shard and the SAME
+ * workspace (sized by cmlpl_workspace_bytes(shape, 2, bt + btu, bank_rows)), which holds the saved activations and
+ * those rows in between -- and NO other cmlpl_forward may run on that workspace between the two (an evaluation or
+ * teacher pass in between needs a workspace of its own: it would overwrite the rows the weight gradient reads).
  *   hp: noise_sigma and dropout_p are used.  Outputs as cmlpl_basenet2_fwd / _bwd with nets = 2. */
 int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
                   const cmlpl_shard* shard /* NULL = one GPU */,
@@ -272,10 +301,22 @@ typedef struct cmlpl_step_io {
   uint64_t seed, step;          /* key / counter of the in-kernel random streams         */
   int32_t apply_update;         /* 0 = stop after the gradients                          */
   int32_t reserved;
+  /* ABI 3 */
+  const int64_t* d_lab_idx; const int64_t* d_unl_idx;   /* as in cmlpl_batch; NULL = consecutive rows */
+  const cmlpl_dyn* d_dyn_table; int32_t* d_dyn_cursor;   /* NULL = the by-value fields above are used  */
 } cmlpl_step_io;
 
 int cmlpl_train_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io,
                      void* stream);
+
+/* The step as a replayable hipGraph (SURVEY.md section 7 stage 6): _create captures ONE cmlpl_train_step(io) on
+ * `stream` (io->d_dyn_table / d_dyn_cursor must be set: everything that changes between steps then lives in device
+ * memory) and instantiates it; _launch enqueues one replay = one training step, no other host work.  Run one eager
+ * step first (lazily-set kernel attributes cannot be set while capturing).  The handle owns the graph; _destroy frees it. */
+int cmlpl_step_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_step_io* io, void* stream,
+                            void** graph_out);
+int cmlpl_step_graph_launch(void* graph, void* stream);
+int cmlpl_step_graph_destroy(void* graph);
 
 /* Caller-side row N3: w x w patch windows gathered on device from the z-scored / PCA'd
  * scene cube instead of materialising XP.npy (tools/hyper_tools.py:35-55 MirrowCut, :226-243

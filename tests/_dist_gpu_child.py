@@ -19,7 +19,7 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dist.init_process_group("gloo")
 shape = O.NetShape(103, 11, 11, 103, 9)
-bt, btu, steps = 32, 64, 3
+bt, btu, steps = (int(os.environ.get(k, v)) for k, v in (("CMLPL_TEST_BT", 32), ("CMLPL_TEST_BTU", 64), ("CMLPL_TEST_STEPS", 3)))
 hp = HyperParams()
 p0, p1 = O.closed_form_params(shape, 51), O.closed_form_params(shape, 52)
 eng = DistTrainEngine(NetShape(103, 11, 11, 103, 9), bt // W, btu // W, hp, device=dev, seed=5)

@@ -18,3 +18,16 @@ def test_multiprocess_sharded_step_equals_single_process(world):
     rc, out = spawn_ranks(world, [sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_child.py")], timeout=600)
     assert rc == 0, out
     assert f"OK world={world}" in out, out
+
+
+def test_multiprocess_at_the_shard_size_of_configs2():
+    """BASELINE configs[2] puts 64 + 64 rows on each of 8 ranks.  A GPU box of this pool admits at most six processes on
+    its card at once (this test process is one of them), so the REAL wiring -- separate processes, rendezvous,
+    DistTrainEngine + TorchDistComm, collectives between the stages -- runs here at that per-rank shard size with
+    FOUR ranks (global 256 + 256); eight ranks are covered in lockstep in tests/test_gpu_distributed.py."""
+    from cmlpl_amd.launch import spawn_ranks
+    env = dict(CMLPL_TEST_BT="256", CMLPL_TEST_BTU="256", CMLPL_TEST_STEPS="2")
+    rc, out = spawn_ranks(4, [sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_child.py")], extra_env=env,
+                          timeout=900)
+    assert rc == 0, out
+    assert "OK world=4" in out, out

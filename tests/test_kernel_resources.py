@@ -38,3 +38,25 @@ def test_hot_kernels_have_no_scratch(tmp_path):
             assert occ >= 2, (name, occ)
         seen += 1
     assert seen >= 20
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_no_kernel_of_the_library_uses_scratch(tmp_path):
+    """Every kernel of the other translation units too: a kernel-argument struct that escapes into a generic pointer
+    (e.g. `p ? p->x : a.x` selecting between two ADDRESSES) is copied to scratch whole -- round 4 doubled
+    pair_exp16_kernel's time that way before this test existed."""
+    files = [f for f in sorted(os.listdir(os.path.join(ROOT, "cmlpl_amd", "csrc")))
+             if f.endswith(".hip") and f not in ("conv3x3.hip", "wgrad3x3.hip")]
+    procs = [(f, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-c",
+                                   os.path.join(ROOT, "cmlpl_amd", "csrc", f), "-o", str(tmp_path / (f + ".o")),
+                                   "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True)) for f in files]
+    seen = 0
+    for f, pr in procs:
+        _, err = pr.communicate(timeout=900)
+        assert pr.returncode == 0, err[-2000:]
+        for b in re.split(r"remark: Function Name: ", err)[1:]:
+            scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+            assert scratch == 0, (f, b.split()[0], scratch)
+            seen += 1
+    assert seen >= 40

@@ -4,8 +4,11 @@
 (train.py:150-278) executed by ``cmlpl_amd.TrainEngine`` (hand-written gfx950 kernels).
 
 Differences from the reference that are deliberate, MI355X-first choices:
-  * the labelled / unlabelled splits live in HBM for the whole run and batches are gathered there by
-    index (the reference copies every batch over PCIe and draws noise on the CPU);
+  * the labelled / unlabelled splits live in HBM for the whole run and a batch is a list of row INDICES into them
+    (the epoch's permutation, also resident): the kernels read the rows where they lie, no batch tensor is gathered
+    (the reference copies every batch over PCIe and draws noise on the CPU);
+  * ``--graph``: the step is captured once as a hipGraph and replayed, one launch per step, its per-step scalars
+    coming from a device-side table filled once per epoch (single GPU);
   * noise and dropout come from in-kernel counter-based streams (PCG4D hash + Box-Muller for the augmentation noise,
     Philox4x32-10 for the dropout masks) seeded with the reference's seed 1088;
   * the five logged scalars of every step (loss_hist, train.py:136,274-278) are written by the step into a
@@ -34,20 +37,27 @@ SYNTH = {"B2": (103, 11, 11, 103, 9), "P": (60, 20, 20, 103, 9), "B4": (200, 11,
 
 class DeviceLoader:
     """shuffle=True DataLoader semantics (one random permutation per epoch, last short batch kept)
-    over arrays that already sit in HBM."""
+    over arrays that already sit in HBM.  A batch is (offset, size) into ``self.perm``, the epoch's permutation in a
+    FIXED device buffer (a captured step keeps reading the same buffer): the step takes the rows by index."""
 
     def __init__(self, arrays, batch_size, generator):
         self.XP, self.X, self.Y = arrays
         self.bs, self.g = batch_size, generator
+        self.perm = torch.zeros(len(self.X), dtype=torch.int64, device=self.X.device)
 
     def __len__(self):
         return (len(self.X) + self.bs - 1) // self.bs
 
     def __iter__(self):
-        perm = torch.randperm(len(self.X), generator=self.g).to(self.X.device)
-        for i in range(0, len(perm), self.bs):
-            idx = perm[i:i + self.bs]
-            yield self.XP[idx], self.X[idx], self.Y[idx]
+        # (stream-ordered behind the previous epoch's steps, which still read the buffer)
+        self.perm.copy_(torch.randperm(len(self.X), generator=self.g))
+        for i in range(0, len(self.X), self.bs):
+            yield i, min(self.bs, len(self.X) - i)
+
+    def rows(self, off, size):
+        """the gathered batch (engines that do not take indices: the CPU stand-in of the tests)"""
+        idx = self.perm[off:off + size]
+        return self.XP[idx], self.X[idx], self.Y[idx]
 
 
 def shard_plan(bt, btu, world):
@@ -121,21 +131,44 @@ def main(args, make_engine=None, device=None):
         if pending:
             loss_hist[pending] = eng.loss_window(len(pending))
             pending.clear()
+    by_index = getattr(eng, "takes_indices", False)
+    use_graph = bool(args.graph) and world == 1 and by_index
+    graph = None
     t_start = time.time()
     for epoch in range(args.num_epochs):                             # train.py:146
-        for batch_index, (lab, unl) in enumerate(zip(lab_loader, unl_loader)):
+        batches = list(zip(lab_loader, unl_loader))                  # (offset, size) pairs; draws this epoch's permutations
+        if use_graph and graph is not None:
+            # the whole epoch's per-step scalars go to the device table at once; full batches are replays
+            graph.program([(epoch, bi, lo, uo) for bi, ((lo, ls), (uo, us)) in enumerate(batches)
+                           if ls == bt and us == btu])
+        for batch_index, ((lo, ls), (uo, us)) in enumerate(batches):
             index_i += 1                                             # train.py:150
-            XPl, Xl, Yl = lab
-            XPu, Xu, _ = unl
+            bl, bul, r = ls, us, 0
             if world > 1:                                            # shard by sample; decided on GLOBAL sizes
-                plan = shard_plan(XPl.shape[0], XPu.shape[0], world)
+                plan = shard_plan(ls, us, world)
                 if plan is None:      # fewer rows than ranks: every rank skips alike (row stays zero in loss_hist)
                     continue
                 bl, bul = plan
-                XPl, Xl, Yl = (t[rank * bl:(rank + 1) * bl] for t in (XPl, Xl, Yl))
-                XPu, Xu = (t[rank * bul:(rank + 1) * bul] for t in (XPu, Xu))
-            eng.step(XPl.contiguous(), Xl.contiguous(), Yl.contiguous(), XPu.contiguous(), Xu.contiguous(),
-                     epoch, batch_index)
+                r = rank
+            if graph is not None and ls == bt and us == btu:
+                graph.launch()
+            elif by_index:
+                eng.step(lab_loader.XP, lab_loader.X, lab_loader.Y, unl_loader.XP, unl_loader.X, epoch, batch_index,
+                         lab_idx=lab_loader.perm[lo + r * bl:lo + (r + 1) * bl],
+                         unl_idx=unl_loader.perm[uo + r * bul:uo + (r + 1) * bul])
+            else:
+                XPl, Xl, Yl = (t[r * bl:(r + 1) * bl].contiguous() for t in lab_loader.rows(lo, ls))
+                XPu, Xu, _ = (t[r * bul:(r + 1) * bul].contiguous() for t in unl_loader.rows(uo, us))
+                eng.step(XPl, Xl, Yl, XPu, Xu, epoch, batch_index)
+            if use_graph and graph is None:
+                # the first step ran eagerly (it sets the kernels' attributes); capture now and hand the rest of this
+                # epoch's full batches to the graph
+                graph = eng.capture(lab_loader.XP, lab_loader.X, lab_loader.Y, unl_loader.XP, unl_loader.X,
+                                    lab_loader.perm, unl_loader.perm, bt, btu, capacity=max(num_batches, 1))
+                rest = [(epoch, bi, lo2, uo2) for bi, ((lo2, ls2), (uo2, us2)) in enumerate(batches)
+                        if bi > batch_index and ls2 == bt and us2 == btu]
+                if rest:
+                    graph.program(rest)
             pending.append(index_i)
             if (batch_index + 1) % ppb == 0 or len(pending) == ppb:
                 read_back()           # the five scalars of train.py:274-278 of those steps: one sync, not five per step
@@ -203,6 +236,8 @@ def build_parser():
                         help='run on seeded synthetic patches of this shape (datasets are not shipped)')
     parser.add_argument('--save_loss_hist', default=None, help='write loss_hist [num_steps,5] (train.py:136) as .npy')
     parser.add_argument('--no_eval', action='store_true', help='skip the whole-image inference after training')
+    parser.add_argument('--graph', action='store_true',
+                        help='capture the training step once as a hipGraph and replay it (single GPU)')
     return parser
 
 

@@ -407,10 +407,7 @@ def run_rank(args):
                      "frac": achieved / kpeak[dom_name],
                      "peak_note": "fp32-equivalent MFMA ceiling of this kernel's own instruction mix: algorithmic "
                                   "FLOPs / (f32-segment FLOPs / 157.3 T + split-segment FLOPs / (2500 T / 6)); "
-                                  "a split-bf16 product costs six bf16 MFMAs.  (Round 3: the fused forward's conv2 "
-                                  "tail moved from the f32-input MFMA to split-bf16 as well -- its ceiling rose from "
-                                  "334 to 416.7, the launch got shorter, 52.8 -> 51.4 us, and this fraction fell from "
-                                  "0.35 to 0.29: compare launches by ms_per_launch, fractions only at an equal mix.)",
+                                  "a split-bf16 product costs six bf16 MFMAs (history of the mix: DESIGN.md section 4)",
                      "flops_by_mfma_kind": kseg[dom_name],
                      "frac_of_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": traffic.get(dom_name),

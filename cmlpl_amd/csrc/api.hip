@@ -48,8 +48,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   const size_t N = (size_t)nets * n;
   Wgrad3Plan w1, w2;
   bool wpair = false;
-  if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, conv3_fused_head_ok(d.H, d.W, d.C, nets * n, d.K), &w1, &w2, &wpair))
-    return false;
+  if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, true, &w1, &w2, &wpair)) return false;
   Conv3Plan c;
   if (!plan_conv3(0, d.H, d.W, nets * n, &c) || !plan_conv3(1, d.H, d.W, nets * n, &c) ||
       !plan_conv3(0, d.H2, d.W2, nets * n, &c) || !plan_conv3(1, d.H2, d.W2, nets * n, &c)) return false;
@@ -77,7 +76,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
 
 // extra regions used only by cmlpl_train_step / cmlpl_loss_fwd_bwd
 struct StepWs {
-  float *xn, *sn, *snT, *dlogits, *dfeat, *probs, *loss;
+  float *xn, *sn, *dlogits, *dfeat, *probs, *loss;
   size_t bytes;
 };
 
@@ -86,7 +85,6 @@ void carve_step(const Dims& d, int n, int bank_rows, char* base, StepWs* w) {
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up256(bytes); return p; };
   w->xn = (float*)take((size_t)2 * n * d.C * d.HW * 4);
   w->sn = (float*)take((size_t)2 * n * d.bands * 4);
-  w->snT = (float*)take((size_t)2 * n * d.bands * 4);
   w->dlogits = (float*)take((size_t)2 * n * d.K * 4);
   w->dfeat = (float*)take((size_t)2 * n * 1024 * 4);
   w->probs = (float*)take((size_t)4 * n * d.K * 4);
@@ -112,46 +110,6 @@ struct Timing {
   std::vector<int> ids;
   size_t used = 0;
 } g_timing;
-
-// ---- fork/join helpers.  Independent branches of the step DAG (spectral vs spatial forward, weight
-// gradients vs data gradients, bank write vs dfeat GEMMs) run on two auxiliary streams forked from /
-// joined to the caller's stream with events: at 256 patches no single kernel fills the chip for its
-// whole duration (staging, drain and tail phases), so overlapping kernels recovers that idle time.
-// The pool is process-global and created on first use; fork/join is graph-capturable.
-struct AuxStreams {
-  hipStream_t s[2] = {nullptr, nullptr};
-  hipEvent_t ev[8];
-  bool ok = false, enabled = true;
-  AuxStreams() {
-    // measured on MI355X at B2/256: forked branches do overlap, but LDS capacity admits one big workgroup
-    // per CU, so co-scheduled kernels time-slice the CUs and every fork/join adds a 6-12 us gap: net zero.
-    // Opt-in only (CMLPL_MULTI_STREAM=1).
-    const char* e = getenv("CMLPL_MULTI_STREAM");
-    enabled = (e && e[0] == '1');
-    if (!enabled) return;
-    for (int i = 0; i < 2; ++i)
-      if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return;
-    for (int i = 0; i < 8; ++i)
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
-    ok = true;
-  }
-};
-AuxStreams& aux() { static AuxStreams a; return a; }
-// aux stream i continues after everything enqueued on `from` so far
-inline hipStream_t fork_to(hipStream_t from, int i, int evi) {
-  AuxStreams& a = aux();
-  if (!a.ok) return from;
-  (void)hipEventRecord(a.ev[evi], from);
-  (void)hipStreamWaitEvent(a.s[i], a.ev[evi], 0);
-  return a.s[i];
-}
-// `to` waits for everything enqueued on aux stream i so far
-inline void join_from(hipStream_t to, int i, int evi) {
-  AuxStreams& a = aux();
-  if (!a.ok) return;
-  (void)hipEventRecord(a.ev[evi], a.s[i]);
-  (void)hipStreamWaitEvent(to, a.ev[evi], 0);
-}
 
 template <class F>
 int timed(int id, hipStream_t st, F f) {
@@ -315,10 +273,8 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
              const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st,
              float* xn_save) {
   int rc;
-  hipStream_t main_st = st;
   const long long pk_ns = L.packed_total;
-  {  // spectral branch (feat_spe + ReLU); with multi-stream enabled it runs beside the spatial conv stack
-    hipStream_t st = fork_to(main_st, 0, 0);
+  {  // spectral branch (feat_spe + ReLU)
     if (xspec != nullptr) {
       // raw spectra: augmentation + GEMM + bias + ReLU in one launch (also writes the augmented rows for the
       // weight gradient)
@@ -335,7 +291,6 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   if (conv3_fused_tail_ok(d.H, d.W, d.C, nets * n, d.K)) {
     // the whole spatial forward + head of a sample in one workgroup: conv0 + conv1 + pool + conv2 + pool + flatten /
     // concat / dropout / classifier / L2-norm.  Needs the spectral branch output (launched above, same stream).
-    join_from(main_st, 0, 1);
     FwdTail t;
     t.w2f = d_packed + pack_off_b3(d.C, d.bands, 2); t.w2f_ns = pk_ns; t.b2 = d_params + L.param_off[5];
     t.wc = d_params + L.param_off[8]; t.bc = d_params + L.param_off[9]; t.p_ns = param_stride;
@@ -343,7 +298,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     t.logits = d_logits; t.feat = d_feat; t.p2 = w.p2; t.m2 = w.m2; t.dropout_p = dropout_p; t.train = train; t.K = d.K;
     return TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0b3(d.C, d.bands),
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
-                               d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, main_st, xn_save)));
+                               d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, st, xn_save)));
   }
   if (conv3_fused_ok(d.H, d.W, d.C, nets * n)) {
     // conv0 + conv1 in one launch, input rows taken where they lie and augmented in LDS: neither an augmented
@@ -361,8 +316,6 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   }
   if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + pack_off_b3(d.C, d.bands, 2),
                              pk_ns, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
-  join_from(main_st, 0, 1);
-  if (shard && shard->nlab + shard->nunl != n) return CMLPL_E_ARG;
   const int nlab = shard ? shard->nlab : n, lab0 = shard ? shard->lab0 : 0;
   const int unl_base = shard ? shard->bt_g + shard->unl0 : n;
   return TIMED(CMLPL_K_HEAD_FWD, chk(launch_head_fwd(nets, n, d.P4, d.K, w.p2, w.y, d_dropmask, w.dropgen, dropout_p,
@@ -396,7 +349,6 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
              int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor) {
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
-  hipStream_t main_st = st;
   const bool fused_head = conv3_fused_head_ok(d.H, d.W, d.C, nets * n, d.K);
   GemmTN gw_cls, gw_spe;
   {
@@ -416,9 +368,6 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     h.C = d_grads + L.param_off[6]; h.ldc = d.bands;
     h.bias = d_grads + L.param_off[7];
   }
-  auto cls_spe_wgrad = [&](hipStream_t st) -> int {
-    return TIMED(CMLPL_K_CLS_WGRAD, chk(launch_gemm_tn2(gw_cls, gw_spe, st)));
-  };
   if (fused_head) {
     // ONE per-sample launch for the whole data-gradient chain: head backward -> conv2 data gradient -> conv1 data
     // gradient -> conv0 weight-gradient partial.  dp2 / dp1 / dy still go to HBM for the weight-gradient kernels
@@ -436,53 +385,44 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
                                   w.p1, w.dp2, w.m2, w.part2, &merged, st))))) return rc;
     (void)merged;
   } else {
-  // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
-  if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,
-                                d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
-  {  // classifier / spectral weight gradients: independent of the spatial backward chain
-    hipStream_t st = fork_to(main_st, 0, 2);
-    if ((rc = cls_spe_wgrad(st))) return rc;
-  }
-  // spatial branch: the data-gradient chain stays on the caller's stream, each weight gradient forks off
-  {  // conv2 weight gradient needs only dp2/m2/p1 (ready since head_bwd): forked before conv2_dgrad is enqueued
-    hipStream_t st = fork_to(main_st, 1, 3);
-    if ((rc = TIMED(CMLPL_K_CONV2_WGRAD, chk(launch_wgrad3(nets, n, d.H2, d.W2, w.p1, w.dp2, w.m2, w.part2, st))))) return rc;
-  }
-  if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + pack_off_b3(d.C, d.bands, 3),
-                             L.packed_total, nullptr, 0, w.dp1, nullptr, st))))) return rc;
-  {  // conv1 weight gradient needs dp1 (conv2_dgrad output): fork after it, runs beside conv1_dgrad
-    hipStream_t st = fork_to(main_st, 0, 4);
-    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, st))))) return rc;
-  }
-  if (conv3_fused_bwd_ok(d.H, d.W, d.C, nets * n)) {
-    // conv1 data gradient + conv0 weight gradient in one launch: da0 never goes to HBM, and the input slab is
-    // re-formed from the raw rows with the forward's noise regenerated
-    if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
-                               d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,
-                               (long long)n * conv0_partial_size(d.C), nullptr, st))))) return rc;
-  } else {
-    if (!d_xn) return CMLPL_E_ARG;
-    if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + pack_off_b3(d.C, d.bands, 1),
-                               L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
-    if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
-      return rc;
-  }
-  join_from(main_st, 0, 5);
-  join_from(main_st, 1, 6);
+    // General path (windows the per-sample kernels do not take: P 20x20, B5 15x15): one launch per stage.  Round 4:
+    // both 3x3 weight gradients in ONE launch here too (the pair kernel, placed behind conv2's data gradient, which
+    // produces conv1's pooled gradient), and the classifier / feat_spe weight-gradient GEMMs ride in the reduce launch --
+    // 17 launches where there were 19; the forked side streams of round 1 are gone (they never paid: DESIGN.md section 7).
+    // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
+    if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,
+                                  d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
+    if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + pack_off_b3(d.C, d.bands, 3),
+                               L.packed_total, nullptr, 0, w.dp1, nullptr, st))))) return rc;
+    bool merged = false;
+    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3_pair(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, d.H2, d.W2,
+                                  w.p1, w.dp2, w.m2, w.part2, &merged, st))))) return rc;
+    (void)merged;
+    if (conv3_fused_bwd_ok(d.H, d.W, d.C, nets * n)) {
+      // conv1 data gradient + conv0 weight gradient in one launch: da0 never goes to HBM
+      if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
+                                 d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,
+                                 (long long)n * conv0_partial_size(d.C), nullptr, st))))) return rc;
+    } else {
+      if (!d_xn) return CMLPL_E_ARG;
+      if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + pack_off_b3(d.C, d.bands, 1),
+                                 L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
+      if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
+        return rc;
+    }
   }
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
   rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride; rt.dyn_cursor = dyn_cursor;
   Wgrad3Plan wp1, wp2;
   bool wpair = false;
-  if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, fused_head, &wp1, &wp2, &wpair)) return CMLPL_E_SHAPE;
+  if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, true, &wp1, &wp2, &wpair)) return CMLPL_E_SHAPE;
   reduce_table_add(rt, w.part1, wp1.G, PART3, 1, 64, d_grads + L.param_off[2], d_grads + L.param_off[3]);
   reduce_table_add(rt, w.part2, wp2.G, PART3, 1, 64, d_grads + L.param_off[4], d_grads + L.param_off[5]);
   reduce_table_add(rt, w.part0, conv0_partials(d, nets, n), conv0_partial_size(d.C), 0, d.C,
                    d_grads + L.param_off[0], d_grads + L.param_off[1]);
-  if (fused_head)   // the classifier / feat_spe weight-gradient GEMMs ride along (independent, short)
-    return TIMED(CMLPL_K_CONV1_WRED, chk(launch_reduce_gemm(nets, rt, gw_cls, gw_spe, st)));
-  return TIMED(CMLPL_K_CONV1_WRED, chk(launch_partial_reduce(nets, rt, st)));
+  // the classifier / feat_spe weight-gradient GEMMs ride along (independent, short)
+  return TIMED(CMLPL_K_CONV1_WRED, chk(launch_reduce_gemm(nets, rt, gw_cls, gw_spe, st)));
 }
 
 // does the step need an augmented copy of the patches in HBM?  (only when a conv0 pass falls back to the unfused kernels)

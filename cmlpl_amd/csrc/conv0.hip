@@ -96,14 +96,19 @@ constexpr int C0_PB = 8;      // pixel pairs per batch (double-buffered); larger
 // instructions per workgroup instead of C*HW/256 scalar load + divide + ds_write per THREAD.
 typedef __attribute__((address_space(3))) void c0_lds_void;
 typedef __attribute__((address_space(1))) const void c0_gbl_void;
+// PS > 1 (no DMA): a sample's pixels are walked in PS equal ranges, one slab of [Ct][HW / PS] at a time -- the 20 x 20
+// window's whole slab is 103 KB, i.e. ONE workgroup per CU whose staging and MFMA phases cannot overlap with anything;
+// half slabs let three workgroups share a CU.
 template <bool DMA>
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ xn, const float* __restrict__ da0,
-                                                          float* __restrict__ part, int n, int C, int HW, int G) {
+                                                          float* __restrict__ part, int n, int C, int HWfull, int G,
+                                                          int PS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // xs[Ct][HWp] (+ 64 zero floats)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = blockIdx.y, g = blockIdx.x;
   const int NT = (C + 31) >> 5, Ct = NT * 32;
+  const int HW = HWfull / PS;                  // pixels per slab (PS == 1 with DMA)
   const int HWp = DMA ? HW : ((HW + 2) | 1);   // odd; without DMA >= HW+1 (one zero pad column for odd HW)
   const int SPG = (n + G - 1) / G;
   const int sbeg = g * SPG, send = (sbeg + SPG < n) ? sbeg + SPG : n;
@@ -117,8 +122,9 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   for (int i = (DMA ? C * HW : 0) + tid; i < Ct * HWp + 64; i += 256) smem[i] = 0.f;
   const int pairs = (HW + 1) >> 1;
 
-  for (int s = sbeg; s < send; ++s) {
-    const float* brow = da0 + ((long long)net * n + s) * HW * 64 + ct * 32 + l31;
+  for (int su = sbeg * PS; su < send * PS; ++su) {
+    const int s = su / PS, p0 = (su - s * PS) * HW;              // sample, first pixel of this slab
+    const float* brow = da0 + (((long long)net * n + s) * HWfull + p0) * 64 + ct * 32 + l31;
     float bq[4][C0_PB];             // ring of four batches: three requested ahead of the one being multiplied
     auto fetch = [&](float (&buf)[C0_PB], int t0) {
 #pragma unroll
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     // in flight while the slab is staged (three batches ahead of the one being multiplied)
     fetch(bq[0], 0); fetch(bq[1], C0_PB); fetch(bq[2], 2 * C0_PB);
     __syncthreads();
-    const float* xs = xn + ((long long)net * n + s) * C * HW;
+    const float* xs = xn + ((long long)net * n + s) * C * HWfull + p0;
     if (DMA) {
       // (the pixel past the end of an odd row is the first element of the next row: finite, and its B operand
       // is zero; the row after the last one is the zeroed tail)
@@ -146,14 +152,15 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
       if ((HW & 3) == 0) {
         // rows of whole 16-byte pieces (e.g. the reference's 20 x 20 window): one load, one divide per FOUR elements
         const int H4 = HW >> 2;
-        staged_copy<8, float4>(C * H4, tid, [&](int i) { return ((const float4*)xs)[i]; },
+        staged_copy<8, float4>(C * H4, tid,
+                               [&](int i) { const int c = i / H4, q = i - c * H4; return *(const float4*)(xs + (long long)c * HWfull + 4 * q); },
                                [&](int i, float4 v) {
                                  const int c = i / H4, p = 4 * (i - c * H4);
                                  float* d = smem + c * HWp + p;
                                  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                                });
       } else {
-        staged_copy<16, float>(C * HW, tid, [&](int i) { return xs[i]; },
+        staged_copy<16, float>(C * HW, tid, [&](int i) { const int c = i / HW; return xs[(long long)c * HWfull + (i - c * HW)]; },
                                [&](int i, float v) { const int c = i / HW, p = i - c * HW; smem[c * HWp + p] = v; });
       }
     }
@@ -313,7 +320,12 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
   if (NT > 2 * C0_MAXT) return hipErrorInvalidValue;
   static const bool dma_off = getenv("CMLPL_CONV0_DMA") && atoi(getenv("CMLPL_CONV0_DMA")) == 0;
   const bool dma = (HW & 1) && !dma_off;
-  const int HWp = dma ? HW : ((HW + 2) | 1);
+  // pixel ranges per sample: halves (of whole 16-byte groups) when the whole slab would leave one workgroup per CU
+  static const int force_ps = getenv("CMLPL_CONV0_PS") ? atoi(getenv("CMLPL_CONV0_PS")) : 0;
+  int PS = (!dma && (HW & 7) == 0 && ((size_t)Ct * ((HW + 2) | 1) + 64) * 4 > LDS_MAX / 2) ? 2 : 1;
+  if (force_ps == 1 || (force_ps == 2 && !dma && (HW & 7) == 0)) PS = force_ps;
+  const int HWs = HW / PS;
+  const int HWp = dma ? HW : ((HWs + 2) | 1);
   const size_t lds = ((size_t)Ct * HWp + 64) * 4;
   if (lds > LDS_MAX) return hipErrorInvalidValue;
   static DevOnce attr_once;
@@ -322,8 +334,8 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
     if (e != hipSuccess) return e;
   }
   const int G = plan_conv0_wgrad_G(n, C, HW);
-  if (dma) hipLaunchKernelGGL(conv0_wgrad_kernel<true>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);
-  else     hipLaunchKernelGGL(conv0_wgrad_kernel<false>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G);
+  if (dma) hipLaunchKernelGGL(conv0_wgrad_kernel<true>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G, 1);
+  else     hipLaunchKernelGGL(conv0_wgrad_kernel<false>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G, PS);
   return hipGetLastError();
 }
 

@@ -125,7 +125,6 @@ struct Conv3Args {
   long long w0t_ns, b0_ns;
   int C;
   float* xn_out;                                  // MODE 2, optional: the augmented rows [net][n][C*HW], kept for the backward pass
-  int rev1;                                       // MODE 2: network 1 walks the slab's band chunks downwards (both networks read the same raw rows)
   // MODE 3 (conv0 weight gradient fused into the conv1 data gradient): da0 never leaves the workgroup; the input
   // slab is re-formed from `xs` (same noise as the forward: counter-based)
   float* part0; long long part0_ns;
@@ -275,11 +274,49 @@ __device__ __forceinline__ void tap_step(const float* __restrict__ img, const ui
     }
   }
   ASplit nxt[NTA];
+  if constexpr (NTA == 1) {
+    acc[0][0] = mfma_b3(cur[0].p1, cur[0].p2, cur[0].p3, b[0], b[2], b[4], acc[0][0]);
+    acc[0][1] = mfma_b3(cur[0].p1, cur[0].p2, cur[0].p3, b[1], b[3], b[5], acc[0][1]);
+    a_split(rn0[0], rn1[0], nxt[0].p1, nxt[0].p2, nxt[0].p3);
+  } else {
+    // Several tiles per wave (the general path: 20 x 20 and 15 x 15 windows, ONE wave per SIMD): the interleave is
+    // written out by hand -- one MFMA, then one element of the next step's split (4 vector instructions) or three of
+    // its pack instructions, with plain scheduling fences between them.  (Left to the compiler, a tile's 44 split
+    // instructions sit in front of its twelve MFMAs and the matrix pipe idles meanwhile: 110 us for conv1's forward at
+    // 20 x 20 against a matrix-pipe floor of 52; sched_group_barrier patterns, what the one-tile waves use, take
+    // minutes to compile at this many groups.)  Same MFMAs in the same order per accumulator: bit-identical results.
 #pragma unroll
-  for (int t = 0; t < NTA; ++t) {
-    acc[t][0] = mfma_b3(cur[t].p1, cur[t].p2, cur[t].p3, b[0], b[2], b[4], acc[t][0]);
-    acc[t][1] = mfma_b3(cur[t].p1, cur[t].p2, cur[t].p3, b[1], b[3], b[5], acc[t][1]);
-    a_split(rn0[t], rn1[t], nxt[t].p1, nxt[t].p2, nxt[t].p3);
+    for (int t = 0; t < NTA; ++t) {
+      const uint4 A1 = cur[t].p1, A2 = cur[t].p2, A3 = cur[t].p3;
+      const float v[8] = {rn0[t].x, rn0[t].y, rn0[t].z, rn0[t].w, rn1[t].x, rn1[t].y, rn1[t].z, rn1[t].w};
+      uint32_t u0[8], u1[8], u2[8];
+      f32x16 c0 = acc[t][0], c1 = acc[t][1];
+#define CMLPL_SPLIT1(j) { u0[j] = __float_as_uint(v[j]); const float r1_ = v[j] - __uint_as_float(u0[j] & 0xffff0000u); \
+                          u1[j] = __float_as_uint(r1_); u2[j] = __float_as_uint(r1_ - __uint_as_float(u1[j] & 0xffff0000u)); }
+#define CMLPL_FENCE __builtin_amdgcn_sched_barrier(0);
+      CMLPL_FENCE
+      c0 = mfma_b16(A1, b[4], c0); CMLPL_FENCE CMLPL_SPLIT1(0) CMLPL_FENCE
+      c0 = mfma_b16(A2, b[2], c0); CMLPL_FENCE CMLPL_SPLIT1(1) CMLPL_FENCE
+      c0 = mfma_b16(A3, b[0], c0); CMLPL_FENCE CMLPL_SPLIT1(2) CMLPL_FENCE
+      c0 = mfma_b16(A1, b[2], c0); CMLPL_FENCE CMLPL_SPLIT1(3) CMLPL_FENCE
+      c0 = mfma_b16(A2, b[0], c0); CMLPL_FENCE CMLPL_SPLIT1(4) CMLPL_FENCE
+      c0 = mfma_b16(A1, b[0], c0); CMLPL_FENCE CMLPL_SPLIT1(5) CMLPL_FENCE
+      c1 = mfma_b16(A1, b[5], c1); CMLPL_FENCE CMLPL_SPLIT1(6) CMLPL_FENCE
+      c1 = mfma_b16(A2, b[3], c1); CMLPL_FENCE CMLPL_SPLIT1(7) CMLPL_FENCE
+      c1 = mfma_b16(A3, b[1], c1); CMLPL_FENCE
+      nxt[t].p1 = make_uint4(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]), hi_pair(u0[4], u0[5]), hi_pair(u0[6], u0[7]));
+      CMLPL_FENCE
+      c1 = mfma_b16(A1, b[3], c1); CMLPL_FENCE
+      nxt[t].p2 = make_uint4(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]), hi_pair(u1[4], u1[5]), hi_pair(u1[6], u1[7]));
+      CMLPL_FENCE
+      c1 = mfma_b16(A2, b[1], c1); CMLPL_FENCE
+      nxt[t].p3 = make_uint4(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]), hi_pair(u2[4], u2[5]), hi_pair(u2[6], u2[7]));
+      CMLPL_FENCE
+      c1 = mfma_b16(A1, b[1], c1); CMLPL_FENCE
+#undef CMLPL_SPLIT1
+#undef CMLPL_FENCE
+      acc[t][0] = c0; acc[t][1] = c1;
+    }
   }
   // pin the interleave: the reads first, four MFMAs while they (and nothing else) are outstanding, then one MFMA
   // per six split instructions
@@ -513,7 +550,6 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const float* nzrow = (sigma != 0.f) ? xsrc_noise_row(a.xs, net, s0, nfl) : nullptr;
     const uint64_t gsample = xsrc_global_sample(a.xs, s0);
     const uint64_t rstep = xsrc_step(a.xs);               // counter of the random streams (launch argument, or the device-side row)
-    const bool rev = (net & 1) && a.rev1;                 // uniform: network 1 walks the bands downwards (see pch)
     // The augmented rows also go to HBM (16-byte stores from the registers that feed the LDS slots): the backward pass
     // lands them by DMA instead of regenerating the noise -- forming 12,463 normals per sample-net costs ~5 us of vector
     // work per workgroup, the longest single item of that kernel's second half, while these stores ride on an idle HBM.
@@ -545,13 +581,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       if (c0 > 0) __syncthreads();                        // every wave is done reading the previous pass's slots
       uint4 bw[2][6];                                     // conv0 weight fragments of two chunks (window): [n tile][piece]
       float4 dv[SLAB_WIN][2], nzv[SLAB_RING][2];
-      // Which chunk of the slab the kq-th step of this pass takes.  Network 0 walks the bands upwards, network 1
-      // DOWNWARDS: both networks of a sample read the same raw rows (their workgroups are 256 block ids apart, i.e. on
-      // the same XCD) and start together -- walking the same way, both miss on every chunk and the slab crosses the
-      // fabric twice (FETCH 22.9 MB for 12.9 MB of patches, round 3); walking in opposite directions each finds the
-      // other's first half in L2 by the time it gets there.  (Only the order of conv0's k-steps differs between the
-      // networks: same products, another summation order.)
-      auto pch = [&](int kq) { return rev ? KQ0 - 1 - (c0 + kq) : c0 + kq; };
+      // (Measured and dropped, round 4: network 1 walking the band chunks DOWNWARDS so that the two networks of a sample,
+      // which read the same raw rows on the same XCD, would find each other's first half in L2 -- no change, 0.1913 ms
+      // either way: the slab's arrival is not what the prologue waits for.)
+      auto pch = [&](int kq) { return c0 + kq; };
       auto fetch_b = [&](int kq, uint4 (&b)[6]) {
         const int kp = pch(kq);
 #pragma unroll
@@ -573,11 +606,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       for (int kq = 0; kq < 2; ++kq) if (kq < nch) fetch_b(kq, bw[kq]);
 #pragma unroll
       for (int kq = 0; kq < SLAB_WIN; ++kq) if (kq < nch) fetch_d(kq, dv[kq]);
-      if (rev ? c0 == 0 : c0 + nch == KQ0) {
-        // the bands beyond C of the last chunk (this pass's slot nch - 1, or slot 0 when walking downwards) meet zero
-        // weights, but must be finite
+      if (c0 + nch == KQ0) {
+        // the bands beyond C of the last chunk meet zero weights, but must be finite
         const int used = nfl - (KQ0 - 1) * 16 * HWl;
-        float* sl = slab + (rev ? 0 : nch - 1) * SLOT;
+        float* sl = slab + (nch - 1) * SLOT;
         for (int i = used + tid; i < 16 * HWl; i += 256) sl[i] = 0.f;
       }
       // The noise of a chunk's elements (pure vector work: a hash + Box-Muller per four normals, ~380 cycles per call and
@@ -1587,7 +1619,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   if (mode == 0) { a.in_ns = (long long)n * HW * 64; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns; a.mask_in_ns = 0; }
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr; a.rev1 = 0;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
 #define CMLPL_DISPATCH(M)                                                      \
@@ -1650,8 +1682,6 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  static const bool rev_off = getenv("CMLPL_FWD_REV") && atoi(getenv("CMLPL_FWD_REV")) == 0;
-  a.rev1 = (!rev_off && nets == 2 && xs.lab[0] == xs.lab[1] && xs.unl[0] == xs.unl[1]) ? 1 : 0;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -1724,7 +1754,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.wpk_ns = wpk_ns; a.bias_ns = 0;
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
-  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr; a.rev1 = 0;
+  a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = conv3_bwd_bp(H, W, C);
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;

@@ -112,13 +112,22 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int f = f0 + lane; f < f1; f += 64) {
-      const float x = row[f];
-      float wv[8];
+    // four features x eight classes per lane and trip: 32 weight loads in flight (one feature per trip made the
+    // 2624-wide row of the 20 x 20 window a chain of 11 memory round trips per class chunk: 17.7 us per launch)
+    for (int fb = f0 + lane; fb < f1; fb += 256) {
+      float x[4], wv[4][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wv[j] = wc[(long long)((kc + j < K) ? kc + j : K - 1) * F + f];
+      for (int i = 0; i < 4; ++i) {
+        const int f = fb + 64 * i;
+        const bool ok = f < f1;
+        x[i] = ok ? row[f] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(x, wv[j], acc[j]);
+        for (int j = 0; j < 8; ++j) wv[i][j] = wc[(long long)((kc + j < K) ? kc + j : K - 1) * F + (ok ? f : f0)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(x[i], wv[i][j], acc[j]);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -190,28 +199,48 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   const float* dm = (a.dropmask != nullptr) ? a.dropmask + rs * F : nullptr;
   float* dp2 = a.dp2 + rs * SF;
   float* dy = a.dy + rs * FD;
-  for (int f = tid; f < F; f += 256) {
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    const float* wf = wc + f;
-    int k = 0;
-    for (; k + 3 < K; k += 4) {
-      const float w0 = wf[(long long)k * F], w1 = wf[(long long)(k + 1) * F];
-      const float w2 = wf[(long long)(k + 2) * F], w3 = wf[(long long)(k + 3) * F];
-      d0 = fmaf(dls[k], w0, d0); d1 = fmaf(dls[k + 1], w1, d1);
-      d2 = fmaf(dls[k + 2], w2, d2); d3 = fmaf(dls[k + 3], w3, d3);
+  // four row elements x sixteen classes per thread and trip: every load of a trip (64 classifier weights, the dropout
+  // multipliers, the spectral values) is requested before the first is used (one element per trip with its K strided
+  // loads in groups of four was a chain of ~30 round trips on the 2624-wide row: 14.7 us per launch)
+  for (int fb = tid; fb < F; fb += 1024) {
+    float dc[4] = {0.f, 0.f, 0.f, 0.f}, dmv[4], yj[4], dfj[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = fb + 256 * i;
+      const bool ok = f < F, spec = ok && f >= SF;
+      dmv[i] = (dm != nullptr && ok) ? dm[f] : 1.f;
+      yj[i] = spec ? y[f - SF] : 0.f;
+      dfj[i] = (spec && df != nullptr) ? df[f - SF] : 0.f;
     }
-    for (; k < K; ++k) d0 = fmaf(dls[k], wf[(long long)k * F], d0);
-    float dc = (d0 + d1) + (d2 + d3);
-    if (dm != nullptr) dc *= dm[f];
-    if (f < SF) {
-      const int c = f / a.HW4, hw = f - c * a.HW4;
-      dp2[hw * 64 + c] = dc;
-    } else {
-      const int j = f - SF;
-      const float yj = y[j];
-      float g = dc;
-      if (df != nullptr) g += (df[j] - (yj / norm) * dot) / norm;
-      dy[j] = relu_open(yj) ? g : 0.f;
+    for (int kc = 0; kc < K; kc += 16) {
+      float wv[4][16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = fb + 256 * i;
+        const float* wf = wc + (f < F ? f : 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wv[i][j] = wf[(long long)((kc + j < K) ? kc + j : K - 1) * F];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float dl = dls[kc + j < 64 ? kc + j : 63];          // zero beyond K
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dc[i] = fmaf((kc + j < K) ? dl : 0.f, wv[i][j], dc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = fb + 256 * i;
+      if (f >= F) continue;
+      const float d = dc[i] * dmv[i];
+      if (f < SF) {
+        const int c = f / a.HW4, hw = f - c * a.HW4;
+        dp2[hw * 64 + c] = d;
+      } else {
+        float g = d;
+        if (df != nullptr) g += (dfj[i] - (yj[i] / norm) * dot) / norm;
+        dy[f - SF] = relu_open(yj[i]) ? g : 0.f;
+      }
     }
   }
 }

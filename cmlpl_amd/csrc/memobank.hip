@@ -886,10 +886,167 @@ hipError_t launch_mb_sum(const float* v, int n, float* out, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---- the whole of compute_unsupervised_loss in ONE launch of ONE workgroup (B <= 8192 rows: what a batch of pixel
+// logits is on this path; round 3 took a fill and five launches, 0.1 ms for 4096 x 9 numbers).  1024 threads, up to
+// eight rows per thread held in registers from the teacher entropy to the gradient.  The two order statistics of the
+// percentile come from a radix select over order-preserving integer keys of the valid entropies (four 8-bit passes,
+// histograms in LDS by integer atomics: the VALUE at a rank does not depend on how ties are ordered), not from B x B
+// rank counting; every per-row formula is the one of the multi-launch kernels above (same instructions, same values:
+// the dropped set is exact either way).
+constexpr int US1_T = 1024, US1_R = 8;
+__device__ __forceinline__ uint32_t us_key(float e) {
+  const uint32_t u = __float_as_uint(e);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float us_unkey(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// value of rank `rank` (0-based, ascending) among the valid keys; all threads call it, all get the answer
+__device__ __forceinline__ uint32_t us_select(const uint32_t (&key)[US1_R], const bool (&valid)[US1_R], int rank,
+                                              int* hist, int* sbin) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t pfx = 0u, msk = 0u;
+  int rem = rank;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < US1_R; ++q)
+      if (valid[q] && (key[q] & msk) == pfx) atomicAdd(&hist[(key[q] >> shift) & 255u], 1);
+    __syncthreads();
+    if (tid < 64) {                                    // wave 0: lane l owns bins 4l .. 4l+3
+      const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      const int mine = (c0 + c1) + (c2 + c3);
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+      const int excl = incl - mine;
+      const unsigned long long hit = __ballot(incl > rem);
+      const int first = __ffsll((long long)hit) - 1;   // (rank < number of valid keys: some lane qualifies)
+      if (lane == first) {
+        int r = rem - excl, b = 4 * lane;
+        if (r >= c0) { r -= c0; ++b; if (r >= c1) { r -= c1; ++b; if (r >= c2) { r -= c2; ++b; } } }
+        sbin[0] = b; sbin[1] = r;
+      }
+    }
+    __syncthreads();
+    pfx |= (uint32_t)sbin[0] << shift; msk |= 255u << shift; rem = sbin[1];
+    __syncthreads();                                   // sbin / hist are rewritten by the next pass
+  }
+  return pfx;
+}
+
+__global__ __launch_bounds__(US1_T) void us_onewg_kernel(const float* __restrict__ predict, long long* __restrict__ target,
+                                                         const float* __restrict__ teacher, int B, int K, double percent,
+                                                         float* __restrict__ loss, float* __restrict__ dpredict) {
+  __shared__ int hist[256];
+  __shared__ int sbin[2];
+  __shared__ int scnt[2];
+  __shared__ float sred[US1_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float ent[US1_R];
+  uint32_t key[US1_R];
+  bool valid[US1_R];
+  long long tg[US1_R];
+  if (tid < 2) scnt[tid] = 0;
+  __syncthreads();
+  int nv = 0;
+#pragma unroll
+  for (int q = 0; q < US1_R; ++q) {
+    const int i = tid + US1_T * q;
+    ent[q] = 0.f; valid[q] = false; tg[q] = 255;
+    if (i < B) {
+      const float* t = teacher + (size_t)i * K;
+      float mx = -3.0e38f;
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, t[k]);
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) se += expf(t[k] - mx);
+      float e = 0.f;
+      for (int k = 0; k < K; ++k) { const float p = expf(t[k] - mx) / se; e -= p * logf(p + 1e-10f); }
+      ent[q] = e;
+      tg[q] = target[i];
+      valid[q] = tg[q] != 255;
+      nv += valid[q] ? 1 : 0;
+    }
+    key[q] = us_key(ent[q]);
+  }
+  if (nv) atomicAdd(&scnt[0], nv);
+  __syncthreads();
+  const int n = scnt[0];
+  float thr = 3.0e38f;
+  if (n > 0) {                                          // uniform
+    const double vidx = (double)(n - 1) * percent / 100.0;
+    const int lo = (int)floor(vidx), hi = lo + 1 < n ? lo + 1 : n - 1;
+    const float vlo = us_unkey(us_select(key, valid, lo, hist, sbin));
+    const float vhi = hi == lo ? vlo : us_unkey(us_select(key, valid, hi, hist, sbin));
+    const double g = vidx - floor(vidx);
+    const double a = (double)vlo, b = (double)vhi, diff = b - a;
+    double t = a + diff * g;
+    if (g >= 0.5) t = b - diff * (1.0 - g);
+    if (diff == 0.0) t = a;
+    thr = (float)t;
+  }
+  float rl[US1_R], part = 0.f;
+  int nk = 0;
+#pragma unroll
+  for (int q = 0; q < US1_R; ++q) {
+    const int i = tid + US1_T * q;
+    rl[q] = 0.f;
+    if (i < B) {
+      if (tg[q] != 255 && ent[q] >= thr) { tg[q] = 255; target[i] = 255; }
+      if (tg[q] != 255) {
+        const float* p = predict + (size_t)i * K;
+        float mx = -3.0e38f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(p[k] - mx);
+        rl[q] = mx + logf(se) - p[tg[q]];
+        ++nk;
+      }
+      part += rl[q];
+    }
+  }
+  if (nk) atomicAdd(&scnt[1], nk);
+  part = wave_sum(part);                                // fixed order: rows by q, lanes by the xor tree, waves in order
+  if (lane == 0) sred[wave] = part;
+  __syncthreads();
+  const float kf = (float)scnt[1];
+  const float weight = (float)B / kf;                   // :256 (inf / NaN when nothing is kept, like the reference)
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < US1_T / 64; ++w) t += sred[w];
+    loss[0] = weight * (t / kf);
+  }
+  const float sc = weight / kf;
+#pragma unroll
+  for (int q = 0; q < US1_R; ++q) {
+    const int i = tid + US1_T * q;
+    if (i < B) {
+      const float* p = predict + (size_t)i * K;
+      float* g = dpredict + (size_t)i * K;
+      if (tg[q] == 255) {
+        for (int k = 0; k < K; ++k) g[k] = 0.f;
+      } else {
+        float mx = -3.0e38f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(p[k] - mx);
+        for (int k = 0; k < K; ++k) g[k] = sc * (expf(p[k] - mx) / se - (k == (int)tg[q] ? 1.f : 0.f));
+      }
+    }
+  }
+}
+
 size_t unsup_ws_bytes(int B) { return ((size_t)3 * B + 16) * 4; }
 
 hipError_t launch_unsup(const float* predict, long long* target, const float* teacher, int B, int K, double percent,
                         float* loss, float* dpredict, void* ws, hipStream_t st) {
+  static const bool onewg_off = getenv("CMLPL_UNSUP_ONEWG") && atoi(getenv("CMLPL_UNSUP_ONEWG")) == 0;
+  if (B <= US1_T * US1_R && !onewg_off) {
+    hipLaunchKernelGGL(us_onewg_kernel, dim3(1), dim3(US1_T), 0, st, predict, target, teacher, B, K, percent, loss, dpredict);
+    return hipGetLastError();
+  }
   float* ent = (float*)ws;
   float* rowloss = ent + B;
   float* sel = rowloss + B;           // [2]

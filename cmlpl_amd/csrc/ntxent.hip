@@ -1,9 +1,20 @@
 // NT-Xent contrastive loss of the reference's tools.models.ContrastiveLoss (tools/models.py:14-39):
 //   z = normalize([emb_i ; emb_j])   S = z z^T (cosine similarity)   positives on the +-B diagonals
 //   loss = mean_a( -log( exp(S[a,p(a)]/T) / sum_{b != a} exp(S[a,b]/T) ) )
-// forward + analytic backward.  S and the gradient products run on the fp32 MFMA through gemm_tn_kernel
-// (k-major copies zT make both operands coalesced); the row pass is one wavefront per row with the
-// denominator reduced by wavefront shuffles.
+// forward + analytic backward in TWO launches (round 3: five -- normalise, S, rows, two gradient GEMMs, embedding
+// gradient -- 0.2 GFLOP spread over five ramps and a k-major copy of z):
+//   ntx_sim_kernel  : 16 x 32 tiles of the RAW products x_a . x_b on the fp32 MFMA, the contraction split over the four
+//                     waves, whole 128-byte lines staged through per-wave LDS tiles (the shape of loss.hip's
+//                     pair_exp16_kernel).  The rows' squared norms are summed from the very elements the tile stages,
+//                     so no normalised copy of the embeddings is ever written: S = raw / (|x_a| |x_b|) in the
+//                     epilogue, plus the tile's share of every row's denominator.
+//   ntx_grad_kernel : one workgroup per (8 rows, 256 embedding columns).  It folds the denominators of ALL rows from the
+//                     column-tile partials (a row's gradient needs the other rows' denominators: the one global
+//                     dependency of this loss, hence the launch boundary), forms its rows of
+//                         W[a][b] = (E[a][b] (1/den_a + 1/den_b) - 2 [b = p(a)]) / (2B T)      (= G + G^T, E = exp(S/T))
+//                     in LDS, and streams the embeddings once: dz[a] = sum_b W[a][b] z[b].  The backward of the
+//                     normalisation needs z_a . dz_a = sum_b W[a][b] S[a][b] -- a row of numbers the workgroup already
+//                     holds, so no column slice waits for another.  Workgroup (0, 0) also sums the loss.
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -11,101 +22,237 @@ namespace cmlpl {
 
 struct NtxArgs {
   const float* ei; const float* ej; int B, D; float T;
-  float *z, *zT, *norm, *S, *G, *GT, *rowloss, *dz1, *dz2, *loss, *gi, *gj;
+  float *S, *rs_part, *nrm, *loss, *gi, *gj;
 };
 
-// one wave per row: z = x / max(||x||, 1e-12) (F.normalize), plus the k-major copy zT[d][r]
-__global__ __launch_bounds__(256) void ntx_normalize_kernel(NtxArgs a) {
-  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), N2 = 2 * a.B, D = a.D;
-  if (r >= N2) return;
-  const float* x = (r < a.B) ? a.ei + (long long)r * D : a.ej + (long long)(r - a.B) * D;
-  float ss = 0.f;
-  for (int d = lane; d < D; d += 64) { const float v = x[d]; ss = fmaf(v, v, ss); }
-  ss = wave_sum(ss);
-  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-  if (lane == 0) a.norm[r] = nrm;
-  for (int d = lane; d < D; d += 64) {
-    const float v = x[d] / nrm;
-    a.z[(long long)r * D + d] = v;
-    a.zT[(long long)d * N2 + r] = v;
+__device__ __forceinline__ const float* ntx_row(const NtxArgs& a, int r) {
+  return (r < a.B) ? a.ei + (long long)r * a.D : a.ej + (long long)(r - a.B) * a.D;
+}
+
+constexpr int NPT = 36;              // per-wave staging tile row stride in floats (32 + 4)
+
+__global__ __launch_bounds__(256) void ntx_sim_kernel(NtxArgs a) {
+  constexpr int WT = 48 * NPT;                                       // per-wave staging: A [16][NPT] + B [32][NPT]
+  __shared__ __attribute__((aligned(16))) float lds[4 * WT];         // later reused: red[4][8][64], then the E tile
+  __shared__ float ssq[4][48];                                       // per-wave squared-norm partials of the 48 rows
+  float (*red)[8][64] = (float (*)[8][64])lds;
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N2 = 2 * a.B, D = a.D;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 32;
+  float* tA = lds + wave * WT;
+  float* tB = tA + 16 * NPT;
+  // loader role: lane -> (row group r8 = lane >> 3, 16-byte chunk c8 = lane & 7); load j covers rows 8j + r8.  The
+  // contraction is cut into 32-float lines; wave w takes lines w, w + 4, ... (any D).
+  const int r8 = lane >> 3, c8 = lane & 7;
+  const int nlines = (D + 31) >> 5;
+  const float* pa[2]; const float* pb[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int r = r0 + 8 * j + r8; pa[j] = ntx_row(a, r < N2 ? r : 0); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int r = c0 + 8 * j + r8; pb[j] = ntx_row(a, r < N2 ? r : 0); }
+  float* wA = tA + r8 * NPT + c8 * 4;
+  float* wB = tB + r8 * NPT + c8 * 4;
+  const float* rA = tA + l16 * NPT + kq * 8;     // lane group kq owns floats [8kq, 8kq+8) of the line
+  const float* rB = tB + l16 * NPT + kq * 8;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float sq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // (rows are only 4-byte aligned when D is not a multiple of 4: dword-aligned 16-byte loads are fine on this
+  //  hardware; the ragged last group of a row is taken element by element)
+  auto ld = [&](const float* p, int ln) {
+    const int o = ln * 32 + c8 * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ln < nlines && o + 3 < D) v = *(const float4*)(p + o);
+    else if (ln < nlines && o < D) { v.x = p[o]; if (o + 1 < D) v.y = p[o + 1]; if (o + 2 < D) v.z = p[o + 2]; }
+    return v;
+  };
+  float4 va[2], vb[4], na[2], nb[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) va[j] = ld(pa[j], wave);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vb[j] = ld(pb[j], wave);
+  for (int ln = wave; ln < nlines; ln += 4) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) na[j] = ld(pa[j], ln + 4);           // next line in flight
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nb[j] = ld(pb[j], ln + 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *(float4*)(wA + 8 * j * NPT) = va[j];
+      sq[j] += (va[j].x * va[j].x + va[j].y * va[j].y) + (va[j].z * va[j].z + va[j].w * va[j].w);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(float4*)(wB + 8 * j * NPT) = vb[j];
+      sq[2 + j] += (vb[j].x * vb[j].x + vb[j].y * vb[j].y) + (vb[j].z * vb[j].z + vb[j].w * vb[j].w);
+    }
+    // (only this wave touches its staging tile: its own writes are ordered before its reads, no block barrier)
+    const float4 x0 = *(const float4*)(rA), x1 = *(const float4*)(rA + 4);
+    const float4 y0 = *(const float4*)(rB), y1 = *(const float4*)(rB + 4);
+    const float4 z0 = *(const float4*)(rB + 16 * NPT), z1 = *(const float4*)(rB + 16 * NPT + 4);
+#define CMLPL_M2(XA, YB, ZB)                                                                 \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA, YB, acc0, 0, 0, 0);                      \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(XA, ZB, acc1, 0, 0, 0);
+    CMLPL_M2(x0.x, y0.x, z0.x) CMLPL_M2(x0.y, y0.y, z0.y) CMLPL_M2(x0.z, y0.z, z0.z) CMLPL_M2(x0.w, y0.w, z0.w)
+    CMLPL_M2(x1.x, y1.x, z1.x) CMLPL_M2(x1.y, y1.y, z1.y) CMLPL_M2(x1.z, y1.z, z1.z) CMLPL_M2(x1.w, y1.w, z1.w)
+#undef CMLPL_M2
+#pragma unroll
+    for (int j = 0; j < 2; ++j) va[j] = na[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = nb[j];
+  }
+  // squared norms: the 8 lanes of a row group (c8) hold its chunks of this wave's lines
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float v = sq[j];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    if (c8 == 0) ssq[wave][8 * j + r8] = v;                          // slot 8j + r8: rows 0..15 = A, 16..47 = B
+  }
+  __syncthreads();                               // every wave is done with its staging tile: reuse as `red`
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { red[wave][r][lane] = acc0[r]; red[wave][4 + r][lane] = acc1[r]; }
+  __syncthreads();
+  // wave w finishes accumulator registers 2w, 2w+1: register g -> column block g >> 2, row 4 * kq + (g & 3)
+  float e[2];
+  int irow[2], col[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = wave * 2 + q;
+    const float u = ((red[0][g][lane] + red[1][g][lane]) + red[2][g][lane]) + red[3][g][lane];
+    col[q] = 16 * (g >> 2) + l16;
+    irow[q] = 4 * kq + (g & 3);
+    const float qa = ((ssq[0][irow[q]] + ssq[1][irow[q]]) + ssq[2][irow[q]]) + ssq[3][irow[q]];
+    const float qb = ((ssq[0][16 + col[q]] + ssq[1][16 + col[q]]) + ssq[2][16 + col[q]]) + ssq[3][16 + col[q]];
+    const float s = u / (fmaxf(sqrtf(qa), 1e-12f) * fmaxf(sqrtf(qb), 1e-12f));     // F.normalize's eps (models.py:24-25)
+    const int gr = r0 + irow[q], gc = c0 + col[q];
+    const bool ok = gr < N2 && gc < N2;
+    if (ok) a.S[(long long)gr * N2 + gc] = s;
+    e[q] = (ok && gr != gc) ? expf(s / a.T) : 0.f;                                  // negatives_mask (models.py:31-33)
+  }
+  if (blockIdx.x == 0 && tid < 16 && r0 + tid < N2)
+    a.nrm[r0 + tid] = fmaxf(sqrtf(((ssq[0][tid] + ssq[1][tid]) + ssq[2][tid]) + ssq[3][tid]), 1e-12f);
+  __syncthreads();                               // all reads of `red` are done
+  float* ew = lds;                               // [16][33]
+#pragma unroll
+  for (int q = 0; q < 2; ++q) ew[irow[q] * 33 + col[q]] = e[q];
+  __syncthreads();
+  if (tid < 16 && r0 + tid < N2) {               // this tile's share of the row's denominator, columns in index order
+    float sum = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) sum += ew[tid * 33 + c];
+    a.rs_part[(long long)blockIdx.x * N2 + r0 + tid] = sum;
   }
 }
 
-// one wave per row a: denominator over b != a by shuffles, loss_a, G = dL/dS (and its transpose)
-__global__ __launch_bounds__(256) void ntx_rows_kernel(NtxArgs a) {
-  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), N2 = 2 * a.B;
-  if (r >= N2) return;
-  const float* Sr = a.S + (long long)r * N2;
-  const int p = (r < a.B) ? r + a.B : r - a.B;
-  float den = 0.f;
-  for (int b = lane; b < N2; b += 64) den += (b != r) ? expf(Sr[b] / a.T) : 0.f;
-  den = wave_sum(den);
-  const float sp = Sr[p];
-  if (lane == 0) a.rowloss[r] = -logf(expf(sp / a.T) / den);
-  const float sc = 1.f / (a.T * (float)N2);
-  for (int b = lane; b < N2; b += 64) {
-    const float g = (b == r) ? 0.f : (expf(Sr[b] / a.T) / den - (b == p ? 1.f : 0.f)) * sc;
-    a.G[(long long)r * N2 + b] = g;
-    a.GT[(long long)b * N2 + r] = g;
-  }
-}
+constexpr int NTX_R = 8;             // rows per workgroup of the gradient kernel
 
-// one wave per row: dz = dz1 + dz2 (= (G + G^T) z), back through the normalisation; row 0's wave also sums the loss
-__global__ __launch_bounds__(256) void ntx_embgrad_kernel(NtxArgs a) {
-  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), N2 = 2 * a.B, D = a.D;
-  if (r >= N2) return;
-  const float* z = a.z + (long long)r * D;
-  const float* t1 = a.dz1 + (long long)r * D;
-  const float* t2 = a.dz2 + (long long)r * D;
-  float dot = 0.f;
-  for (int d = lane; d < D; d += 64) dot = fmaf(z[d], t1[d] + t2[d], dot);
-  dot = wave_sum(dot);
-  const float nrm = a.norm[r];
-  float* g = (r < a.B) ? a.gi + (long long)r * D : a.gj + (long long)(r - a.B) * D;
-  for (int d = lane; d < D; d += 64) g[d] = ((t1[d] + t2[d]) - z[d] * dot) / nrm;
-  if (r == 0) {
-    float s = 0.f;
-    for (int b = lane; b < N2; b += 64) s += a.rowloss[b];
-    s = wave_sum(s);
-    if (lane == 0) a.loss[0] = s / (float)N2;
+__global__ __launch_bounds__(256) void ntx_grad_kernel(NtxArgs a, int CT) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];         // iden[N2] | W[NTX_R][N2] | red[4][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N2 = 2 * a.B, D = a.D, B = a.B;
+  const int r0 = blockIdx.x * NTX_R, d = blockIdx.y * 256 + tid;
+  float* iden = sm;
+  float* W = sm + N2;
+  float* red = W + NTX_R * N2;
+  const float invT = 1.f / a.T, sc = 1.f / (a.T * (float)N2);
+  // denominators of all rows (column tiles summed in index order), and the loss (workgroup (0, 0))
+  float lsum = 0.f;
+  for (int b = tid; b < N2; b += 256) {
+    float den = 0.f;
+    for (int ct = 0; ct < CT; ++ct) den += a.rs_part[(long long)ct * N2 + b];
+    iden[b] = 1.f / den;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      const int p = (b < B) ? b + B : b - B;
+      lsum += logf(den) - a.S[(long long)b * N2 + p] * invT;          // -log(exp(S_ap / T) / den_a)
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wave] = lsum;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)N2;
+  // this workgroup's rows of W = G + G^T, and z_a . dz_a = sum_b W[a][b] S[a][b]
+  float dotp[NTX_R];
+#pragma unroll
+  for (int i = 0; i < NTX_R; ++i) dotp[i] = 0.f;
+  for (int b = tid; b < N2; b += 256) {
+    const float idb = iden[b];
+#pragma unroll
+    for (int i = 0; i < NTX_R; ++i) {
+      const int ra = r0 + i;
+      float w = 0.f;
+      if (ra < N2 && b != ra) {
+        const float s = a.S[(long long)ra * N2 + b];
+        const int p = (ra < B) ? ra + B : ra - B;
+        w = (expf(s * invT) * (iden[ra] + idb) - (b == p ? 2.f : 0.f)) * sc;
+        dotp[i] = fmaf(w, s, dotp[i]);
+      }
+      W[i * N2 + b] = w;
+    }
+  }
+  __syncthreads();                               // (also: red[] has been read)
+#pragma unroll
+  for (int i = 0; i < NTX_R; ++i) {
+    const float v = wave_sum(dotp[i]);
+    if (lane == 0) red[wave * 16 + i] = v;
+  }
+  __syncthreads();
+  // dz[a][d] = sum_b W[a][b] x[b][d] / |x_b|: the embeddings stream through once, eight rows in flight per thread
+  float acc[NTX_R];
+#pragma unroll
+  for (int i = 0; i < NTX_R; ++i) acc[i] = 0.f;
+  const bool dv = d < D;
+  for (int b0 = 0; b0 < N2; b0 += 8) {
+    float xv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int b = b0 + q;
+      const float v = (dv && b < N2) ? ntx_row(a, b)[d] : 0.f;
+      xv[q] = (b < N2) ? v / a.nrm[b] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int b = (b0 + q < N2) ? b0 + q : N2 - 1;
+#pragma unroll
+      for (int i = 0; i < NTX_R; ++i) acc[i] = fmaf(W[i * N2 + b], xv[q], acc[i]);
+    }
+  }
+  if (!dv) return;
+#pragma unroll
+  for (int i = 0; i < NTX_R; ++i) {
+    const int ra = r0 + i;
+    if (ra < N2) {
+      const float n = a.nrm[ra], z = ntx_row(a, ra)[d] / n;
+      const float dot = (red[i] + red[16 + i]) + (red[32 + i] + red[48 + i]);
+      float* g = (ra < B) ? a.gi + (long long)ra * D : a.gj + (long long)(ra - B) * D;
+      g[d] = (acc[i] - z * dot) / n;             // backward of x / max(|x|, eps) (for |x| above eps)
+    }
   }
 }
 
 size_t ntxent_ws_floats(int B, int D) {
-  const size_t N2 = 2 * (size_t)B;
-  return 4 * N2 * D + 3 * N2 * N2 + 2 * N2 + 64;
+  (void)D;
+  const size_t N2 = 2 * (size_t)B, CT = (N2 + 31) / 32;
+  return N2 * N2 + CT * N2 + N2 + 64;
 }
 
 hipError_t launch_ntxent(const float* ei, const float* ej, int B, int D, float T, float* loss, float* gi, float* gj,
                          float* ws, hipStream_t st) {
   const size_t N2 = 2 * (size_t)B;
+  const int CT = (int)((N2 + 31) / 32);
   NtxArgs a;
   a.ei = ei; a.ej = ej; a.B = B; a.D = D; a.T = T; a.loss = loss; a.gi = gi; a.gj = gj;
-  a.z = ws; ws += N2 * D;
-  a.zT = ws; ws += N2 * D;
-  a.dz1 = ws; ws += N2 * D;
-  a.dz2 = ws; ws += N2 * D;
   a.S = ws; ws += N2 * N2;
-  a.G = ws; ws += N2 * N2;
-  a.GT = ws; ws += N2 * N2;
-  a.norm = ws; ws += N2;
-  a.rowloss = ws;
-  const dim3 rows((unsigned)((N2 + 3) / 4));
-  hipLaunchKernelGGL(ntx_normalize_kernel, rows, dim3(256), 0, st, a);
+  a.rs_part = ws; ws += (size_t)CT * N2;
+  a.nrm = ws;
+  const size_t lds = (N2 + (size_t)NTX_R * N2 + 64) * 4;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;        // 2B <= 1800 rows
+  hipLaunchKernelGGL(ntx_sim_kernel, dim3(CT, (unsigned)((N2 + 15) / 16)), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  GemmTN g;
-  g.A = a.zT; g.lda = (int)N2; g.M = (int)N2; g.B = a.zT; g.ldb = (int)N2; g.N = (int)N2; g.R = D;
-  g.C = a.S; g.ldc = (int)N2; g.a_bstride = g.b_bstride = g.c_bstride = 0; g.bias = nullptr; g.bias_bstride = 0;
-  g.bias_in = nullptr; g.bias_in_bstride = 0; g.relu = 0; g.batches = 1; g.scale = 1.f;
-  if ((e = launch_gemm_tn(g, st)) != hipSuccess) return e;                  // S = z z^T
-  hipLaunchKernelGGL(ntx_rows_kernel, rows, dim3(256), 0, st, a);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  GemmTN h = g;
-  g.A = a.GT; g.B = a.z; g.ldb = D; g.N = D; g.R = (int)N2; g.C = a.dz1; g.ldc = D;   // dz1 = G z
-  h.A = a.G;  h.B = a.z; h.ldb = D; h.N = D; h.R = (int)N2; h.C = a.dz2; h.ldc = D;   // dz2 = G^T z
-  if ((e = launch_gemm_tn2(g, h, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(ntx_embgrad_kernel, rows, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ntx_grad_kernel, dim3((unsigned)((N2 + NTX_R - 1) / NTX_R), (unsigned)((D + 255) / 256)), dim3(256),
+                     lds, st, a, CT);
   return hipGetLastError();
 }
 

@@ -745,6 +745,21 @@ static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
   return ((size_t)U * (RU + 2) * PW * 64 + D * (64 / cspl)) * 4;
 }
 
+// compute units of the current device (cached per device: the pair launch shares them between its two maps; a
+// host without a device -- the library loaded for its symbols only -- plans for a full MI355X)
+static int device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
   const int RO = 2 * (H / 2);
   if (RO <= 0) return false;
@@ -785,7 +800,8 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
   if (rsp && p->cspl == 1 && CO >= 2 && (long long)n * H * W * 64 < (1LL << 31)) {
     const int PW = W + 2, cpr = CO / 2;
     const long long NUr = (long long)n * (H / 2);
-    long long Gt = 256 / (3 * nets);                          // one workgroup per CU over (chunks, nets, 3 rows)
+    const int CUS = device_cus();                              // 256 on an MI355X; fewer on a partitioned or smaller part
+    long long Gt = CUS / (3 * nets);                           // one workgroup per CU over (chunks, nets, 3 rows)
     // In the pair launch (wgrad3b_pair_kernel) a workgroup of either map fills a CU, so the first map's workgroups
     // must not take ALL the CUs: with 240 of them the second map's 192 short ones ran almost entirely AFTER the first
     // map's had finished (25 us + 10 us).  The first map gets 3/4 of the CUs (192 workgroups of ten stages instead of
@@ -796,11 +812,11 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
     // map has finished (512 + 512 rows on one GPU: 0.680 -> 0.703 ms with 72 workgroups for 64 CUs).
     static const int force_pg1 = getenv("CMLPL_WGRAD3_PG1") ? atoi(getenv("CMLPL_WGRAD3_PG1")) : 0;
     static const int force_pg2 = getenv("CMLPL_WGRAD3_PG2") ? atoi(getenv("CMLPL_WGRAD3_PG2")) : 0;
-    if (role == 1) { Gt = (256 * 3 / 4) / (3 * nets); if (force_pg1 > 0) Gt = force_pg1; }
+    if (role == 1) { Gt = (CUS * 3 / 4) / (3 * nets); if (force_pg1 > 0) Gt = force_pg1; }
     if (role == 2) {
-      long long g1 = (256 * 3 / 4) / (3 * nets);
+      long long g1 = (CUS * 3 / 4) / (3 * nets);
       if (force_pg1 > 0) g1 = force_pg1;
-      const long long spare = 256 - 3 * nets * g1;
+      const long long spare = CUS - 3 * nets * g1;
       Gt = spare / (3 * nets);                                  // ONE round on the CUs left over, at every batch size
       if (force_pg2 > 0) Gt = force_pg2;
     }

@@ -347,7 +347,8 @@ class DistTrainEngine(TrainEngine):
                          smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
                          adap=float(self.hp.thr * self.hp.adap_thr(epoch)),
                          keep=(keep, XPl, Xl, Y, XPu, Xu, noise, lab_idx, unl_idx), batch=batch)
-        # augmentation + both forwards; the raw rows are handed over as they are (no augmented copy in HBM)
+        # augmentation + both forwards; the raw rows are handed over as they are (the fused forward leaves the
+        # augmented rows in the workspace for stage_backward: no other cmlpl_forward may use this workspace in between)
         _lib.check("cmlpl_forward", lib.cmlpl_forward(
             C.byref(self.cshape), C.byref(self._chp), C.byref(batch), C.byref(self.cshard), self.params.data_ptr(),
             self.packed.data_ptr(), None if dropmask is None else dropmask.data_ptr(), 1, self.seed, self.step_count,

@@ -178,6 +178,7 @@ class ContrastiveLoss(nn.Module):
     def __init__(self, batch_size, device="cuda", temperature=0.5):
         super().__init__()
         self.batch_size = batch_size
+        self._temperature = float(temperature)       # host copy: float(buffer) would synchronise with the device per call
         self.register_buffer("temperature", torch.tensor(float(temperature)))
         # state_dict() parity with the reference (models.py:19-20); the kernel masks the diagonal itself
         self.register_buffer("negatives_mask", (~torch.eye(batch_size * 2, batch_size * 2, dtype=torch.bool)).float())
@@ -187,4 +188,4 @@ class ContrastiveLoss(nn.Module):
             raise RuntimeError("cmlpl_amd.ContrastiveLoss runs on the GPU only (no CPU fallback)")
         if emb_i.shape != emb_j.shape or emb_i.shape[0] != self.batch_size:
             raise ValueError("emb_i / emb_j must both be [batch_size, D]")
-        return _NTXentFn.apply(emb_i.contiguous().float(), emb_j.contiguous().float(), float(self.temperature))
+        return _NTXentFn.apply(emb_i.contiguous().float(), emb_j.contiguous().float(), self._temperature)

@@ -65,7 +65,7 @@ def n4():
             ei.grad = ej.grad = None
             crit(ei, ej).backward()
         dt = min(timeit(step) for _ in range(3))
-        print(f"N4 NT-Xent forward+backward, B={B}, D={D}: {dt * 1e6:.1f} us")
+        print(f"N4 NT-Xent forward+backward, B={B}, D={D}: {dt * 1e6:.1f} us/call wall")
 
 
 def n2():
@@ -91,13 +91,13 @@ def n2():
         _, loss = LH.compute_contra_memobank_loss(rep, args["label_l"], args["label_u"], args["prob_l"], args["prob_u"],
                                                   args["low_mask"], args["high_mask"], bank, None, None, rep_t)
         loss.backward()
-    # the call is host-bound (Python + autograd around three launches): best of five batches of 100 calls
+    # wall time of a call (Python + autograd around three launches): best of five batches of 100 calls.  Per-kernel
+    # device times are NOT printed here (a constant in a program's output goes stale): scripts/kstats_next_rows.sh
+    # takes them from rocprofv3 for the same calls.
     dt = min(timeit(step, warm=10, reps=100) for _ in range(5))
     gathered = K * 256 * 51 * D * 4 / 1e9          # every key row crosses HBM once (the backward re-uses the registers)
     print(f"N2 compute_contra_memobank_loss fwd+bwd, N={N}, D={D}, K={K}, banks of 20000+ rows (cap {cap}): "
-          f"{dt * 1e6:.0f} us/call wall (host-bound; the three launches take ~61 us: prepare 15 + InfoNCE 35 + scatter 11, "
-          f"rocprofv3), no host read-back (round 2: 180 us; round 1: 730 us, ~30 launches, two read-backs); "
-          f"{gathered:.2f} GB of key gathers in the 35-us InfoNCE launch -> {gathered / 35e-6:.0f} GB/s")
+          f"{dt * 1e6:.0f} us/call wall, no host read-back; {gathered:.2f} GB of key gathers per call")
     B = 4096
     pred = torch.randn(B, K, device=DEV, requires_grad=True)
     teach = torch.randn(B, K, device=DEV) * 3
@@ -107,7 +107,7 @@ def n2():
         pred.grad = None
         LH.compute_unsupervised_loss(pred, tgt0.clone(), 80.0, teach).backward()
     dt = min(timeit(ustep, warm=10, reps=100) for _ in range(3))
-    print(f"N2 compute_unsupervised_loss fwd+bwd, B={B}, K={K}: {dt * 1e6:.0f} us/call")
+    print(f"N2 compute_unsupervised_loss fwd+bwd, B={B}, K={K}: {dt * 1e6:.0f} us/call wall")
 
 
 if __name__ == "__main__":

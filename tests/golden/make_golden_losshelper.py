@@ -16,7 +16,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from tests.golden._refload import load_reference_module  # noqa: E402
-from tests.losshelper_util import CASES_CONTRA, CASES_UNSUP, contra_inputs, unsup_inputs  # noqa: E402
+from tests.losshelper_util import CASES_CONTRA, CASES_UNSUP, GRAD_ROWS, contra_inputs, unsup_inputs  # noqa: E402
 
 torch.Tensor.cuda = lambda self, *a, **k: self
 ref = load_reference_module("loss_helper.py", "ref_loss_helper")
@@ -44,8 +44,9 @@ for name, cfg in CASES_UNSUP.items():
     loss = ref.compute_unsupervised_loss(predict, tgt, cfg["percent"], teacher)
     loss.backward()
     out[f"u_{name}_loss"] = np.array([loss.item()])
-    out[f"u_{name}_target"] = tgt.numpy()
-    out[f"u_{name}_grad"] = predict.grad.numpy()
+    out[f"u_{name}_target"] = tgt.numpy().astype(np.int16) if cfg["B"] > 2048 else tgt.numpy()
+    out[f"u_{name}_grad"] = predict.grad.numpy()[:GRAD_ROWS] if cfg["B"] > 2048 else predict.grad.numpy()
+    out[f"u_{name}_gnorm"] = np.array([np.sqrt((predict.grad.double().numpy() ** 2).sum())])
 
 for name, cfg in CASES_CONTRA.items():
     inp = contra_inputs(cfg)

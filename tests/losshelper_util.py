@@ -8,7 +8,10 @@ CASES_UNSUP = {
     "b": dict(B=300, K=16, percent=50.0, seed=302, ignored=17),
     "c": dict(B=1024, K=9, percent=100.0, seed=303, ignored=5),       # percentile 100: only the maximum is dropped
     "d": dict(B=37, K=4, percent=12.5, seed=304, ignored=3),
+    "e": dict(B=4096, K=9, percent=20.0, seed=305, ignored=100),      # eight rows per thread of the one-workgroup kernel
+    "f": dict(B=9000, K=9, percent=70.0, seed=306, ignored=11),       # beyond it: the rank-counting kernels
 }
+GRAD_ROWS = 256   # fixtures of the big cases keep the gradient's first rows and its norm
 
 CASES_CONTRA = {
     # N = Nl + Nu rows, D features, K classes, bank capacity per class, rows already in each bank

@@ -242,7 +242,8 @@ def test_eight_rank_baseline_configs_match_the_oracle(cfg):
         got = dict(zip(SCALARS, sum(e.scalars for e in engines).tolist()))      # shares are additive
         want = dict(ctr_s=ref["ctr_s"], total_s=ref["total_s"], cls_s=ref["cls_s"], con_s=ref["con_s"], acc=ref["acc"],
                     total_w=ref["total_w"], cls_w=ref["cls_w"], con_w=ref["con_w"], ctr_w=ref["ctr_w"])
-        print(f"[{cfg}] step {s}: " + " ".join(f"{k}={got[k]:.6g}/{float(v):.6g}" for k, v in want.items()))
+        want = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in want.items()}
+        print(f"[{cfg}] step {s}: " + " ".join(f"{k}={got[k]:.6g}/{v:.6g}" for k, v in want.items()))
         for k, v in want.items():
             assert abs(got[k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-6, (s, k, got[k], float(v))
         assert [got["n_mask_w"], got["n_mask_s"], got["n_pos"], got["n_neg"]] == \

@@ -34,6 +34,11 @@ def test_general_memobank_infonce_kernel_passes_losshelper_parity():
     _run({"CMLPL_MB_FAST": "0"}, ["tests/test_losshelper.py"])
 
 
+def test_multi_launch_unsupervised_loss_passes_losshelper_parity():
+    """the rank-counting kernels (what more than 8192 rows take) instead of the one-workgroup radix-select kernel"""
+    _run({"CMLPL_UNSUP_ONEWG": "0"}, ["tests/test_losshelper.py", "-k", "unsupervised"])
+
+
 def test_general_wgrad_fallback_passes_backward_parity():
     _run({"CMLPL_WGRAD3_R": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
 

@@ -937,19 +937,41 @@ __device__ __forceinline__ uint32_t us_select(const uint32_t (&key)[US1_R], cons
   return pfx;
 }
 
+// a row of K <= 16 logits in registers: every load of the row requested at once (with K a run-time number the per-k
+// loops re-load the row for every pass and the passes become chains of dependent L1 round trips)
+constexpr int US1_K = 16;
+struct UsRow { float v[US1_K]; };
+__device__ __forceinline__ UsRow us_load_row(const float* __restrict__ p, int K) {
+  UsRow r;
+#pragma unroll
+  for (int k = 0; k < US1_K; ++k) r.v[k] = p[k < K ? k : 0];
+  return r;
+}
+// max, sum of exp(. - max) over the K real entries (same operation order as the per-k loops of the kernels above)
+__device__ __forceinline__ void us_max_se(const UsRow& r, int K, float& mx, float& se) {
+  mx = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < US1_K; ++k) if (k < K) mx = fmaxf(mx, r.v[k]);
+  se = 0.f;
+#pragma unroll
+  for (int k = 0; k < US1_K; ++k) if (k < K) se += expf(r.v[k] - mx);
+}
+
+template <bool REGROWS>
 __global__ __launch_bounds__(US1_T) void us_onewg_kernel(const float* __restrict__ predict, long long* __restrict__ target,
                                                          const float* __restrict__ teacher, int B, int K, double percent,
                                                          float* __restrict__ loss, float* __restrict__ dpredict) {
   __shared__ int hist[256];
   __shared__ int sbin[2];
-  __shared__ int scnt[2];
+  __shared__ int scnt[3];
+  __shared__ uint32_t smin[US1_T / 64];
   __shared__ float sred[US1_T / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float ent[US1_R];
   uint32_t key[US1_R];
   bool valid[US1_R];
   long long tg[US1_R];
-  if (tid < 2) scnt[tid] = 0;
+  if (tid < 3) scnt[tid] = 0;
   __syncthreads();
   int nv = 0;
 #pragma unroll
@@ -958,14 +980,23 @@ __global__ __launch_bounds__(US1_T) void us_onewg_kernel(const float* __restrict
     ent[q] = 0.f; valid[q] = false; tg[q] = 255;
     if (i < B) {
       const float* t = teacher + (size_t)i * K;
-      float mx = -3.0e38f;
-      for (int k = 0; k < K; ++k) mx = fmaxf(mx, t[k]);
-      float se = 0.f;
-      for (int k = 0; k < K; ++k) se += expf(t[k] - mx);
       float e = 0.f;
-      for (int k = 0; k < K; ++k) { const float p = expf(t[k] - mx) / se; e -= p * logf(p + 1e-10f); }
+      if (REGROWS) {
+        const UsRow r = us_load_row(t, K);
+        tg[q] = target[i];
+        float mx, se;
+        us_max_se(r, K, mx, se);
+#pragma unroll
+        for (int k = 0; k < US1_K; ++k) if (k < K) { const float p = expf(r.v[k] - mx) / se; e -= p * logf(p + 1e-10f); }
+      } else {
+        float mx = -3.0e38f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, t[k]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(t[k] - mx);
+        for (int k = 0; k < K; ++k) { const float p = expf(t[k] - mx) / se; e -= p * logf(p + 1e-10f); }
+        tg[q] = target[i];
+      }
       ent[q] = e;
-      tg[q] = target[i];
       valid[q] = tg[q] != 255;
       nv += valid[q] ? 1 : 0;
     }
@@ -978,8 +1009,27 @@ __global__ __launch_bounds__(US1_T) void us_onewg_kernel(const float* __restrict
   if (n > 0) {                                          // uniform
     const double vidx = (double)(n - 1) * percent / 100.0;
     const int lo = (int)floor(vidx), hi = lo + 1 < n ? lo + 1 : n - 1;
-    const float vlo = us_unkey(us_select(key, valid, lo, hist, sbin));
-    const float vhi = hi == lo ? vlo : us_unkey(us_select(key, valid, hi, hist, sbin));
+    const uint32_t klo = us_select(key, valid, lo, hist, sbin);
+    // a[hi] without a second select: it equals a[lo] when more than lo + 1 valid keys are <= a[lo], else it is the
+    // smallest valid key above a[lo]
+    uint32_t khi = klo;
+    if (hi != lo) {
+      int le = 0;
+      uint32_t mn = 0xffffffffu;
+#pragma unroll
+      for (int q = 0; q < US1_R; ++q)
+        if (valid[q]) { if (key[q] <= klo) ++le; else mn = key[q] < mn ? key[q] : mn; }
+      if (le) atomicAdd(&scnt[2], le);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mn, o, 64); mn = v < mn ? v : mn; }
+      if (lane == 0) smin[wave] = mn;
+      __syncthreads();
+      if (scnt[2] <= hi) {
+        khi = 0xffffffffu;
+        for (int w = 0; w < US1_T / 64; ++w) khi = smin[w] < khi ? smin[w] : khi;
+      }
+    }
+    const float vlo = us_unkey(klo), vhi = us_unkey(khi);
     const double g = vidx - floor(vidx);
     const double a = (double)vlo, b = (double)vhi, diff = b - a;
     double t = a + diff * g;
@@ -987,24 +1037,32 @@ __global__ __launch_bounds__(US1_T) void us_onewg_kernel(const float* __restrict
     if (diff == 0.0) t = a;
     thr = (float)t;
   }
-  float rl[US1_R], part = 0.f;
+  float part = 0.f;
   int nk = 0;
 #pragma unroll
   for (int q = 0; q < US1_R; ++q) {
     const int i = tid + US1_T * q;
-    rl[q] = 0.f;
     if (i < B) {
       if (tg[q] != 255 && ent[q] >= thr) { tg[q] = 255; target[i] = 255; }
       if (tg[q] != 255) {
         const float* p = predict + (size_t)i * K;
-        float mx = -3.0e38f;
-        for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
-        float se = 0.f;
-        for (int k = 0; k < K; ++k) se += expf(p[k] - mx);
-        rl[q] = mx + logf(se) - p[tg[q]];
+        float mx, se, pt;
+        if (REGROWS) {
+          const UsRow r = us_load_row(p, K);
+          us_max_se(r, K, mx, se);
+          pt = 0.f;
+#pragma unroll
+          for (int k = 0; k < US1_K; ++k) if (k == (int)tg[q]) pt = r.v[k];
+        } else {
+          mx = -3.0e38f;
+          for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
+          se = 0.f;
+          for (int k = 0; k < K; ++k) se += expf(p[k] - mx);
+          pt = p[tg[q]];
+        }
+        part += mx + logf(se) - pt;
         ++nk;
       }
-      part += rl[q];
     }
   }
   if (nk) atomicAdd(&scnt[1], nk);
@@ -1027,6 +1085,13 @@ __global__ __launch_bounds__(US1_T) void us_onewg_kernel(const float* __restrict
       float* g = dpredict + (size_t)i * K;
       if (tg[q] == 255) {
         for (int k = 0; k < K; ++k) g[k] = 0.f;
+      } else if (REGROWS) {
+        const UsRow r = us_load_row(p, K);
+        float mx, se;
+        us_max_se(r, K, mx, se);
+#pragma unroll
+        for (int k = 0; k < US1_K; ++k)
+          if (k < K) g[k] = sc * (expf(r.v[k] - mx) / se - (k == (int)tg[q] ? 1.f : 0.f));
       } else {
         float mx = -3.0e38f;
         for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
@@ -1038,13 +1103,174 @@ __global__ __launch_bounds__(US1_T) void us_onewg_kernel(const float* __restrict
   }
 }
 
+// ---- three launches for 1024 < B <= 8192 rows (one workgroup alone is compute-bound there: 4096 x 9 logits cost one
+// CU 32 us of exp / log / divide issue): row entropies on the grid, the radix select + threshold + kept count in ONE
+// workgroup (nothing but keys: 10 us), then drop / CE / gradient on the grid with the loss summed by the last
+// workgroup to arrive (integer ticket, block partials in index order: deterministic, no float atomics).
+struct UsMid { float thr; int kept; int ticket; int pad; };
+
+__global__ __launch_bounds__(256) void us_entropy2_kernel(const float* __restrict__ teacher, int B, int K,
+                                                          float* __restrict__ ent) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  const float* t = teacher + (size_t)i * K;
+  float e = 0.f;
+  if (K <= US1_K) {
+    const UsRow r = us_load_row(t, K);
+    float mx, se;
+    us_max_se(r, K, mx, se);
+#pragma unroll
+    for (int k = 0; k < US1_K; ++k) if (k < K) { const float p = expf(r.v[k] - mx) / se; e -= p * logf(p + 1e-10f); }
+  } else {
+    float mx = -3.0e38f;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, t[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(t[k] - mx);
+    for (int k = 0; k < K; ++k) { const float p = expf(t[k] - mx) / se; e -= p * logf(p + 1e-10f); }
+  }
+  ent[i] = e;
+}
+
+__global__ __launch_bounds__(US1_T) void us_select1_kernel(const float* __restrict__ ent, const long long* __restrict__ target,
+                                                           int B, double percent, UsMid* __restrict__ mid) {
+  __shared__ int hist[256];
+  __shared__ int sbin[2];
+  __shared__ int scnt[3];
+  __shared__ uint32_t smin[US1_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float ev[US1_R];
+  uint32_t key[US1_R];
+  bool valid[US1_R];
+  if (tid < 3) scnt[tid] = 0;
+  __syncthreads();
+  int nv = 0;
+#pragma unroll
+  for (int q = 0; q < US1_R; ++q) {                      // every load of the thread's rows first
+    const int i = tid + US1_T * q;
+    ev[q] = ent[i < B ? i : 0];
+    valid[q] = (i < B) && target[i < B ? i : 0] != 255;
+  }
+#pragma unroll
+  for (int q = 0; q < US1_R; ++q) { key[q] = us_key(ev[q]); nv += valid[q] ? 1 : 0; }
+  if (nv) atomicAdd(&scnt[0], nv);
+  __syncthreads();
+  const int n = scnt[0];
+  float thr = 3.0e38f;
+  if (n > 0) {                                          // uniform
+    const double vidx = (double)(n - 1) * percent / 100.0;
+    const int lo = (int)floor(vidx), hi = lo + 1 < n ? lo + 1 : n - 1;
+    const uint32_t klo = us_select(key, valid, lo, hist, sbin);
+    uint32_t khi = klo;
+    if (hi != lo) {                                     // a[hi]: a[lo] again, or the smallest key above it
+      int le = 0;
+      uint32_t mn = 0xffffffffu;
+#pragma unroll
+      for (int q = 0; q < US1_R; ++q)
+        if (valid[q]) { if (key[q] <= klo) ++le; else mn = key[q] < mn ? key[q] : mn; }
+      if (le) atomicAdd(&scnt[2], le);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mn, o, 64); mn = v < mn ? v : mn; }
+      if (lane == 0) smin[wave] = mn;
+      __syncthreads();
+      if (scnt[2] <= hi) {
+        khi = 0xffffffffu;
+        for (int w = 0; w < US1_T / 64; ++w) khi = smin[w] < khi ? smin[w] : khi;
+      }
+    }
+    const float vlo = us_unkey(klo), vhi = us_unkey(khi);
+    const double g = vidx - floor(vidx);
+    const double a = (double)vlo, b = (double)vhi, diff = b - a;
+    double t = a + diff * g;
+    if (g >= 0.5) t = b - diff * (1.0 - g);
+    if (diff == 0.0) t = a;
+    thr = (float)t;
+  }
+  int nk = 0;
+#pragma unroll
+  for (int q = 0; q < US1_R; ++q) nk += (valid[q] && !(ev[q] >= thr)) ? 1 : 0;     // rows that stay
+  if (nk) atomicAdd(&scnt[1], nk);
+  __syncthreads();
+  if (tid == 0) { mid->thr = thr; mid->kept = scnt[1]; mid->ticket = 0; mid->pad = 0; }
+}
+
+__global__ __launch_bounds__(256) void us_apply_kernel(const float* __restrict__ predict, long long* __restrict__ target,
+                                                       const float* __restrict__ ent, int B, int K, UsMid* __restrict__ mid,
+                                                       float* __restrict__ bpart, float* __restrict__ loss,
+                                                       float* __restrict__ dpredict) {
+  __shared__ float sred[4];
+  __shared__ int slast;
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  const float thr = mid->thr, kf = (float)mid->kept;
+  const float weight = (float)B / kf;                   // :256 (inf / NaN when nothing is kept, like the reference)
+  const float sc = weight / kf;
+  float l = 0.f;
+  if (i < B) {
+    long long tg = target[i];
+    if (tg != 255 && ent[i] >= thr) { tg = 255; target[i] = 255; }
+    const float* p = predict + (size_t)i * K;
+    float* g = dpredict + (size_t)i * K;
+    if (tg == 255) {
+      for (int k = 0; k < K; ++k) g[k] = 0.f;
+    } else if (K <= US1_K) {
+      const UsRow r = us_load_row(p, K);
+      float mx, se;
+      us_max_se(r, K, mx, se);
+      float pt = 0.f;
+#pragma unroll
+      for (int k = 0; k < US1_K; ++k) if (k == (int)tg) pt = r.v[k];
+      l = mx + logf(se) - pt;
+#pragma unroll
+      for (int k = 0; k < US1_K; ++k)
+        if (k < K) g[k] = sc * (expf(r.v[k] - mx) / se - (k == (int)tg ? 1.f : 0.f));
+    } else {
+      float mx = -3.0e38f;
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, p[k]);
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) se += expf(p[k] - mx);
+      l = mx + logf(se) - p[tg];
+      for (int k = 0; k < K; ++k) g[k] = sc * (expf(p[k] - mx) / se - (k == (int)tg ? 1.f : 0.f));
+    }
+  }
+  l = wave_sum(l);
+  if ((tid & 63) == 0) sred[tid >> 6] = l;
+  __syncthreads();
+  if (tid == 0) {
+    // publish this workgroup's partial (release at agent scope; the explicit wait keeps the compiler from letting the
+    // ticket overtake the write-back: MI355X guide, "compiler hazard"), take a ticket; the last arriver sums
+    bpart[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = atomicAdd(&mid->ticket, 1);
+    slast = (t == (int)gridDim.x - 1) ? 1 : 0;
+    if (slast) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float tot = 0.f;
+      for (int b = 0; b < (int)gridDim.x; ++b) tot += __builtin_nontemporal_load(bpart + b);   // index order
+      loss[0] = weight * (tot / kf);
+    }
+  }
+}
+
 size_t unsup_ws_bytes(int B) { return ((size_t)3 * B + 16) * 4; }
 
 hipError_t launch_unsup(const float* predict, long long* target, const float* teacher, int B, int K, double percent,
                         float* loss, float* dpredict, void* ws, hipStream_t st) {
   static const bool onewg_off = getenv("CMLPL_UNSUP_ONEWG") && atoi(getenv("CMLPL_UNSUP_ONEWG")) == 0;
+  static const bool three_off = getenv("CMLPL_UNSUP_3L") && atoi(getenv("CMLPL_UNSUP_3L")) == 0;
+  if (B > US1_T && B <= US1_T * US1_R && !onewg_off && !three_off) {
+    float* ent3 = (float*)ws;                          // [B]
+    float* bpart = ent3 + B;                            // [blocks]
+    UsMid* mid = (UsMid*)(bpart + B);                   // (16-byte aligned: the workspace is, B floats twice)
+    const int nb3 = (B + 255) / 256;
+    hipLaunchKernelGGL(us_entropy2_kernel, dim3(nb3), dim3(256), 0, st, teacher, B, K, ent3);
+    hipLaunchKernelGGL(us_select1_kernel, dim3(1), dim3(US1_T), 0, st, ent3, target, B, percent, mid);
+    hipLaunchKernelGGL(us_apply_kernel, dim3(nb3), dim3(256), 0, st, predict, target, ent3, B, K, mid, bpart, loss, dpredict);
+    return hipGetLastError();
+  }
   if (B <= US1_T * US1_R && !onewg_off) {
-    hipLaunchKernelGGL(us_onewg_kernel, dim3(1), dim3(US1_T), 0, st, predict, target, teacher, B, K, percent, loss, dpredict);
+    if (K <= US1_K) hipLaunchKernelGGL(us_onewg_kernel<true>, dim3(1), dim3(US1_T), 0, st, predict, target, teacher, B, K, percent, loss, dpredict);
+    else            hipLaunchKernelGGL(us_onewg_kernel<false>, dim3(1), dim3(US1_T), 0, st, predict, target, teacher, B, K, percent, loss, dpredict);
     return hipGetLastError();
   }
   float* ent = (float*)ws;

@@ -66,16 +66,16 @@ __global__ __launch_bounds__(256) void ntx_sim_kernel(NtxArgs a) {
     else if (ln < nlines && o < D) { v.x = p[o]; if (o + 1 < D) v.y = p[o + 1]; if (o + 2 < D) v.z = p[o + 2]; }
     return v;
   };
-  float4 va[2], vb[4], na[2], nb[4];
+  // three line sets in flight (a line is only 16 MFMAs per wave; with one line of look-ahead every line waited out most
+  // of a memory round trip: 13 us for 2B = 256).  Lines past the end load zeros and add nothing.
+  float4 a0[2], b0[4], a1[2], b1[4], a2[2], b2[4];
+  auto fill = [&](float4 (&va)[2], float4 (&vb)[4], int ln) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) va[j] = ld(pa[j], wave);
+    for (int j = 0; j < 2; ++j) va[j] = ld(pa[j], ln);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) vb[j] = ld(pb[j], wave);
-  for (int ln = wave; ln < nlines; ln += 4) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) na[j] = ld(pa[j], ln + 4);           // next line in flight
-#pragma unroll
-    for (int j = 0; j < 4; ++j) nb[j] = ld(pb[j], ln + 4);
+    for (int j = 0; j < 4; ++j) vb[j] = ld(pb[j], ln);
+  };
+  auto step = [&](const float4 (&va)[2], const float4 (&vb)[4]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       *(float4*)(wA + 8 * j * NPT) = va[j];
@@ -96,10 +96,12 @@ __global__ __launch_bounds__(256) void ntx_sim_kernel(NtxArgs a) {
     CMLPL_M2(x0.x, y0.x, z0.x) CMLPL_M2(x0.y, y0.y, z0.y) CMLPL_M2(x0.z, y0.z, z0.z) CMLPL_M2(x0.w, y0.w, z0.w)
     CMLPL_M2(x1.x, y1.x, z1.x) CMLPL_M2(x1.y, y1.y, z1.y) CMLPL_M2(x1.z, y1.z, z1.z) CMLPL_M2(x1.w, y1.w, z1.w)
 #undef CMLPL_M2
-#pragma unroll
-    for (int j = 0; j < 2; ++j) va[j] = na[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) vb[j] = nb[j];
+  };
+  fill(a0, b0, wave); fill(a1, b1, wave + 4); fill(a2, b2, wave + 8);
+  for (int ln = wave; ln < nlines; ln += 12) {
+    step(a0, b0); fill(a0, b0, ln + 12);
+    step(a1, b1); fill(a1, b1, ln + 16);
+    step(a2, b2); fill(a2, b2, ln + 20);
   }
   // squared norms: the 8 lanes of a row group (c8) hold its chunks of this wave's lines
 #pragma unroll
@@ -147,20 +149,28 @@ __global__ __launch_bounds__(256) void ntx_sim_kernel(NtxArgs a) {
 constexpr int NTX_R = 8;             // rows per workgroup of the gradient kernel
 
 __global__ __launch_bounds__(256) void ntx_grad_kernel(NtxArgs a, int CT) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];         // iden[N2] | W[NTX_R][N2] | red[4][16]
+  extern __shared__ __attribute__((aligned(16))) float sm[];         // iden[N2] | W[NTX_R][N2] | red[4][16] | inrm[N2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N2 = 2 * a.B, D = a.D, B = a.B;
   const int r0 = blockIdx.x * NTX_R, d = blockIdx.y * 256 + tid;
   float* iden = sm;
   float* W = sm + N2;
   float* red = W + NTX_R * N2;
+  float* inrm = red + 64;                                            // 1 / |x_b| of every row
   const float invT = 1.f / a.T, sc = 1.f / (a.T * (float)N2);
   // denominators of all rows (column tiles summed in index order), and the loss (workgroup (0, 0))
   float lsum = 0.f;
   for (int b = tid; b < N2; b += 256) {
     float den = 0.f;
-    for (int ct = 0; ct < CT; ++ct) den += a.rs_part[(long long)ct * N2 + b];
+    for (int c0 = 0; c0 < CT; c0 += 8) {               // eight partials requested together, added in index order
+      float pv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pv[q] = a.rs_part[(long long)(c0 + q < CT ? c0 + q : CT - 1) * N2 + b];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) den += (c0 + q < CT) ? pv[q] : 0.f;
+    }
     iden[b] = 1.f / den;
+    inrm[b] = 1.f / a.nrm[b];
     if (blockIdx.x == 0 && blockIdx.y == 0) {
       const int p = (b < B) ? b + B : b - B;
       lsum += logf(den) - a.S[(long long)b * N2 + p] * invT;          // -log(exp(S_ap / T) / den_a)
@@ -178,16 +188,17 @@ __global__ __launch_bounds__(256) void ntx_grad_kernel(NtxArgs a, int CT) {
   for (int i = 0; i < NTX_R; ++i) dotp[i] = 0.f;
   for (int b = tid; b < N2; b += 256) {
     const float idb = iden[b];
+    float sv[NTX_R];                                     // the eight similarities first (unconditional loads: behind a
+#pragma unroll                                           // branch each one waited out its own round trip)
+    for (int i = 0; i < NTX_R; ++i) sv[i] = a.S[(long long)(r0 + i < N2 ? r0 + i : N2 - 1) * N2 + b];
 #pragma unroll
     for (int i = 0; i < NTX_R; ++i) {
       const int ra = r0 + i;
-      float w = 0.f;
-      if (ra < N2 && b != ra) {
-        const float s = a.S[(long long)ra * N2 + b];
-        const int p = (ra < B) ? ra + B : ra - B;
-        w = (expf(s * invT) * (iden[ra] + idb) - (b == p ? 2.f : 0.f)) * sc;
-        dotp[i] = fmaf(w, s, dotp[i]);
-      }
+      const int rc = ra < N2 ? ra : N2 - 1;
+      const int p = (ra < B) ? ra + B : ra - B;
+      const float wv = (expf(sv[i] * invT) * (iden[rc] + idb) - (b == p ? 2.f : 0.f)) * sc;
+      const float w = (ra < N2 && b != ra) ? wv : 0.f;
+      dotp[i] = fmaf(w, sv[i], dotp[i]);
       W[i * N2 + b] = w;
     }
   }
@@ -203,27 +214,42 @@ __global__ __launch_bounds__(256) void ntx_grad_kernel(NtxArgs a, int CT) {
 #pragma unroll
   for (int i = 0; i < NTX_R; ++i) acc[i] = 0.f;
   const bool dv = d < D;
-  for (int b0 = 0; b0 < N2; b0 += 8) {
-    float xv[8];
+  // sixteen rows per trip, the NEXT trip's sixteen loads requested before this trip's arithmetic (the first version
+  // loaded eight rows, used them, loaded the next eight: one memory round trip per eight rows, 50 us at 2B = 256 and
+  // 260 us at 2B = 1024 for a few MFLOP)
+  constexpr int NB = 16;
+  const int dc = dv ? d : 0;
+  // the rows are two plain arrays (emb_i, emb_j): each is walked with a running offset (the generic row lookup -- a
+  // 64-bit select per load -- cost more instructions than the arithmetic it fed)
+  auto walk = [&](const float* __restrict__ base, int nrows, int col0) {
+    const float* p = base + dc;
+    float cur[NB], nxt[NB];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int b = b0 + q;
-      const float v = (dv && b < N2) ? ntx_row(a, b)[d] : 0.f;
-      xv[q] = (b < N2) ? v / a.nrm[b] : 0.f;
+    for (int q = 0; q < NB; ++q) cur[q] = p[(size_t)(q < nrows ? q : nrows - 1) * D];
+    for (int b0 = 0; b0 < nrows; b0 += NB) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q) { const int b = b0 + NB + q; nxt[q] = p[(size_t)(b < nrows ? b : nrows - 1) * D]; }
+      const float* wrow = W + col0 + b0;
+      const float* nrow = inrm + col0 + b0;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const bool ok = b0 + q < nrows;
+        const float xv = ok ? cur[q] * nrow[ok ? q : 0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NTX_R; ++i) acc[i] = fmaf(wrow[i * N2 + (ok ? q : 0)], xv, acc[i]);
+      }
+#pragma unroll
+      for (int q = 0; q < NB; ++q) cur[q] = nxt[q];
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int b = (b0 + q < N2) ? b0 + q : N2 - 1;
-#pragma unroll
-      for (int i = 0; i < NTX_R; ++i) acc[i] = fmaf(W[i * N2 + b], xv[q], acc[i]);
-    }
-  }
+  };
+  walk(a.ei, B, 0);
+  walk(a.ej, B, B);
   if (!dv) return;
 #pragma unroll
   for (int i = 0; i < NTX_R; ++i) {
     const int ra = r0 + i;
     if (ra < N2) {
-      const float n = a.nrm[ra], z = ntx_row(a, ra)[d] / n;
+      const float n = a.nrm[ra], z = ntx_row(a, ra)[d] * inrm[ra];
       const float dot = (red[i] + red[16 + i]) + (red[32 + i] + red[48 + i]);
       float* g = (ra < B) ? a.gi + (long long)ra * D : a.gj + (long long)(ra - B) * D;
       g[d] = (acc[i] - z * dot) / n;             // backward of x / max(|x|, eps) (for |x| above eps)
@@ -246,8 +272,8 @@ hipError_t launch_ntxent(const float* ei, const float* ej, int B, int D, float T
   a.S = ws; ws += N2 * N2;
   a.rs_part = ws; ws += (size_t)CT * N2;
   a.nrm = ws;
-  const size_t lds = (N2 + (size_t)NTX_R * N2 + 64) * 4;
-  if (lds > 64 * 1024) return hipErrorInvalidValue;        // 2B <= 1800 rows
+  const size_t lds = (2 * N2 + (size_t)NTX_R * N2 + 64) * 4;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;        // 2B <= 1600 rows
   hipLaunchKernelGGL(ntx_sim_kernel, dim3(CT, (unsigned)((N2 + 15) / 16)), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

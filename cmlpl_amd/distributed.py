@@ -340,7 +340,7 @@ class DistTrainEngine(TrainEngine):
             noise8 = C.cast(keep, C.POINTER(C.c_void_p))
         if dropmask is not None:
             _chk_f32(dropmask, (2, n_l, s.cls_in), "dropmask")
-        self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
+        self._cur_row = self.step_count % self.hist_rows
         batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), Y.data_ptr(), noise8, bt_l, btu_l,
                            None if lab_idx is None else lab_idx.data_ptr(), None if unl_idx is None else unl_idx.data_ptr())
         self._ctx = dict(epoch=epoch, batch_index=batch_index, apply_update=apply_update, dropmask=dropmask,

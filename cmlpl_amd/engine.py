@@ -70,7 +70,7 @@ class TrainEngine:
         # back once per print_per_batches steps.
         self.hist_rows = max(1, int(hist_rows))
         self.scalar_hist = z(self.hist_rows, 16)
-        self.scalars = self.scalar_hist[0]
+        self._cur_row = 0
         self.logits, self.feat = z(2, self.n_max, shape.K), z(2, self.n_max, FEAT_DIM)
         ws = self.lib.cmlpl_workspace_bytes(C.byref(self.cshape), 2, self.n_max, self.Q)
         if ws == 0:
@@ -81,6 +81,16 @@ class TrainEngine:
         self.seed = int(seed)
         self._chp = self._make_hp()
         self._packed_dirty = True
+        # the step's argument record is kept: what never changes (state buffers, sizes) is set once, a step writes the
+        # rest -- building the record anew and re-checking the same resident tensors cost ~40 us of Python per step
+        self._io = _lib.StepIO()
+        self._fill_state(self._io)
+        self._checked = None
+
+    @property
+    def scalars(self) -> torch.Tensor:
+        """the logged row of the last step (a view of the device ring)"""
+        return self.scalar_hist[self._cur_row]
 
     # ------------------------------------------------------------------ parameters
     def _make_hp(self) -> _lib.HParams:
@@ -149,6 +159,14 @@ class TrainEngine:
         """Shapes of a batch: the rows themselves, or (lab_idx / unl_idx given) the resident splits the int64 index
         lists point into (hsi_loader.py:109-133 hands rows out by index; here the kernels follow the index)."""
         s = self.shape
+        if lab_idx is not None and unl_idx is not None:
+            # the same resident splits as last time (by identity and storage): only the index lists are new
+            key = (id(XPl), id(Xl), id(Y), id(XPu), id(Xu), XPl.data_ptr(), XPu.data_ptr(), XPl.shape[0], XPu.shape[0])
+            if key == self._checked and lab_idx.dtype == torch.int64 and unl_idx.dtype == torch.int64 \
+                    and lab_idx.is_cuda and unl_idx.is_cuda and lab_idx.dim() == 1 and unl_idx.dim() == 1:
+                bt, btu = lab_idx.shape[0], unl_idx.shape[0]
+                if 1 <= bt <= self.bt_max and btu >= 1 and bt + btu <= self.n_max:
+                    return bt, btu
         if (lab_idx is None) != (unl_idx is None):
             raise ValueError("lab_idx and unl_idx come together")
         for name, t in (("lab_idx", lab_idx), ("unl_idx", unl_idx)):
@@ -164,13 +182,18 @@ class TrainEngine:
         _chk_f32(XPu, (nu, s.C, s.H, s.W), "XPu"); _chk_f32(Xu, (nu, s.bands), "Xu")
         if Y.dtype != torch.int64 or tuple(Y.shape) != (nl,) or not Y.is_cuda:
             raise ValueError("Y: need int64 cuda tensor, one label per labelled row")
+        if lab_idx is not None:
+            self._checked = (id(XPl), id(Xl), id(Y), id(XPu), id(Xu), XPl.data_ptr(), XPu.data_ptr(), XPl.shape[0], XPu.shape[0])
         return bt, btu
 
     def _fill_io(self, io, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu):
         io.d_xpl, io.d_xl, io.d_labels = XPl.data_ptr(), Xl.data_ptr(), Y.data_ptr()
         io.d_xpu, io.d_xu = XPu.data_ptr(), Xu.data_ptr()
-        if lab_idx is not None:
-            io.d_lab_idx, io.d_unl_idx = lab_idx.data_ptr(), unl_idx.data_ptr()
+        io.d_lab_idx = None if lab_idx is None else lab_idx.data_ptr()
+        io.d_unl_idx = None if unl_idx is None else unl_idx.data_ptr()
+        io.bt, io.btu = bt, btu
+
+    def _fill_state(self, io):
         io.d_params, io.d_m, io.d_v = self.params.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
         io.d_grads, io.d_packed = self.grads.data_ptr(), self.packed.data_ptr()
         for i in range(2):
@@ -180,7 +203,6 @@ class TrainEngine:
         # outputs are laid out [2][n][..] for THIS n (views of the max-size buffers)
         io.d_logits, io.d_feat = self.logits.data_ptr(), self.feat.data_ptr()
         io.d_workspace, io.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
-        io.bt, io.btu = bt, btu
         io.seed = self.seed
 
     def _advance(self, n, apply_update=True):
@@ -211,8 +233,9 @@ class TrainEngine:
         n = bt + btu
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._ensure_packed(stream)
-        io = _lib.StepIO()
+        io = self._io
         self._fill_io(io, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu)
+        io.noise8, io.d_dropmask = None, None
         keep = None
         if noise is not None:
             xpl, xl, xpu, xu = (bt, s.C, s.H, s.W), (bt, s.bands), (btu, s.C, s.H, s.W), (btu, s.bands)
@@ -226,8 +249,8 @@ class TrainEngine:
             io.d_dropmask = dropmask.data_ptr()
         for i in range(2):
             io.banks.ptr[i] = self.ptr[i]
-        self.scalars = self.scalar_hist[self.step_count % self.hist_rows]
-        io.d_scalars = self.scalars.data_ptr()
+        self._cur_row = self.step_count % self.hist_rows
+        io.d_scalars = self.scalar_hist.data_ptr() + 64 * self._cur_row
         io.smooth = 1 if self.hp.smooth_gate(epoch, batch_index) else 0
         io.adap_mask = float(self.hp.thr * self.hp.adap_thr(epoch))        # train.py:221
         io.adam_t = self.adam_t + 1
@@ -310,6 +333,7 @@ class StepGraph:
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         eng._ensure_packed(stream)
         io = _lib.StepIO()
+        eng._fill_state(io)
         eng._fill_io(io, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, self.bt, self.btu)
         io.d_scalars = eng.scalar_hist.data_ptr()          # ring base: the row comes from the table
         io.apply_update = 1
@@ -336,23 +360,34 @@ class StepGraph:
             raise RuntimeError(f"{self.pending} programmed steps have not been launched")
         if not 1 <= len(steps) <= self.capacity:
             raise ValueError(f"1..{self.capacity} steps per program")
-        ptr, adam_t, count = list(eng.ptr), eng.adam_t, eng.step_count
-        a, b = C.c_float(), C.c_float()
-        for j, (epoch, batch_index, lab_off, unl_off) in enumerate(steps):
-            if lab_off < 0 or unl_off < 0 or lab_off + self.bt > self.n_lab_idx or unl_off + self.btu > self.n_unl_idx:
-                raise ValueError("batch offsets outside the index buffers")
-            r = self.rows[j]
-            r["step"], r["adam_t"] = count + j, adam_t + 1 + j
-            r["lab_off"], r["unl_off"] = lab_off, unl_off
-            r["ptr"][0], r["ptr"][1] = ptr
-            r["smooth"] = 1 if hp.smooth_gate(epoch, batch_index) else 0
-            r["adap_mask"] = float(hp.thr * hp.adap_thr(epoch))
-            r["hist_row"] = (count + j) % eng.hist_rows
-            _lib.check("cmlpl_dyn_adam", eng.lib.cmlpl_dyn_adam(C.byref(eng._chp), adam_t + 1 + j, C.byref(a), C.byref(b)))
-            r["adam_step_size"], r["adam_bc2_sqrt"] = a.value, b.value
-            p0 = (ptr[0] + hp.bank_step) % eng.Q
-            ptr = [p0, (p0 + hp.bank_step) % eng.Q]
-        k = len(steps) * 64
+        if getattr(self, "_copied", None) is not None:
+            self._copied.synchronize()        # the previous program's staging rows have left the pinned buffer
+        import numpy as np
+        k = len(steps)
+        st = np.asarray(steps, dtype=np.int64).reshape(k, 4)
+        if (st[:, 2:] < 0).any() or (st[:, 2] + self.bt > self.n_lab_idx).any() or (st[:, 3] + self.btu > self.n_unl_idx).any():
+            raise ValueError("batch offsets outside the index buffers")
+        j = np.arange(k, dtype=np.int64)
+        rows = self.rows[:k]
+        rows["step"] = eng.step_count + j
+        rows["adam_t"] = eng.adam_t + 1 + j
+        rows["lab_off"], rows["unl_off"] = st[:, 2], st[:, 3]
+        # bank pointers BEFORE step j (train.py:234,237: ptr0 advances by the literal step, ptr1 follows ptr0)
+        p0 = (eng.ptr[0] + j * hp.bank_step) % eng.Q
+        rows["ptr"][:, 0] = p0
+        rows["ptr"][:, 1] = (p0 + hp.bank_step) % eng.Q
+        rows["ptr"][0, 1] = eng.ptr[1]
+        rows["smooth"] = [1 if hp.smooth_gate(int(e), int(bi)) else 0 for e, bi in st[:, :2]]
+        adap = {int(e): float(hp.thr * hp.adap_thr(int(e))) for e in np.unique(st[:, 0])}
+        rows["adap_mask"] = [adap[int(e)] for e in st[:, 0]]
+        rows["hist_row"] = (eng.step_count + j) % eng.hist_rows
+        a, b = C.c_float(), C.c_float()       # Adam's two scalars: formed by the library, exactly as the eager step does
+        ss, bc = np.empty(k, np.float32), np.empty(k, np.float32)
+        for i in range(k):
+            eng.lib.cmlpl_dyn_adam(C.byref(eng._chp), eng.adam_t + 1 + i, C.byref(a), C.byref(b))
+            ss[i], bc[i] = a.value, b.value
+        rows["adam_step_size"], rows["adam_bc2_sqrt"] = ss, bc
+        k = k * 64
         self.table[:k].copy_(self.host[:k], non_blocking=True)
         self.cursor.zero_()
         self.pending = len(steps)
@@ -367,11 +402,9 @@ class StepGraph:
             raise RuntimeError("no programmed step left: call program() first")
         stream = C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
         _lib.check("cmlpl_step_graph_launch", eng.lib.cmlpl_step_graph_launch(self.handle, stream))
-        eng.scalars = eng.scalar_hist[eng.step_count % eng.hist_rows]
+        eng._cur_row = eng.step_count % eng.hist_rows
         eng._advance(self.bt + self.btu, True)
         self.pending -= 1
-        if self.pending == 0:
-            self._copied.synchronize()        # cheap: that copy ran long ago
 
     def close(self) -> None:
         if self.handle:

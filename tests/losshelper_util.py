@@ -10,6 +10,7 @@ CASES_UNSUP = {
     "d": dict(B=37, K=4, percent=12.5, seed=304, ignored=3),
     "e": dict(B=4096, K=9, percent=20.0, seed=305, ignored=100),      # eight rows per thread of the one-workgroup kernel
     "f": dict(B=9000, K=9, percent=70.0, seed=306, ignored=11),       # beyond it: the rank-counting kernels
+    "g": dict(B=512, K=20, percent=35.0, seed=307, ignored=9),        # more classes than the register-row variant holds
 }
 GRAD_ROWS = 256   # fixtures of the big cases keep the gradient's first rows and its norm
 

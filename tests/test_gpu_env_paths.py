@@ -39,6 +39,11 @@ def test_multi_launch_unsupervised_loss_passes_losshelper_parity():
     _run({"CMLPL_UNSUP_ONEWG": "0"}, ["tests/test_losshelper.py", "-k", "unsupervised"])
 
 
+def test_one_workgroup_unsupervised_loss_up_to_8192_rows():
+    """the single-workgroup kernel also where the three-launch path (1024 < B <= 8192) is the default"""
+    _run({"CMLPL_UNSUP_3L": "0"}, ["tests/test_losshelper.py", "-k", "unsupervised"])
+
+
 def test_general_wgrad_fallback_passes_backward_parity():
     _run({"CMLPL_WGRAD3_R": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
 

@@ -135,6 +135,7 @@ def main(args, make_engine=None, device=None):
     use_graph = bool(args.graph) and world == 1 and by_index
     graph = None
     t_start = time.time()
+    t_warm, steps_warm = t_start, 0
     for epoch in range(args.num_epochs):                             # train.py:146
         batches = list(zip(lab_loader, unl_loader))                  # (offset, size) pairs; draws this epoch's permutations
         if use_graph and graph is not None:
@@ -180,11 +181,17 @@ def main(args, make_engine=None, device=None):
                                             np.mean(w[:, 0]), np.mean(w[:, 1]), np.mean(w[:, 2]), np.mean(w[:, 3]),
                                             np.mean(w[:, 4]) * 100))
         read_back()                   # rows of the epoch's tail (num_batches % print_per_batches steps)
+        if epoch == 0:                # (the read-back has drained the device) what follows runs on warm kernels
+            t_warm, steps_warm = time.time(), eng.step_count
     if device.type == "cuda":
         torch.cuda.synchronize()
     if rank == 0:
         steps = eng.step_count
-        print('training: %d steps in %.2f s' % (steps, time.time() - t_start))
+        t_end = time.time()
+        print('training: %d steps in %.3f s' % (steps, t_end - t_start))
+        if steps > steps_warm:        # the first epoch carries the one-time loading of the kernels
+            print('after the first epoch: %d steps in %.3f s = %.4f ms/step' %
+                  (steps - steps_warm, t_end - t_warm, (t_end - t_warm) / (steps - steps_warm) * 1e3))
         if args.save_loss_hist:
             np.save(args.save_loss_hist, loss_hist)
     if rank == 0 and not args.no_eval:

@@ -66,16 +66,18 @@ __global__ __launch_bounds__(256) void ntx_sim_kernel(NtxArgs a) {
     else if (ln < nlines && o < D) { v.x = p[o]; if (o + 1 < D) v.y = p[o + 1]; if (o + 2 < D) v.z = p[o + 2]; }
     return v;
   };
-  // three line sets in flight (a line is only 16 MFMAs per wave; with one line of look-ahead every line waited out most
-  // of a memory round trip: 13 us for 2B = 256).  Lines past the end load zeros and add nothing.
-  float4 a0[2], b0[4], a1[2], b1[4], a2[2], b2[4];
-  auto fill = [&](float4 (&va)[2], float4 (&vb)[4], int ln) {
+  // (one line of look-ahead; three line sets in flight -- pair_exp16's recipe -- made this kernel SLOWER, 13 -> 17 us at
+  //  2B = 256 and 43 -> 81 us at 2B = 1024: measured and reverted, round 4)
+  float4 va[2], vb[4], na[2], nb[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) va[j] = ld(pa[j], ln);
+  for (int j = 0; j < 2; ++j) va[j] = ld(pa[j], wave);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vb[j] = ld(pb[j], ln);
-  };
-  auto step = [&](const float4 (&va)[2], const float4 (&vb)[4]) {
+  for (int j = 0; j < 4; ++j) vb[j] = ld(pb[j], wave);
+  for (int ln = wave; ln < nlines; ln += 4) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) na[j] = ld(pa[j], ln + 4);           // next line in flight
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nb[j] = ld(pb[j], ln + 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       *(float4*)(wA + 8 * j * NPT) = va[j];
@@ -96,12 +98,10 @@ __global__ __launch_bounds__(256) void ntx_sim_kernel(NtxArgs a) {
     CMLPL_M2(x0.x, y0.x, z0.x) CMLPL_M2(x0.y, y0.y, z0.y) CMLPL_M2(x0.z, y0.z, z0.z) CMLPL_M2(x0.w, y0.w, z0.w)
     CMLPL_M2(x1.x, y1.x, z1.x) CMLPL_M2(x1.y, y1.y, z1.y) CMLPL_M2(x1.z, y1.z, z1.z) CMLPL_M2(x1.w, y1.w, z1.w)
 #undef CMLPL_M2
-  };
-  fill(a0, b0, wave); fill(a1, b1, wave + 4); fill(a2, b2, wave + 8);
-  for (int ln = wave; ln < nlines; ln += 12) {
-    step(a0, b0); fill(a0, b0, ln + 12);
-    step(a1, b1); fill(a1, b1, ln + 16);
-    step(a2, b2); fill(a2, b2, ln + 20);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) va[j] = na[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = nb[j];
   }
   // squared norms: the 8 lanes of a row group (c8) hold its chunks of this wave's lines
 #pragma unroll

@@ -7,6 +7,9 @@ python3 bench.py --steps 200 > $OUT/${TAG}_bench.json 2> /dev/null
 python3 scripts/bench_next_rows.py > $OUT/${TAG}_next_rows.txt 2>&1
 for w in 1 2 4 8; do python3 scripts/rank_cost.py $w 2>&1 | grep -av amdgpu.ids | tail -14; done > $OUT/${TAG}_rank_cost.txt
 python3 scripts/dist_overhead.py > $OUT/${TAG}_dist_overhead.txt 2>&1
+python3 scripts/graph_overhead.py 2>&1 | grep -av amdgpu.ids > $OUT/${TAG}_graph_overhead.txt
+bash scripts/train_e2e.sh B2 > $OUT/${TAG}_train_e2e.txt 2>&1
+bash scripts/kstats_next_rows.sh ${TAG} > $OUT/${TAG}_next_rows_kernels.txt 2>&1
 # (the timeline library is built BEFORE the run, where hipcc is known to work: bash scripts/build_abl.sh 9; conv_timeline.py
 #  prints the source hash the library carries, so a stale one shows)
 CMLPL_LIB=cmlpl_amd/libabl9.so python3 scripts/conv_timeline.py 2>&1 | grep -av amdgpu.ids > $OUT/${TAG}_timeline.txt

@@ -34,3 +34,20 @@ def test_train_py_synthetic_epoch(tmp_path):
         assert tuple(m.group(i) for i in range(5, 10)) == want, (m.group(0), want)
     assert "training: 6 steps" in r.stdout
     assert r.stdout.count("Result:") == 2 and "OA1=" in r.stdout and "AA=" in r.stdout   # both networks evaluated
+
+
+def test_train_py_graph_mode_logs_the_same_rows(tmp_path):
+    """`--graph`: full batches replayed from the captured step, the short last batch of every epoch (another shape) and
+    the very first step run eagerly -- loss_hist must equal the eager run's bit for bit (same kernels, same in-kernel
+    random streams, the per-step scalars read from the device table instead of launch arguments)."""
+    hists = []
+    for extra in ([], ["--graph"]):
+        path = str(tmp_path / f"hist{len(extra)}.npy")
+        r = subprocess.run([sys.executable, "train.py", "--synthetic", "B2", "--num_unlabel", "700", "--num_epochs", "3",
+                            "--print_per_batches", "4", "--no_eval", "--save_loss_hist", path] + extra,
+                           cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "training: 18 steps" in r.stdout          # 700 samples, 128 + 128: five full batches and one of 60 per epoch
+        hists.append(np.load(path))
+    assert hists[0].shape == (18, 5) and np.isfinite(hists[0]).all()
+    assert np.array_equal(hists[0], hists[1])

@@ -243,7 +243,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor = nullptr);
+             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor = nullptr, cmlpl_dyn* dyn_table = nullptr);
 }  // namespace
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
@@ -346,7 +346,7 @@ namespace {
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor) {
+             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor, cmlpl_dyn* dyn_table) {
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
   const bool fused_head = conv3_fused_head_ok(d.H, d.W, d.C, nets * n, d.K);
@@ -413,7 +413,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
   }
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
-  rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride; rt.dyn_cursor = dyn_cursor;
+  rt.count = 0; rt.total_blocks = 0; rt.grad_ns = grad_stride; rt.dyn_cursor = dyn_cursor; rt.dyn_table = dyn_table;
   Wgrad3Plan wp1, wp2;
   bool wpair = false;
   if (!plan_wgrad3_both(nets, n, d.H, d.W, d.H2, d.W2, true, &wp1, &wp2, &wpair)) return CMLPL_E_SHAPE;
@@ -529,7 +529,7 @@ int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
                         : xsrc_raw(batch, hp->noise_sigma, seed, step, shard, dyn);
   return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xs,
                   copy ? sw.xn : nullptr, sw.sn, d_dropmask, hp->dropout_p, train, d_dlogits, d_dfeat, d_grads,
-                  grad_stride, nw, (hipStream_t)stream, dyn_cursor);
+                  grad_stride, nw, (hipStream_t)stream, dyn_cursor, dyn_cursor ? (cmlpl_dyn*)dyn.table : nullptr);
 }
 }  // namespace
 extern "C" {

@@ -10,13 +10,16 @@ namespace cmlpl {
 // Per-step scalars in device memory (cmlpl_dyn, include/cmlpl.h): a step captured in a hipGraph reads what changes
 // from step to step -- random-stream counter, Adam step, bank pointers, gates, batch offsets, logging row -- from
 // table[*cursor (+ bias)] instead of from its launch arguments.  table == null: the by-value arguments are used.
-// The cursor is advanced once per step by the weight-gradient reduce launch (conv0.hip); launches behind it (Adam)
-// read the row with bias -1.
+// table[0] is the WORKING COPY of the current step's row: every launch in front of the weight-gradient reduce reads
+// it there (ONE dependent load; through the cursor it was two, and the replayed step ran 2-3 % longer than the eager
+// one).  The reduce launch (conv0.hip), which reads none of it, advances the cursor and copies the next row into
+// table[0]; Adam, behind it, still needs the finished step's row: table[*cursor - 1] (bias -1).
 struct DynRef { const cmlpl_dyn* table; const int* cursor; };
 // (by VALUE: a reference to a member of a kernel-argument struct makes hipcc copy the whole struct to scratch --
 //  pair_exp16_kernel went from 0 to 352 bytes of scratch per lane and from 15 to 30 us that way)
 __device__ __forceinline__ const cmlpl_dyn* dyn_row(DynRef d, int bias = 0) {
-  return d.table != nullptr ? d.table + (__builtin_amdgcn_readfirstlane(*d.cursor) + bias) : nullptr;
+  if (d.table == nullptr) return nullptr;
+  return bias == 0 ? d.table : d.table + (__builtin_amdgcn_readfirstlane(*d.cursor) + bias);
 }
 // values read through a row are the same for every lane: say so (they then live in scalar registers whatever kind of
 // load fetched them -- without this hipcc 7.2 dies in the backend on "illegal VGPR to SGPR copy" in conv3x3.hip)

@@ -230,7 +230,14 @@ __device__ __forceinline__ void partial_reduce_block(const ReduceTable& t, int b
   const int tid = threadIdx.x, el = tid & 63, sl = tid >> 6;
   // graph replay: this launch is where the device-side step cursor advances (no workgroup of this launch reads it;
   // the launches before it took their row at the old value, Adam behind it takes the row before the new one)
-  if (t.dyn_cursor != nullptr && bx == 0 && net == 0 && tid == 0) *t.dyn_cursor += 1;
+  if (t.dyn_cursor != nullptr && bx == 0 && net == 0 && tid == 0) {
+    const int c = *t.dyn_cursor + 1;
+    *t.dyn_cursor = c;
+    const uint4* src = (const uint4*)(t.dyn_table + c);          // the next step's row becomes the working copy
+    uint4* dst = (uint4*)t.dyn_table;
+    const uint4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+    dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+  }
   const int G = pr.G, PS = pr.PS;                      // PS is a multiple of 4 (64-float tail, 4096-float taps)
   const int e0 = ((bx - pr.blk0) * 64 + el) * 4;
   const bool ev = e0 < PS;

@@ -122,7 +122,8 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
 int plan_conv0_wgrad_G(int n, int C, int HW);
 // deterministic sum of per-workgroup weight-gradient partials, up to 3 tensors in one launch
 struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C, blk0, el; };
-struct ReduceTable { ReduceProb p[3]; int count, total_blocks; long long grad_ns; int* dyn_cursor /* advanced by 1, or null */; };
+struct ReduceTable { ReduceProb p[3]; int count, total_blocks; long long grad_ns;
+                     int* dyn_cursor; cmlpl_dyn* dyn_table; /* graph replay: cursor advanced by 1, next row -> table[0]; or null */ };
 void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode, int C, float* dW, float* db);
 hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st);
 struct GemmTN;

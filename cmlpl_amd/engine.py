@@ -325,10 +325,11 @@ class StepGraph:
         self._keep = (XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
         self.n_lab_idx, self.n_unl_idx = int(lab_idx.shape[0]), int(unl_idx.shape[0])
         dev = eng.device
-        self.table = torch.zeros(self.capacity * 64, dtype=torch.uint8, device=dev)
-        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.host = torch.zeros(self.capacity * 64, dtype=torch.uint8).pin_memory()
-        self.rows = self.host.numpy().view(np.dtype(_lib.DYN_DTYPE))
+        # row 0 = the working copy the kernels read, rows 1 .. k the programmed steps, one spare row behind them
+        self.table = torch.zeros((self.capacity + 2) * 64, dtype=torch.uint8, device=dev)
+        self.cursor = torch.ones(1, dtype=torch.int32, device=dev)
+        self.host = torch.zeros((self.capacity + 2) * 64, dtype=torch.uint8).pin_memory()
+        self.rows = self.host.numpy().view(np.dtype(_lib.DYN_DTYPE))[1:]
         self.pending = 0
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         eng._ensure_packed(stream)
@@ -387,9 +388,10 @@ class StepGraph:
             eng.lib.cmlpl_dyn_adam(C.byref(eng._chp), eng.adam_t + 1 + i, C.byref(a), C.byref(b))
             ss[i], bc[i] = a.value, b.value
         rows["adam_step_size"], rows["adam_bc2_sqrt"] = ss, bc
-        k = k * 64
+        self.host[:64].copy_(self.host[64:128])            # row 0: the working copy starts as the first step's row
+        k = (k + 1) * 64
         self.table[:k].copy_(self.host[:k], non_blocking=True)
-        self.cursor.zero_()
+        self.cursor.fill_(1)
         self.pending = len(steps)
         # (the pinned staging rows may be rewritten only after that copy has run)
         self._copied = torch.cuda.Event()

@@ -165,9 +165,14 @@ typedef struct cmlpl_batch {
 /* One step's scalars in DEVICE memory (ABI 3): what changes from step to step, for a step captured ONCE in a hipGraph
  * and replayed (SURVEY.md section 7 stage 6; the reference's loop passes them as Python scalars, train.py:146-150,
  * 212,221,234-237).  The caller fills a table of rows ahead of time (e.g. one epoch) and passes it with a device
- * cursor: a launch of cmlpl_train_step with d_dyn_table != NULL takes these values from d_dyn_table[*d_dyn_cursor]
- * instead of from cmlpl_step_io, and advances the cursor itself (in its weight-gradient reduce launch), so that
- * replaying the captured launch sequence walks the table with no host work per step. */
+ * cursor: a launch of cmlpl_train_step with d_dyn_table != NULL takes these values from the table instead of from
+ * cmlpl_step_io, and advances the cursor itself (in its weight-gradient reduce launch), so that replaying the captured
+ * launch sequence walks the table with no host work per step.
+ * Table layout: row 0 is the WORKING COPY of the current step's row (the kernels read it there: one dependent load
+ * instead of cursor -> row); the rows of steps 1, 2, .. follow at indices 1, 2, ..  To start (or restart) a run of
+ * steps the caller writes its rows at 1 .. k, copies row 1 into row 0 as well and sets *d_dyn_cursor = 1; every step
+ * then moves the cursor on and copies the next row into row 0 (so the table needs one row beyond the last step's:
+ * k + 2 rows for k steps; the extra row's contents do not matter). */
 typedef struct cmlpl_dyn {
   uint64_t step;            /* counter of the in-kernel random streams (cmlpl_step_io.step)            */
   int64_t adam_t;           /* 1-based Adam step                                                       */

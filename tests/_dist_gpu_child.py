@@ -37,7 +37,15 @@ for s in range(steps):
     nz = b["noise"]
     noise = [d(nz[0][ls]), d(nz[1][ls]), d(nz[2][ls]), d(nz[3][ls]), d(nz[4][us]), d(nz[5][us]), d(nz[6][us]), d(nz[7][us])]
     dm = torch.stack([torch.cat([m[ls], m[bt:][us]]) for m in b["dropmask"]]).to(dev).contiguous()
-    eng.step(d(b["XPl"][ls]), d(b["Xl"][ls]), d(b["Y"][ls]), d(b["XPu"][us]), d(b["Xu"][us]), 1, s, noise=noise, dropmask=dm)
+    if os.environ.get("CMLPL_TEST_BYIDX") == "1":
+        # the shard BY INDEX: every rank holds the whole (shuffled) splits and takes its rows through index lists
+        g = torch.Generator().manual_seed(40 + s)
+        pl, pu = torch.randperm(bt, generator=g), torch.randperm(btu, generator=g)
+        inv_l, inv_u = torch.argsort(pl), torch.argsort(pu)            # row r of the batch sits at inv[r] of the split
+        eng.step(d(b["XPl"][pl]), d(b["Xl"][pl]), d(b["Y"][pl]), d(b["XPu"][pu]), d(b["Xu"][pu]), 1, s, noise=noise,
+                 dropmask=dm, lab_idx=inv_l[ls].to(dev).contiguous(), unl_idx=inv_u[us].to(dev).contiguous())
+    else:
+        eng.step(d(b["XPl"][ls]), d(b["Xl"][ls]), d(b["Y"][ls]), d(b["XPu"][us]), d(b["Xu"][us]), 1, s, noise=noise, dropmask=dm)
     got = eng.read_scalars()                       # all-reduced over the ranks
     if rank == 0:
         ref.step(d(b["XPl"]), d(b["Xl"]), d(b["Y"]), d(b["XPu"]), d(b["Xu"]), 1, s, noise=[d(t) for t in nz],

@@ -20,6 +20,16 @@ def test_multiprocess_sharded_step_equals_single_process(world):
     assert f"OK world={world}" in out, out
 
 
+def test_multiprocess_shards_by_index_equal_single_process():
+    """the same job with every rank holding the whole (shuffled) splits and taking ITS rows through index lists
+    (DistTrainEngine.step(lab_idx=, unl_idx=): what train.py does under torch.distributed.run)"""
+    from cmlpl_amd.launch import spawn_ranks
+    rc, out = spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_child.py")],
+                          extra_env=dict(CMLPL_TEST_BYIDX="1"), timeout=600)
+    assert rc == 0, out
+    assert "OK world=2" in out, out
+
+
 def test_multiprocess_at_the_shard_size_of_configs2():
     """BASELINE configs[2] puts 64 + 64 rows on each of 8 ranks.  A GPU box of this pool admits at most six processes on
     its card at once (this test process is one of them), so the REAL wiring -- separate processes, rendezvous,

@@ -640,7 +640,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             nzv[kq][k] = z;
           }
       }
-      if (c0 == 0) STAMP(0, 4);
+      if (c0 == 0 && CMLPL_ABL != 25) STAMP(0, 4);
       // One chunk AHEAD: chunk kq + 1 is put into LDS (noise added) and published before the MFMAs of chunk kq are
       // issued, and its operand reads go out in front of them -- the split of chunk kq + 1 then runs while the matrix
       // pipe works on chunk kq (a chunk at a time, every wave walked read -> split -> MFMA -> barrier in series).
@@ -674,7 +674,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       put_chunk(0);
       if (SLAB_WIN < nch) fetch_d(SLAB_WIN, dv[0]);
       __syncthreads();                                    // chunk 0 complete in LDS
-      if (c0 == 0) STAMP(0, 12);
+      if (c0 == 0 && CMLPL_ABL != 25) STAMP(0, 12);
       read_chunk(0);
       a_split(make_float4(rn[0], rn[1], rn[2], rn[3]), make_float4(rn[4], rn[5], rn[6], rn[7]), A1, A2, A3);
 #pragma unroll
@@ -686,7 +686,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             __syncthreads();                              // chunk kq + 1 complete in LDS
             read_chunk(kq + 1);
           }
-          if (c0 == 0 && kq == 3) STAMP(0, 13);
+          if (c0 == 0 && kq == 3 && CMLPL_ABL != 25) STAMP(0, 13);
           z0 = mfma_b3(A1, A2, A3, bw[kq % 2][0], bw[kq % 2][1], bw[kq % 2][2], z0);
           z1 = mfma_b3(A1, A2, A3, bw[kq % 2][3], bw[kq % 2][4], bw[kq % 2][5], z1);
           if (kq + 2 < nch) fetch_b(kq + 2, bw[kq % 2]);
@@ -696,7 +696,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       }
     }
     __syncthreads();                                      // every wave is done with the slab
-    STAMP(0, 5);
+    if (CMLPL_ABL != 25) STAMP(0, 5);
     {  // now the region becomes the zero-bordered image (the interior is written just below) and the LUT
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       const int nbp = 2 * PW + 2 * H;                     // border pixels: top row, bottom row, left / right columns
@@ -714,7 +714,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         lut[m] = (r + 1) * PW + (cc + 1);
       }
     }
-    STAMP(0, 6);
+    if (CMLPL_ABL != 25) STAMP(0, 6);
     const float* b0 = a.b0 + (long long)net * a.b0_ns;
     const float bv0 = b0[l31], bv1 = b0[32 + l31];
     const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for m < 128, W <= 128 (checked on the host)
@@ -858,11 +858,17 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   //   (((tap*4 + 2 ks + (kg >> 1)) * 3 + p) * 2 + (wave >> 1)) * 64 + (kg & 1) * 32 + 16 (wave & 1) + j
   const uint4* wq = (const uint4*)(a.w2f + (long long)net * a.w2f_ns) + ((kg >> 1) * 6 + (wave >> 1)) * 64 + (kg & 1) * 32 +
                     16 * (wave & 1) + j;
-  uint4 bcur[6], bnxt[6];                    // [ks][piece]
+  // ring of C2_AHEAD + 1 fragment sets [ks][piece]: tap t's twelve MFMAs are ~0.1 us of matrix pipe, an L2 round trip is
+  // several times that -- with ONE tap of look-ahead every tap waited out most of a round trip (9 in a row: 5 of the
+  // 6 us this convolution took); the loop below is fully unrolled, so the ring indices are compile-time constants
+  constexpr int C2_AHEAD = 3;
+  uint4 bq[C2_AHEAD + 1][6];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  for (int t0 = 0; t0 < C2_AHEAD; ++t0)
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) bcur[3 * ks + pc] = wq[((0 * 4 + 2 * ks) * 3 + pc) * 128];
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bq[t0][3 * ks + pc] = wq[((t0 * 4 + 2 * ks) * 3 + pc) * 128];
   const float4 y4 = *(const float4*)(a.yin + rs * FD + 4 * tid);
   const float bias2 = (a.b2 + (long long)net * a.p_ns)[wave * 16 + j];
   // ... and what the head will want after conv2, so that its L2 round trips run under conv2's: the classifier rows of
@@ -899,7 +905,9 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
       }
     }
   }
+  if (CMLPL_ABL == 25) STAMP(0, 4);          // (tail-detail timeline build: the prologue's stamp slots are re-used)
   __syncthreads();                           // img2 interior complete; every thread is done pooling from img
+  if (CMLPL_ABL == 25) STAMP(0, 5);
   *(float4*)(row + SF + 4 * tid) = y4;       // spectral part of the head row (pre-dropout); row aliases the dead img
   // ---- the pooled map as three bf16 planes [pixel][64 ch] (pixel stride 36 dwords: the 16-byte reads of the 16 output
   // pixels land two-way on the banks at worst), behind the head row in the dead image region
@@ -925,32 +933,49 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
     *(uint2*)(d + 2 * PLN) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
   }
   __syncthreads();
+  if (CMLPL_ABL == 25) STAMP(0, 6);
   // ---- conv2: pixel i = lane & 15 = (oh, ow) = (i >> 2, i & 3); lane group kg holds ci 8 kg .. 8 kg + 7 of a k-step
   const uint32_t* ap0 = pl + (size_t)(((j >> 2) + 1) * PW2 + (j & 3) + 1) * PS2 + 4 * kg;
   f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   auto mm = [](const uint4& x, const uint4& y, f32x4v cc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), cc, 0, 0, 0);
   };
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    if (tap + 1 < 9) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) bnxt[3 * ks + pc] = wq[(((tap + 1) * 4 + 2 * ks) * 3 + pc) * 128];
-    }
+  // A fragments (three planes x two k-steps = six ds_read_b128) are read a whole tap AHEAD of their MFMAs: written as
+  // read -> multiply per k-step, every MFMA group sat behind an LDS round trip (54 waits, ~2 us of this 4.5-us loop)
+  uint4 af[2][6];
+  auto read_a = [&](int tap, uint4 (&x)[6]) {
     const uint32_t* ap = ap0 + ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * PS2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const uint4 a1 = *(const uint4*)(ap + 16 * ks), a2 = *(const uint4*)(ap + PLN + 16 * ks),
-                  a3 = *(const uint4*)(ap + 2 * PLN + 16 * ks);
+      x[3 * ks] = *(const uint4*)(ap + 16 * ks); x[3 * ks + 1] = *(const uint4*)(ap + PLN + 16 * ks);
+      x[3 * ks + 2] = *(const uint4*)(ap + 2 * PLN + 16 * ks);
+    }
+  };
+  read_a(0, af[0]);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    if (tap + C2_AHEAD < 9) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          bq[(tap + C2_AHEAD) % (C2_AHEAD + 1)][3 * ks + pc] = wq[(((tap + C2_AHEAD) * 4 + 2 * ks) * 3 + pc) * 128];
+    }
+    if (tap + 1 < 9) read_a(tap + 1, af[(tap + 1) & 1]);
+    const uint4 (&bcur)[6] = bq[tap % (C2_AHEAD + 1)];
+    const uint4 (&acur)[6] = af[tap & 1];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 a1 = acur[3 * ks], a2 = acur[3 * ks + 1], a3 = acur[3 * ks + 2];
       const uint4 b1 = bcur[3 * ks], b2 = bcur[3 * ks + 1], b3 = bcur[3 * ks + 2];
       // the six products of weight >= 2^-16, two accumulator chains (a dependent MFMA waits for its predecessor)
       acc0 = mm(a1, b3, acc0); acc1 = mm(a2, b2, acc1); acc0 = mm(a3, b1, acc0);
       acc1 = mm(a1, b2, acc1); acc0 = mm(a2, b1, acc0); acc1 = mm(a1, b1, acc1);
     }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) bcur[q] = bnxt[q];
+    // pin the order: this tap's loads and reads first, then its twelve MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);    // VMEM reads (none in the last taps: the group is then empty)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   // MFMA
   }
   STAMP(0, 8);
   // ---- conv2 epilogue: lane (co = 16 wave + j, output row oh = kg) holds the 4 pixels ow = 0..3 of that row
@@ -978,11 +1003,13 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
       row[co * 4 + ph * 2 + 1] = o1;
     }
   }
+  if (CMLPL_ABL == 25) STAMP(0, 12);
   // ---- head
   float ss = (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
   ss = wave_sum(ss);
   if (lane == 0) red[wave] = ss;
   __syncthreads();                           // row[0..256) complete, red[] written
+  if (CMLPL_ABL == 25) STAMP(0, 13);
   const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
   if (tid == 0) a.ynorm[rs] = norm;
   {
@@ -1073,11 +1100,15 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   const int nt = wave & 1, kh2 = wave >> 1;
   // ---- loads up front: tap-0 B fragments of the conv2 data gradient, this thread's spectral elements
   const uint4* wq = (const uint4*)(a.w2d + (long long)net * a.w2d_ns) + lane;
-  uint4 bcur[6], bnxt[6];
+  // (a ring of C2_AHEAD + 1 fragment sets, as in conv3_fwd_tail: a tap is 12 MFMAs, far less than an L2 round trip)
+  constexpr int C2_AHEAD = 3;
+  uint4 bq[C2_AHEAD + 1][6];
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int t0 = 0; t0 < C2_AHEAD; ++t0)
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) bcur[3 * q + pc] = wq[(((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bq[t0][3 * q + pc] = wq[(size_t)t0 * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
   if (tid < 64) dls[tid] = (tid < K) ? a.dlogits[rs * K + tid] : 0.f;
   const float* y = a.yin + rs * FD;
   const float* df = (a.dfeat != nullptr) ? a.dfeat + rs * FD : nullptr;
@@ -1195,27 +1226,47 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   const int posA = l31 < P2 ? ((l31 / W2) + 1) * PW2 + (l31 % W2) + 1 : 0;
   const float* ap = img2 + (size_t)posA * CS + kh2 * 32 + hh * 8;
   f32x16 acc = zero16();
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    if (tap + 1 < 9) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          bnxt[3 * q + pc] = wq[(size_t)(tap + 1) * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
-    }
+  // Units u = (tap, k-step q) of 16 input channels, software-pipelined as in ks_unit: unit u's two ds_read_b128 are
+  // issued two units ahead, its split runs between the six MFMAs of unit u - 1 (pinned: left alone, the scheduler
+  // sinks each read to just in front of its split and every k-step waits out an LDS round trip).
+  auto raw_ptr = [&](int u) {
+    const int tap = u >> 1;
     const int toff = ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * CS;
     // the dummy rows (p >= P2) sit at the zero corner: a negative tap offset would leave the image, keep them there
-    const float* q = (l31 < P2) ? ap + toff : ap;
-    const float4 r0 = *(const float4*)(q), r1 = *(const float4*)(q + 4);
-    const float4 r2 = *(const float4*)(q + 16), r3 = *(const float4*)(q + 20);
-    uint4 A1, A2, A3;
-    a_split(r0, r1, A1, A2, A3);
-    acc = mfma_b3(A1, A2, A3, bcur[0], bcur[1], bcur[2], acc);
-    a_split(r2, r3, A1, A2, A3);
-    acc = mfma_b3(A1, A2, A3, bcur[3], bcur[4], bcur[5], acc);
+    return ((l31 < P2) ? ap + toff : ap) + 16 * (u & 1);
+  };
+  ASplit cur;
+  float4 rn0, rn1;
+  {
+    const float* p0 = raw_ptr(0);
+    a_split(*(const float4*)p0, *(const float4*)(p0 + 4), cur.p1, cur.p2, cur.p3);
+    const float* p1 = raw_ptr(1);
+    rn0 = *(const float4*)p1; rn1 = *(const float4*)(p1 + 4);
+  }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bcur[i] = bnxt[i];
+  for (int u = 0; u < 18; ++u) {
+    const int tap = u >> 1, q = u & 1;
+    if (q == 0 && tap + C2_AHEAD < 9) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          bq[(tap + C2_AHEAD) % (C2_AHEAD + 1)][3 * q2 + pc] =
+              wq[(size_t)(tap + C2_AHEAD) * TAPW + (((kh2 * 2 + q2) * 3 + pc) * 2 + nt) * 64];
+    }
+    if (q == 0) __builtin_amdgcn_sched_barrier(0);        // the loads stay in front of the pinned groups of this tap's units
+    float4 rnn0 = rn0, rnn1 = rn1;
+    if (u + 2 < 18) {
+      const float* p2 = raw_ptr(u + 2);
+      rnn0 = *(const float4*)p2; rnn1 = *(const float4*)(p2 + 4);
+    }
+    const uint4 (&bcur)[6] = bq[tap % (C2_AHEAD + 1)];
+    acc = mfma_b3(cur.p1, cur.p2, cur.p3, bcur[3 * q], bcur[3 * q + 1], bcur[3 * q + 2], acc);
+    ASplit nxt = cur;
+    if (u + 1 < 18) a_split(rn0, rn1, nxt.p1, nxt.p2, nxt.p3);
+    if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    SchedInterleave<6>::run();                             // (6 VALU, 1 MFMA) x 6; the rest of the split behind them
+    cur = nxt; rn0 = rnn0; rn1 = rnn1;
   }
   // ---- fold the two channel halves through LDS (the dz2 image region, once every wave is done reading it) and
   // finish: lane (ci = 32 nt + l31) holds pixels p = acc_row(r); the residual branch adds dz2 itself

@@ -35,7 +35,13 @@ for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1 wor
     full = buf[mode, :nwg, :].astype(np.int64)
     full = full[t[:, 0] > 0]
     t = t[t[:, 0] > 0]
-    if mode == 0 and full[:, 4].max() > 0:
+    if mode == 0 and os.environ.get("CMLPL_LIB", "").endswith("libabl25.so"):
+        f = (full - full[:, :1]) / 100.0
+        print(f"fwd tail detail (CMLPL_ABL=25; us from workgroup start): pooled {f[:,7].mean():.2f}  up-front loads issued + dropout "
+              f"formed {f[:,4].mean():.2f}  barrier passed {f[:,5].mean():.2f}  planes split + barrier {f[:,6].mean():.2f}  conv2 MFMAs done "
+              f"{f[:,8].mean():.2f}  conv2 epilogue done {f[:,12].mean():.2f}  head barrier passed {f[:,13].mean():.2f}  dropout row "
+              f"done {f[:,9].mean():.2f}  end {f[:,3].mean():.2f}")
+    elif mode == 0 and full[:, 4].max() > 0:
         f = (full - full[:, :1]) / 100.0
         print(f"fwd fused prologue (us from workgroup start): loads issued + noise formed {f[:,4].mean():.2f}  chunk 0 in LDS "
               f"{f[:,12].mean():.2f}  chunk 3 in LDS {f[:,13].mean():.2f}  conv0 MFMAs done {f[:,5].mean():.2f}  "

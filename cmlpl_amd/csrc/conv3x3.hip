@@ -102,7 +102,7 @@ hipError_t launch_pack_weights(int nets, const float* params, long long pstride,
 // ------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------
-#if CMLPL_ABL == 9 || CMLPL_ABL >= 20
+#if CMLPL_ABL == 9 || (CMLPL_ABL >= 20 && CMLPL_ABL != 26)
 // phase timeline instrumentation (ablation build only): constant-rate 100 MHz stamps per workgroup
 __device__ unsigned long long g_stamps[3][2048][16];
 #define STAMP(MODE_, i) do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) \
@@ -1307,6 +1307,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
 template <int MODE, int MTW, int TAIL = 0>
 __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (CMLPL_ABL == 26) return;             // ablation: the launch itself (grid, LDS allocation, end of kernel) and nothing else
   Conv3Ctx c;
   STAMP(MODE & 1, 0);
   const float* dp_lds = nullptr;

@@ -15,7 +15,7 @@
 
 namespace cmlpl {
 
-#if CMLPL_ABL == 9 || CMLPL_ABL >= 20
+#if CMLPL_ABL == 9 || (CMLPL_ABL >= 20 && CMLPL_ABL != 26)
 // phase timeline instrumentation (ablation build only): constant-rate 100 MHz stamps per workgroup; mode 2 of
 // scripts/conv_timeline.py (device globals are per translation unit: conv3x3.hip has its own for modes 0 / 1)
 __device__ unsigned long long g_wstamps[2048][16];

@@ -237,6 +237,17 @@ __device__ __forceinline__ f32x16 mfma_b3(const uint4& A1, const uint4& A2, cons
 }
 
 
+// scheduling pattern of the software-pipelined MFMA loops: N x (six vector instructions, one MFMA), pinned with
+// sched_group_barrier (left alone, the compiler puts a step's split instructions in front of its MFMAs)
+template <int N> struct SchedInterleave {
+  static __device__ __forceinline__ void run() {
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    SchedInterleave<N - 1>::run();
+  }
+};
+template <> struct SchedInterleave<0> { static __device__ __forceinline__ void run() {} };
+
 // Batches by index (cmlpl_batch.d_lab_idx / d_unl_idx): labelled (unlabelled) batch row r is row idx[off + r] of the
 // resident split; idx == null: row r.  The offsets come from the device-side row when one is given (graph replay).
 struct RowSel {

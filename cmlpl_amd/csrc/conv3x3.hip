@@ -244,14 +244,6 @@ __device__ __forceinline__ int tap_step_off(int step, int PW) {
 }
 
 // one k-step (KQ = its position inside the tap) for NTA tiles
-template <int N> struct SchedInterleave {
-  static __device__ __forceinline__ void run() {
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    SchedInterleave<N - 1>::run();
-  }
-};
-template <> struct SchedInterleave<0> { static __device__ __forceinline__ void run() {} };
 
 template <int NTA, int KQ, int MTW>
 __device__ __forceinline__ void tap_step(const float* __restrict__ img, const uint4* __restrict__ bl,

@@ -164,6 +164,21 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
                            float* dy, float* dp2, hipStream_t st);
 
 // ---- loss.hip   (row-sharded: see the header of loss.hip)
+// compute units of the current device (cached per device: the pair launch shares them between its two maps; a
+// host without a device -- the library loaded for its symbols only -- plans for a full MI355X)
+inline int device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 struct LossArgs {
   const float* logits; const float* feat; const int64_t* labels;   // GLOBAL [2][n][K], [2][n][1024], [bt]  (plain mode)
   // packed mode (recv != null): the global rows are read where the all-gather left them, rank-major blocks
@@ -184,6 +199,8 @@ struct LossArgs {
   float* dfw_part;                        // [btu][1024] partial of dfeat_w over this shard's rows
   // workspace
   float* rs_part; float* ep_part; float* Smat; float* G; float* GT; float* masks; float* rowloss;
+  int ctw;                                // bank columns per partial of rs_part / ep_part (set by launch_loss_phase1: 32, or the
+                                          // wide kernel's columns per wave)
 };
 size_t loss_ws_floats(int nlab, int nunl, int btu_g, int K, int Q);
 void loss_ws_carve(LossArgs& a, float* ws);

@@ -381,8 +381,8 @@ __global__ __launch_bounds__(256) void pair_exp16_kernel(LossArgs a) {
   }
 }
 
-// Tall-tile variant for wide products (data parallelism: the banks hold 10 x the GLOBAL labelled batch, so a rank's
-// 128 local rows meet W x more columns).  One workgroup = up to 128 local rows x 32 columns; wave w owns rows
+// Tall-tile variant for wide products with MORE than 128 local rows (configs[2] whole on one or two GPUs; up to 128
+// rows pair_exp_wide_kernel below is faster).  One workgroup = up to 128 local rows x 32 columns; wave w owns rows
 // 32w..32w+31 over the WHOLE contraction, so there is no cross-wave reduction and the column tile is read once
 // instead of once per 32 rows.  K is walked in 32-float lines staged in LDS (whole 128-B lines per row, row stride
 // PT floats), double-buffered, one barrier per line, the next line's loads in flight in registers.  The products run
@@ -524,6 +524,280 @@ __global__ __launch_bounds__(256) void pair_exp_tall_kernel(LossArgs a) {
   }
 }
 
+// Wide products (data parallelism: the banks hold 10 x the GLOBAL labelled batch, so a rank's local rows meet W x more
+// columns -- 84 MB of bank rows at W = 8).  The tall tile above (128 x 32, four waves, one 32 x 32 MFMA tile each) re-reads
+// the local rows once per 32 bank rows and splits the same 32 bank columns in each of its waves.
+// Ablations of this kernel at W = 8 (57 us as is: 53 without its global loads, 36 without its MFMAs) say what bounds
+// both: not HBM but the operand traffic through LDS -- every six MFMAs want three 16-byte fragment reads per lane, and
+// neither more waves per SIMD, more workgroups per CU nor deeper prefetch changed the time.  Here:
+//   * one workgroup = all local rows (MT = 128, or 64) x NT = 32..128 bank columns, NT chosen on the host so that the
+//     launch is ONE round of about one workgroup per CU;
+//   * EIGHT waves: MB row blocks x CG column groups x the two halves of every 32-float line (k-half kh: a wave
+//     multiplies 16 of a line's 32 k into its 32 rows x 32 NBW columns), so that each SIMD holds two waves whose LDS /
+//     vector phases run under each other's MFMAs; the two k-halves are folded through LDS once, after the last line;
+//   * the contraction is walked in 32-float lines (whole 128-B lines per row and load instruction), three lines in
+//     flight in registers, double-buffered LDS stages, one barrier per line;
+//   * a bank line is split into its three bf16 planes ONCE, by the thread that loaded it, on its way into LDS
+//     ([plane][column][32 k], row stride 20 dwords: conflict-free ds_read_b128 fragments); a wave splits only its own
+//     rows and k-half of the local features (read as fp32 from LDS);
+//   * partial row sums / E . bank_probs are written per wave tile (32 NBW columns: LossArgs.ctw), not per 32 columns, so
+//     the row kernel folds NBW times fewer partials.
+// Same six bf16 products per fp32 product as the convolutions (common.hpp).
+// staging helpers: this thread's pieces of a line, registers -> LDS stage
+// (A: rebuilt member by member -- storing wa[q] itself is a 16-byte struct copy out of the array, and with it the compiler
+//  kept the A sets in scratch, 144 bytes per lane)
+template <int NA, int RP>
+__device__ __forceinline__ void wide_stage_a(float* st, const float4 (&wa)[NA], int lr, int c8) {
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const float4 t = wa[q];
+    *(float4*)(st + (lr + RP * q) * PT + c8 * 4) = make_float4(t.x, t.y, t.z, t.w);
+  }
+}
+// four consecutive k of bank column `col` -> the three bf16 planes ([NTP columns][BPS dwords] each)
+template <int NTP, int BPS>
+__device__ __forceinline__ void wide_stage_b(uint32_t* bpl, const float4& v, int col, int c8) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t u0[4], u1[4], u2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u0[j] = __float_as_uint(x[j]);
+    const float r1 = x[j] - __uint_as_float(u0[j] & 0xffff0000u);
+    u1[j] = __float_as_uint(r1);
+    u2[j] = __float_as_uint(r1 - __uint_as_float(u1[j] & 0xffff0000u));
+  }
+  uint32_t* d = bpl + col * BPS + c8 * 2;
+  *(uint2*)(d) = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
+  *(uint2*)(d + NTP * BPS) = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
+  *(uint2*)(d + 2 * NTP * BPS) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
+}
+
+template <int MB, int CG, int NBW>
+struct WideCfg {
+  static constexpr int NW = 2 * MB * CG, NTHR = 64 * NW;        // waves (two k-halves), threads
+  static constexpr int MT = 32 * MB, NT = 32 * CG * NBW;        // local rows, bank columns per workgroup
+  static constexpr int RP = NTHR / 8;                           // rows per loader pass (8 threads x 16 B per line)
+  static constexpr int NA = (MT + RP - 1) / RP, NBL = (NT + RP - 1) / RP;   // 16-byte pieces per thread and line
+  static constexpr int MTP = NA * RP, NTP = NBL * RP;           // rows held in LDS (>= MT, NT: the loader's passes are whole)
+  static constexpr int BPS = 20;                                // dwords per column of a B plane: 16 (32 bf16) + 4 pad
+  static constexpr int A_FL = MTP * PT, B_DW = 3 * NTP * BPS, STAGE = A_FL + B_DW;
+  static constexpr size_t FOLD = (size_t)MB * CG * NBW * 16 * 64;          // floats: the k-half exchange
+  static constexpr size_t EPI = (size_t)MB * CG * 2 * 32 * 33;             // floats: per-wave E / p tiles
+  static constexpr size_t LDS_FL = 2 * STAGE > FOLD + EPI ? 2 * STAGE : FOLD + EPI;
+};
+
+template <int MB, int CG, int NBW>
+__global__ __launch_bounds__(128 * MB * CG) void pair_exp_wide_kernel(LossArgs a) {
+  typedef WideCfg<MB, CG, NBW> Cf;
+  constexpr int MT = Cf::MT, NT = Cf::NT, RP = Cf::RP, NA = Cf::NA, NBL = Cf::NBL, NTP = Cf::NTP, BPS = Cf::BPS;
+  constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, NTHR = Cf::NTHR;
+  constexpr int NL = FD / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][STAGE]; then the k-half exchange and the E / p tiles
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave / (MB * CG), w2 = wave - kh * (MB * CG);   // k-half; (row block, column group)
+  const int rb = w2 / CG, cg = w2 - rb * CG;
+  const int prob = blockIdx.z;
+  if (prob < 2 && !loss_smooth(a)) return;
+  const int btu = a.btu, nunl = a.nunl, K = a.K;
+  const float* A = feat_unl(a, prob == 0 ? 1 : 0, a.unl0);
+  const float* B = (prob == 0) ? a.bank_f[0] : (prob == 1) ? a.bank_f[1] : nullptr;
+  const int NB = (prob < 2) ? a.Q : btu;
+  const int r0 = blockIdx.y * MT, c0 = blockIdx.x * NT;
+  if (c0 >= NB || r0 >= nunl) return;
+  // loader: piece q of this thread = row (tid >> 3) + RP q of the A (B) tile, 16-byte chunk c8 = tid & 7 of the line
+  // (rows past the tile or the matrix are clamped: they land in LDS rows nobody multiplies)
+  const int lr = tid >> 3, c8 = tid & 7;
+  const float* pa[NA];
+  const float* pb[NBL];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int r = r0 + lr + RP * q;
+    pa[q] = A + (long long)((r < nunl && lr + RP * q < MT) ? r : 0) * FD + c8 * 4;
+  }
+#pragma unroll
+  for (int q = 0; q < NBL; ++q) {
+    const int c = c0 + lr + RP * q, cc = (c < NB && lr + RP * q < NT) ? c : c0;
+    pb[q] = (B != nullptr ? B + (long long)cc * FD : feat_unl(a, 1, cc)) + c8 * 4;
+  }
+  // three register sets: the set of line x is x % 3, requested three lines before it is staged
+  // (named arrays, not one indexed by the line: that one ends up in scratch even when fully unrolled)
+  float4 va0[NA], vb0[NBL], va1[NA], vb1[NBL], va2[NA], vb2[NBL];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) { va0[q] = *(const float4*)(pa[q]); va1[q] = *(const float4*)(pa[q] + 32); va2[q] = *(const float4*)(pa[q] + 64); }
+#pragma unroll
+  for (int q = 0; q < NBL; ++q) { vb0[q] = *(const float4*)(pb[q]); vb1[q] = *(const float4*)(pb[q] + 32); vb2[q] = *(const float4*)(pb[q] + 64); }
+  f32x16 acc[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) acc[nb] = zero16();
+  // line 0 goes into stage 0 before the loop (both tiles); line 3 is requested into set 0
+  {
+    wide_stage_a<NA, RP>(lds, va0, lr, c8);
+#pragma unroll
+    for (int q = 0; q < NBL; ++q) wide_stage_b<NTP, BPS>((uint32_t*)(lds + A_FL), vb0[q], lr + RP * q, c8);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) va0[q] = *(const float4*)(pa[q] + 96);
+#pragma unroll
+    for (int q = 0; q < NBL; ++q) vb0[q] = *(const float4*)(pb[q] + 96);
+  }
+  // One line of the contraction = ONE barrier (line LN is staged; the other stage, read during line LN - 1, is free), then
+  // this wave's NBW units (column block nb, its k-half) of six MFMAs each.  Everything else rides in the units' shadow, in
+  // program order pinned by scheduling fences (left alone, the compiler stages first, multiplies afterwards and issues
+  // the prefetch last): the fragment reads of unit u + 1 in front of unit u's MFMAs; line LN + 1's pieces split and
+  // stored into the other stage, one bank piece per unit; the request for line LN + 4 as soon as the set's last piece
+  // has been staged.  (Row blocks past the local rows multiply clamped rows like everyone else.)
+  constexpr int ULAST = (NBL - 1 < NBW - 1) ? NBL - 1 : NBW - 1;   // unit that stages the set's last bank piece
+#define CMLPL_WLINE(LN, WA, WB) {\
+    __syncthreads();\
+    const float* st = lds + ((LN) & 1) * STAGE;\
+    float* sn = lds + (((LN) + 1) & 1) * STAGE;\
+    uint32_t* bpn = (uint32_t*)(sn + A_FL);\
+    const float* rA = st + (rb * 32 + l31) * PT + 16 * kh + hh * 8;\
+    const uint32_t* rB = (const uint32_t*)(st + A_FL) + (cg * NBW * 32 + l31) * BPS + 8 * kh + hh * 4;\
+    const float4 x0 = *(const float4*)(rA), x1 = *(const float4*)(rA + 4);\
+    uint4 P1 = *(const uint4*)rB, P2 = *(const uint4*)(rB + NTP * BPS), P3 = *(const uint4*)(rB + 2 * NTP * BPS);\
+    wide_stage_a<NA, RP>(sn, WA, lr, c8);\
+    uint4 A1, A2, A3;\
+    a_split(x0, x1, A1, A2, A3);\
+    __builtin_amdgcn_sched_barrier(0);\
+_Pragma("unroll")\
+    for (int u = 0; u < NBW; ++u) {\
+      uint4 N1 = P1, N2 = P2, N3 = P3;\
+      if (u + 1 < NBW) {\
+        const uint32_t* pp = rB + (u + 1) * 32 * BPS;\
+        N1 = *(const uint4*)pp; N2 = *(const uint4*)(pp + NTP * BPS); N3 = *(const uint4*)(pp + 2 * NTP * BPS);\
+      }\
+      acc[u] = mfma_b3(A1, A2, A3, P1, P2, P3, acc[u]);\
+_Pragma("unroll")\
+      for (int q = 0; q < NBL; ++q)\
+        if (q == u || (u == NBW - 1 && q > u)) wide_stage_b<NTP, BPS>(bpn, WB[q], lr + RP * q, c8);\
+      if (u == ULAST && (LN) + 4 < NL) {\
+        const int o = ((LN) + 4) * 32;\
+_Pragma("unroll")\
+        for (int q = 0; q < NA; ++q) WA[q] = *(const float4*)(pa[q] + o);\
+_Pragma("unroll")\
+        for (int q = 0; q < NBL; ++q) WB[q] = *(const float4*)(pb[q] + o);\
+      }\
+      P1 = N1; P2 = N2; P3 = N3;\
+      if (u + 1 < NBW) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);\
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);\
+      SchedInterleave<5>::run();\
+      __builtin_amdgcn_sched_barrier(0);\
+    }\
+  }
+  // Written out 32 times (not a loop under #pragma unroll: beyond ~16 K instructions the compiler unrolls only partly,
+  // and across a loop back-edge it loses count of the outstanding loads and waits vmcnt(0) in front of the staging,
+  // i.e. for the prefetch it has just issued).  Line L stages line L + 1 from set (L + 1) % 3 and requests line L + 4.
+  static_assert(NL == 32, "the line sequence below is written out for FD = 1024");
+#define CMLPL_W3(L) CMLPL_WLINE(L, va1, vb1) CMLPL_WLINE((L) + 1, va2, vb2) CMLPL_WLINE((L) + 2, va0, vb0)
+  CMLPL_W3(0) CMLPL_W3(3) CMLPL_W3(6) CMLPL_W3(9) CMLPL_W3(12) CMLPL_W3(15) CMLPL_W3(18) CMLPL_W3(21) CMLPL_W3(24) CMLPL_W3(27)
+  CMLPL_WLINE(30, va1, vb1) CMLPL_WLINE(31, va2, vb2)
+#undef CMLPL_W3
+#undef CMLPL_WLINE
+  // ---- fold the two k-halves: waves kh = 1 hand their accumulators to their partner through LDS
+  const int rw = r0 + rb * 32;
+  const int cw = c0 + cg * NBW * 32;                      // first column of this wave
+  // the bank-probability tiles of the epilogue ([NBW][32 columns][K] of this wave), requested before the exchange
+  constexpr int PQN = 16;                                 // K <= 32: 32 K / 64 values per lane and column block
+  float pq[NBW][PQN];
+  if (kh == 0 && prob < 2) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int i = 0; i < PQN; ++i) {
+        const int idx = lane + 64 * i, c = idx / K, col = cw + nb * 32 + c;
+        float v = 0.f;
+        if (idx < 32 * K && col < NB) v = a.bank_p[prob][(long long)col * K + (idx - c * K)];
+        pq[nb][i] = v;
+      }
+  }
+  __syncthreads();                                        // every wave has finished its last line: the stages are free
+  float* xch = lds + (size_t)w2 * NBW * 16 * 64;
+  if (kh == 1) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[(nb * 16 + r) * 64 + lane] = acc[nb][r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] += xch[(nb * 16 + r) * 64 + lane];
+  // ---- epilogue: this wave's 32 rows x NBW x 32 columns (lane = column, register r = row acc_row(r))
+  if (rw >= nunl || cw >= NB) return;
+  if (prob == 2) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int jb = cw + nb * 32 + l31;
+      if (jb < NB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ir = rw + acc_row(r, lane);
+          if (ir < nunl) a.Smat[(long long)ir * btu + jb] = expf(acc[nb][r] / a.T);
+        }
+      }
+    }
+    return;
+  }
+  // Row sums and E . bank_probs over this wave's columns: per 32-column block E [32][33] and the probability tile
+  // [32 columns][33] go to the wave's own LDS region (behind the exchange) and each lane forms whole outputs (row, class |
+  // row sum), columns summed in index order, blocks in order -- a [32 x 32 NBW] . [32 NBW x (K + 1)] product without
+  // shuffles.
+  float* ew = lds + Cf::FOLD + (size_t)w2 * (2 * 32 * 33);
+  float* pw = ew + 32 * 33;
+  constexpr int ON = (32 * 33 + 63) / 64;                 // outputs per lane: 32 rows x (K + 1 <= 33)
+  float outv[ON];
+#pragma unroll
+  for (int i = 0; i < ON; ++i) outv[i] = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const bool jv = cw + nb * 32 + l31 < NB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ew[acc_row(r, lane) * 33 + l31] = jv ? expf(acc[nb][r] / a.T) : 0.f;
+#pragma unroll
+    for (int i = 0; i < PQN; ++i) {
+      const int idx = lane + 64 * i, c = idx / K;
+      if (idx < 32 * K) pw[c * 33 + (idx - c * K)] = pq[nb][i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): wave-private region, other lanes wrote what this lane reads
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < ON; ++i) {
+      const int o = lane + 64 * i;
+      if (o < 32 * (K + 1)) {
+        const int row = o & 31, kk = o >> 5;               // kk == K: the plain row sum
+        const float* er = ew + row * 33;
+        float sum = 0.f;
+        if (kk < K) {
+#pragma unroll 8
+          for (int c = 0; c < 32; ++c) sum += er[c] * pw[c * 33 + kk];
+        } else {
+#pragma unroll 8
+          for (int c = 0; c < 32; ++c) sum += er[c];
+        }
+        outv[i] += sum;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();                      // every lane is done reading before the next block's tiles land
+  }
+  const int CT = (a.Q + a.ctw - 1) / a.ctw, ctile = cw / (32 * NBW);
+  float* rs = a.rs_part + ((long long)prob * CT + ctile) * nunl;
+  float* ep = a.ep_part + ((long long)prob * CT + ctile) * nunl * K;
+#pragma unroll
+  for (int i = 0; i < ON; ++i) {
+    const int o = lane + 64 * i;
+    if (o < 32 * (K + 1)) {
+      const int row = o & 31, kk = o >> 5, ir = rw + row;
+      if (ir < nunl) {
+        if (kk < K) ep[(long long)ir * K + kk] = outv[i]; else rs[ir] = outv[i];
+      }
+    }
+  }
+}
+
 // Bank write of the GLOBAL batch (train.py:223-236), one workgroup per written row, identical on every shard:
 //   bank0 <- [fU_w ; fL_s], [p_w0 ; onehot]     bank1 <- [fU_s ; fL_w], [p_s0 ; onehot]      (rows modulo Q)
 // It runs in the loss_rows launch: pair_exp_kernel (the launch before) was the last reader of the banks, and the
@@ -619,7 +893,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
   // split into 64/KP groups of KP >= K lanes; group gq takes tiles ct = gq, gq+G, ... for class (lane % KP), LRD loads
   // of each product in flight at a time.
   constexpr int LRD = 16;
-  const int CT = (a.Q + 31) >> 5;
+  const int CT = (a.Q + a.ctw - 1) / a.ctw;
   int KP = 1;
   while (KP < K) KP <<= 1;
   const int G = 64 / KP, gq = lane / KP, kq = lane - gq * KP;
@@ -827,19 +1101,60 @@ __global__ __launch_bounds__(256) void loss_dfeat_kernel(GemmTN2 t, int gemm_blo
   else loss_scalars_block(a, &sh.ared[0][0]);
 }
 
-hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st) {
+template <int MB, int CG, int NBW>
+static hipError_t launch_pair_wide(const LossArgs& a, int maxc, hipStream_t st) {
+  typedef WideCfg<MB, CG, NBW> Cf;
+  constexpr size_t lds = Cf::LDS_FL * 4;
+  static DevOnce once;
+  hipError_t e = ensure_max_lds(once, pair_exp_wide_kernel<MB, CG, NBW>);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((pair_exp_wide_kernel<MB, CG, NBW>), dim3((maxc + Cf::NT - 1) / Cf::NT, (a.nunl + Cf::MT - 1) / Cf::MT, 3),
+                     dim3(Cf::NTHR), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_loss_phase1(const LossArgs& a_in, hipStream_t st) {
   hipError_t e;
+  LossArgs a = a_in;
+  a.ctw = 32;
   const int nl = a.nlab + a.nunl;
   // (device-side step scalars: whether the banks are read is decided in the kernels, the grid covers them)
-  const int maxc = ((a.smooth || a.sel.dyn.table != nullptr) && a.Q > a.btu) ? a.Q : a.btu;
-  // wide products (many column tiles): tall tiles; narrow ones: 32x32 tiles with the contraction split over the waves
-  static const int force_tall = getenv("CMLPL_PAIR_TALL") ? atoi(getenv("CMLPL_PAIR_TALL")) : -1;
+  const bool banks = a.smooth || a.sel.dyn.table != nullptr;
+  const int maxc = (banks && a.Q > a.btu) ? a.Q : a.btu;
   const int ctiles = (maxc + 31) / 32;
-  // measured per rank (scripts/rank_cost.py, B2, 128 local rows; pair_exp + row kernel): 32x32 tiles (f32-input MFMA)
-  // 27.4 / 42.0 / 60.0 / 89 us at W = 1 / 2 / 4 / 8 against 43.4 / 45.4 / 56.0 / 78 us for tall tiles (split-bf16)
-  const bool tall = force_tall >= 0 ? force_tall != 0 : (ctiles >= 128 && a.nunl >= 64);
+  // Wide products (data parallelism: >= 4096 columns): pair_exp_wide_kernel up to 128 local rows, pair_exp_tall_kernel
+  // beyond.  Narrow ones: 16 x 32 tiles, the contraction split over the waves.  CMLPL_PAIR_WIDE=0 / 1: never / at every
+  // size (tests); CMLPL_PAIR_MB, CMLPL_PAIR_NBW force its tile shape; CMLPL_PAIR_TALL=0 / 1: the tall tiles never / always.
+  static const int wide_mode = getenv("CMLPL_PAIR_WIDE") ? atoi(getenv("CMLPL_PAIR_WIDE")) : -1;   // 0 off, 1 at every size (tests)
+  static const int force_nbw = getenv("CMLPL_PAIR_NBW") ? atoi(getenv("CMLPL_PAIR_NBW")) : 0;
+  static const int force_mb = getenv("CMLPL_PAIR_MB") ? atoi(getenv("CMLPL_PAIR_MB")) : 0;
   static const bool pair16 = !(getenv("CMLPL_PAIR16") && atoi(getenv("CMLPL_PAIR16")) == 0);
-  if (tall) {
+  // (per rank, configs[2] = 512 + 512 rows over W GPUs, Q = 5120; pair_exp + row kernel: wide 153.7 / 73.0 / 49.9 / 45.0 us at
+  //  W = 1 / 2 / 4 / 8 against 115.4 / 69.9 / 55.7 / 55.0 us for the tall tiles: wide up to 128 local rows, tall beyond)
+  static const int force_tall = getenv("CMLPL_PAIR_TALL") ? atoi(getenv("CMLPL_PAIR_TALL")) : -1;
+  const bool wide = force_tall <= 0 && wide_mode != 0 && a.K <= 32 && ((ctiles >= 128 && a.nunl <= 128) || wide_mode == 1);
+  const bool tall = !wide && (force_tall >= 0 ? force_tall != 0 : (ctiles >= 128 && a.nunl >= 64));
+  if (wide) {
+    const long long total = (banks ? 2LL * a.Q : 0) + a.btu;                 // columns of the three products
+    // 64 x 64 tiles (three workgroups fit a CU) while they make at most one and a half rounds; beyond that 128 x 32 NBW
+    // tiles, NBW such that the launch is one round of about one workgroup per CU
+    // (measured per rank, B2 128 + 128 rows: W = 4 36.0 us with 64-row tiles / 43.5 with 128-row tiles; W = 8 60.8 / 57.2)
+    const long long n64 = ((a.nunl + 63) / 64) * ((total + 63) / 64);
+    const int MB = force_mb == 2 || force_mb == 4 ? force_mb : ((a.nunl <= 64 || n64 * 2 <= 3LL * device_cus()) ? 2 : 4);
+    const int CG = 4 / MB;
+    const int rowblk = (a.nunl + 32 * MB - 1) / (32 * MB);                   // > 1 only beyond 128 local rows
+    const long long per = (total * rowblk + device_cus() - 1) / device_cus();   // columns per workgroup for one round
+    int NBW = (int)((per + 32 * CG - 1) / (32 * CG));
+    const int nbw_max = MB == 4 ? 4 : 2;
+    if (MB == 2 && a.nunl > 64) NBW = 1;                                     // the 64 x 64 tiles of the rule above
+    if (force_nbw > 0) NBW = force_nbw;
+    NBW = NBW < 1 ? 1 : NBW > nbw_max ? nbw_max : NBW;
+    a.ctw = 32 * NBW;
+    if (MB == 4) e = NBW == 1 ? launch_pair_wide<4, 1, 1>(a, maxc, st) : NBW == 2 ? launch_pair_wide<4, 1, 2>(a, maxc, st)
+                   : NBW == 3 ? launch_pair_wide<4, 1, 3>(a, maxc, st) : launch_pair_wide<4, 1, 4>(a, maxc, st);
+    else         e = NBW == 1 ? launch_pair_wide<2, 2, 1>(a, maxc, st) : launch_pair_wide<2, 2, 2>(a, maxc, st);
+    if (e != hipSuccess) return e;
+  } else if (tall) {
     hipLaunchKernelGGL(pair_exp_tall_kernel, dim3(ctiles, (a.nunl + 127) / 128, 3), dim3(256), 0, st, a);
   } else if (a.K <= 32 && pair16) {
     hipLaunchKernelGGL(pair_exp16_kernel, dim3(ctiles, (a.nunl + 15) / 16, 3), dim3(256), 0, st, a);

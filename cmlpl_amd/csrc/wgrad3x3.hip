@@ -745,20 +745,6 @@ static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
   return ((size_t)U * (RU + 2) * PW * 64 + D * (64 / cspl)) * 4;
 }
 
-// compute units of the current device (cached per device: the pair launch shares them between its two maps; a
-// host without a device -- the library loaded for its symbols only -- plans for a full MI355X)
-static int device_cus() {
-  static std::atomic<int> cache[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
-  int v = cache[dev & 63].load(std::memory_order_relaxed);
-  if (v == 0) {
-    hipDeviceProp_t prop;
-    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    cache[dev & 63].store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
 
 bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
   const int RO = 2 * (H / 2);

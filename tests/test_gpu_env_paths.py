@@ -1,5 +1,5 @@
-"""Kernel variants that the default planners do not pick at test sizes -- the tall-tile pair_exp kernel (chosen for
->= 256 bank column tiles, i.e. data-parallel jobs of 8 ranks), the general weight-gradient fallback, the unfused
+"""Kernel variants that the default planners do not pick at test sizes -- the wide pair_exp kernel (chosen for >= 4096
+bank columns, i.e. data-parallel jobs of 4 ranks and more), the general weight-gradient fallback, the unfused
 conv0 kernels on a fusable shape -- are forced through their environment switches (read once per process, hence a
 child process each) and must pass the same parity tests."""
 import os
@@ -20,7 +20,17 @@ def _run(env_extra, select):
 
 
 def test_tall_pair_exp_kernel_passes_loss_parity():
-    _run({"CMLPL_PAIR_TALL": "1"}, ["tests/test_gpu_ops.py", "-k", "loss_block", "tests/test_gpu_distributed.py"])
+    """pair_exp_tall_kernel (wide products with more than 128 local rows) forced at the test sizes"""
+    _run({"CMLPL_PAIR_TALL": "1"}, ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "-k", "loss_block or eight_rank"])
+
+
+@pytest.mark.parametrize("mb,nbw", [("0", "0"), ("4", "4"), ("2", "2")])
+def test_wide_pair_exp_kernel_passes_loss_parity(mb, nbw):
+    """pair_exp_wide_kernel (what >= 4096 bank columns take: data-parallel jobs) forced at the test sizes, with the planner's
+    tile shape and with every other one forced: local row counts from 4 to 128 go through the 64-row (one or two row
+    blocks of workgroups) and 128-row instantiations"""
+    _run({"CMLPL_PAIR_WIDE": "1", "CMLPL_PAIR_MB": mb, "CMLPL_PAIR_NBW": nbw},
+         ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "tests/test_gpu_step.py", "-k", "loss_block or eight_rank or b2_b256"])
 
 
 def test_32_row_pair_exp_kernel_passes_loss_parity():

@@ -16,3 +16,15 @@ CMLPL_LIB=cmlpl_amd/libabl9.so python3 scripts/conv_timeline.py 2>&1 | grep -av 
 for wl in P B4 B5; do python3 bench.py --workload $wl --steps 100 --no-cpu-baseline 2> /dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$wl', '%.4f ms/step' % d['ms_per_step'], '%.0f patches/s' % d['value'])"; done > $OUT/${TAG}_other_shapes.txt
 python3 bench.py --workload B3 --gpus 1 --steps 100 --no-cpu-baseline 2> /dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B3 (512+512 on one GPU)', '%.4f ms/step' % d['ms_per_step'], '%.0f patches/s' % d['value'])" >> $OUT/${TAG}_other_shapes.txt
 python3 bench.py --workload B5 --global-batch 64+512 --steps 100 --no-cpu-baseline 2> /dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B5 64+512 on one GPU', '%.4f ms/step' % d['ms_per_step'], '%.0f patches/s' % d['value'])" >> $OUT/${TAG}_other_shapes.txt
+# strong-scaling rank costs (configs[2] over 1 / 2 / 4 / 8 ranks, configs[4] at 1 and 8), per-kernel times of a rank at W = 8
+(for w in 1 2 4 8; do python3 scripts/rank_cost.py $w B3 $((512/w)) $((512/w)) 2>&1 | grep -av amdgpu.ids | tail -12; done
+ python3 scripts/rank_cost.py 1 B5 64 512 2>&1 | grep -av amdgpu.ids | tail -20
+ python3 scripts/rank_cost.py 8 B5 8 64 2>&1 | grep -av amdgpu.ids | tail -20) > $OUT/${TAG}_rank_cost_strong.txt
+(echo "B2 128+128 rows per rank, W = 8"; bash scripts/kstats_rank.sh ${TAG}_w8 8 B2 128 128 pair_exp loss_ gemm
+ echo "configs[2] 64+64 rows per rank, W = 8"; bash scripts/kstats_rank.sh ${TAG}_b3w8 8 B3 64 64 pair_exp loss_ gemm) > $OUT/${TAG}_rank_kernels.txt 2>&1
+# machine floors the analysis leans on: launch-to-launch time of empty / small kernels, cold HBM read rate of the bank pattern
+mkdir -p scripts/micro/bin
+for m in launch_floor strided_read; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/micro/$m.hip -o scripts/micro/bin/$m > /dev/null 2>&1 && timeout -k 5 120 scripts/micro/bin/$m
+done > $OUT/${TAG}_machine_floors.txt 2>&1
+bash scripts/pmc_instmix.sh ${TAG} > /dev/null 2>&1   # -> gpurun_out/TAG_instmix.txt

@@ -24,7 +24,7 @@ def test_tall_pair_exp_kernel_passes_loss_parity():
     _run({"CMLPL_PAIR_TALL": "1"}, ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "-k", "loss_block or eight_rank"])
 
 
-@pytest.mark.parametrize("mb,nbw", [("0", "0"), ("4", "4"), ("2", "2")])
+@pytest.mark.parametrize("mb,nbw", [("0", "0"), ("4", "1"), ("4", "2"), ("4", "3"), ("4", "4"), ("2", "2")])
 def test_wide_pair_exp_kernel_passes_loss_parity(mb, nbw):
     """pair_exp_wide_kernel (what >= 4096 bank columns take: data-parallel jobs) forced at the test sizes, with the planner's
     tile shape and with every other one forced: local row counts from 4 to 128 go through the 64-row (one or two row

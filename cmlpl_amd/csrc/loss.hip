@@ -1094,6 +1094,114 @@ __device__ __forceinline__ void loss_scalars_block(const LossArgs& a, float* red
   }
 }
 
+// The two feature-gradient GEMMs with their operands through LDS: one workgroup per 16 x 64 output tile (wave w: columns
+// 16 w .. 16 w + 15 on v_mfma_f32_16x16x4_f32), the contraction walked in chunks of DF_KC rows that are fetched as whole
+// 16-byte pieces (A: one row of 16 floats = 64 B per quarter-wave; B: 256 B per row), two chunks in flight in registers,
+// double-buffered in LDS, one barrier per chunk.  gemm_tn_block feeds its MFMAs straight from 4-byte global loads -- fine
+// while the contraction is one batch of loads long (one GPU: 128 rows), 25 us at eight ranks (1024 rows: a thousand
+// dword loads per wave).  No bias / batch / ReLU epilogue: C = A^T . B.
+constexpr int DF_KC = 64, DF_AS = 16, DF_BS = 80;       // chunk rows; LDS row strides in floats (16 apart modulo 32 banks: the four k of
+                                                         // an MFMA operand read land on disjoint banks two by two)
+struct DfeatShared { __attribute__((aligned(16))) float a[2][DF_KC * DF_AS]; __attribute__((aligned(16))) float b[2][DF_KC * DF_BS]; };
+inline int dfeat_lds_blocks(const GemmTN& g) { return ((g.M + 15) / 16) * ((g.N + 63) / 64); }
+
+__device__ __forceinline__ void dfeat_lds_block(const GemmTN2& t, int bid, DfeatShared& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pi = (bid >= t.nblk0) ? 1 : 0;
+  const GemmTN g = t.p[pi];
+  const int b = bid - (pi ? t.nblk0 : 0);
+  const int NTg = (g.N + 63) >> 6;
+  const int nt = b % NTg, mt = b / NTg;
+  const int m0 = mt * 16, n0 = nt * 64, R = g.R;
+  // loader roles: A piece = (row ra = tid >> 2 of the chunk, floats 4 (tid & 3) ..) ; B pieces q = 0..3: row rb = (tid >> 4) + 16 q,
+  // floats 4 (tid & 15) ..
+  const int ra = tid >> 2, ca = (tid & 3) * 4, rb = tid >> 4, cb = (tid & 15) * 4;
+  const bool a_ok = m0 + ca < g.M, b_ok = n0 + cb < g.N;        // (M and N are multiples of 4 where this kernel is used: checked on the host)
+  // B rows may be spread over rank-major blocks (packed mode): row r lives in segment r / seg_rows.  One division per piece
+  // up front, then (segment, offset) are carried from chunk to chunk (the fetches walk the chunks in order)
+  int bseg[4], boff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rb + 16 * q;
+    bseg[q] = g.b_seg_rows > 0 ? r / g.b_seg_rows : 0;
+    boff[q] = g.b_seg_rows > 0 ? r - bseg[q] * g.b_seg_rows : r;
+  }
+  const float* bcol = g.B + n0 + (b_ok ? cb : 0);
+  auto fetch = [&](int k0, float4& va, float4 (&vb)[4]) {   // chunks must be fetched in order: 0, 1, 2, ...
+    const int r = k0 + ra;
+    const float4 x = *(const float4*)(g.A + (long long)(r < R ? r : 0) * g.lda + (a_ok ? m0 + ca : 0));
+    va = (r < R && a_ok) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = k0 + rb + 16 * q;
+      const bool ok = rr < R;
+      const long long bo = (long long)bseg[q] * g.b_seg_stride + (long long)boff[q] * g.ldb;
+      const float4 y = *(const float4*)(bcol + (ok ? bo : 0));
+      vb[q] = (ok && b_ok) ? y : make_float4(0.f, 0.f, 0.f, 0.f);
+      boff[q] += DF_KC;
+      while (g.b_seg_rows > 0 && boff[q] >= g.b_seg_rows) { boff[q] -= g.b_seg_rows; ++bseg[q]; }
+    }
+  };
+  auto stage = [&](int buf, const float4& va, const float4 (&vb)[4]) {
+    *(float4*)(&sh.a[buf][ra * DF_AS + ca]) = make_float4(va.x, va.y, va.z, va.w);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(float4*)(&sh.b[buf][(rb + 16 * q) * DF_BS + cb]) = make_float4(vb[q].x, vb[q].y, vb[q].z, vb[q].w);
+  };
+  const int NC = (R + DF_KC - 1) / DF_KC;
+  // DF_PF chunks in flight in registers (set of chunk c: c % DF_PF; four instead of two changed nothing at 16 chunks)
+  constexpr int DF_PF = 2;
+  float4 va[DF_PF], vb[DF_PF][4];
+#pragma unroll
+  for (int c = 0; c < DF_PF; ++c) if (c < NC) fetch(c * DF_KC, va[c], vb[c]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  stage(0, va[0], vb[0]);
+  if (DF_PF < NC) fetch(DF_PF * DF_KC, va[0], vb[0]);
+  // (sixteen chunks written out per trip: across a loop back-edge hipcc loses count of the outstanding loads and waits
+  //  vmcnt(0) in front of the staging, i.e. for the prefetch it has just issued -- a memory round trip per chunk)
+  static_assert(16 % DF_PF == 0, "the set of a chunk is a compile-time constant inside a trip");
+  for (int cb = 0; cb < NC; cb += 16) {
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) {
+      const int c = cb + ci;
+      if (c < NC) {                                    // uniform
+        __syncthreads();                               // chunk c staged; the other buffer (read during chunk c - 1) is free
+        if (c + 1 < NC) {
+          stage((ci + 1) & 1, va[(ci + 1) % DF_PF], vb[(ci + 1) % DF_PF]);
+          if (c + 1 + DF_PF < NC) fetch((c + 1 + DF_PF) * DF_KC, va[(ci + 1) % DF_PF], vb[(ci + 1) % DF_PF]);
+        }
+        const float* as = &sh.a[ci & 1][kq * DF_AS + l16];
+        const float* bs = &sh.b[ci & 1][kq * DF_BS + wave * 16 + l16];
+        // every operand of the chunk first (32 reads in flight), then the MFMAs
+        float av[DF_KC / 4], bv[DF_KC / 4];
+#pragma unroll
+        for (int k4 = 0; k4 < DF_KC / 4; ++k4) { av[k4] = as[(4 * k4) * DF_AS]; bv[k4] = bs[(4 * k4) * DF_BS]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 0; k4 < DF_KC / 4; k4 += 2) {    // two accumulator chains (a dependent MFMA waits for its predecessor)
+          acc  = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4], bv[k4], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4 + 1], bv[k4 + 1], acc2, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D register r of lane l: row 4 (l >> 4) + r, column l & 15
+  const int col = n0 + wave * 16 + l16;
+  if (col < g.N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * kq + r;
+      if (row < g.M) g.C[(long long)row * g.ldc + col] = (acc[r] + acc2[r]) * g.scale;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_dfeat_lds_kernel(GemmTN2 t, int gemm_blocks, LossArgs a) {
+  __shared__ DfeatShared sh;
+  if ((int)blockIdx.x < gemm_blocks) dfeat_lds_block(t, (int)blockIdx.x, sh);
+  else loss_scalars_block(a, &sh.a[0][0]);
+}
+
 // dfeat_s / dfeat_w GEMMs (blocks [0, gemm blocks)) + the scalar block (last block)
 __global__ __launch_bounds__(256) void loss_dfeat_kernel(GemmTN2 t, int gemm_blocks, LossArgs a) {
   __shared__ GemmTNShared sh;
@@ -1207,7 +1315,20 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   h.C = a.dfw_part;
   (void)e;
   GemmTN2 t;
-  t.p[0] = g; t.p[1] = h; t.nblk0 = gemm_tn_blocks(g);
+  t.p[0] = g; t.p[1] = h;
+  // operands through LDS wherever every row is a whole number of 16-byte pieces (measured per rank, B2 128 + 128 rows: 6.7 -> 5.2 us
+  // on one GPU, 25.9 -> 22.4 us at W = 8); CMLPL_DFEAT_LDS=0: the direct-load tiles always
+  static const int lds_mode = getenv("CMLPL_DFEAT_LDS") ? atoi(getenv("CMLPL_DFEAT_LDS")) : -1;
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  const bool lds_ok = (g.M % 4) == 0 && (h.M % 4) == 0 && (g.lda % 4) == 0 && (h.lda % 4) == 0 && (g.b_seg_stride % 4) == 0 &&
+                      al16(g.A) && al16(g.B) && al16(h.A) && al16(h.B) && al16(g.C) && al16(h.C);   // 16-byte pieces everywhere
+  if (lds_ok && lds_mode != 0) {
+    t.nblk0 = dfeat_lds_blocks(g);
+    const int gb = t.nblk0 + dfeat_lds_blocks(h);
+    hipLaunchKernelGGL(loss_dfeat_lds_kernel, dim3(gb + 1), dim3(256), 0, st, t, gb, a);
+    return hipGetLastError();
+  }
+  t.nblk0 = gemm_tn_blocks(g);
   const int gb = t.nblk0 + gemm_tn_blocks(h);
   hipLaunchKernelGGL(loss_dfeat_kernel, dim3(gb + 1), dim3(256), 0, st, t, gb, a);
   return hipGetLastError();

@@ -33,6 +33,12 @@ def test_wide_pair_exp_kernel_passes_loss_parity(mb, nbw):
          ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "tests/test_gpu_step.py", "-k", "loss_block or eight_rank or b2_b256"])
 
 
+def test_direct_load_feature_gradient_gemms_pass_loss_parity():
+    """gemm_tn_block for the two feature-gradient GEMMs (what row counts that are not multiples of four take) instead of
+    loss_dfeat_lds_kernel"""
+    _run({"CMLPL_DFEAT_LDS": "0"}, ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "-k", "loss_block or eight_rank"])
+
+
 def test_32_row_pair_exp_kernel_passes_loss_parity():
     """pair_exp_kernel (32 x 32 tiles, the round-2 default; still what K > 32 classes take) instead of pair_exp16_kernel"""
     _run({"CMLPL_PAIR16": "0"}, ["tests/test_gpu_ops.py", "tests/test_gpu_step.py", "-k", "loss_block or b2_64"])

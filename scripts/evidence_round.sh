@@ -24,7 +24,7 @@ python3 bench.py --workload B5 --global-batch 64+512 --steps 100 --no-cpu-baseli
  echo "configs[2] 64+64 rows per rank, W = 8"; bash scripts/kstats_rank.sh ${TAG}_b3w8 8 B3 64 64 pair_exp loss_ gemm) > $OUT/${TAG}_rank_kernels.txt 2>&1
 # machine floors the analysis leans on: launch-to-launch time of empty / small kernels, cold HBM read rate of the bank pattern
 mkdir -p scripts/micro/bin
-for m in launch_floor strided_read; do
+for m in launch_floor strided_read chunk_loop; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/micro/$m.hip -o scripts/micro/bin/$m > /dev/null 2>&1 && timeout -k 5 120 scripts/micro/bin/$m
 done > $OUT/${TAG}_machine_floors.txt 2>&1
 bash scripts/pmc_instmix.sh ${TAG} > /dev/null 2>&1   # -> gpurun_out/TAG_instmix.txt

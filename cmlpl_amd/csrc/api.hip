@@ -53,7 +53,6 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   if (!plan_conv3(0, d.H, d.W, nets * n, &c) || !plan_conv3(1, d.H, d.W, nets * n, &c) ||
       !plan_conv3(0, d.H2, d.W2, nets * n, &c) || !plan_conv3(1, d.H2, d.W2, nets * n, &c)) return false;
   const int G0 = conv0_partials(d, nets, n);
-  const int Ct = ((d.C + 31) / 32) * 32;
   w->a0 = (float*)take(N * d.HW * 64 * 4);
   w->p1 = (float*)take(N * d.P2 * 64 * 4);
   w->m1 = (uint8_t*)take(N * d.P2 * 64);
@@ -69,7 +68,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   w->da0 = (float*)take(N * d.HW * 64 * 4);
   w->part1 = (float*)take((size_t)nets * w1.G * PART3 * 4);
   w->part2 = (float*)take((size_t)nets * w2.G * PART3 * 4);
-  w->part0 = (float*)take((size_t)nets * G0 * ((size_t)Ct * 64 + 64) * 4);
+  w->part0 = (float*)take((size_t)nets * G0 * (size_t)conv0_partial_size(d.C) * 4);
   w->bytes = off;
   return true;
 }

@@ -200,18 +200,22 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     }
   }
   // partial layout [c][co] (+ 64 db)
-  float* pp = part + ((long long)net * G + g) * ((long long)Ct * 64 + 64);
+  const int Cw = conv0_partial_rows(C);
+  float* pp = part + ((long long)net * G + g) * ((long long)Cw * 64 + 64);
 #pragma unroll
   for (int k = 0; k < C0_MAXT; ++k) {
     const int tile = it0 + 2 * k;
     if (tile < NT) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pp[(tile * 32 + acc_row(r, lane)) * 64 + ct * 32 + l31] = acc[k][r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = tile * 32 + acc_row(r, lane);
+        if (row < Cw) pp[row * 64 + ct * 32 + l31] = acc[k][r];
+      }
     }
   }
   if (it0 == 0) {
     const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
-    if (hh == 0) pp[(long long)Ct * 64 + ct * 32 + l31] = tot;
+    if (hh == 0) pp[(long long)Cw * 64 + ct * 32 + l31] = tot;
   }
 }
 
@@ -313,7 +317,7 @@ hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st)
   return hipGetLastError();
 }
 
-int conv0_partial_size(int C) { return ((C + 31) / 32) * 32 * 64 + 64; }
+int conv0_partial_size(int C) { return conv0_partial_rows(C) * 64 + 64; }
 
 int plan_conv0_wgrad_G(int n, int C, int HW) {
   (void)C; (void)HW;

@@ -1426,7 +1426,8 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
     float* slab = smem;                                   // [min(C, BP)][HW]
     float* dal = smem + (C < BP ? C : BP) * HW;           // [HW + 1][64]
     const int Ct = ((C + 31) >> 5) * 32;
-    float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Ct * 64 + 64);
+    const int Cw = conv0_partial_rows(C);                 // rows of the partial (kernels.hpp)
+    float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Cw * 64 + 64);
     SlabRange rg = slab_range(a.xs, net, s0, C * HW, 0, (C < BP ? C : BP) * HW);
     slab_issue(rg, slab, wave, lane);                     // the forward's input again (first pass)
 #pragma unroll
@@ -1488,16 +1489,16 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cc = wave * 32 + acc_row(r, lane);
-          // single pass: whole band tiles as before (rows >= C are dropped by the reduce); several passes: only this
-          // pass's bands (the rows behind them belong to the next pass)
-          if (has_tile && (cc < nb || (C <= BP && cc < Ct))) {
+          // single pass: the partial's rows (C rounded up to 4; rows >= C are dropped by the reduce); several passes: only
+          // this pass's bands (the rows behind them belong to the next pass)
+          if (has_tile && (cc < nb || (C <= BP && cc < Cw))) {
             pp[(size_t)(cb + cc) * 64 + l31] = g0[r];
             pp[(size_t)(cb + cc) * 64 + 32 + l31] = g1[r];
           }
         }
         if (has_db) {
           const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
-          if (hh == 0) pp[(size_t)Ct * 64 + wave * 32 + l31] = tot;
+          if (hh == 0) pp[(size_t)Cw * 64 + wave * 32 + l31] = tot;
         }
       }
     }

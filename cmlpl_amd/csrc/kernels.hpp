@@ -128,6 +128,9 @@ void reduce_table_add(ReduceTable& t, const float* part, int G, int PS, int mode
 hipError_t launch_partial_reduce(int nets, const ReduceTable& t, hipStream_t st);
 struct GemmTN;
 hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, const GemmTN& g1, hipStream_t st);
+// a conv0 weight-gradient partial: [rows = C rounded up to 4][64 co] + 64 bias sums (rounds 1-3 kept whole 32-band tiles:
+// at 103 bands a fifth of the partial bytes -- written by every sample-net, re-read by the reduce -- were padding)
+__host__ __device__ inline int conv0_partial_rows(int C) { return (C + 3) & ~3; }
 int conv0_partial_size(int C);
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
                               hipStream_t st);

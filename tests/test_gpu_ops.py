@@ -234,7 +234,8 @@ def _loss_inputs(shape, bt, btu, Q, seed, peaky):
 
 @pytest.mark.parametrize("bt,btu,smooth,peaky,K", [(32, 32, True, False, 9), (128, 128, True, True, 9),
                                                    (16, 48, False, True, 9), (24, 40, True, True, 20),
-                                                   (128, 128, False, False, 16)])
+                                                   (128, 128, False, False, 16), (20, 44, True, False, 9),
+                                                   (10, 42, True, True, 9), (8, 120, True, False, 12)])
 def test_loss_block(bt, btu, smooth, peaky, K):
     from cmlpl_amd import _lib
     lib = _lib.load()

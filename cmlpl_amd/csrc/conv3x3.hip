@@ -404,17 +404,39 @@ __device__ __forceinline__ void ks_unit(const float* __restrict__ img, const int
   cur = nxt; rn0 = rnn0; rn1 = rnn1;
 }
 
+// one tap of conv3_taps_ks: request the next tap's fragments into `nb`, run this tap's four units on `bq`
+template <class Side>
+__device__ __forceinline__ void ks_tap(const float* __restrict__ img, const uint4* __restrict__ wq, const int (&abase)[2],
+                                       f32x16 (&acc)[2][2], ASplit& cur, float4& rn0, float4& rn1, const uint4 (&bq)[2][6],
+                                       uint4 (&nb)[2][6], int s, int kh, int PW, bool active, Side& side) {
+  if (s + 1 < 9) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        nb[q][i] = wq[(size_t)(s + 1) * TAPW + (((2 * kh + q) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
+  }
+  side(s);
+  if (active) {        // wave-uniform: a pixel half without real pixels (HW <= 64) only keeps the barriers' company
+    ks_unit<0>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    ks_unit<1>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    ks_unit<2>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    ks_unit<3>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+  }
+}
+
 template <class Side = NoSide>
 __device__ __forceinline__ void conv3_taps_ks(const float* __restrict__ img, const uint4* __restrict__ wq,
                                               const int (&abase)[2], f32x16 (&acc)[2][2], int PW, int wave, bool active,
                                               Side side = Side()) {
   const int kh = wave & 1;
-  // this wave's fragments of a tap: [k-step q][piece * 2 + n tile]
-  uint4 bq[2][6], nb[2][6];
+  // this wave's fragments of a tap: [k-step q][piece * 2 + n tile]; two sets that swap roles from tap to tap (taps in
+  // pairs: copying the set that was fetched ahead into the set in use was 24 64-bit moves per tap and wave)
+  uint4 ba[2][6], bb[2][6];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bq[q][i] = wq[(((2 * kh + q) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
+    for (int i = 0; i < 6; ++i) ba[q][i] = wq[(((2 * kh + q) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
   ASplit cur;
   float4 rn0, rn1;
   {  // pipeline fill: units 0 and 1 of tap 0 (the staged image is complete: the caller's barrier)
@@ -424,26 +446,11 @@ __device__ __forceinline__ void conv3_taps_ks(const float* __restrict__ img, con
     rn0 = *(const float4*)p1; rn1 = *(const float4*)(p1 + 4);
   }
 #pragma unroll 1
-  for (int s = 0; s < 9; ++s) {
-    if (s + 1 < 9) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-          nb[q][i] = wq[(size_t)(s + 1) * TAPW + (((2 * kh + q) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
-    }
-    side(s);
-    if (active) {        // wave-uniform: a pixel half without real pixels (HW <= 64) only keeps the barriers' company
-      ks_unit<0>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
-      ks_unit<1>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
-      ks_unit<2>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
-      ks_unit<3>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int i = 0; i < 6; ++i) bq[q][i] = nb[q][i];
+  for (int s = 0; s < 8; s += 2) {
+    ks_tap(img, wq, abase, acc, cur, rn0, rn1, ba, bb, s, kh, PW, active, side);
+    ks_tap(img, wq, abase, acc, cur, rn0, rn1, bb, ba, s + 1, kh, PW, active, side);
   }
+  ks_tap(img, wq, abase, acc, cur, rn0, rn1, ba, bb, 8, kh, PW, active, side);
 }
 
 // After conv3_taps_ks: fold the two channel halves.  Wave w keeps tile w = 2mh + kh (acc[kh]) and gives acc[kh ^ 1]

@@ -329,10 +329,10 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
                               hipStream_t st) {
   const int NT = (C + 31) / 32, Ct = NT * 32;
   if (NT > 2 * C0_MAXT) return hipErrorInvalidValue;
-  static const bool dma_off = getenv("CMLPL_CONV0_DMA") && atoi(getenv("CMLPL_CONV0_DMA")) == 0;
+  const bool dma_off = switches().conv0_dma == 0;
   const bool dma = (HW & 1) && !dma_off;
   // pixel ranges per sample: halves (of whole 16-byte groups) when the whole slab would leave one workgroup per CU
-  static const int force_ps = getenv("CMLPL_CONV0_PS") ? atoi(getenv("CMLPL_CONV0_PS")) : 0;
+  const int force_ps = switches().conv0_ps;
   int PS = (!dma && (HW & 7) == 0 && ((size_t)Ct * ((HW + 2) | 1) + 64) * 4 > LDS_MAX / 2) ? 2 : 1;
   if (force_ps == 1 || (force_ps == 2 && !dma && (HW & 7) == 0)) PS = force_ps;
   const int HWs = HW / PS;

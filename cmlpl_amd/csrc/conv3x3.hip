@@ -1625,7 +1625,7 @@ static size_t conv3_lds(int S, int H, int W, int MTW) {
 bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
   const int PX = (mode == 0) ? (2 * (H / 2)) * (2 * (W / 2)) : H * W;
   if (PX <= 0) return false;
-  static const int force_s = getenv("CMLPL_CONV3_S") ? atoi(getenv("CMLPL_CONV3_S")) : 0;
+  const int force_s = switches().conv3_s;
   double best = 1e30;
   bool ok = false;
   for (int S = 1; S <= 16; ++S) {
@@ -1703,7 +1703,7 @@ static size_t conv3_fused_lds(int H, int W, int C, size_t plain) {
 }
 
 bool conv3_fused_ok(int H, int W, int C, int rows) {
-  static const bool off = getenv("CMLPL_FUSE_CONV0") && atoi(getenv("CMLPL_FUSE_CONV0")) == 0;
+  const bool off = switches().fuse_conv0 == 0;
   if (off || C < 1) return false;
   Conv3Plan pl;
   if (!plan_conv3(0, H, W, rows, &pl)) return false;
@@ -1714,7 +1714,7 @@ bool conv3_fused_ok(int H, int W, int C, int rows) {
 }
 
 bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K) {
-  static const bool off = getenv("CMLPL_FUSE_TAIL") && atoi(getenv("CMLPL_FUSE_TAIL")) == 0;
+  const bool off = switches().fuse_tail == 0;
   const int H2 = H / 2, W2 = W / 2;
   return !off && conv3_fused_ok(H, W, C, rows) && H2 / 2 == 2 && W2 / 2 == 2 && (H2 + 2) * (W2 + 2) * CS <= 4096 &&
          K >= 1 && K <= 64;
@@ -1770,8 +1770,8 @@ static size_t conv3_fused_bwd_lds(int H, int W, int C, size_t plain) {
 }
 
 bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
-  static const bool off = getenv("CMLPL_FUSE_CONV0") && atoi(getenv("CMLPL_FUSE_CONV0")) == 0;
-  static const bool offb = getenv("CMLPL_FUSE_CONV0_BWD") && atoi(getenv("CMLPL_FUSE_CONV0_BWD")) == 0;
+  const bool off = switches().fuse_conv0 == 0;
+  const bool offb = switches().fuse_conv0_bwd == 0;
   if (off || offb || C < 1 || C > 256) return false;
   Conv3Plan pl;
   if (!plan_conv3(1, H, W, rows, &pl)) return false;
@@ -1783,7 +1783,7 @@ bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
 }
 
 bool conv3_fused_head_ok(int H, int W, int C, int rows, int K) {
-  static const bool off = getenv("CMLPL_FUSE_TAIL") && atoi(getenv("CMLPL_FUSE_TAIL")) == 0;
+  const bool off = switches().fuse_tail == 0;
   const int H2 = H / 2, W2 = W / 2;
   if (off || !conv3_fused_bwd_ok(H, W, C, rows) || H2 / 2 != 2 || W2 / 2 != 2 || (H2 + 2) * (W2 + 2) * CS > 4096 ||
       H2 * W2 > 32 || K < 1 || K > 64)

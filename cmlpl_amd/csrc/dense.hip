@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * NW) void spe_fused_kernel(SpeArgs a) {
 }
 
 bool spe_fused_ok(int bands) {
-  static const bool off = getenv("CMLPL_FUSE_SPE") && atoi(getenv("CMLPL_FUSE_SPE")) == 0;
+  const bool off = switches().fuse_spe == 0;
   return !off && bands <= 256;
 }
 

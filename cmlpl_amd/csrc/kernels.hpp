@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <atomic>
 
 #include "common.hpp"
@@ -167,6 +168,36 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
                            float* dy, float* dp2, hipStream_t st);
 
 // ---- loss.hip   (row-sharded: see the header of loss.hip)
+// Planner / path switches: environment variables, read ONCE per process, all of them here.
+// -1 / 0 = "not set" where the comment says so; every default is the product path.
+struct Switches {
+  int fuse_conv0, fuse_conv0_bwd, fuse_tail, fuse_spe;        // CMLPL_FUSE_*: 0 = the unfused round-1 kernels (default 1)
+  int conv3_s, conv0_dma, conv0_ps;                           // CMLPL_CONV3_S (0 = planner), CMLPL_CONV0_DMA (default 1), CMLPL_CONV0_PS (0 = planner)
+  int wgrad3_u, wgrad3_cspl, wgrad3_r, wgrad3_ru, wgrad3_rg, wgrad3_pg1, wgrad3_pg2, wgrad3_b3, wgrad3_pair;   // CMLPL_WGRAD3_*
+  int pair_wide, pair_nbw, pair_mb, pair16, pair_tall;        // CMLPL_PAIR_WIDE / _TALL (-1 = planner), _NBW / _MB (0 = planner), CMLPL_PAIR16 (default 1)
+  int dfeat_lds;                                              // CMLPL_DFEAT_LDS (-1 = wherever the operands allow, 0 = never)
+  int mb_fast, unsup_onewg, unsup_3l;                         // CMLPL_MB_FAST, CMLPL_UNSUP_ONEWG, CMLPL_UNSUP_3L (default 1)
+};
+inline const Switches& switches() {
+  static const Switches sw = [] {
+    auto env = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+    Switches w;
+    w.fuse_conv0 = env("CMLPL_FUSE_CONV0", 1); w.fuse_conv0_bwd = env("CMLPL_FUSE_CONV0_BWD", 1);
+    w.fuse_tail = env("CMLPL_FUSE_TAIL", 1); w.fuse_spe = env("CMLPL_FUSE_SPE", 1);
+    w.conv3_s = env("CMLPL_CONV3_S", 0); w.conv0_dma = env("CMLPL_CONV0_DMA", 1); w.conv0_ps = env("CMLPL_CONV0_PS", 0);
+    w.wgrad3_u = env("CMLPL_WGRAD3_U", 0); w.wgrad3_cspl = env("CMLPL_WGRAD3_CSPL", 0); w.wgrad3_r = env("CMLPL_WGRAD3_R", 1);
+    w.wgrad3_ru = env("CMLPL_WGRAD3_RU", 0); w.wgrad3_rg = env("CMLPL_WGRAD3_RG", 0);
+    w.wgrad3_pg1 = env("CMLPL_WGRAD3_PG1", 0); w.wgrad3_pg2 = env("CMLPL_WGRAD3_PG2", 0);
+    w.wgrad3_b3 = env("CMLPL_WGRAD3_B3", 1); w.wgrad3_pair = env("CMLPL_WGRAD3_PAIR", 1);
+    w.pair_wide = env("CMLPL_PAIR_WIDE", -1); w.pair_nbw = env("CMLPL_PAIR_NBW", 0); w.pair_mb = env("CMLPL_PAIR_MB", 0);
+    w.pair16 = env("CMLPL_PAIR16", 1); w.pair_tall = env("CMLPL_PAIR_TALL", -1);
+    w.dfeat_lds = env("CMLPL_DFEAT_LDS", -1);
+    w.mb_fast = env("CMLPL_MB_FAST", 1); w.unsup_onewg = env("CMLPL_UNSUP_ONEWG", 1); w.unsup_3l = env("CMLPL_UNSUP_3L", 1);
+    return w;
+  }();
+  return sw;
+}
+
 // compute units of the current device (cached per device: the pair launch shares them between its two maps; a
 // host without a device -- the library loaded for its symbols only -- plans for a full MI355X)
 inline int device_cus() {

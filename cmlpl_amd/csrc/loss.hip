@@ -1233,13 +1233,13 @@ hipError_t launch_loss_phase1(const LossArgs& a_in, hipStream_t st) {
   // Wide products (data parallelism: >= 4096 columns): pair_exp_wide_kernel up to 128 local rows, pair_exp_tall_kernel
   // beyond.  Narrow ones: 16 x 32 tiles, the contraction split over the waves.  CMLPL_PAIR_WIDE=0 / 1: never / at every
   // size (tests); CMLPL_PAIR_MB, CMLPL_PAIR_NBW force its tile shape; CMLPL_PAIR_TALL=0 / 1: the tall tiles never / always.
-  static const int wide_mode = getenv("CMLPL_PAIR_WIDE") ? atoi(getenv("CMLPL_PAIR_WIDE")) : -1;   // 0 off, 1 at every size (tests)
-  static const int force_nbw = getenv("CMLPL_PAIR_NBW") ? atoi(getenv("CMLPL_PAIR_NBW")) : 0;
-  static const int force_mb = getenv("CMLPL_PAIR_MB") ? atoi(getenv("CMLPL_PAIR_MB")) : 0;
-  static const bool pair16 = !(getenv("CMLPL_PAIR16") && atoi(getenv("CMLPL_PAIR16")) == 0);
+  const int wide_mode = switches().pair_wide;   // 0 off, 1 at every size (tests), -1 the planner
+  const int force_nbw = switches().pair_nbw;
+  const int force_mb = switches().pair_mb;
+  const bool pair16 = switches().pair16 != 0;
   // (per rank, configs[2] = 512 + 512 rows over W GPUs, Q = 5120; pair_exp + row kernel: wide 153.7 / 73.0 / 49.9 / 45.0 us at
   //  W = 1 / 2 / 4 / 8 against 115.4 / 69.9 / 55.7 / 55.0 us for the tall tiles: wide up to 128 local rows, tall beyond)
-  static const int force_tall = getenv("CMLPL_PAIR_TALL") ? atoi(getenv("CMLPL_PAIR_TALL")) : -1;
+  const int force_tall = switches().pair_tall;
   const bool wide = force_tall <= 0 && wide_mode != 0 && a.K <= 32 && ((ctiles >= 128 && a.nunl <= 128) || wide_mode == 1);
   const bool tall = !wide && (force_tall >= 0 ? force_tall != 0 : (ctiles >= 128 && a.nunl >= 64));
   if (wide) {
@@ -1318,7 +1318,7 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   t.p[0] = g; t.p[1] = h;
   // operands through LDS wherever every row is a whole number of 16-byte pieces (measured per rank, B2 128 + 128 rows: 6.7 -> 5.2 us
   // on one GPU, 25.9 -> 22.4 us at W = 8); CMLPL_DFEAT_LDS=0: the direct-load tiles always
-  static const int lds_mode = getenv("CMLPL_DFEAT_LDS") ? atoi(getenv("CMLPL_DFEAT_LDS")) : -1;
+  const int lds_mode = switches().dfeat_lds;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   const bool lds_ok = (g.M % 4) == 0 && (h.M % 4) == 0 && (g.lda % 4) == 0 && (h.lda % 4) == 0 && (g.b_seg_stride % 4) == 0 &&
                       al16(g.A) && al16(g.B) && al16(h.A) && al16(h.B) && al16(g.C) && al16(h.C);   // 16-byte pieces everywhere

@@ -801,7 +801,7 @@ hipError_t launch_mb_onepass(const MbPrep& pa, const MbLoss& la, hipStream_t st)
     // keys in registers where they fit (mb_infonce_fast_kernel), else the general kernel (keys re-read from L2)
     const int NK = la.NN + 1, nch = (la.D / 4 + 63) / 64;
     const bool fast = la.D % 4 == 0 && la.D >= 4 && la.D <= 1024 && la.K <= 64 && ((NK + 3) / 4) * nch <= 16 &&
-                      !(getenv("CMLPL_MB_FAST") && atoi(getenv("CMLPL_MB_FAST")) == 0);
+                      switches().mb_fast != 0;
     const size_t lds = (size_t)4 * la.D * 4;
     if (fast && nch == 1) hipLaunchKernelGGL(mb_infonce_fast_kernel<1>, dim3(la.Q, la.K), dim3(256), lds, st, la);
     else if (fast && nch == 2) hipLaunchKernelGGL(mb_infonce_fast_kernel<2>, dim3(la.Q, la.K), dim3(256), lds, st, la);
@@ -1256,8 +1256,8 @@ size_t unsup_ws_bytes(int B) { return ((size_t)3 * B + 16) * 4; }
 
 hipError_t launch_unsup(const float* predict, long long* target, const float* teacher, int B, int K, double percent,
                         float* loss, float* dpredict, void* ws, hipStream_t st) {
-  static const bool onewg_off = getenv("CMLPL_UNSUP_ONEWG") && atoi(getenv("CMLPL_UNSUP_ONEWG")) == 0;
-  static const bool three_off = getenv("CMLPL_UNSUP_3L") && atoi(getenv("CMLPL_UNSUP_3L")) == 0;
+  const bool onewg_off = switches().unsup_onewg == 0;
+  const bool three_off = switches().unsup_3l == 0;
   if (B > US1_T && B <= US1_T * US1_R && !onewg_off && !three_off) {
     float* ent3 = (float*)ws;                          // [B]
     float* bpart = ent3 + B;                            // [blocks]

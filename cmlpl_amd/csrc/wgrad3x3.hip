@@ -759,14 +759,14 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
   if (RU == 0) return false;
   const int UPS = (RO + RU - 1) / RU;
   const long long NU = (long long)n * UPS;
-  static const int force_u = getenv("CMLPL_WGRAD3_U") ? atoi(getenv("CMLPL_WGRAD3_U")) : 0;
+  const int force_u = switches().wgrad3_u;
   int U = 1;
   while (U < 8 && wgrad3_lds(RU, U + 1, W) <= LDS_MAX && (NU + U) / (U + 1) >= 128) ++U;
   if (force_u > 0 && wgrad3_lds(RU, force_u, W) <= LDS_MAX) U = force_u;
   // Experiment (CMLPL_WGRAD3_CSPL=2): split the output channels over two workgroups and walk the units one at
   // a time so that 2-3 workgroups are co-resident per CU.  Measured on B2/256: 67.5 us vs 59.0 us for conv1 --
   // the image is staged twice and that costs more than the overlap buys -- so it is off by default.
-  static const int force_c = getenv("CMLPL_WGRAD3_CSPL") ? atoi(getenv("CMLPL_WGRAD3_CSPL")) : 0;
+  const int force_c = switches().wgrad3_cspl;
   p->cspl = 1;
   if (force_c == 2 && wgrad3_lds(RU, 1, W, 2) <= LDS_MAX) {
     p->cspl = 2;
@@ -780,9 +780,9 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
   p->rsplit = 0; p->UPG = 0; p->b3 = 0;
   const int CO = 2 * (W / 2);
   // row-split kernel: blockIdx.z = kernel row; units of one pooled row, U (even) per stage
-  static const int rsp = getenv("CMLPL_WGRAD3_R") ? atoi(getenv("CMLPL_WGRAD3_R")) : 1;
-  static const int force_ru = getenv("CMLPL_WGRAD3_RU") ? atoi(getenv("CMLPL_WGRAD3_RU")) : 0;
-  static const int force_rg = getenv("CMLPL_WGRAD3_RG") ? atoi(getenv("CMLPL_WGRAD3_RG")) : 0;
+  const int rsp = switches().wgrad3_r;
+  const int force_ru = switches().wgrad3_ru;
+  const int force_rg = switches().wgrad3_rg;
   if (rsp && p->cspl == 1 && CO >= 2 && (long long)n * H * W * 64 < (1LL << 31)) {
     const int PW = W + 2, cpr = CO / 2;
     const long long NUr = (long long)n * (H / 2);
@@ -796,8 +796,8 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
     // row 36.5 + 13.3 us, (36, 16) 38.2 + 12.4, (32, 16) 33.8 + 12.2, (32, 12) 33.5 + 12.1, (28, 12) 37.9 + 11.9.  The
     // second map's workgroup count must not exceed the CUs left over: stragglers of a second round run on after the first
     // map has finished (512 + 512 rows on one GPU: 0.680 -> 0.703 ms with 72 workgroups for 64 CUs).
-    static const int force_pg1 = getenv("CMLPL_WGRAD3_PG1") ? atoi(getenv("CMLPL_WGRAD3_PG1")) : 0;
-    static const int force_pg2 = getenv("CMLPL_WGRAD3_PG2") ? atoi(getenv("CMLPL_WGRAD3_PG2")) : 0;
+    const int force_pg1 = switches().wgrad3_pg1;
+    const int force_pg2 = switches().wgrad3_pg2;
     if (role == 1) { Gt = (CUS * 3 / 4) / (3 * nets); if (force_pg1 > 0) Gt = force_pg1; }
     if (role == 2) {
       long long g1 = (CUS * 3 / 4) / (3 * nets);
@@ -811,7 +811,7 @@ bool plan_wgrad3(int nets, int n, int H, int W, Wgrad3Plan* p, int role) {
     const size_t red = (size_t)(4 * 48 * 64 + 512 * 4) * 4;   // fold area + per-thread bias sums
     // split-bf16 variant (default wherever two three-piece stage buffers fit in LDS: every window the 3x3 kernels
     // themselves can hold)
-    static const int b3on = getenv("CMLPL_WGRAD3_B3") ? atoi(getenv("CMLPL_WGRAD3_B3")) : 1;
+    const int b3on = switches().wgrad3_b3;
     if (b3on && cpr <= WG3B_MAXCPR) {
       const int Ub = wg3b_U(cpr);
       long long upgb = (NUr + Gt - 1) / Gt;
@@ -915,7 +915,7 @@ static bool wgrad3_pair_instantiated(int ca, int cb) {
 }
 bool plan_wgrad3_both(int nets, int n, int H1, int W1, int H2, int W2, bool want_pair, Wgrad3Plan* p1, Wgrad3Plan* p2,
                       bool* pair) {
-  static const bool off = getenv("CMLPL_WGRAD3_PAIR") && atoi(getenv("CMLPL_WGRAD3_PAIR")) == 0;
+  const bool off = switches().wgrad3_pair == 0;
   *pair = false;
   if (!plan_wgrad3(nets, n, H1, W1, p1, 0) || !plan_wgrad3(nets, n, H2, W2, p2, 0)) return false;
   if (want_pair && !off && p1->b3 && p2->b3 && wgrad3_pair_instantiated(p1->rsplit, p2->rsplit)) {

@@ -420,7 +420,8 @@ class DistTrainEngine(TrainEngine):
                    lab_idx=lab_idx, unl_idx=unl_idx)
 
     def capture(self, *a, **k):
-        raise NotImplementedError("the sharded step is not captured: its collectives run between the launches")
+        raise RuntimeError("the sharded step cannot be captured as one graph: its collectives run between the launches "
+                           "(replay is a single-GPU feature; run sharded steps eagerly)")
 
     def outputs(self):
         """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..], in global row order [labelled of all

@@ -257,6 +257,139 @@ __global__ __launch_bounds__(256) void ntx_grad_kernel(NtxArgs a, int CT) {
   }
 }
 
+// The gradient on the MFMA (D a multiple of 4, 16-byte aligned rows: the case that matters; ntx_grad_kernel above keeps
+// the rest).  One workgroup per (16 rows a, 64 embedding columns d) -- 256 of them at 2B = 256, D = 1024 where the
+// vector version had 128 and spent 33 us streaming rows through 8 x 256 fused multiply-adds per thread.  The prologue is
+// the same (denominators of all rows, this workgroup's rows of W = G + G^T, z_a . dz_a), but W goes to LDS TRANSPOSED and
+// already divided by |x_b| -- Wt[b][a] = W[a][b] / |x_b| is the A operand of dz = Wt^T . x, complete before the first
+// multiply -- and only the embedding rows are staged: chunks of 64 rows x 64 columns in 16-byte pieces, two chunks in
+// flight in registers, double-buffered in LDS, one barrier per chunk; wave w owns columns 16 w .. 16 w + 15 on
+// v_mfma_f32_16x16x4_f32.
+constexpr int NTG_R = 16, NTG_KC = 64, NTG_BS = 80;      // rows per workgroup; chunk rows; LDS row stride of a chunk (64 + 16)
+
+__global__ __launch_bounds__(256) void ntx_grad_mfma_kernel(NtxArgs a, int CT) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // iden[N2] | inrm[N2] | red[64] | Wt[N2p][16] | xs[2][KC][BS]
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N2 = 2 * a.B, D = a.D, B = a.B;
+  const int N2p = ((N2 + NTG_KC - 1) / NTG_KC) * NTG_KC;            // rows of Wt, padded to whole chunks (zeros)
+  const int r0 = blockIdx.x * NTG_R, d0 = blockIdx.y * 64;
+  float* iden = sm;
+  float* inrm = iden + N2;
+  float* red = inrm + N2;
+  float* Wt = sm + (((2 * N2 + 64) + 3) & ~3);                       // [N2p][16], 16-byte aligned
+  float* xs = Wt + (size_t)N2p * NTG_R;                             // [2][NTG_KC][NTG_BS]
+  const float invT = 1.f / a.T, sc = 1.f / (a.T * (float)N2);
+  // ---- the first two chunks of embedding rows are requested before anything else
+  const int rb = tid >> 4, cb = (tid & 15) * 4;                     // piece q: row rb + 16 q of the chunk, floats cb .. cb + 3
+  const bool b_ok = d0 + cb < D;
+  auto fetch = [&](int k0, float4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = k0 + rb + 16 * q;
+      const float4 y = *(const float4*)(ntx_row(a, r < N2 ? r : 0) + (b_ok ? d0 + cb : 0));
+      v[q] = (r < N2 && b_ok) ? y : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&](int buf, const float4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(float4*)(xs + (size_t)buf * NTG_KC * NTG_BS + (rb + 16 * q) * NTG_BS + cb) = make_float4(v[q].x, v[q].y, v[q].z, v[q].w);
+  };
+  const int NC = N2p / NTG_KC;
+  float4 v0[4], v1[4];
+  fetch(0, v0);
+  if (NC > 1) fetch(NTG_KC, v1);
+  // ---- denominators of all rows (column tiles summed in index order), and the loss (workgroup (0, 0))
+  float lsum = 0.f;
+  for (int b = tid; b < N2; b += 256) {
+    float den = 0.f;
+    for (int c0 = 0; c0 < CT; c0 += 8) {               // eight partials requested together, added in index order
+      float pv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pv[q] = a.rs_part[(long long)(c0 + q < CT ? c0 + q : CT - 1) * N2 + b];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) den += (c0 + q < CT) ? pv[q] : 0.f;
+    }
+    iden[b] = 1.f / den;
+    inrm[b] = 1.f / a.nrm[b];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+      const int p = (b < B) ? b + B : b - B;
+      lsum += logf(den) - a.S[(long long)b * N2 + p] * invT;          // -log(exp(S_ap / T) / den_a)
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wave] = lsum;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)N2;
+  // ---- this workgroup's rows of W = G + G^T (transposed, scaled by 1 / |x_b|), and z_a . dz_a = sum_b W[a][b] S[a][b]
+  float dotp[NTG_R];
+#pragma unroll
+  for (int i = 0; i < NTG_R; ++i) dotp[i] = 0.f;
+  for (int b = tid; b < N2p; b += 256) {
+    const bool bv = b < N2;
+    const float idb = bv ? iden[b] : 0.f, inb = bv ? inrm[b] : 0.f;
+    float sv[NTG_R];                                     // the sixteen similarities first (unconditional loads)
+#pragma unroll
+    for (int i = 0; i < NTG_R; ++i) sv[i] = a.S[(long long)(r0 + i < N2 ? r0 + i : N2 - 1) * N2 + (bv ? b : 0)];
+    float wr[NTG_R];
+#pragma unroll
+    for (int i = 0; i < NTG_R; ++i) {
+      const int ra = r0 + i;
+      const int rc = ra < N2 ? ra : N2 - 1;
+      const int p = (ra < B) ? ra + B : ra - B;
+      const float wv = (expf(sv[i] * invT) * (iden[rc] + idb) - (b == p ? 2.f : 0.f)) * sc;
+      const float w = (bv && ra < N2 && b != ra) ? wv : 0.f;
+      dotp[i] = fmaf(w, sv[i], dotp[i]);
+      wr[i] = w * inb;
+    }
+#pragma unroll
+    for (int i = 0; i < NTG_R; i += 4) *(float4*)(Wt + (size_t)b * NTG_R + i) = make_float4(wr[i], wr[i + 1], wr[i + 2], wr[i + 3]);
+  }
+  __syncthreads();                               // (also: red[] has been read)
+#pragma unroll
+  for (int i = 0; i < NTG_R; ++i) {
+    const float v = wave_sum(dotp[i]);
+    if (lane == 0) red[wave * 16 + i] = v;
+  }
+  // ---- dz[a][d] = sum_b Wt[b][a] x[b][d]
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  stage(0, v0);
+  if (NC > 2) fetch(2 * NTG_KC, v0);
+  for (int c = 0; c < NC; ++c) {
+    __syncthreads();                             // chunk c staged (and, c = 0: Wt, red complete); the other buffer is free
+    if (c + 1 < NC) {
+      if ((c & 1) == 0) { stage(1, v1); if (c + 3 < NC) fetch((c + 3) * NTG_KC, v1); }
+      else              { stage(0, v0); if (c + 3 < NC) fetch((c + 3) * NTG_KC, v0); }
+    }
+    const float* as = Wt + (size_t)(c * NTG_KC + kq) * NTG_R + l16;
+    const float* bs = xs + (size_t)(c & 1) * NTG_KC * NTG_BS + kq * NTG_BS + wave * 16 + l16;
+    float av[NTG_KC / 4], bv[NTG_KC / 4];
+#pragma unroll
+    for (int k4 = 0; k4 < NTG_KC / 4; ++k4) { av[k4] = as[(4 * k4) * NTG_R]; bv[k4] = bs[(4 * k4) * NTG_BS]; }
+#pragma unroll
+    for (int k4 = 0; k4 < NTG_KC / 4; k4 += 2) {
+      acc  = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4], bv[k4], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4 + 1], bv[k4 + 1], acc2, 0, 0, 0);
+    }
+  }
+  // ---- backward of x / max(|x|, eps): D register r of lane l is row 4 (l >> 4) + r, column l & 15
+  const int d = d0 + wave * 16 + l16;
+  if (d >= D) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * kq + r, ra = r0 + i;
+    if (ra < N2) {
+      const float n = a.nrm[ra], z = ntx_row(a, ra)[d] * inrm[ra];
+      const float dot = (red[i] + red[16 + i]) + (red[32 + i] + red[48 + i]);
+      float* g = (ra < B) ? a.gi + (long long)ra * D : a.gj + (long long)(ra - B) * D;
+      g[d] = ((acc[r] + acc2[r]) - z * dot) / n;
+    }
+  }
+}
+
 size_t ntxent_ws_floats(int B, int D) {
   (void)D;
   const size_t N2 = 2 * (size_t)B, CT = (N2 + 31) / 32;
@@ -272,11 +405,22 @@ hipError_t launch_ntxent(const float* ei, const float* ej, int B, int D, float T
   a.S = ws; ws += N2 * N2;
   a.rs_part = ws; ws += (size_t)CT * N2;
   a.nrm = ws;
-  const size_t lds = (2 * N2 + (size_t)NTX_R * N2 + 64) * 4;
-  if (lds > 64 * 1024) return hipErrorInvalidValue;        // 2B <= 1600 rows
   hipLaunchKernelGGL(ntx_sim_kernel, dim3(CT, (unsigned)((N2 + 15) / 16)), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  // the MFMA gradient wherever the rows are whole 16-byte pieces (CMLPL_NTX_MFMA=0: the vector kernel always)
+  const size_t N2p = ((N2 + NTG_KC - 1) / NTG_KC) * NTG_KC;
+  const size_t lds_m = ((((2 * N2 + 64) + 3) & ~(size_t)3) + N2p * NTG_R + 2 * (size_t)NTG_KC * NTG_BS) * 4;
+  const bool aligned = D % 4 == 0 && (((uintptr_t)ei | (uintptr_t)ej) & 15) == 0;
+  if (aligned && switches().ntx_mfma != 0 && lds_m <= LDS_MAX) {
+    static DevOnce once;
+    if ((e = ensure_max_lds(once, ntx_grad_mfma_kernel)) != hipSuccess) return e;
+    hipLaunchKernelGGL(ntx_grad_mfma_kernel, dim3((unsigned)((N2 + NTG_R - 1) / NTG_R), (unsigned)((D + 63) / 64)), dim3(256),
+                       lds_m, st, a, CT);
+    return hipGetLastError();
+  }
+  const size_t lds = (2 * N2 + (size_t)NTX_R * N2 + 64) * 4;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;        // 2B <= 1600 rows
   hipLaunchKernelGGL(ntx_grad_kernel, dim3((unsigned)((N2 + NTX_R - 1) / NTX_R), (unsigned)((D + 255) / 256)), dim3(256),
                      lds, st, a, CT);
   return hipGetLastError();

@@ -44,6 +44,11 @@ def test_32_row_pair_exp_kernel_passes_loss_parity():
     _run({"CMLPL_PAIR16": "0"}, ["tests/test_gpu_ops.py", "tests/test_gpu_step.py", "-k", "loss_block or b2_64"])
 
 
+def test_vector_ntxent_gradient_kernel_passes_oracle_parity():
+    """ntx_grad_kernel (embedding widths that are not a multiple of 4) instead of ntx_grad_mfma_kernel"""
+    _run({"CMLPL_NTX_MFMA": "0"}, ["tests/test_ntxent.py"])
+
+
 def test_general_memobank_infonce_kernel_passes_losshelper_parity():
     """mb_infonce_all_kernel (keys re-read from L2; what D > 1024, K > 64 or more than 16 key slots per wave take) instead
     of the keys-in-registers kernel"""

@@ -283,7 +283,7 @@ def run_rank(args):
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29513", RANK="0", WORLD_SIZE="1")
         from cmlpl_amd.distributed import DistStartupError, DistTrainEngine, init_distributed
         try:     # checked start-up: one device per local rank, rendezvous and first collectives under a watchdog
-            dist = init_distributed(backend, device, timeout_s=float(os.environ.get("CMLPL_DIST_TIMEOUT", "180")),
+            dist = init_distributed(backend, device, timeout_s=float(os.environ.get("CMLPL_DIST_TIMEOUT", "300")),
                                     one_gpu=one_gpu)
         except DistStartupError as e:
             raise SystemExit(f"bench.py: {e}")

@@ -57,7 +57,7 @@ def _fail_after(seconds: float, what: str):
     return t
 
 
-def init_distributed(backend: str = "nccl", device: Optional[torch.device] = None, timeout_s: float = 180.0,
+def init_distributed(backend: str = "nccl", device: Optional[torch.device] = None, timeout_s: float = 300.0,
                      one_gpu: bool = False):
     """Create the process group of a one-process-per-GPU job and CHECK it before anything else runs on it.
 

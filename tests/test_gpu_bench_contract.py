@@ -42,6 +42,17 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert all(v == v for v in d["final_losses"].values())                               # finite
 
 
+def _run_bench_ranks(args, env, timeout):
+    """bench.py with its own ranks; exit code 3 is the start-up watchdog (cmlpl_amd.distributed: the rendezvous or the
+    first collective did not finish in time -- seen once on a box that was loading RCCL for the first time): such a
+    run is repeated ONCE, the library then being resident; any other failure is the test's."""
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+        if r.returncode != 3:
+            break
+    return r
+
+
 def test_bench_self_launch_path():
     """`python bench.py --gpus N` typed directly starts its own ranks (cmlpl_amd/launch.py).  One GPU here, so the
     spawn path is exercised at N = 1 (CMLPL_BENCH_SPAWN=1 forces it): the child is a real rank with its own
@@ -49,9 +60,8 @@ def test_bench_self_launch_path():
     env = dict(os.environ, CMLPL_BENCH_SPAWN="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
-                        "--workload", "B5", "--global-batch", "64+512"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    r = _run_bench_ranks(["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--workload", "B5",
+                          "--global-batch", "64+512"], env, 900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -68,8 +78,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     env = dict(os.environ, CMLPL_ONE_GPU="1", CMLPL_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "8", "--warmup", "2", "--workload", "B3"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    r = _run_bench_ranks(["--gpus", "2", "--steps", "8", "--warmup", "2", "--workload", "B3"], env, 900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines

@@ -522,10 +522,12 @@ int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
   carve_step(d, n, n, (char*)d_workspace + nw.bytes, &sw);
   if (nw.bytes + ((char*)sw.dlogits - ((char*)d_workspace + nw.bytes)) > workspace_bytes) return CMLPL_E_WORKSPACE;
   const bool copy = need_xn_copy(d, 2 * n);
-  // the patches as the forward saw them: the rows cmlpl_forward left in sw.xn (fused kernels: augmented, or plain copies
-  // when no noise is added -- the data gradient reads plain rows by batch row, it knows neither noise nor index lists)
-  const XSrc xs = !copy ? xsrc_plain(sw.xn, 2, n, (long long)d.C * d.HW, seed, step, shard, dyn)
-                        : xsrc_raw(batch, hp->noise_sigma, seed, step, shard, dyn);
+  // the patches as the forward saw them: sw.xn holds them in [nets][n][C*HW] layout either way -- written by the fused
+  // forward (augmented, or plain copies when no noise is added) or, when a conv0 pass fell back to the unfused kernels
+  // (`copy`), by the augmentation launch.  The fused data gradient reads plain rows by batch row: it knows neither noise
+  // nor index lists, so it must never be handed the raw batch (a 9x9 window at 128 + 128 rows plans an unfused forward
+  // and a fused backward: with the raw rows conv0's weight gradient came from un-augmented rows 0..n-1 of the split).
+  const XSrc xs = xsrc_plain(sw.xn, 2, n, (long long)d.C * d.HW, seed, step, shard, dyn);
   return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xs,
                   copy ? sw.xn : nullptr, sw.sn, d_dropmask, hp->dropout_p, train, d_dlogits, d_dfeat, d_grads,
                   grad_stride, nw, (hipStream_t)stream, dyn_cursor, dyn_cursor ? (cmlpl_dyn*)dyn.table : nullptr);
@@ -781,7 +783,9 @@ int cmlpl_step_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, c
   if (!io || !graph_out || !io->d_dyn_table || !io->d_dyn_cursor) return CMLPL_E_ARG;
   if (g_timing.on) return CMLPL_E_ARG;                     // (event pairs are not part of the product's graph)
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  hipError_t e = loss_prepare_capture();
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return (int)e;
   const int rc = cmlpl_train_step(shape, hp, io, stream);
   hipGraph_t g = nullptr;

@@ -1800,6 +1800,8 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
                                   const BwdHead* head, hipStream_t st) {
   Conv3Plan pl;
   if (!conv3_fused_bwd_ok(H, W, C, nets * n) || !plan_conv3(1, H, W, nets * n, &pl)) return hipErrorInvalidValue;
+  // slab_range() reads plain rows by batch row: no noise, no index lists (the rows the forward saw, api.hip)
+  if (xs.sigma != 0.f || xs.sel.lab_idx != nullptr || xs.sel.unl_idx != nullptr) return hipErrorInvalidValue;
   const int P2 = (H / 2) * (W / 2);
   Conv3Args a;
   a.in = dpool; a.mask_in = mask; a.wpk = wpk; a.bias = nullptr; a.out = nullptr; a.mask_out = nullptr;

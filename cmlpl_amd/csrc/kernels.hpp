@@ -240,6 +240,7 @@ struct LossArgs {
 size_t loss_ws_floats(int nlab, int nunl, int btu_g, int K, int Q);
 void loss_ws_carve(LossArgs& a, float* ws);
 hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st);
+hipError_t loss_prepare_capture();   // kernel attributes a captured step may need for the first time
 hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st);
 hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st);
 

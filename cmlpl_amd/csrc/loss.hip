@@ -590,7 +590,7 @@ template <int MB, int CG, int NBW>
 __global__ __launch_bounds__(128 * MB * CG) void pair_exp_wide_kernel(LossArgs a) {
   typedef WideCfg<MB, CG, NBW> Cf;
   constexpr int MT = Cf::MT, NT = Cf::NT, RP = Cf::RP, NA = Cf::NA, NBL = Cf::NBL, NTP = Cf::NTP, BPS = Cf::BPS;
-  constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, NTHR = Cf::NTHR;
+  constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE;
   constexpr int NL = FD / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][STAGE]; then the k-half exchange and the E / p tiles
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -1210,15 +1210,30 @@ __global__ __launch_bounds__(256) void loss_dfeat_kernel(GemmTN2 t, int gemm_blo
 }
 
 template <int MB, int CG, int NBW>
-static hipError_t launch_pair_wide(const LossArgs& a, int maxc, hipStream_t st) {
+static hipError_t launch_pair_wide(const LossArgs& a, int maxc, hipStream_t st, bool attr_only = false) {
   typedef WideCfg<MB, CG, NBW> Cf;
   constexpr size_t lds = Cf::LDS_FL * 4;
   static DevOnce once;
   hipError_t e = ensure_max_lds(once, pair_exp_wide_kernel<MB, CG, NBW>);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || attr_only) return e;
   hipLaunchKernelGGL((pair_exp_wide_kernel<MB, CG, NBW>), dim3((maxc + Cf::NT - 1) / Cf::NT, (a.nunl + Cf::MT - 1) / Cf::MT, 3),
                      dim3(Cf::NTHR), lds, st, a);
   return hipGetLastError();
+}
+
+// A captured step picks its pair_exp kernel for the banks' width whatever the smoothing gate says (the gate is read on
+// the device), while the eager warm-up step in front of the capture may have run a narrow kernel (gate closed): the
+// wide kernels' LDS attribute must not be set for the first time INSIDE the capture, so cmlpl_step_graph_create sets
+// all of them before it begins.
+hipError_t loss_prepare_capture() {
+  const LossArgs a = LossArgs();
+  hipError_t e;
+  if ((e = launch_pair_wide<4, 1, 1>(a, 0, nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_pair_wide<4, 1, 2>(a, 0, nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_pair_wide<4, 1, 3>(a, 0, nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_pair_wide<4, 1, 4>(a, 0, nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_pair_wide<2, 2, 1>(a, 0, nullptr, true)) != hipSuccess) return e;
+  return launch_pair_wide<2, 2, 2>(a, 0, nullptr, true);
 }
 
 hipError_t launch_loss_phase1(const LossArgs& a_in, hipStream_t st) {

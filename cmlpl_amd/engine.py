@@ -13,8 +13,13 @@ from typing import Dict, Optional, Sequence
 
 import torch
 
+import os
+import weakref
+
 from . import _lib
 from .config import FEAT_DIM, HyperParams, NetShape
+
+_CHECK_INDICES = os.environ.get("CMLPL_CHECK_INDICES", "0") not in ("", "0")
 
 SCALAR_NAMES = ("ctr_s", "total_s", "cls_s", "con_s", "acc", "total_w", "cls_w", "con_w", "ctr_w",
                 "n_mask_w", "n_mask_s", "n_pos", "n_neg")
@@ -86,6 +91,7 @@ class TrainEngine:
         self._io = _lib.StepIO()
         self._fill_state(self._io)
         self._checked = None
+        self._graph = None          # weak reference to the StepGraph that has programmed replays (see step())
 
     @property
     def scalars(self) -> torch.Tensor:
@@ -163,7 +169,8 @@ class TrainEngine:
             # the same resident splits as last time (by identity and storage): only the index lists are new
             key = (id(XPl), id(Xl), id(Y), id(XPu), id(Xu), XPl.data_ptr(), XPu.data_ptr(), XPl.shape[0], XPu.shape[0])
             if key == self._checked and lab_idx.dtype == torch.int64 and unl_idx.dtype == torch.int64 \
-                    and lab_idx.is_cuda and unl_idx.is_cuda and lab_idx.dim() == 1 and unl_idx.dim() == 1:
+                    and lab_idx.is_cuda and unl_idx.is_cuda and lab_idx.dim() == 1 and unl_idx.dim() == 1 \
+                    and lab_idx.is_contiguous() and unl_idx.is_contiguous():
                 bt, btu = lab_idx.shape[0], unl_idx.shape[0]
                 if 1 <= bt <= self.bt_max and btu >= 1 and bt + btu <= self.n_max:
                     return bt, btu
@@ -185,6 +192,18 @@ class TrainEngine:
         if lab_idx is not None:
             self._checked = (id(XPl), id(Xl), id(Y), id(XPu), id(Xu), XPl.data_ptr(), XPu.data_ptr(), XPl.shape[0], XPu.shape[0])
         return bt, btu
+
+    @staticmethod
+    def check_index_range(idx: torch.Tensor, rows: int, name: str = "index") -> None:
+        """Every entry of an index list inside [0, rows): the kernels follow the indices without a bounds check, so a
+        stale or corrupt permutation would be an out-of-bounds device read.  One synchronising min / max: call it
+        where a list is FILLED (the loader's per-epoch permutation, StepGraph's buffers), not per step;
+        ``CMLPL_CHECK_INDICES=1`` makes ``step()`` call it on every batch (bring-up only)."""
+        if idx.numel() == 0:
+            return
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= rows:
+            raise ValueError(f"{name}: entries span [{lo}, {hi}], the resident split has {rows} rows")
 
     def _fill_io(self, io, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu):
         io.d_xpl, io.d_xl, io.d_labels = XPl.data_ptr(), Xl.data_ptr(), Y.data_ptr()
@@ -229,7 +248,15 @@ class TrainEngine:
                    no gathered copy of the batch is made (noise / dropmask stay indexed by batch row)
         """
         s = self.shape
+        g = self._graph() if self._graph is not None else None
+        if g is not None and g.pending > 0:
+            # the remaining replays were programmed from the state BEFORE this step (counters, bank pointers, Adam step)
+            raise RuntimeError(f"{g.pending} programmed graph replays are pending: launch them (or program() anew) "
+                               "before an eager step")
         bt, btu = self._check_rows(XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
+        if _CHECK_INDICES and lab_idx is not None:
+            self.check_index_range(lab_idx, XPl.shape[0], "lab_idx")
+            self.check_index_range(unl_idx, XPu.shape[0], "unl_idx")
         n = bt + btu
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._ensure_packed(stream)
@@ -311,7 +338,9 @@ class StepGraph:
     table of ``cmlpl_dyn`` rows that ``program()`` fills for a run of steps ahead of time (an epoch, say); a device
     cursor walks it, advanced by the step itself.  ``launch()`` is then ONE hipGraphLaunch per step: no arguments to
     marshal, nothing else enqueued.  The engine's host-side bookkeeping advances exactly as in ``TrainEngine.step``,
-    so eager steps and replays can be mixed (an epoch's short last batch runs eagerly: its shape is not the graph's).
+    so eager steps and replays can be mixed (an epoch's short last batch runs eagerly: its shape is not the graph's)
+    -- but only BETWEEN programs: an eager step while programmed replays are pending raises (their rows were formed
+    from the state before it).
     """
 
     def __init__(self, eng: TrainEngine, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt: int, btu: int, capacity: int = 1024):
@@ -321,8 +350,12 @@ class StepGraph:
             raise ValueError("a captured step reads its rows through index buffers")
         if lab_idx.shape[0] < bt or unl_idx.shape[0] < btu:
             raise ValueError("index buffers shorter than one batch")
+        for name, t in (("lab_idx", lab_idx), ("unl_idx", unl_idx)):
+            if t.dtype != torch.int64 or t.dim() != 1 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError(f"{name}: need a contiguous int64 cuda vector")
         eng._check_rows(XPl, Xl, Y, XPu, Xu, lab_idx[:bt], unl_idx[:btu])
         self._keep = (XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
+        self.validate_indices()
         self.n_lab_idx, self.n_unl_idx = int(lab_idx.shape[0]), int(unl_idx.shape[0])
         dev = eng.device
         # row 0 = the working copy the kernels read, rows 1 .. k the programmed steps, one spare row behind them
@@ -351,6 +384,13 @@ class StepGraph:
                 C.byref(eng.cshape), C.byref(eng._chp), C.byref(io), C.c_void_p(cap.cuda_stream), C.byref(handle)))
         torch.cuda.current_stream(dev).wait_stream(cap)
         self.handle = handle
+
+    def validate_indices(self) -> None:
+        """Range check of the two index buffers (synchronising): at capture, and whenever the caller has re-filled them
+        in place and wants the check (the kernels follow the indices blindly)."""
+        XPl, _, _, XPu, _, lab_idx, unl_idx = self._keep
+        TrainEngine.check_index_range(lab_idx, XPl.shape[0], "lab_idx")
+        TrainEngine.check_index_range(unl_idx, XPu.shape[0], "unl_idx")
 
     def program(self, steps) -> None:
         """``steps``: (epoch, batch_index, lab_off, unl_off) of the next replays, in order.  Fills the table from the
@@ -393,6 +433,7 @@ class StepGraph:
         self.table[:k].copy_(self.host[:k], non_blocking=True)
         self.cursor.fill_(1)
         self.pending = len(steps)
+        eng._graph = weakref.ref(self)
         # (the pinned staging rows may be rewritten only after that copy has run)
         self._copied = torch.cuda.Event()
         self._copied.record(torch.cuda.current_stream(eng.device))
@@ -403,6 +444,7 @@ class StepGraph:
         if self.pending < 1:
             raise RuntimeError("no programmed step left: call program() first")
         stream = C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+        eng._ensure_packed(stream)            # set_params / load_state_dict between replays: the packed copies follow
         _lib.check("cmlpl_step_graph_launch", eng.lib.cmlpl_step_graph_launch(self.handle, stream))
         eng._cur_row = eng.step_count % eng.hist_rows
         eng._advance(self.bt + self.btu, True)

@@ -50,6 +50,13 @@ def _run_bench_ranks(args, env, timeout):
         r = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
         if r.returncode != 3:
             break
+        # a watchdog exit is made visible (pytest -rP / the captured output of a failing run): a RECURRING one is a
+        # real rendezvous / first-collective hang, not a cold library
+        print(f"[bench-retry] bench.py {' '.join(args)} ended with the start-up watchdog (exit 3) on attempt {attempt + 1}:\n"
+              f"{r.stderr[-1500:]}", file=sys.stderr)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_retries.log"), "a") as f:
+            f.write(f"attempt {attempt + 1}: bench.py {' '.join(args)} -> exit 3\n{r.stderr[-1500:]}\n")
     return r
 
 

@@ -322,3 +322,47 @@ def test_device_noise_is_the_documented_generator():
             want = noise_normal4(seed, step, 0x100 + net, _ctr(row, groups)).T.reshape(-1)[:per]
             got = xn[net, row].cpu().numpy()
             assert np.abs(got - want).max() < 2e-5, (net, row, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("win,C", [(9, 30), (8, 103)])
+def test_step_by_index_where_forward_and_backward_plans_differ(win, C):
+    """A 9x9 window at 128 + 128 rows plans an UNFUSED forward (two samples per conv1 workgroup) and a FUSED data
+    gradient: conv0's weight gradient must then come from the rows the forward saw (augmented, taken through the index
+    lists) -- the fused data gradient reads plain rows by batch row, so it has to be handed the augmented copy in the
+    workspace, never the raw batch (round 4 handed it the raw batch).  Batches by index into larger resident splits,
+    explicit noise on, every gradient against the oracle on the gathered rows; 8x8 (fused both ways) rides along."""
+    from cmlpl_amd import TrainEngine
+    shape = O.NetShape(C, win, win, 103, 9)
+    bt = btu = 128
+    n = bt + btu
+    hp = O.HyperParams()
+    p0, p1 = O.closed_form_params(shape, 51), O.closed_form_params(shape, 52)
+    eng = TrainEngine(to_shape(shape), bt, btu, to_hp(hp), device=DEV)
+    eng.load_state_dict(0, p0); eng.load_state_dict(1, p1)
+    st = O.StepState.create(shape, p0, p1, bt, hp)
+    g = torch.Generator().manual_seed(9)
+    NL, NU = 200, 333
+    for s in range(2):
+        b = O.synthetic_batch(shape, bt, btu, 7700 + s)
+        li, ui = torch.randperm(NL, generator=g)[:bt], torch.randperm(NU, generator=g)[:btu]
+        # resident splits: the batch rows scattered to positions li / ui, other rows filled with junk the step must not see
+        XPl = torch.full((NL, C, win, win), 7.0); Xl = torch.full((NL, 103), -5.0); Y = torch.zeros(NL, dtype=torch.int64)
+        XPu = torch.full((NU, C, win, win), -9.0); Xu = torch.full((NU, 103), 3.0)
+        XPl[li], Xl[li], Y[li] = b["XPl"], b["Xl"], b["Y"]
+        XPu[ui], Xu[ui] = b["XPu"], b["Xu"]
+        cb = cuda_batch(b)
+        eng.step(XPl.to(DEV), Xl.to(DEV), Y.to(DEV), XPu.to(DEV), Xu.to(DEV), 1, s, noise=cb["noise"],
+                 dropmask=cb["dropmask"], lab_idx=li.to(DEV), unl_idx=ui.to(DEV))
+        gates = hip_relu_gates(eng, shape, n)
+        ref = O.train_step(st, b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], b["noise"], b["dropmask"], 1, s, hp,
+                           relu_gates=gates)
+        sc = eng.read_scalars()
+        for k in ("ctr_s", "total_s", "cls_s", "con_s", "total_w", "cls_w", "con_w", "ctr_w"):
+            want = float(ref[k].detach())
+            assert abs(sc[k] - want) <= LOSS_RTOL * abs(want) + 1e-6, (s, k, sc[k], want)
+        relu_mask_audit(eng, ref["taps"], shape, n, ztol_y=2e-5 + 0.25 * hp.lr * s)
+        for net in range(2):
+            for k in O.LIVE_KEYS:
+                gr = ref["grads"][net][k]
+                mx = max(float(gr.abs().max()), 1e-4)
+                report(f"[{win}x{win}] step {s} grad[{net}] {k}", eng.grad(net, k), gr, 5e-4, 5e-5 * mx)

@@ -132,7 +132,8 @@ def main(args, make_engine=None, device=None):
             loss_hist[pending] = eng.loss_window(len(pending))
             pending.clear()
     by_index = getattr(eng, "takes_indices", False)
-    use_graph = bool(args.graph) and world == 1 and by_index
+    # (a split smaller than one batch has no full batch to replay: such a run stays eager)
+    use_graph = bool(args.graph) and world == 1 and by_index and len(lab_loader.X) >= bt and len(unl_loader.X) >= btu
     graph = None
     t_start = time.time()
     t_warm, steps_warm = t_start, 0

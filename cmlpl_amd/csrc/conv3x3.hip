@@ -180,11 +180,12 @@ __device__ __forceinline__ SlabRange slab_range(const XSrc& x, int net, int s, i
   r.nfl = nfl;
   return r;
 }
+template <int NW = 4>
 __device__ __forceinline__ void slab_issue(const SlabRange& r, float* slab, int wave, int lane) {
   const int nf4 = r.nfl >> 2;
 #pragma unroll
-  for (int k = 0; k < SLAB_MAXQ; ++k) {
-    const int q = wave + 4 * k;                           // wave-uniform
+  for (int k = 0; k < SLAB_MAXQ * 4 / NW; ++k) {
+    const int q = wave + NW * k;                          // wave-uniform
     if (q * 64 < nf4) {
       const int f = q * 64 + lane;
       if (f < nf4) __builtin_amdgcn_global_load_lds((slab_gbl_void*)(r.xs + 4 * f), (slab_lds_void*)(slab + q * 256), 16, 0, 0);
@@ -379,17 +380,22 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
 // w and hands the other tile of its pair to wave w ^ 1 (see conv3_ks_fold).
 // Unit = (tile t, k-step q): two ds_read_b128 of raw activations, their split, 12 MFMAs; units are pipelined as in
 // tap_step (raw reads two units ahead, split one unit ahead between the MFMAs).
-template <int I>
-__device__ __forceinline__ void ks_unit(const float* __restrict__ img, const int (&abase)[2], f32x16 (&acc)[2][2],
+// TPW = M tiles per wave: 2 in the four-wave workgroups (wave = (pixel half, channel half), two workgroups per CU), 1 in
+// the eight-wave workgroups (wave = (pixel tile, channel half): ONE sample-net per CU, two waves per SIMD, half the
+// MFMAs, splits and fragment reads per wave -- what a rank of a data-parallel job launches when its sample-net
+// workgroups do not exceed the CUs).  Units of a tap: I = 0 .. 2 TPW - 1, tile t = I % TPW, k-step q = I / TPW.
+template <int I, int TPW>
+__device__ __forceinline__ void ks_unit(const float* __restrict__ img, const int (&abase)[TPW], f32x16 (&acc)[TPW][2],
                                         ASplit& cur, float4& rn0, float4& rn1, const uint4 (&bq)[2][6], int s,
                                         int kh, int PW) {
-  constexpr int t = I & 1, q = I >> 1;
+  constexpr int U = 2 * TPW;
+  constexpr int t = I % TPW, q = I / TPW;
   // raw reads of unit u + 2
   float4 rnn0, rnn1;
   {
-    constexpr int I2 = (I + 2) & 3;
-    constexpr int t2 = I2 & 1, q2 = I2 >> 1;
-    const int s2 = (I + 2 >= 4) ? (s + 1 < 9 ? s + 1 : 8) : s;
+    constexpr int I2 = (I + 2) % U;
+    constexpr int t2 = I2 % TPW, q2 = I2 / TPW;
+    const int s2 = (I + 2 >= U) ? (s + 1 < 9 ? s + 1 : 8) : s;
     const int kh2 = s2 / 3, kw2 = s2 - kh2 * 3;
     const float* p = img + abase[t2] + ((kh2 - 1) * PW + (kw2 - 1)) * CS + (2 * kh + q2) * 16;
     rnn0 = *(const float4*)p; rnn1 = *(const float4*)(p + 4);
@@ -404,10 +410,10 @@ __device__ __forceinline__ void ks_unit(const float* __restrict__ img, const int
   cur = nxt; rn0 = rnn0; rn1 = rnn1;
 }
 
-// one tap of conv3_taps_ks: request the next tap's fragments into `nb`, run this tap's four units on `bq`
-template <class Side>
-__device__ __forceinline__ void ks_tap(const float* __restrict__ img, const uint4* __restrict__ wq, const int (&abase)[2],
-                                       f32x16 (&acc)[2][2], ASplit& cur, float4& rn0, float4& rn1, const uint4 (&bq)[2][6],
+// one tap of conv3_taps_ks: request the next tap's fragments into `nb`, run this tap's units on `bq`
+template <int TPW, class Side>
+__device__ __forceinline__ void ks_tap(const float* __restrict__ img, const uint4* __restrict__ wq, const int (&abase)[TPW],
+                                       f32x16 (&acc)[TPW][2], ASplit& cur, float4& rn0, float4& rn1, const uint4 (&bq)[2][6],
                                        uint4 (&nb)[2][6], int s, int kh, int PW, bool active, Side& side) {
   if (s + 1 < 9) {
 #pragma unroll
@@ -418,16 +424,18 @@ __device__ __forceinline__ void ks_tap(const float* __restrict__ img, const uint
   }
   side(s);
   if (active) {        // wave-uniform: a pixel half without real pixels (HW <= 64) only keeps the barriers' company
-    ks_unit<0>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
-    ks_unit<1>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
-    ks_unit<2>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
-    ks_unit<3>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    ks_unit<0, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    ks_unit<1, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    if constexpr (TPW == 2) {
+      ks_unit<2, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+      ks_unit<3, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW);
+    }
   }
 }
 
-template <class Side = NoSide>
+template <int TPW, class Side = NoSide>
 __device__ __forceinline__ void conv3_taps_ks(const float* __restrict__ img, const uint4* __restrict__ wq,
-                                              const int (&abase)[2], f32x16 (&acc)[2][2], int PW, int wave, bool active,
+                                              const int (&abase)[TPW], f32x16 (&acc)[TPW][2], int PW, int wave, bool active,
                                               Side side = Side()) {
   const int kh = wave & 1;
   // this wave's fragments of a tap: [k-step q][piece * 2 + n tile]; two sets that swap roles from tap to tap (taps in
@@ -442,33 +450,156 @@ __device__ __forceinline__ void conv3_taps_ks(const float* __restrict__ img, con
   {  // pipeline fill: units 0 and 1 of tap 0 (the staged image is complete: the caller's barrier)
     const float* p0 = img + abase[0] + (-PW - 1) * CS + (2 * kh) * 16;
     a_split(*(const float4*)p0, *(const float4*)(p0 + 4), cur.p1, cur.p2, cur.p3);
-    const float* p1 = img + abase[1] + (-PW - 1) * CS + (2 * kh) * 16;
+    // unit 1: the second tile's first k-step (TPW == 2) or this tile's second k-step (TPW == 1)
+    const float* p1 = img + abase[TPW - 1] + (-PW - 1) * CS + (2 * kh + (TPW == 1 ? 1 : 0)) * 16;
     rn0 = *(const float4*)p1; rn1 = *(const float4*)(p1 + 4);
   }
 #pragma unroll 1
   for (int s = 0; s < 8; s += 2) {
-    ks_tap(img, wq, abase, acc, cur, rn0, rn1, ba, bb, s, kh, PW, active, side);
-    ks_tap(img, wq, abase, acc, cur, rn0, rn1, bb, ba, s + 1, kh, PW, active, side);
+    ks_tap<TPW>(img, wq, abase, acc, cur, rn0, rn1, ba, bb, s, kh, PW, active, side);
+    ks_tap<TPW>(img, wq, abase, acc, cur, rn0, rn1, bb, ba, s + 1, kh, PW, active, side);
   }
-  ks_tap(img, wq, abase, acc, cur, rn0, rn1, ba, bb, 8, kh, PW, active, side);
+  ks_tap<TPW>(img, wq, abase, acc, cur, rn0, rn1, ba, bb, 8, kh, PW, active, side);
 }
 
-// After conv3_taps_ks: fold the two channel halves.  Wave w keeps tile w = 2mh + kh (acc[kh]) and gives acc[kh ^ 1]
-// to its partner w ^ 1, one n tile at a time through `x` (16 KiB: [4 waves][16][64] floats).  The caller's barrier
-// before (every wave out of its tap loop) and the last barrier here (x free again) are part of the protocol.
-template <int MTW>
-__device__ __forceinline__ void conv3_ks_fold(f32x16 (&acc)[2][2], f32x16 (&out)[MTW][2], float* x, int wave, int lane) {
-  const int kh = wave & 1;
+// Tap loop of the EIGHT-wave per-sample workgroups (one workgroup per CU).  Measured with conv3_taps_ks at eight waves
+// (round 5): a wave = (pixel tile, channel half) still needs its twelve fragments per tap, so eight waves pull 864 KB of
+// weight fragments per sample through the CU's vector-memory path where four pull 432 -- the loop got SLOWER (11.2 us
+// against 9.9 for a four-wave workgroup alone on its CU, matrix-pipe floor 6.6), and with nothing else resident every
+// tap waits out its own L2 round trip.  With the CU to itself the workgroup has the LDS for what two co-resident
+// workgroups could not afford: every tap's 24 KiB of fragments go global -> registers -> LDS ONCE per workgroup (three
+// 16-byte pieces per thread, requested two taps ahead), double-buffered (the tap-weight buffer and the fold's exchange
+// region), ONE barrier per tap; a wave reads a k-step's six fragments a unit ahead of their MFMAs.
+struct TapRegs8 { float4 w0, w1, w2; };
+__device__ __forceinline__ TapRegs8 tap_fetch8(const float4* wg, int tap, int tid) {
+  TapRegs8 t;
+  const float4* wn = wg + tap * TAPW + tid;
+  t.w0 = wn[0]; t.w1 = wn[512]; t.w2 = wn[1024];
+  return t;
+}
+__device__ __forceinline__ void tap_put8(float4* wl, const TapRegs8& t, int tid) {
+  wl[tid] = t.w0; wl[tid + 512] = t.w1; wl[tid + 1024] = t.w2;
+}
+
+// one unit (tile t = I % TPW, k-step q = I / TPW) with this unit's six fragments in `b`; on exit `b` holds the next
+// unit's (read from this tap's LDS copy when the k-step changes inside the tap)
+template <int I, int TPW>
+__device__ __forceinline__ void ks8_unit(const float* __restrict__ img, const uint4* __restrict__ fl, const int (&abase)[TPW],
+                                         f32x16 (&acc)[TPW][2], ASplit& cur, float4& rn0, float4& rn1, uint4 (&b)[6], int s,
+                                         int kh, int PW) {
+  constexpr int U = 2 * TPW;
+  constexpr int t = I % TPW, q = I / TPW;
+  constexpr bool next_q = (I + 1 < U) && ((I + 1) / TPW != q);
+  uint4 nb[6];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const f32x16 give = kh ? acc[0][nt] : acc[1][nt];
-    f32x16 own = kh ? acc[1][nt] : acc[0][nt];
+  for (int i = 0; i < 6; ++i) nb[i] = b[i];
+  if constexpr (next_q) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nb[i] = fl[((2 * kh + q + 1) * 6 + i) * 64];
+  }
+  float4 rnn0, rnn1;
+  {
+    constexpr int I2 = (I + 2) % U;
+    constexpr int t2 = I2 % TPW, q2 = I2 / TPW;
+    const int s2 = (I + 2 >= U) ? (s + 1 < 9 ? s + 1 : 8) : s;
+    const int kh2 = s2 / 3, kw2 = s2 - kh2 * 3;
+    const float* p = img + abase[t2] + ((kh2 - 1) * PW + (kw2 - 1)) * CS + (2 * kh + q2) * 16;
+    rnn0 = *(const float4*)p; rnn1 = *(const float4*)(p + 4);
+  }
+  acc[t][0] = mfma_b3(cur.p1, cur.p2, cur.p3, b[0], b[2], b[4], acc[t][0]);
+  acc[t][1] = mfma_b3(cur.p1, cur.p2, cur.p3, b[1], b[3], b[5], acc[t][1]);
+  ASplit nxt;
+  a_split(rn0, rn1, nxt.p1, nxt.p2, nxt.p3);
+  __builtin_amdgcn_sched_group_barrier(0x100, (next_q ? 6 : 0) + 2, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  SchedInterleave<8>::run();
+  cur = nxt; rn0 = rnn0; rn1 = rnn1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) b[i] = nb[i];
+}
+
+// One tap: its units on the fragments in `cb`, then the NEXT tap's fragments (register set `w`, requested two taps ago)
+// into the other buffer -- free since every wave passed the barrier that ended tap s - 1 -- the request for tap s + 3 into
+// the same set, and the barrier that ends the tap.
+template <int TPW, class Side>
+__device__ __forceinline__ void ks8_tap(const float* __restrict__ img, const float* cb, float* nbuf,
+                                        const float4* __restrict__ wg, TapRegs8& w, const int (&abase)[TPW],
+                                        f32x16 (&acc)[TPW][2], ASplit& cur, float4& rn0, float4& rn1, int s, int kh, int PW,
+                                        int tid, int lane, bool active, Side& side) {
+  side(s);
+  if (active) {
+    const uint4* fl = (const uint4*)cb + lane;
+    uint4 b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = fl[((2 * kh) * 6 + i) * 64];
+    ks8_unit<0, TPW>(img, fl, abase, acc, cur, rn0, rn1, b, s, kh, PW);
+    ks8_unit<1, TPW>(img, fl, abase, acc, cur, rn0, rn1, b, s, kh, PW);
+    if constexpr (TPW == 2) {
+      ks8_unit<2, TPW>(img, fl, abase, acc, cur, rn0, rn1, b, s, kh, PW);
+      ks8_unit<3, TPW>(img, fl, abase, acc, cur, rn0, rn1, b, s, kh, PW);
+    }
+  }
+  if (s + 1 < 9) tap_put8((float4*)nbuf, w, tid);
+  if (s + 3 < 9) w = tap_fetch8(wg, s + 3, tid);
+  __syncthreads();   // tap s is done everywhere (its buffer is free), tap s + 1's fragments are complete
+}
+
+// buf0 holds tap 0's fragments and `wa` tap 1's (in registers) on entry, published by the caller's barrier.  Two
+// register sets that take turns (taps in pairs), so that a tap's fragments have two tap bodies to arrive.
+template <int TPW, class Side = NoSide>
+__device__ __forceinline__ void conv3_taps_lds8(const float* __restrict__ img, float* buf0, float* buf1,
+                                                const float4* __restrict__ wg, TapRegs8 wa, const int (&abase)[TPW],
+                                                f32x16 (&acc)[TPW][2], int PW, int tid, int wave, int lane, bool active,
+                                                Side side = Side()) {
+  const int kh = wave & 1;
+  TapRegs8 wb = tap_fetch8(wg, 2, tid);
+  ASplit cur;
+  float4 rn0, rn1;
+  {  // pipeline fill: units 0 and 1 of tap 0
+    const float* p0 = img + abase[0] + (-PW - 1) * CS + (2 * kh) * 16;
+    a_split(*(const float4*)p0, *(const float4*)(p0 + 4), cur.p1, cur.p2, cur.p3);
+    const float* p1 = img + abase[TPW - 1] + (-PW - 1) * CS + (2 * kh + (TPW == 1 ? 1 : 0)) * 16;
+    rn0 = *(const float4*)p1; rn1 = *(const float4*)(p1 + 4);
+  }
+#pragma unroll 1
+  for (int s = 0; s < 8; s += 2) {
+    ks8_tap<TPW>(img, buf0, buf1, wg, wa, abase, acc, cur, rn0, rn1, s, kh, PW, tid, lane, active, side);
+    ks8_tap<TPW>(img, buf1, buf0, wg, wb, abase, acc, cur, rn0, rn1, s + 1, kh, PW, tid, lane, active, side);
+  }
+  ks8_tap<TPW>(img, buf0, buf1, wg, wa, abase, acc, cur, rn0, rn1, 8, kh, PW, tid, lane, active, side);
+}
+
+// After conv3_taps_ks: fold the two channel halves.  The caller's barrier before (every wave out of its tap loop) and
+// the last barrier here (x free again) are part of the protocol.
+//   TPW == 2: wave w keeps tile w = 2 (w >> 1) + kh (acc[kh]) and gives acc[kh ^ 1] to its partner w ^ 1, one n tile at
+//             a time through `x` (16 KiB: [4 waves][16][64] floats); out[nt] = the kept tile's n tile nt.
+//   TPW == 1: both waves of a pair hold the same tile; wave w keeps ITS n tile kh and gives n tile kh ^ 1, in one
+//             round through `x` ([8 waves][16][64] floats); out[0] = (tile w >> 1, n tile kh).
+template <int TPW>
+__device__ __forceinline__ void conv3_ks_fold(f32x16 (&acc)[TPW][2], f32x16 (&out)[TPW], float* x, int wave, int lane) {
+  const int kh = wave & 1;
+  if constexpr (TPW == 2) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x16 give = kh ? acc[0][nt] : acc[1][nt];
+      f32x16 own = kh ? acc[1][nt] : acc[0][nt];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[(wave * 16 + r) * 64 + lane] = give[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) own[r] += x[((wave ^ 1) * 16 + r) * 64 + lane];
+      out[nt] = own;
+      __syncthreads();
+    }
+  } else {
+    const f32x16 give = kh ? acc[0][0] : acc[0][1];
+    f32x16 own = kh ? acc[0][1] : acc[0][0];
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[(wave * 16 + r) * 64 + lane] = give[r];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) own[r] += x[((wave ^ 1) * 16 + r) * 64 + lane];
-    out[0][nt] = own;
+    out[0] = own;
     __syncthreads();
   }
 }
@@ -480,13 +611,16 @@ struct Conv3Ctx {
   int tid, lane, l31, hh, wave, net, s0, H, W, HW, PW, IMG, H2, W2, P2, RO, CO, PX, S, npx;
   float* img; float* wbuf; int* lut; const float4* wg;
   TapRegs wp;
-  f32x16 z0, z1;          // MODE 2: this wave's a0 tile (+ bias), stored to HBM from inside the tap loop
-  float* a0g;
+  TapRegs8 wp8;           // eight-wave workgroups: tap 1's fragments (tap 0's are in LDS when conv3_stage returns)
 };
 
-template <int MODE>
+// NW = waves of the workgroup: 4 (every MODE), or 8 for the per-sample kernels (MODE >= 2) when one workgroup has a CU
+// to itself (see ks_unit); NT = its threads, TPW = M tiles per wave in the tap loop.
+template <int MODE, int NW = 4>
 __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c,
                                             const float* dp_lds = nullptr, const uint32_t* mpre = nullptr) {
+  constexpr int NT = 64 * NW, TPW = 8 / NW;
+  static_assert(NW == 4 || (NW == 8 && MODE >= 2), "eight waves: per-sample kernels only");
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int net, s0;
@@ -514,7 +648,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   }
   const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
   // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
-  if (MODE < 2) c.wp = tap_fetch(wg, 0, tid);   // (the per-sample kernels fetch their fragments themselves)
+  if (MODE < 2) c.wp = tap_fetch(wg, 0, tid);   // (the four-wave per-sample kernels fetch their fragments themselves)
+  if constexpr (NW == 8 && MODE == 3) c.wp8 = tap_fetch8(wg, 0, tid);
   __syncthreads();
 
   if (MODE == 2) {
@@ -538,8 +673,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     // accumulators carried.
     const int C = a.C, KQ0 = (C + 15) >> 4;
     const int CH4 = 4 * HW;                               // float4 per chunk (16 bands x HW floats)
-    const int PPW = (CH4 + 255) >> 8;                     // float4 per lane and chunk: 1 (HW <= 64) or 2 (HW <= 128)
-    const int SLOT = PPW << 10;                           // floats per LDS slot (>= 16 * HW)
+    const int PPW = (CH4 + NT - 1) / NT;                  // float4 per lane and chunk: 1 (HW <= 16 NW) or 2 (HW <= 32 NW)
+    const int SLOT = PPW * NT * 4;                        // floats per LDS slot (>= 16 * HW)
     float* slab = smem;                                   // [SLAB_RING][SLOT], aliases img | wbuf | lut
     // wave = pixel tile (32 pixels), BOTH output-channel tiles: the band values of a pixel are split into bf16 pieces
     // once (not once per output-channel tile, as with wave = (channel tile, pixel half))
@@ -568,8 +703,14 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         tailv = fmaf(zt, sigma, tailv);
       }
     }
-    f32x16 z0 = zero16(), z1 = zero16();                  // output-channel tiles 0 / 1 of pixel tile `wave`
-    const int pix0 = (wave * 32 + l31 < HW) ? wave * 32 + l31 : HW - 1;
+    // four waves: wave = pixel tile, BOTH output-channel tiles (C0N = 2); eight waves: wave = (pixel tile, channel tile)
+    // -- the same (tile, channel tiles) a wave owns after conv1's fold, see the kernel's epilogue
+    constexpr int C0N = TPW;
+    const int pt = (TPW == 2) ? wave : (wave >> 1), nt0 = (TPW == 2) ? 0 : (wave & 1);
+    f32x16 z[C0N];
+#pragma unroll
+    for (int i = 0; i < C0N; ++i) z[i] = zero16();
+    const int pix0 = (pt * 32 + l31 < HW) ? pt * 32 + l31 : HW - 1;
     for (int c0 = 0; c0 < KQ0; c0 += SLAB_RING) {         // uniform; one pass up to 112 bands
       const int nch = (KQ0 - c0 < SLAB_RING) ? KQ0 - c0 : SLAB_RING;
       // (opaque copy: keeps the compiler from hoisting this pass body's per-lane offsets out of the loop and holding
@@ -578,24 +719,24 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       asm volatile("" : "+s"(CH4l));
       const int HWl = CH4l >> 2;
       if (c0 > 0) __syncthreads();                        // every wave is done reading the previous pass's slots
-      uint4 bw[2][6];                                     // conv0 weight fragments of two chunks (window): [n tile][piece]
-      float4 dv[SLAB_WIN][2], nzv[SLAB_RING][2];
+      uint4 bw[2][3 * C0N];                               // conv0 weight fragments of two chunks (window): [n tile][piece]
+      float4 dv[SLAB_WIN][TPW], nzv[SLAB_RING][TPW];      // (a lane's float4 pieces of a chunk: TPW = 512 / NT at most)
       // (Measured and dropped, round 4: network 1 walking the band chunks DOWNWARDS so that the two networks of a sample,
       // which read the same raw rows on the same XCD, would find each other's first half in L2 -- no change, 0.1913 ms
       // either way: the slab's arrival is not what the prologue waits for.)
       auto pch = [&](int kq) { return c0 + kq; };
-      auto fetch_b = [&](int kq, uint4 (&b)[6]) {
+      auto fetch_b = [&](int kq, uint4 (&b)[3 * C0N]) {
         const int kp = pch(kq);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < C0N; ++nt)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) b[3 * nt + pc] = wq0[((kp * 3 + pc) * 2 + nt) * 64];
+          for (int pc = 0; pc < 3; ++pc) b[3 * nt + pc] = wq0[((kp * 3 + pc) * 2 + nt0 + nt) * 64];
       };
       // this lane's float4 k of chunk kq: local index g inside the chunk, global index gg inside the slab
-      auto fetch_d = [&](int kq, float4 (&d)[2]) {
+      auto fetch_d = [&](int kq, float4 (&d)[TPW]) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+        for (int k = 0; k < TPW; ++k) {
+          const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
           const bool ok = k < PPW && g < CH4l && gg < nf4;
           const float4 v = *(const float4*)(xrow + 4 * (ok ? gg : 0));
           d[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -609,7 +750,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         // the bands beyond C of the last chunk meet zero weights, but must be finite
         const int used = nfl - (KQ0 - 1) * 16 * HWl;
         float* sl = slab + (nch - 1) * SLOT;
-        for (int i = used + tid; i < 16 * HWl; i += 256) sl[i] = 0.f;
+        for (int i = used + tid; i < 16 * HWl; i += NT) sl[i] = 0.f;
       }
       // The noise of a chunk's elements (pure vector work: a hash + Box-Muller per four normals, ~380 cycles per call and
       // wave: 5 us per workgroup pair, the largest item of this prologue).  The first SLAB_NUP chunks' noise is formed
@@ -617,13 +758,13 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       // (Two bodies behind ONE uniform branch, not a branch per piece: with "load the reference's draw OR generate" inside
       // one lambda both paths write the same registers, and the compiler guards the generated values' write with a
       // vmcnt(0) against the possibly outstanding load -- which also waits for every chunk load in flight, 14 times.)
-      auto noise_live = [&](int kq, int k) { return sigma != 0.f && kq < nch && k < PPW && (wave + 4 * k) * 64 < CH4l; };   // uniform
+      auto noise_live = [&](int kq, int k) { return sigma != 0.f && kq < nch && k < PPW && (wave + NW * k) * 64 < CH4l; };   // uniform
       if (nzrow != nullptr) {                             // parity mode: the reference's own draws
 #pragma unroll
         for (int kq = 0; kq < SLAB_NUP; ++kq)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+          for (int k = 0; k < TPW; ++k) {
+            const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
             float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             if (noise_live(kq, k)) z = *(const float4*)(nzrow + 4 * ((g < CH4l && gg < nf4) ? gg : 0));
             nzv[kq][k] = z;
@@ -632,8 +773,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 #pragma unroll
         for (int kq = 0; kq < SLAB_NUP; ++kq)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+          for (int k = 0; k < TPW; ++k) {
+            const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
             float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             if (noise_live(kq, k)) z = noise_normal4(a.xs.seed, rstep, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
             nzv[kq][k] = z;
@@ -646,8 +787,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       auto put_chunk = [&](int kq) {                      // registers -> (+ noise) -> LDS slot kq
         float* sl = slab + kq * SLOT;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int g = (wave + 4 * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+        for (int k = 0; k < TPW; ++k) {
+          const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
           if (k < PPW && g < CH4l && gg < nf4) {
             float4 v = dv[kq % SLAB_WIN][k];
             if (sigma != 0.f) {
@@ -686,8 +827,9 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             read_chunk(kq + 1);
           }
           if (c0 == 0 && kq == 3 && CMLPL_ABL != 25) STAMP(0, 13);
-          z0 = mfma_b3(A1, A2, A3, bw[kq % 2][0], bw[kq % 2][1], bw[kq % 2][2], z0);
-          z1 = mfma_b3(A1, A2, A3, bw[kq % 2][3], bw[kq % 2][4], bw[kq % 2][5], z1);
+#pragma unroll
+          for (int nt = 0; nt < C0N; ++nt)
+            z[nt] = mfma_b3(A1, A2, A3, bw[kq % 2][3 * nt], bw[kq % 2][3 * nt + 1], bw[kq % 2][3 * nt + 2], z[nt]);
           if (kq + 2 < nch) fetch_b(kq + 2, bw[kq % 2]);
           if (kq + 1 < nch)
             a_split(make_float4(rn[0], rn[1], rn[2], rn[3]), make_float4(rn[4], rn[5], rn[6], rn[7]), A1, A2, A3);
@@ -696,10 +838,11 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     }
     __syncthreads();                                      // every wave is done with the slab
     if (CMLPL_ABL != 25) STAMP(0, 5);
+    if constexpr (NW == 8) c.wp8 = tap_fetch8(wg, 0, tid);  // (its L2 round trip runs under the border fill / LUT / a0 write)
     {  // now the region becomes the zero-bordered image (the interior is written just below) and the LUT
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       const int nbp = 2 * PW + 2 * H;                     // border pixels: top row, bottom row, left / right columns
-      for (int i = tid; i < nbp * (CS / 4); i += 256) {
+      for (int i = tid; i < nbp * (CS / 4); i += NT) {
         const int bp = i / (CS / 4), f = i - bp * (CS / 4);
         int pos;
         if (bp < PW) pos = bp;
@@ -707,7 +850,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         else { const int k = bp - 2 * PW; pos = (1 + (k >> 1)) * PW + ((k & 1) ? W + 1 : 0); }
         ((float4*)img)[pos * (CS / 4) + f] = z;
       }
-      for (int m = tid; m < lut_entries; m += 256) {
+      for (int m = tid; m < lut_entries; m += NT) {
         const int mm = (m < npx) ? m : 0;
         const int r = mm / CO, cc = mm - r * CO;
         lut[m] = (r + 1) * PW + (cc + 1);
@@ -715,16 +858,23 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     }
     if (CMLPL_ABL != 25) STAMP(0, 6);
     const float* b0 = a.b0 + (long long)net * a.b0_ns;
-    const float bv0 = b0[l31], bv1 = b0[32 + l31];
+    float bv[C0N];
+#pragma unroll
+    for (int nt = 0; nt < C0N; ++nt) bv[nt] = b0[32 * (nt0 + nt) + l31];
     const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for m < 128, W <= 128 (checked on the host)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = wave * 32 + acc_row(r, lane);
+      const int m = pt * 32 + acc_row(r, lane);
       if (m < HW) {
         const int h = (m * magic) >> 16, w = m - h * W;
-        float* d = img + (size_t)((h + 1) * PW + w + 1) * CS + l31;
-        d[0] = z0[r] + bv0; d[32] = z1[r] + bv1;
+        float* d = img + (size_t)((h + 1) * PW + w + 1) * CS + 32 * nt0 + l31;
+#pragma unroll
+        for (int nt = 0; nt < C0N; ++nt) d[32 * nt] = z[nt][r] + bv[nt];
       }
+    }
+    if constexpr (NW == 8) {                              // tap 0's fragments into the tap-weight buffer, tap 1's requested
+      tap_put8((float4*)wbuf, c.wp8, tid);
+      c.wp8 = tap_fetch8(wg, 1, tid);
     }
 
     __syncthreads();                                      // the LUT (and the image) are complete
@@ -746,7 +896,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     // mask words were fetched at kernel start; one (pooled pixel, 4 channels) item -> its 2x2 window
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int idx = tid + 256 * q;
+      const int idx = tid + NT * q;
       if (idx < P2 * 16) {
         const int c4 = idx & 15, pp = idx >> 4, ph = pp / W2, pw = pp - ph * W2;
         const float4 d = *(const float4*)(dp_lds + pp * 64 + c4 * 4);
@@ -762,6 +912,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           *(float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4) = v;
         }
       }
+    }
+    if constexpr (NW == 8) {       // (the tap-weight buffer held the head's dz2 image, dead since the head's last barrier)
+      tap_put8((float4*)wbuf, c.wp8, tid);
+      c.wp8 = tap_fetch8(wg, 1, tid);
     }
   } else {
     const float* dp = a.in + (long long)net * a.in_ns;
@@ -800,12 +954,13 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 }
 
 // avgpool2 + ReLU-mask epilogue shared by the forward kernels (img holds relu(z) at the pixel centres)
+template <int NT = 256>
 __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c, float* img2 = nullptr) {
   float* out = a.out + (long long)c.net * a.out_ns;
   uint8_t* mo = a.mask_out + (long long)c.net * a.mask_out_ns;
   // one (pooled pixel, 4 channels) item per thread and pass: four ds_read_b128, one 16-B and one 4-B store
   const int tot = c.S * c.P2 * 16;
-  for (int idx = c.tid; idx < tot; idx += 256) {
+  for (int idx = c.tid; idx < tot; idx += NT) {
     const int c4 = idx & 15, pp = idx >> 4;
     const int s = pp / c.P2, q = pp - s * c.P2, ph = q / c.W2, pw = q - ph * c.W2;
     const int sample = c.s0 + s;
@@ -843,7 +998,12 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
 //   flatten (NCHW order) + concat with the spectral branch + dropout + classifier, and the L2-normalised spectral
 //   feature (models.py:141-152) -- head_fwd_kernel's math on the row this workgroup already holds.
 // Requires H4 == W4 == 2 and (H2+2)*(W2+2)*CS <= 4096 floats (windows 8..11).
+// Eight-wave workgroups: conv2 and the head stay on waves 0..3 (their chains are one sample's latency, not issue
+// slots); waves 4..7 share the strided LDS passes and keep the barriers' company (the same number of barriers on both
+// paths: s_barrier counts arrivals).
+template <int NW = 4>
 __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ctx& c, float* smem) {
+  constexpr int NT = 64 * NW;
   const int tid = c.tid, lane = c.lane, wave = c.wave, net = c.net, sample = c.s0;
   const int PW2 = c.W2 + 2;
   const float* img2 = c.wbuf;
@@ -851,6 +1011,40 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   const int SF = 256, F = SF + FD, K = a.K;
   float* red = smem + F;                     // [4] + [4][64]
   const long long rs = (long long)net * a.n + sample;
+  // ---- the pooled map as three bf16 planes [pixel][64 ch] (pixel stride 36 dwords: the 16-byte reads of the 16 output
+  // pixels land two-way on the banks at worst), behind the head row in the dead image region
+  constexpr int PS2 = 36;
+  const int NPX2 = (c.H2 + 2) * PW2, PLN = NPX2 * PS2;
+  uint32_t* pl = (uint32_t*)(smem + 2048);
+  auto split_planes = [&]() {
+    for (int it = tid; it < NPX2 * 16; it += NT) {
+      const int px = it >> 4, c4 = it & 15;
+      const float4 v = *(const float4*)(img2 + (size_t)px * CS + 4 * c4);
+      const float x[4] = {v.x, v.y, v.z, v.w};
+      uint32_t u0[4], u1[4], u2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u0[q] = __float_as_uint(x[q]);
+        const float r1 = x[q] - __uint_as_float(u0[q] & 0xffff0000u);
+        u1[q] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[q] & 0xffff0000u);
+        u2[q] = __float_as_uint(r2);
+      }
+      uint32_t* d = pl + px * PS2 + 2 * c4;
+      *(uint2*)(d) = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
+      *(uint2*)(d + PLN) = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
+      *(uint2*)(d + 2 * PLN) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
+    }
+  };
+  if (NW == 8 && wave >= 4) {                // (uniform) the barriers of the path below, one for one
+    __syncthreads();
+    split_planes();
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   // ---- loads issued up front: tap-0 B fragments, this thread's slice of the spectral row
   const int j = lane & 15, kg = lane >> 4;
   // B fragment (tap, k-step ks of 32 ci, piece p) of this wave's 16 output channels: uint4 index
@@ -908,29 +1102,7 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   __syncthreads();                           // img2 interior complete; every thread is done pooling from img
   if (CMLPL_ABL == 25) STAMP(0, 5);
   *(float4*)(row + SF + 4 * tid) = y4;       // spectral part of the head row (pre-dropout); row aliases the dead img
-  // ---- the pooled map as three bf16 planes [pixel][64 ch] (pixel stride 36 dwords: the 16-byte reads of the 16 output
-  // pixels land two-way on the banks at worst), behind the head row in the dead image region
-  constexpr int PS2 = 36;
-  const int NPX2 = (c.H2 + 2) * PW2, PLN = NPX2 * PS2;
-  uint32_t* pl = (uint32_t*)(smem + 2048);
-  for (int it = tid; it < NPX2 * 16; it += 256) {
-    const int px = it >> 4, c4 = it & 15;
-    const float4 v = *(const float4*)(img2 + (size_t)px * CS + 4 * c4);
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    uint32_t u0[4], u1[4], u2[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      u0[q] = __float_as_uint(x[q]);
-      const float r1 = x[q] - __uint_as_float(u0[q] & 0xffff0000u);
-      u1[q] = __float_as_uint(r1);
-      const float r2 = r1 - __uint_as_float(u1[q] & 0xffff0000u);
-      u2[q] = __float_as_uint(r2);
-    }
-    uint32_t* d = pl + px * PS2 + 2 * c4;
-    *(uint2*)(d) = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
-    *(uint2*)(d + PLN) = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
-    *(uint2*)(d + 2 * PLN) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
-  }
+  split_planes();
   __syncthreads();
   if (CMLPL_ABL == 25) STAMP(0, 6);
   // ---- conv2: pixel i = lane & 15 = (oh, ow) = (i >> 2, i & 3); lane group kg holds ci 8 kg .. 8 kg + 7 of a k-step
@@ -1080,7 +1252,11 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
 //         16w..16w+15, B fragments ready-made in L2.
 // dy, dp2 and dp1 also go to HBM (the weight-gradient kernels read them); dp1 stays in LDS (returned region) for the
 // conv1 staging.  LDS use: img2d in the tap-weight buffer, everything else behind the LUT (dead before the tap loop).
+// Eight-wave workgroups: the head and the conv2 data gradient stay on waves 0..3 (first version); waves 4..7 fetch their
+// share of conv1's mask words and keep the barriers' company.
+template <int NW = 4>
 __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float* smem, uint32_t (&mpre)[2]) {
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int net, sample;
@@ -1094,6 +1270,16 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   float* dls = dp2s + 256;                                         // [64]
   float* red = dls + 64;                                           // [4]
   const long long rs = (long long)net * a.n + sample;
+  // conv1's ReLU-mask words of this thread's staging items (consumed after the conv2 data gradient)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + NT * q;
+    mpre[q] = (idx < P2 * 16) ? *(const uint32_t*)(a.mask_in + (long long)net * a.mask_in_ns + ((size_t)sample * P2 + (idx >> 4)) * 64 + (idx & 15) * 4) : 0u;
+  }
+  if (NW == 8 && wave >= 4) {                // (uniform) the barriers of the path below, one for one
+    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+    return dp1s;
+  }
   const int l31 = lane & 31, hh = lane >> 5;
   // conv2 data gradient: wave = (output-channel tile nt, half kh2 of every tap's 64 input channels)
   const int nt = wave & 1, kh2 = wave >> 1;
@@ -1117,12 +1303,6 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   for (int q = 0; q < 4; ++q) {
     yv[q] = y[tid + 256 * q];
     dv[q] = (df != nullptr) ? df[tid + 256 * q] : 0.f;
-  }
-  // conv1's ReLU-mask words of this thread's staging items (consumed after the conv2 data gradient)
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int idx = tid + 256 * q;
-    mpre[q] = (idx < P2 * 16) ? *(const uint32_t*)(a.mask_in + (long long)net * a.mask_in_ns + ((size_t)sample * P2 + (idx >> 4)) * 64 + (idx & 15) * 4) : 0u;
   }
   // conv2's ReLU-mask word of this thread's dz2 item (threads 0..63: pooled pixel tid >> 4, channels 4 (tid & 15)..)
   const uint32_t m2pre = (tid < 64) ? *(const uint32_t*)(a.m2in + (rs * 4 + (tid >> 4)) * 64 + (tid & 15) * 4) : 0u;
@@ -1302,17 +1482,19 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   return dp1s;
 }
 
-// (the per-sample kernels, MODE >= 2, count on two workgroups per CU: two waves per SIMD, at most 256 registers)
-template <int MODE, int MTW, int TAIL = 0>
-__global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
+// (the per-sample kernels, MODE >= 2, count on two waves per SIMD, at most 256 registers: two four-wave workgroups per
+//  CU, or -- NW = 8 -- one eight-wave workgroup that has the CU to itself)
+template <int MODE, int MTW, int TAIL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 64 * NW, TPW = 8 / NW;
   if (CMLPL_ABL == 26) return;             // ablation: the launch itself (grid, LDS allocation, end of kernel) and nothing else
   Conv3Ctx c;
   STAMP(MODE & 1, 0);
   const float* dp_lds = nullptr;
   uint32_t mpre[2] = {0u, 0u};
-  if (MODE == 3 && TAIL) dp_lds = conv3_bwd_head(a, smem, mpre);
-  conv3_stage<MODE>(a, smem, MTW * 128, c, dp_lds, mpre);
+  if (MODE == 3 && TAIL) dp_lds = conv3_bwd_head<NW>(a, smem, mpre);
+  conv3_stage<MODE, NW>(a, smem, MTW * 128, c, dp_lds, mpre);
   STAMP(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
@@ -1321,57 +1503,95 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
   const int MT = (npx + 31) >> 5;
   int abase[MTW];
   f32x16 acc[MTW][2];
-#pragma unroll
-  for (int t = 0; t < MTW; ++t) {
-    abase[t] = lut[(wave + 4 * t) * 32 + l31] * CS + 8 * hh;
-    acc[t][0] = zero16();
-    acc[t][1] = zero16();
-  }
   // per-sample fused kernels (S == 1, MTW == 1): the barrier-free tap loop, see conv3_taps_ks
   constexpr bool KS = (MODE >= 2);
-  int ab2[2];
-  f32x16 acc2[2][2];
+  if constexpr (!KS) {
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+      abase[t] = lut[(wave + 4 * t) * 32 + l31] * CS + 8 * hh;
+      acc[t][0] = zero16();
+      acc[t][1] = zero16();
+    }
+  }
+  int ab2[TPW];
+  f32x16 acc2[TPW][2];
   if (KS) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      ab2[t] = lut[(2 * (wave >> 1) + t) * 32 + l31] * CS + 8 * hh;
+    for (int t = 0; t < TPW; ++t) {
+      ab2[t] = lut[(TPW * (wave >> 1) + t) * 32 + l31] * CS + 8 * hh;
       acc2[t][0] = zero16();
       acc2[t][1] = zero16();
     }
   }
   const uint4* wq = (const uint4*)wg + lane;
-  const bool ks_active = (wave >> 1) * 64 < npx;
+  float* x8 = (float*)(lut + MTW * 128);   // eight waves: [8][16][64] floats behind the LUT (second tap buffer, then the fold's exchange)
+  const bool ks_active = (wave >> 1) * TPW * 32 < npx;
+  // What a wave of the per-sample kernels owns after the fold of the two channel halves -- and, in the forward, already
+  // in the conv0 stage: TPW == 2: pixel tile `wave`, both channel tiles; TPW == 1: pixel tile wave >> 1, channel tile
+  // wave & 1.  own[i] = channel tile nt0 + i of pixel tile `ot`.
+  const int ot = (TPW == 2) ? wave : (wave >> 1), nt0 = (TPW == 2) ? 0 : (wave & 1);
+  f32x16 own[TPW];
 
   // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
   STAMP(MODE & 1, 14);
   if (MODE == 2) {
     // a0 goes to HBM (the backward pass reads it) from the LDS image itself, which is read-only during the tap
-    // loop: tap s copies items 256 s + tid (pixel, 16-byte channel chunk) -- coalesced 16-byte stores, no registers
+    // loop: tap s copies items NT s + tid (pixel, 16-byte channel chunk) -- coalesced 16-byte stores, no registers
     // held across the loop.
     float* a0g = a.a0out + ((long long)net * a.n + s0) * (long long)HW * 64;
     const int magicW = (65536 + c.W - 1) / c.W;          // m / W == (m * magic) >> 16 for m < 128 (checked on the host)
     auto side = [&](int s) {
-      const int idx = s * 256 + tid, m = idx >> 4, c4 = idx & 15;
-      if (s < 8 && m < HW) {
+      const int idx = s * NT + tid, m = idx >> 4, c4 = idx & 15;
+      if (s < 2048 / NT && m < HW) {
         const int h = (m * magicW) >> 16, w = m - h * c.W;
         *(float4*)(a0g + (size_t)m * 64 + c4 * 4) = *(const float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4);
       }
     };
-    conv3_taps_ks(img, wq, ab2, acc2, PW, wave, ks_active, side);
+    if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active, side);
+    else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active, side);
   } else if constexpr (KS) {
     __syncthreads();   // the staged image is complete (conv3_taps has this barrier in front of its first tap)
-    conv3_taps_ks(img, wq, ab2, acc2, PW, wave, ks_active);
+    if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active);
+    else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
   }
   else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   STAMP(MODE & 1, 15);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
-  if constexpr (KS) conv3_ks_fold<MTW>(acc2, acc, wbuf, wave, lane);
+  // (eight waves: the exchange needs [8][16][64] floats = 32 KiB, more than the tap-weight buffer: its own region behind
+  //  the LUT -- where the backward's head kept its hand-off buffers, dead since the staging; one workgroup per CU, LDS
+  //  is plentiful: conv3_ks8_lds)
+  if constexpr (KS) conv3_ks_fold<TPW>(acc2, own, NW == 8 ? x8 : wbuf, wave, lane);
   STAMP(MODE & 1, 2);
 
   if (!(MODE & 1)) {
     const float* bias = a.bias + (long long)net * a.bias_ns;
     const float bv0 = bias[l31], bv1 = bias[32 + l31];
+    if constexpr (KS) {
+      // this wave's tile `ot`, channel tiles nt0 .. nt0 + TPW - 1: three passes -- positions, residual reads, writes
+      if (ot < MT) {
+        int pos[16];
+        float xr[TPW][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = ot * 32 + acc_row(r, lane);
+          pos[r] = lut[m < npx ? m : 0] * CS + 32 * nt0 + l31;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int i = 0; i < TPW; ++i) xr[i][r] = img[pos[r] + 32 * i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = ot * 32 + acc_row(r, lane);
+          if (m < npx) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+              img[pos[r] + 32 * i] = relu_nan(own[i][r] + ((nt0 + i) ? bv1 : bv0) + xr[i][r]);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
       const int tile = wave + 4 * t;
@@ -1397,16 +1617,17 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
         }
       }
     }
+    }
     if (TAIL) {   // the tap-weight buffer is dead: it becomes the zero-bordered conv2 input image
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = tid; i < 1024; i += 256) ((float4*)wbuf)[i] = z4;
+      for (int i = tid; i < 1024; i += NT) ((float4*)wbuf)[i] = z4;
     }
     STAMP(0, 10);
     __syncthreads();
     STAMP(0, 11);
-    conv3_pool_store(a, c, TAIL ? wbuf : nullptr);
+    conv3_pool_store<NT>(a, c, TAIL ? wbuf : nullptr);
     STAMP(0, 7);
-    if (TAIL) conv3_fwd_tail(a, c, smem);
+    if (TAIL) conv3_fwd_tail<NW>(a, c, smem);
   } else if (MODE == 3) {
     // conv0 weight gradient fused in (S == 1, MTW == 1):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
     // This wave's da0 tile = accumulators + dz (the residual branch); it goes to LDS as the B operand [pix][64]
@@ -1416,31 +1637,37 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
     // da0 (two workgroups per CU): more bands (B4: 200) take further PASSES over [bp][HW] ranges of the slab through
     // the same region, da0 staying where it is.
     const int C = a.C, BP = a.bp;
-    float v0[16], v1[16];
+    float vv[TPW][16];                                    // da0 of tile `ot`, channel tiles nt0 ..
     {
       int pos[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = wave * 32 + acc_row(r, lane);
-        pos[r] = lut[m < PX ? m : 0] * CS;
+        const int m = ot * 32 + acc_row(r, lane);
+        pos[r] = lut[m < PX ? m : 0] * CS + 32 * nt0 + l31;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { v0[r] = img[pos[r] + l31]; v1[r] = img[pos[r] + 32 + l31]; }
+      for (int r = 0; r < 16; ++r)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { v0[r] += acc[0][0][r]; v1[r] += acc[0][1][r]; }
+        for (int i = 0; i < TPW; ++i) vv[i][r] = img[pos[r] + 32 * i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) vv[i][r] += own[i][r];
     }
     __syncthreads();                                      // image and LUT are dead from here on
     float* slab = smem;                                   // [min(C, BP)][HW]
     float* dal = smem + (C < BP ? C : BP) * HW;           // [HW + 1][64]
-    const int Ct = ((C + 31) >> 5) * 32;
     const int Cw = conv0_partial_rows(C);                 // rows of the partial (kernels.hpp)
     float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Cw * 64 + 64);
     SlabRange rg = slab_range(a.xs, net, s0, C * HW, 0, (C < BP ? C : BP) * HW);
-    slab_issue(rg, slab, wave, lane);                     // the forward's input again (first pass)
+    slab_issue<NW>(rg, slab, wave, lane);                 // the forward's input again (first pass)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = wave * 32 + acc_row(r, lane);
-      if (m < HW) { dal[m * 64 + l31] = v0[r]; dal[m * 64 + 32 + l31] = v1[r]; }
+      const int m = ot * 32 + acc_row(r, lane);
+      if (m < HW) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) dal[m * 64 + 32 * (nt0 + i) + l31] = vv[i][r];
+      }
     }
     if (tid < 64) dal[HW * 64 + tid] = 0.f;               // the pixel past the end of an odd map
     STAMP(1, 12);
@@ -1454,7 +1681,7 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
       if (cb > 0) {
         __syncthreads();                                  // every wave is done reading the previous pass's rows
         rg = slab_range(a.xs, net, s0, C * HW, (cb * HW) >> 2, nb * HW);   // (BP * HW is a multiple of 4)
-        slab_issue(rg, slab, wave, lane);
+        slab_issue<NW>(rg, slab, wave, lane);
       }
       slab_tail(rg, slab, tid);
       if (cb == 0) STAMP(1, 13);
@@ -1462,45 +1689,51 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 2 : 1)) void conv3x3_kernel(Conv3
       // dW0 tile of this wave on the split-bf16 MFMA: k-steps of 16 pixels; lane (row = band c, half h) takes pixels
       // 16 kq + 8h .. + 7 of its slab row, lane (col = co, half h) the same pixels of da0; both are split in registers
       // (132 VALU instructions per 12 MFMAs).  Pixels >= HW of the last step read the zero row behind da0.
-      const bool has_tile = wave * 32 < nb;               // uniform: this wave's band tile exists in this pass
-      const bool has_db = cb == 0 && wave < 2;            // waves 0 / 1 also sum the bias gradient (first pass)
+      // four waves: wave = band tile, both co tiles; eight waves: wave = (band tile, co tile)
+      const int btile = (TPW == 2) ? wave : (wave >> 1), cn0 = (TPW == 2) ? 0 : (wave & 1);
+      const bool has_tile = btile * 32 < nb;              // uniform: this wave's band tile exists in this pass
+      const bool has_db = cb == 0 && wave < 2;            // waves 0 / 1 also sum the bias gradient of co tile 0 / 1 (first pass)
       if (has_tile || has_db) {
-        f32x16 g0 = zero16(), g1 = zero16();
+        f32x16 g[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) g[i] = zero16();
         float dbacc = 0.f;
-        const int crow = wave * 32 + l31;                 // band cb + crow of this lane (rows >= nb: finite garbage, not stored)
+        const int crow = btile * 32 + l31;                // band cb + crow of this lane (rows >= nb: finite garbage, not stored)
         const float* ap = slab + (size_t)crow * HWl + 8 * hh;
-        const float* bp = dal + l31;
+        const float* bp = dal + 32 * cn0 + l31;
         const int NS = (HWl + 15) >> 4;
 #pragma unroll
         for (int kq = 0; kq < 8; ++kq) {                  // HW <= 128 (conv3_fused_bwd_ok)
           if (kq < NS) {                                  // uniform
-            float ra[8], rb0[8], rb1[8];
+            float ra[8], rb[TPW][8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int k = kq * 16 + 8 * hh + j;
               const int kc = k < HWl ? k : HWl;           // the zero row
               ra[j] = ap[kq * 16 + j];
-              rb0[j] = bp[kc * 64]; rb1[j] = bp[kc * 64 + 32];
+#pragma unroll
+              for (int i = 0; i < TPW; ++i) rb[i][j] = bp[kc * 64 + 32 * i];
             }
             uint4 A1, A2, A3, P1, P2, P3;
             a_split(make_float4(ra[0], ra[1], ra[2], ra[3]), make_float4(ra[4], ra[5], ra[6], ra[7]), A1, A2, A3);
-            a_split(make_float4(rb0[0], rb0[1], rb0[2], rb0[3]), make_float4(rb0[4], rb0[5], rb0[6], rb0[7]), P1, P2, P3);
-            g0 = mfma_b3(A1, A2, A3, P1, P2, P3, g0);
-            a_split(make_float4(rb1[0], rb1[1], rb1[2], rb1[3]), make_float4(rb1[4], rb1[5], rb1[6], rb1[7]), P1, P2, P3);
-            g1 = mfma_b3(A1, A2, A3, P1, P2, P3, g1);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+              a_split(make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]), make_float4(rb[i][4], rb[i][5], rb[i][6], rb[i][7]), P1, P2, P3);
+              g[i] = mfma_b3(A1, A2, A3, P1, P2, P3, g[i]);
+            }
             // waves 0 / 1 sum co tile 0 / 1 for the bias gradient (fixed order: j, then k-step, then the two halves)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dbacc += (wave == 0) ? rb0[j] : rb1[j];
+            for (int j = 0; j < 8; ++j) dbacc += (TPW == 2 && wave != 0) ? rb[TPW - 1][j] : rb[0][j];
           }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int cc = wave * 32 + acc_row(r, lane);
+          const int cc = btile * 32 + acc_row(r, lane);
           // single pass: the partial's rows (C rounded up to 4; rows >= C are dropped by the reduce); several passes: only
           // this pass's bands (the rows behind them belong to the next pass)
           if (has_tile && (cc < nb || (C <= BP && cc < Cw))) {
-            pp[(size_t)(cb + cc) * 64 + l31] = g0[r];
-            pp[(size_t)(cb + cc) * 64 + 32 + l31] = g1[r];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) pp[(size_t)(cb + cc) * 64 + 32 * (cn0 + i) + l31] = g[i][r];
           }
         }
         if (has_db) {
@@ -1695,12 +1928,24 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
 // conv0 fused into the conv1 forward (MODE 2).  Possible when the plain forward plan is one sample per workgroup
 // with one pixel tile per wave (H*W <= 128) and two workgroups still fit a CU with the slab + conv0 weights in LDS.
 // LDS of the fused kernel: the plain forward's regions, or slab [Cp][HW] + 64 + weights [Cp][64] if that is larger
-static size_t conv3_fused_lds(int H, int W, int C, size_t plain) {
+static size_t conv3_fused_lds(int H, int W, int C, size_t plain, int NW = 4) {
   const int KQ0 = (C + 15) / 16, ring = KQ0 < SLAB_RING ? KQ0 : SLAB_RING;
-  const size_t slot = (size_t)((4 * H * W + 255) / 256) * 1024;           // floats per chunk slot
+  const int NT = 64 * NW;
+  const size_t slot = (size_t)((4 * H * W + NT - 1) / NT) * NT * 4;       // floats per chunk slot
   const size_t need = ring * slot * 4;
   return need > plain ? need : plain;
 }
+
+// Eight-wave per-sample workgroups (one per CU): what a launch takes when its sample-net workgroups do not exceed the
+// CUs (a rank's shard of a data-parallel job: 64 + 64 rows of both networks = 256 workgroups) -- a four-wave workgroup
+// alone on a CU runs one wave per SIMD, nothing to issue while it waits: 39.5 / 33.6 us for half the rows of a 52.5 /
+// 46.3 us launch (round 4).  CMLPL_KS8 = 0 / 1: never / at every size.  LDS: the plain regions + the [8][16][64] fold
+// exchange behind the LUT.
+static bool conv3_ks8(int rows) {
+  const int m = switches().ks8;
+  return m == 0 ? false : (m == 1 ? true : rows <= device_cus());
+}
+static size_t conv3_ks8_lds(size_t plain) { return plain + (size_t)8 * 16 * 64 * 4; }
 
 bool conv3_fused_ok(int H, int W, int C, int rows) {
   const bool off = switches().fuse_conv0 == 0;
@@ -1742,8 +1987,14 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
     a.logits = tail->logits; a.feat = tail->feat; a.p2out = tail->p2; a.m2out = tail->m2;
     a.dropout_p = tail->dropout_p; a.train = tail->train; a.K = tail->K;
     static DevOnce attr_once;
-    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>);
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>, conv3x3_kernel<2, 1, 1, 8>);
     if (e != hipSuccess) return e;
+    if (conv3_ks8(nets * n)) {
+      const size_t lds8 = conv3_fused_lds(H, W, C, conv3_ks8_lds(pl.lds), 8);
+      if (lds8 > LDS_MAX) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8>), dim3(n, nets), dim3(512), lds8, st, a);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), dim3(n, nets), dim3(256),
                        conv3_fused_lds(H, W, C, pl.lds), st, a);
     return hipGetLastError();
@@ -1816,8 +2067,14 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
     a.yin = head->y; a.ynrm = head->ynorm; a.m2in = head->m2; a.w2d = head->w2d; a.w2d_ns = head->w2d_ns;
     a.dy = head->dy; a.dp2out = head->dp2; a.dp1out = head->dp1; a.K = head->K;
     static DevOnce attr_once;
-    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>);
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>, conv3x3_kernel<3, 1, 1, 8>);
     if (e != hipSuccess) return e;
+    if (conv3_ks8(nets * n)) {
+      const size_t lds8 = conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pl.lds));
+      if (lds8 > LDS_MAX) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8>), dim3(n, nets), dim3(512), lds8, st, a);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), dim3(n, nets), dim3(256),
                        conv3_fused_bwd_lds(H, W, C, pl.lds), st, a);
     return hipGetLastError();

@@ -8,14 +8,16 @@ from cmlpl_amd import TrainEngine, NetShape, HyperParams, _lib
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 103          # bands: 103 = B2, 200 = B4
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+BT = int(sys.argv[3]) if len(sys.argv) > 3 else 128          # rows per network: 64 64 = a rank's shard of configs[2] at 8 GPUs
+BTU = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 shape = NetShape(C, 11, 11, C, K)
-eng = TrainEngine(shape, 128, 128, HyperParams(), device="cuda:0", seed=1)
+eng = TrainEngine(shape, BT, BTU, HyperParams(), device="cuda:0", seed=1)
 g = torch.Generator(device="cuda:0").manual_seed(0)
-XPl = torch.randn(128, C, 11, 11, device="cuda:0", generator=g)
-XPu = torch.randn(128, C, 11, 11, device="cuda:0", generator=g)
-Xl = torch.randn(128, C, device="cuda:0", generator=g)
-Xu = torch.randn(128, C, device="cuda:0", generator=g)
-Y = torch.randint(0, K, (128,), device="cuda:0", generator=g)
+XPl = torch.randn(BT, C, 11, 11, device="cuda:0", generator=g)
+XPu = torch.randn(BTU, C, 11, 11, device="cuda:0", generator=g)
+Xl = torch.randn(BT, C, device="cuda:0", generator=g)
+Xu = torch.randn(BTU, C, device="cuda:0", generator=g)
+Y = torch.randint(0, K, (BT,), device="cuda:0", generator=g)
 for i in range(20):
     eng.step(XPl, Xl, Y, XPu, Xu, 1, i)
 torch.cuda.synchronize()
@@ -30,7 +32,9 @@ wbuf = np.zeros((2048, 16), dtype=np.uint64)          # the weight-gradient kern
 rc = lib.cmlpl_abl_read_wstamps(wbuf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 buf[2] = wbuf
-for mode, name, nwg in ((0, "fwd", 512), (1, "dgrad", 512), (2, "wgrad(conv1 workgroups of the pair launch)", 192)):
+NWG = 2 * (BT + BTU)
+print(f"{BT}+{BTU} rows, {NWG} sample-net workgroups, CMLPL_KS8={os.environ.get('CMLPL_KS8', '(planner)')}")
+for mode, name, nwg in ((0, "fwd", NWG), (1, "dgrad", NWG), (2, "wgrad(conv1 workgroups of the pair launch)", 192)):
     t = buf[mode, :nwg, :4].astype(np.int64)
     full = buf[mode, :nwg, :].astype(np.int64)
     full = full[t[:, 0] > 0]

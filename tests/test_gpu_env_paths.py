@@ -106,3 +106,32 @@ def test_fused_and_unfused_conv0_form_the_same_noise():
     for a, b in zip(f0[:9], u0[:9]):                          # first step: same inputs, same noise
         assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (f0, u0)
     assert f0[9:13] == u0[9:13]                               # mask / graph counts
+
+
+@pytest.mark.parametrize("shape,bt,btu", [("B2", 64, 64), ("B2", 128, 128), ("B4", 24, 40), ("W8", 16, 16), ("W10", 8, 24)])
+def test_eight_wave_per_sample_kernels_are_bit_identical_to_the_four_wave_ones(shape, bt, btu):
+    """conv3x3_kernel<2 / 3, 1, 1, 8> (one eight-wave workgroup per sample-net: what a launch of at most one workgroup per CU
+    takes, CMLPL_KS8=1 forces it at every size) against the four-wave kernels (CMLPL_KS8=0) on the same in-kernel random
+    streams: every accumulator sees the same operands in the same order (wave = (pixel tile, channel half) instead of
+    (pixel half, channel half); the halves meet in the same sum), so three steps must agree BIT for bit -- parameters,
+    Adam moments, gradients, banks, logits, features."""
+    outs = []
+    for ks8 in ("0", "1"):
+        env = dict(os.environ, CMLPL_KS8=ks8)
+        r = subprocess.run([sys.executable, "tests/_philox_traj_child.py", shape, str(bt), str(btu)], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines())
+    assert outs[0][-1].startswith("sha ") and outs[0] == outs[1], (outs[0][-2:], outs[1][-2:])
+
+
+def test_eight_wave_per_sample_kernels_pass_parity():
+    """... and the oracle / golden parity tests with the eight-wave kernels forced at every batch size (explicit noise, explicit
+    dropout masks, batches by index, graph replay)"""
+    _run({"CMLPL_KS8": "1"}, ["tests/test_gpu_step.py", "tests/test_gpu_ops.py", "tests/test_gpu_indexed_graph.py",
+                              "-k", "b2_b256 or b2_peaky or b4_b256 or deadrelu or (forward_backward and (B2 or B4)) or (indexed and B2) or (graph_replay and B2)"])
+
+
+def test_four_wave_per_sample_kernels_pass_parity_at_small_batches():
+    """the four-wave kernels where the planner now picks the eight-wave ones (grids of at most one workgroup per CU)"""
+    _run({"CMLPL_KS8": "0"}, ["tests/test_gpu_step.py", "tests/test_gpu_ops.py", "-k", "b2_64 or b4_64 or (forward_backward and B2)"])

@@ -616,10 +616,10 @@ struct Conv3Ctx {
 
 // NW = waves of the workgroup: 4 (every MODE), or 8 for the per-sample kernels (MODE >= 2) when one workgroup has a CU
 // to itself (see ks_unit); NT = its threads, TPW = M tiles per wave in the tap loop.
-template <int MODE, int NW = 4>
+template <int MODE, int NW = 4, int TPW = 8 / NW>
 __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c,
                                             const float* dp_lds = nullptr, const uint32_t* mpre = nullptr) {
-  constexpr int NT = 64 * NW, TPW = 8 / NW;
+  constexpr int NT = 64 * NW;
   static_assert(NW == 4 || (NW == 8 && MODE >= 2), "eight waves: per-sample kernels only");
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -861,7 +861,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     float bv[C0N];
 #pragma unroll
     for (int nt = 0; nt < C0N; ++nt) bv[nt] = b0[32 * (nt0 + nt) + l31];
-    const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for m < 128, W <= 128 (checked on the host)
+    const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for every m of the map (checked on the host)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = pt * 32 + acc_row(r, lane);
@@ -1482,19 +1482,420 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   return dp1s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Generalised tail / head of the eight-wave, eight-tile per-sample kernels (windows of 129 .. 256 pixels: BASELINE
+// configs[4]'s 15 x 15 x 48): final pooled maps H4 x W4 of up to 12 pixels (conv3_fwd_tail / conv3_bwd_head above are
+// the 2 x 2 case, hand-fitted to four waves), pooled conv1 maps of up to 64 pixels, classifier rows of any length
+// F = 64 H4 W4 + 1024 taken as 16-byte groups (one group per thread).
+// ------------------------------------------------------------------------------------------
+// conv2 3x3 + bias + residual + ReLU + avgpool (models.py:137-140) on the 16x16x32 split-bf16 MFMA with the output pixels
+// in WINDOW-major order: pixel i of tile t is sub-pixel (i & 3) of pooling window 4 t + (i >> 2), so a lane's four
+// accumulator registers are one 2 x 2 window -- pooling and the ReLU nibble need no shuffle.  wave = (16 output channels
+// w & 3, tiles (w >> 2), (w >> 2) + 2, ..).  Then flatten / concat / dropout / classifier / L2-norm (models.py:141-152):
+// thread t owns the 16-byte group t of the head row (its dropout multipliers, its classifier weights), the eight waves'
+// partial logits meet in LDS.
+__device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3Ctx& c, float* smem) {
+  constexpr int NT = 512;
+  const int tid = c.tid, lane = c.lane, wave = c.wave, net = c.net, sample = c.s0;
+  const int H2 = c.H2, W2 = c.W2, PW2 = W2 + 2, H4 = H2 >> 1, W4 = W2 >> 1, P4 = H4 * W4;
+  const int SF = 64 * P4, F = SF + FD, K = a.K, F4 = F >> 2;
+  const float* img2 = c.wbuf;                // zero-bordered pooled conv1 map [(H2+2)*(W2+2)][CS]
+  float* row = smem;                         // [F] head row (the conv1 image is dead); F <= 1792
+  float* red = smem + 1792;                  // [8] + [8 waves][64 classes]
+  float* part = red + 8;
+  constexpr int PS2 = 36;
+  const int NPX2 = (H2 + 2) * PW2, PLN = NPX2 * PS2;
+  uint32_t* pl = (uint32_t*)(smem + 2560);   // three bf16 planes [pixel][PS2 dwords]
+  const long long rs = (long long)net * a.n + sample;
+  const int cog = wave & 3, th = wave >> 2, NTL = (P4 + 3) >> 2;
+  const int j = lane & 15, kg = lane >> 4;
+  const uint4* wq = (const uint4*)(a.w2f + (long long)net * a.w2f_ns) + ((kg >> 1) * 6 + (cog >> 1)) * 64 + (kg & 1) * 32 +
+                    16 * (cog & 1) + j;
+  constexpr int C2_AHEAD = 2;   // (three fragment sets: a fourth one spills -- 8-byte address spills around the tile loop)
+  uint4 bq[C2_AHEAD + 1][6];
+  auto prime_b = [&]() {
+#pragma unroll
+    for (int t0 = 0; t0 < C2_AHEAD; ++t0)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bq[t0][3 * ks + pc] = wq[((t0 * 4 + 2 * ks) * 3 + pc) * 128];
+  };
+  prime_b();
+  // ---- loads up front: the spectral row (threads 0..255), conv2's bias, this thread's dropout multipliers and the first
+  // eight classes' classifier weights of its 16-byte group
+  float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 256) y4 = *(const float4*)(a.yin + rs * FD + 4 * tid);
+  const float bias2 = (a.b2 + (long long)net * a.p_ns)[cog * 16 + j];
+  const float* wc = a.wc + (long long)net * a.p_ns;
+  const bool grp = tid < F4;                 // this thread owns group tid of the row
+  const int f0 = 4 * (grp ? tid : 0);
+  const int dmode = (!a.train || a.dropout_p <= 0.f) ? 0 : (a.dropmask != nullptr ? 1 : 2);
+  const float keep_scale = 1.0f / (1.0f - a.dropout_p);
+  float4 dm4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (grp) {
+    if (dmode == 1) {
+      dm4 = *(const float4*)(a.dropmask + rs * F + f0);
+    } else if (dmode == 2) {
+      const unsigned long long gs = xsrc_global_sample(a.xs, sample);
+      const float4 u = philox_uniform4(a.xs.seed, xsrc_step(a.xs), STREAM_DROPOUT + net, (gs * F + f0) >> 2);
+      dm4.x = (u.x >= a.dropout_p) ? keep_scale : 0.f; dm4.y = (u.y >= a.dropout_p) ? keep_scale : 0.f;
+      dm4.z = (u.z >= a.dropout_p) ? keep_scale : 0.f; dm4.w = (u.w >= a.dropout_p) ? keep_scale : 0.f;
+      *(float4*)(a.dropgen + rs * F + f0) = dm4;
+    }
+  }
+  __syncthreads();                           // img2 interior complete; every thread is done pooling from img
+  if (tid < 256) *(float4*)(row + SF + 4 * tid) = y4;
+  for (int it = tid; it < NPX2 * 16; it += NT) {   // the pooled map as three bf16 planes
+    const int px = it >> 4, c4 = it & 15;
+    const float4 v = *(const float4*)(img2 + (size_t)px * CS + 4 * c4);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t u0[4], u1[4], u2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u0[q] = __float_as_uint(x[q]);
+      const float r1 = x[q] - __uint_as_float(u0[q] & 0xffff0000u);
+      u1[q] = __float_as_uint(r1);
+      u2[q] = __float_as_uint(r1 - __uint_as_float(u1[q] & 0xffff0000u));
+    }
+    uint32_t* d = pl + px * PS2 + 2 * c4;
+    *(uint2*)(d) = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
+    *(uint2*)(d + PLN) = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
+    *(uint2*)(d + 2 * PLN) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
+  }
+  {  // the spectral row's squared norm (waves 0..3 hold it)
+    float ss = (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
+    ss = wave_sum(ss);
+    if (lane == 0 && wave < 4) red[wave] = ss;
+  }
+  __syncthreads();
+  auto mm = [](const uint4& x, const uint4& y, f32x4v cc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), cc, 0, 0, 0);
+  };
+  const int co = cog * 16 + j;
+#pragma unroll 1
+  for (int t = th; t < NTL; t += 2) {
+    // A row of this lane: sub-pixel (j & 3) of window 4 t + (j >> 2); windows past the map multiply a real pixel's
+    // operands (results dropped)
+    const int wa = 4 * t + (j >> 2), wac = wa < P4 ? wa : 0;
+    const int oh = 2 * (wac / W4) + ((j >> 1) & 1), ow = 2 * (wac % W4) + (j & 1);
+    const uint32_t* ap0 = pl + (size_t)((oh + 1) * PW2 + ow + 1) * PS2 + 4 * kg;
+    if (t != th) prime_b();
+    f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    uint4 af[2][6];
+    auto read_a = [&](int tap, uint4 (&x)[6]) {
+      const uint32_t* ap = ap0 + ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * PS2;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        x[3 * ks] = *(const uint4*)(ap + 16 * ks); x[3 * ks + 1] = *(const uint4*)(ap + PLN + 16 * ks);
+        x[3 * ks + 2] = *(const uint4*)(ap + 2 * PLN + 16 * ks);
+      }
+    };
+    read_a(0, af[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + C2_AHEAD < 9) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            bq[(tap + C2_AHEAD) % (C2_AHEAD + 1)][3 * ks + pc] = wq[(((tap + C2_AHEAD) * 4 + 2 * ks) * 3 + pc) * 128];
+      }
+      if (tap + 1 < 9) read_a(tap + 1, af[(tap + 1) & 1]);
+      const uint4 (&bcur)[6] = bq[tap % (C2_AHEAD + 1)];
+      const uint4 (&acur)[6] = af[tap & 1];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint4 a1 = acur[3 * ks], a2 = acur[3 * ks + 1], a3 = acur[3 * ks + 2];
+        const uint4 b1 = bcur[3 * ks], b2 = bcur[3 * ks + 1], b3 = bcur[3 * ks + 2];
+        acc0 = mm(a1, b3, acc0); acc1 = mm(a2, b2, acc1); acc0 = mm(a3, b1, acc0);
+        acc1 = mm(a1, b2, acc1); acc0 = mm(a2, b1, acc0); acc1 = mm(a1, b1, acc1);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    }
+    // epilogue: lane (co, kg) holds window 4 t + kg, registers = its four sub-pixels (dh, dw) = (r >> 1, r & 1)
+    const int win = 4 * t + kg;
+    if (win < P4) {
+      const int ph = win / W4, pw = win - ph * W4;
+      float r_[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float res = img2[(size_t)((2 * ph + (r >> 1) + 1) * PW2 + 2 * pw + (r & 1) + 1) * CS + co];   // residual branch
+        r_[r] = relu_nan((acc0[r] + acc1[r]) + bias2 + res);
+      }
+      const float o = ((r_[0] + r_[1]) + (r_[2] + r_[3])) * 0.25f;
+      const uint32_t nib = (relu_open(r_[0]) ? 1u : 0u) | (relu_open(r_[1]) ? 2u : 0u) | (relu_open(r_[2]) ? 4u : 0u) |
+                           (relu_open(r_[3]) ? 8u : 0u);
+      a.p2out[(rs * P4 + win) * 64 + co] = o;
+      a.m2out[(rs * P4 + win) * 64 + co] = (uint8_t)nib;
+      row[co * P4 + win] = o;                // canonical flatten order f = c * P4 + hw (x.view, models.py:141)
+    }
+  }
+  // (the first eight classes' classifier weights of this thread's group: requested here, not at kernel start -- the
+  //  conv2 loop's fragment rings leave no registers for them -- their round trip runs under the barrier and the row read)
+  float4 wv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(q < K ? q : K - 1) * F + f0);
+  __syncthreads();                           // row[0 .. SF) complete
+  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  if (tid == 0) a.ynorm[rs] = norm;
+  if (tid < 256) {
+    float4 o = y4;
+    o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
+    *(float4*)(a.feat + rs * FD + 4 * tid) = o;
+  }
+  float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (grp) {
+    x4 = *(const float4*)(row + f0);
+    if (dmode != 0) { x4.x *= dm4.x; x4.y *= dm4.y; x4.z *= dm4.z; x4.w *= dm4.w; }
+    *(float4*)(a.catd + rs * F + f0) = x4;
+  }
+  // logits: eight classes at a time, every weight of a chunk requested before the first is used
+  for (int kc = 0; kc < K; kc += 8) {
+    if (kc > 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(kc + q < K ? kc + q : K - 1) * F + f0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (kc + q < K) {                      // uniform
+        float acc = (x4.x * wv[q].x + x4.y * wv[q].y) + (x4.z * wv[q].z + x4.w * wv[q].w);
+        acc = wave_sum(grp ? acc : 0.f);
+        if (lane == 0) part[wave * 64 + kc + q] = acc;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < K) {
+    const float* bc = a.bc + (long long)net * a.p_ns;
+    float sacc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sacc += part[w * 64 + tid];
+    a.logits[rs * K + tid] = sacc + bc[tid];
+  }
+}
+
+// Head backward + conv2 data gradient of the eight-tile kernels (see conv3_bwd_head for the math).  Thread t owns the
+// 16-byte group t of the head row; the conv2 data gradient covers up to 64 pooled pixels: wave = (pixel tile w >> 2,
+// input-channel tile (w >> 1) & 1, half (w & 1) of every tap's 64 output channels).
+__device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, float* smem, uint32_t (&mpre)[2]) {
+  constexpr int NT = 512;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int net, sample;
+  wg_decode(a, net, sample);
+  const int H2 = a.H >> 1, W2 = a.W >> 1, P2 = H2 * W2, PW2 = W2 + 2;
+  const int H4 = H2 >> 1, W4 = W2 >> 1, P4 = H4 * W4;
+  const int SF = 64 * P4, F = SF + FD, K = a.K, F4 = F >> 2;
+  const int PW = a.W + 2, IMG = (a.H + 2) * PW;
+  float* img2 = smem + (size_t)IMG * CS;                           // = wbuf: dz2 image [(H2+2)*(W2+2)][CS] <= WBUF floats
+  float* ext = img2 + WBUF + 256;                                  // behind the LUT (256 entries)
+  float* dp1s = ext;                                               // [P2][64]
+  float* dp2s = dp1s + P2 * 64;                                    // [P4][64]  pooled conv2 gradient [hw][c]
+  float* dls = dp2s + P4 * 64;                                     // [64]
+  float* red = dls + 64;                                           // [8]
+  const long long rs = (long long)net * a.n + sample;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int mtile = wave >> 2, nt = (wave >> 1) & 1, kh2 = wave & 1;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {       // conv1's ReLU-mask words of this thread's staging items
+    const int idx = tid + NT * q;
+    mpre[q] = (idx < P2 * 16) ? *(const uint32_t*)(a.mask_in + (long long)net * a.mask_in_ns + ((size_t)sample * P2 + (idx >> 4)) * 64 + (idx & 15) * 4) : 0u;
+  }
+  const uint4* wq = (const uint4*)(a.w2d + (long long)net * a.w2d_ns) + lane;
+  constexpr int C2_AHEAD = 3;
+  uint4 bq[C2_AHEAD + 1][6];
+#pragma unroll
+  for (int t0 = 0; t0 < C2_AHEAD; ++t0)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bq[t0][3 * q + pc] = wq[(size_t)t0 * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
+  if (tid < 64) dls[tid] = (tid < K) ? a.dlogits[rs * K + tid] : 0.f;
+  const bool grp = tid < F4;
+  const int f0 = 4 * (grp ? tid : 0);
+  const bool spec = grp && f0 >= SF;                                // (SF is a multiple of 4: a group is all spatial or all spectral)
+  const int j0 = spec ? f0 - SF : 0;
+  const float norm = a.ynrm[rs];
+  float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f), df4 = y4;
+  if (spec) {
+    y4 = *(const float4*)(a.yin + rs * FD + j0);
+    if (a.dfeat != nullptr) df4 = *(const float4*)(a.dfeat + rs * FD + j0);
+  }
+  const uint32_t m2pre = (tid < P4 * 16) ? *(const uint32_t*)(a.m2in + (rs * P4 + (tid >> 4)) * 64 + (tid & 15) * 4) : 0u;
+  const float* wc = a.wc + (long long)net * a.p_ns;
+  float4 dm4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (a.hmask != nullptr && grp) dm4 = *(const float4*)(a.hmask + rs * F + f0);
+  float4 wv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(q < K ? q : K - 1) * F + f0);
+  {  // while those loads fly: zero-bordered dz2 image, conv1 image zero fill, output-pixel LUT
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < WBUF / 4; i += NT) ((float4*)img2)[i] = z4;
+    for (int i = tid; i < IMG * (CS / 4); i += NT) ((float4*)smem)[i] = z4;
+    int* lut = (int*)(img2 + WBUF);
+    const int HWl = a.H * a.W;
+    for (int m = tid; m < 256; m += NT) {
+      const int mm = (m < HWl) ? m : 0;
+      const int r = mm / a.W, cc = mm - r * a.W;
+      lut[m] = (r + 1) * PW + (cc + 1);
+    }
+  }
+  float dot = (y4.x / norm) * df4.x + (y4.y / norm) * df4.y + (y4.z / norm) * df4.z + (y4.w / norm) * df4.w;
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int kc = 0; kc < K; kc += 8) {
+    if (kc > 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(kc + q < K ? kc + q : K - 1) * F + f0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float dl = (kc + q < K) ? dls[kc + q] : 0.f;
+      dc.x = fmaf(dl, wv[q].x, dc.x); dc.y = fmaf(dl, wv[q].y, dc.y);
+      dc.z = fmaf(dl, wv[q].z, dc.z); dc.w = fmaf(dl, wv[q].w, dc.w);
+    }
+  }
+  if (grp) {
+    const float d[4] = {dc.x * dm4.x, dc.y * dm4.y, dc.z * dm4.z, dc.w * dm4.w};
+    if (!spec) {                                                     // spatial part: f = c * P4 + hw
+      float* dp2g = a.dp2out + rs * SF;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = f0 + e, cc = f / P4, hw = f - cc * P4;
+        dp2s[hw * 64 + cc] = d[e];
+        dp2g[hw * 64 + cc] = d[e];
+      }
+    } else {
+      const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, dv[4] = {df4.x, df4.y, df4.z, df4.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = d[e];
+        if (a.dfeat != nullptr) g += (dv[e] - (yv[e] / norm) * dot) / norm;
+        o[e] = relu_open(yv[e]) ? g : 0.f;
+      }
+      *(float4*)(a.dy + rs * FD + j0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  __syncthreads();                                                 // dp2s complete, img2 zeroed
+  if (tid < P4 * 16) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
+    const int c4 = tid & 15, pp = tid >> 4, ph = pp / W4, pw = pp - ph * W4;
+    const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
+    const uint32_t m = m2pre;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      float4 v;
+      v.x = ((m >> sub) & 1u) ? d.x * 0.25f : 0.f;
+      v.y = ((m >> (8 + sub)) & 1u) ? d.y * 0.25f : 0.f;
+      v.z = ((m >> (16 + sub)) & 1u) ? d.z * 0.25f : 0.f;
+      v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
+      const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
+      *(float4*)(img2 + (size_t)((h + 1) * PW2 + w + 1) * CS + c4 * 4) = v;
+    }
+  }
+  __syncthreads();
+  // ---- conv2 data gradient (split-bf16, 32x32x16): this wave's pixel tile x input-channel tile x output-channel half
+  const int pA = mtile * 32 + l31;
+  const int posA = pA < P2 ? ((pA / W2) + 1) * PW2 + (pA % W2) + 1 : 0;
+  const float* ap = img2 + (size_t)posA * CS + kh2 * 32 + hh * 8;
+  f32x16 acc = zero16();
+  auto raw_ptr = [&](int u) {
+    const int tap = u >> 1;
+    const int toff = ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * CS;
+    return ((pA < P2) ? ap + toff : ap) + 16 * (u & 1);
+  };
+  ASplit cur;
+  float4 rn0, rn1;
+  {
+    const float* p0 = raw_ptr(0);
+    a_split(*(const float4*)p0, *(const float4*)(p0 + 4), cur.p1, cur.p2, cur.p3);
+    const float* p1 = raw_ptr(1);
+    rn0 = *(const float4*)p1; rn1 = *(const float4*)(p1 + 4);
+  }
+#pragma unroll
+  for (int u = 0; u < 18; ++u) {
+    const int tap = u >> 1, q = u & 1;
+    if (q == 0 && tap + C2_AHEAD < 9) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          bq[(tap + C2_AHEAD) % (C2_AHEAD + 1)][3 * q2 + pc] =
+              wq[(size_t)(tap + C2_AHEAD) * TAPW + (((kh2 * 2 + q2) * 3 + pc) * 2 + nt) * 64];
+    }
+    if (q == 0) __builtin_amdgcn_sched_barrier(0);
+    float4 rnn0 = rn0, rnn1 = rn1;
+    if (u + 2 < 18) {
+      const float* p2 = raw_ptr(u + 2);
+      rnn0 = *(const float4*)p2; rnn1 = *(const float4*)(p2 + 4);
+    }
+    const uint4 (&bcur)[6] = bq[tap % (C2_AHEAD + 1)];
+    acc = mfma_b3(cur.p1, cur.p2, cur.p3, bcur[3 * q], bcur[3 * q + 1], bcur[3 * q + 2], acc);
+    ASplit nxt = cur;
+    if (u + 1 < 18) a_split(rn0, rn1, nxt.p1, nxt.p2, nxt.p3);
+    if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    SchedInterleave<6>::run();
+    cur = nxt; rn0 = rnn0; rn1 = rnn1;
+  }
+  {
+    const int ci = nt * 32 + l31;
+    float res[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = mtile * 32 + acc_row(r, lane);
+      res[r] = (kh2 == 0 && p < P2) ? img2[(size_t)(((p / W2) + 1) * PW2 + (p % W2) + 1) * CS + ci] : 0.f;
+    }
+    __syncthreads();                                               // every wave has finished reading img2
+    float* xch = img2 + (mtile * 2 + nt) * 1024;                   // [16][64] per (pixel tile, channel tile)
+    if (kh2 == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh2 == 0) {
+      float* dp1g = a.dp1out + rs * (long long)P2 * 64;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = mtile * 32 + acc_row(r, lane);
+        if (p < P2) {
+          const float v = (acc[r] + xch[r * 64 + lane]) + res[r];
+          dp1s[p * 64 + ci] = v;
+          dp1g[p * 64 + ci] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();                                                 // dp1s complete; img2 (= wbuf) is free again
+  return dp1s;
+}
+
 // (the per-sample kernels, MODE >= 2, count on two waves per SIMD, at most 256 registers: two four-wave workgroups per
 //  CU, or -- NW = 8 -- one eight-wave workgroup that has the CU to itself)
-template <int MODE, int MTW, int TAIL = 0, int NW = 4>
+//  TPW = pixel tiles per wave of the tap loop: NW * TPW / 2 tiles of 32 pixels -- 4 (windows up to 128 pixels: NW = 4 with
+//  TPW = 2, or NW = 8 with TPW = 1) or 8 (NW = 8, TPW = 2: windows up to 256 pixels, e.g. BASELINE configs[4]'s 15 x 15)
+template <int MODE, int MTW, int TAIL = 0, int NW = 4, int TPW = 8 / NW>
 __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NT = 64 * NW, TPW = 8 / NW;
+  constexpr int NT = 64 * NW;
+  constexpr int KMT = NW * TPW / 2;        // pixel tiles of the per-sample kernels
+  constexpr int LUTN = (MODE >= 2) ? KMT * 32 : MTW * 128;
+  constexpr bool BIG = (KMT == 8);         // the generalised tail / head (final maps up to 12 pooled pixels)
   if (CMLPL_ABL == 26) return;             // ablation: the launch itself (grid, LDS allocation, end of kernel) and nothing else
   Conv3Ctx c;
   STAMP(MODE & 1, 0);
   const float* dp_lds = nullptr;
   uint32_t mpre[2] = {0u, 0u};
-  if (MODE == 3 && TAIL) dp_lds = conv3_bwd_head<NW>(a, smem, mpre);
-  conv3_stage<MODE, NW>(a, smem, MTW * 128, c, dp_lds, mpre);
+  if constexpr (MODE == 3 && TAIL) {
+    if constexpr (BIG) dp_lds = conv3_bwd_head_g(a, smem, mpre);
+    else dp_lds = conv3_bwd_head<NW>(a, smem, mpre);
+  }
+  conv3_stage<MODE, NW, TPW>(a, smem, LUTN, c, dp_lds, mpre);
   STAMP(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
@@ -1524,7 +1925,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     }
   }
   const uint4* wq = (const uint4*)wg + lane;
-  float* x8 = (float*)(lut + MTW * 128);   // eight waves: [8][16][64] floats behind the LUT (second tap buffer, then the fold's exchange)
+  float* x8 = (float*)(lut + LUTN);        // eight waves: [8][16][64] floats behind the LUT (second tap buffer, then the fold's exchange)
   const bool ks_active = (wave >> 1) * TPW * 32 < npx;
   // What a wave of the per-sample kernels owns after the fold of the two channel halves -- and, in the forward, already
   // in the conv0 stage: TPW == 2: pixel tile `wave`, both channel tiles; TPW == 1: pixel tile wave >> 1, channel tile
@@ -1539,10 +1940,10 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     // loop: tap s copies items NT s + tid (pixel, 16-byte channel chunk) -- coalesced 16-byte stores, no registers
     // held across the loop.
     float* a0g = a.a0out + ((long long)net * a.n + s0) * (long long)HW * 64;
-    const int magicW = (65536 + c.W - 1) / c.W;          // m / W == (m * magic) >> 16 for m < 128 (checked on the host)
+    const int magicW = (65536 + c.W - 1) / c.W;          // m / W == (m * magic) >> 16 for every m of the map (checked on the host)
     auto side = [&](int s) {
       const int idx = s * NT + tid, m = idx >> 4, c4 = idx & 15;
-      if (s < 2048 / NT && m < HW) {
+      if (s < KMT * 512 / NT && m < HW) {
         const int h = (m * magicW) >> 16, w = m - h * c.W;
         *(float4*)(a0g + (size_t)m * 64 + c4 * 4) = *(const float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4);
       }
@@ -1620,14 +2021,17 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     }
     if (TAIL) {   // the tap-weight buffer is dead: it becomes the zero-bordered conv2 input image
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = tid; i < 1024; i += NT) ((float4*)wbuf)[i] = z4;
+      for (int i = tid; i < (BIG ? WBUF / 4 : 1024); i += NT) ((float4*)wbuf)[i] = z4;
     }
     STAMP(0, 10);
     __syncthreads();
     STAMP(0, 11);
     conv3_pool_store<NT>(a, c, TAIL ? wbuf : nullptr);
     STAMP(0, 7);
-    if (TAIL) conv3_fwd_tail<NW>(a, c, smem);
+    if constexpr (TAIL != 0) {
+      if constexpr (BIG) conv3_fwd_tail_g(a, c, smem);
+      else conv3_fwd_tail<NW>(a, c, smem);
+    }
   } else if (MODE == 3) {
     // conv0 weight gradient fused in (S == 1, MTW == 1):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
     // This wave's da0 tile = accumulators + dz (the residual branch); it goes to LDS as the B operand [pix][64]
@@ -1703,7 +2107,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
         const float* bp = dal + 32 * cn0 + l31;
         const int NS = (HWl + 15) >> 4;
 #pragma unroll
-        for (int kq = 0; kq < 8; ++kq) {                  // HW <= 128 (conv3_fused_bwd_ok)
+        for (int kq = 0; kq < 2 * KMT; ++kq) {            // HW <= 32 KMT (conv3_fused_bwd_ok)
           if (kq < NS) {                                  // uniform
             float ra[8], rb[TPW][8];
 #pragma unroll
@@ -1947,9 +2351,59 @@ static bool conv3_ks8(int rows) {
 }
 static size_t conv3_ks8_lds(size_t plain) { return plain + (size_t)8 * 16 * 64 * 4; }
 
+// Windows of 129 .. 256 pixels (BASELINE configs[4]: 15 x 15 x 48): the eight-wave, eight-tile per-sample kernels
+// conv3x3_kernel<2 | 3, 1, 1, 8, 2> with the generalised tail / head (final pooled maps of up to 12 pixels, pooled
+// conv1 maps of up to 64), ONE workgroup per CU whatever the grid.  CMLPL_FUSE_BIG=0: the general kernels instead.
+struct BigGeom { int HW, IMG, H2, W2, P2, NPX2, P4; };
+static bool conv3_big_geom(int H, int W, BigGeom* g) {
+  g->HW = H * W; g->IMG = (H + 2) * (W + 2); g->H2 = H / 2; g->W2 = W / 2; g->P2 = g->H2 * g->W2;
+  g->NPX2 = (g->H2 + 2) * (g->W2 + 2); g->P4 = (g->H2 / 2) * (g->W2 / 2);
+  if (switches().fuse_big == 0 || switches().fuse_conv0 == 0 || switches().fuse_tail == 0) return false;
+  if (g->HW <= 128 || g->HW > 256 || g->P2 > 64 || g->P4 < 1 || g->P4 > 12) return false;
+  if ((size_t)g->NPX2 * CS > WBUF) return false;                                  // the pooled map / dz2 image in the tap-weight buffer
+  if ((size_t)2560 + 3 * (size_t)g->NPX2 * 36 > (size_t)g->IMG * CS) return false;   // head row + partials + bf16 planes in the dead image
+  for (int m = 0; m < 256; ++m)                                                   // the magic-number divide of the kernel
+    if (((m * ((65536 + W - 1) / W)) >> 16) != m / W) return false;
+  return true;
+}
+static size_t conv3_big_plain(const BigGeom& g) { return ((size_t)g.IMG * CS + WBUF + 256 + 8192) * 4; }
+static size_t conv3_big_fwd_lds(const BigGeom& g, int C) {
+  const int KQ0 = (C + 15) / 16, ring = KQ0 < SLAB_RING ? KQ0 : SLAB_RING;
+  const size_t slot = (size_t)((4 * g.HW + 511) / 512) * 512 * 4;                  // floats per chunk slot
+  const size_t need = ring * slot * 4, plain = conv3_big_plain(g);
+  return need > plain ? need : plain;
+}
+static int conv3_big_bp(const BigGeom& g, int C) {
+  const long long avail = (long long)(LDS_MAX / 4) - (long long)(g.HW + 1) * 64;   // floats left for the slab rows
+  long long bp = avail / g.HW;
+  if (bp > 256) bp = 256;
+  if (bp * g.HW > 4 * SLAB_MAXQ * 256) bp = 4 * SLAB_MAXQ * 256 / g.HW;
+  if (C <= bp) return C;
+  return (int)(bp & ~31LL);                                                        // whole band tiles per pass
+}
+static size_t conv3_big_bwd_lds(const BigGeom& g, int C) {
+  const int bp = conv3_big_bp(g, C);
+  const size_t rows = (size_t)((bp + 31) / 32) * 32;                               // band rows a partial tile reads (garbage rows are dropped)
+  const size_t slab = (size_t)bp * g.HW + (size_t)(g.HW + 1) * 64, reach = rows * g.HW + 256;
+  const size_t need = (slab > reach ? slab : reach) * 4, plain = conv3_big_plain(g);
+  return need > plain ? need : plain;
+}
+static bool conv3_big_fwd_ok(int H, int W, int C, BigGeom* g) {
+  return C >= 1 && conv3_big_geom(H, W, g) && conv3_big_fwd_lds(*g, C) <= LDS_MAX;
+}
+static bool conv3_big_bwd_ok(int H, int W, int C, BigGeom* g) {
+  if (switches().fuse_conv0_bwd == 0 || C < 1 || C > 256 || !conv3_big_geom(H, W, g)) return false;
+  if (conv3_big_bp(*g, C) < 32 && conv3_big_bp(*g, C) < C) return false;
+  // the head's hand-off buffers behind the LUT: dp1s [P2][64] + dp2s [P4][64] + dls [64] + red [8] share the fold exchange
+  if ((size_t)g->P2 * 64 + (size_t)g->P4 * 64 + 64 + 8 > 8192) return false;
+  return conv3_big_bwd_lds(*g, C) <= LDS_MAX;
+}
+
 bool conv3_fused_ok(int H, int W, int C, int rows) {
   const bool off = switches().fuse_conv0 == 0;
   if (off || C < 1) return false;
+  BigGeom bg;
+  if (conv3_big_fwd_ok(H, W, C, &bg)) return true;
   Conv3Plan pl;
   if (!plan_conv3(0, H, W, rows, &pl)) return false;
   if (pl.S != 1 || pl.MTW != 1 || H * W > 128) return false;
@@ -1961,6 +2415,8 @@ bool conv3_fused_ok(int H, int W, int C, int rows) {
 bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K) {
   const bool off = switches().fuse_tail == 0;
   const int H2 = H / 2, W2 = W / 2;
+  BigGeom bg;
+  if (conv3_big_fwd_ok(H, W, C, &bg)) return K >= 1 && K <= 64;
   return !off && conv3_fused_ok(H, W, C, rows) && H2 / 2 == 2 && W2 / 2 == 2 && (H2 + 2) * (W2 + 2) * CS <= 4096 &&
          K >= 1 && K <= 64;
 }
@@ -1972,6 +2428,9 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   Conv3Plan pl;
   if (!conv3_fused_ok(H, W, C, nets * n) || !plan_conv3(0, H, W, nets * n, &pl)) return hipErrorInvalidValue;
   const int HW = H * W, P2 = (H / 2) * (W / 2);
+  BigGeom bg;
+  const bool big = conv3_big_fwd_ok(H, W, C, &bg);
+  if (big && tail == nullptr) return hipErrorInvalidValue;          // (the eight-tile kernels exist with their tail only)
   Conv3Args a;
   a.in = nullptr; a.mask_in = nullptr; a.wpk = wpk; a.bias = bias; a.out = out; a.mask_out = mask_out;
   a.wpk_ns = wpk_ns; a.bias_ns = bias_ns;
@@ -1987,8 +2446,12 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
     a.logits = tail->logits; a.feat = tail->feat; a.p2out = tail->p2; a.m2out = tail->m2;
     a.dropout_p = tail->dropout_p; a.train = tail->train; a.K = tail->K;
     static DevOnce attr_once;
-    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>, conv3x3_kernel<2, 1, 1, 8>);
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>, conv3x3_kernel<2, 1, 1, 8>, conv3x3_kernel<2, 1, 1, 8, 2>);
     if (e != hipSuccess) return e;
+    if (big) {
+      hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_fwd_lds(bg, C), st, a);
+      return hipGetLastError();
+    }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_lds(H, W, C, conv3_ks8_lds(pl.lds), 8);
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;
@@ -2024,6 +2487,8 @@ bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
   const bool off = switches().fuse_conv0 == 0;
   const bool offb = switches().fuse_conv0_bwd == 0;
   if (off || offb || C < 1 || C > 256) return false;
+  BigGeom bg;
+  if (conv3_big_bwd_ok(H, W, C, &bg)) return true;
   Conv3Plan pl;
   if (!plan_conv3(1, H, W, rows, &pl)) return false;
   if (pl.S != 1 || pl.MTW != 1 || H * W > 128 || conv3_bwd_bp(H, W, C) < 32) return false;
@@ -2036,6 +2501,8 @@ bool conv3_fused_bwd_ok(int H, int W, int C, int rows) {
 bool conv3_fused_head_ok(int H, int W, int C, int rows, int K) {
   const bool off = switches().fuse_tail == 0;
   const int H2 = H / 2, W2 = W / 2;
+  BigGeom bg;
+  if (conv3_big_bwd_ok(H, W, C, &bg)) return K >= 1 && K <= 64;
   if (off || !conv3_fused_bwd_ok(H, W, C, rows) || H2 / 2 != 2 || W2 / 2 != 2 || (H2 + 2) * (W2 + 2) * CS > 4096 ||
       H2 * W2 > 32 || K < 1 || K > 64)
     return false;
@@ -2054,21 +2521,28 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   // slab_range() reads plain rows by batch row: no noise, no index lists (the rows the forward saw, api.hip)
   if (xs.sigma != 0.f || xs.sel.lab_idx != nullptr || xs.sel.unl_idx != nullptr) return hipErrorInvalidValue;
   const int P2 = (H / 2) * (W / 2);
+  BigGeom bg;
+  const bool big = conv3_big_bwd_ok(H, W, C, &bg);
+  if (big && head == nullptr) return hipErrorInvalidValue;          // (the eight-tile kernels exist with their head only)
   Conv3Args a;
   a.in = dpool; a.mask_in = mask; a.wpk = wpk; a.bias = nullptr; a.out = nullptr; a.mask_out = nullptr;
   a.wpk_ns = wpk_ns; a.bias_ns = 0;
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
-  a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = conv3_bwd_bp(H, W, C);
+  a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
     a.yin = head->y; a.ynrm = head->ynorm; a.m2in = head->m2; a.w2d = head->w2d; a.w2d_ns = head->w2d_ns;
     a.dy = head->dy; a.dp2out = head->dp2; a.dp1out = head->dp1; a.K = head->K;
     static DevOnce attr_once;
-    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>, conv3x3_kernel<3, 1, 1, 8>);
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>, conv3x3_kernel<3, 1, 1, 8>, conv3x3_kernel<3, 1, 1, 8, 2>);
     if (e != hipSuccess) return e;
+    if (big) {
+      hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_bwd_lds(bg, C), st, a);
+      return hipGetLastError();
+    }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pl.lds));
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;

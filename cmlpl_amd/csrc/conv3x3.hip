@@ -20,6 +20,7 @@
 // so the 9 taps are pure address offsets.  Weights are kept re-packed by the optimizer (kernels.hpp, PACK_*) as
 // ready-made split-bf16 B fragments [tap][k16][piece][n tile][lane][8 bf16]: a fragment is one 16-byte read.
 #include <stdlib.h>
+#include <type_traits>
 
 // Ablation / timeline builds (scripts/conv_timeline.py): -DCMLPL_ABL=n removes one ingredient
 // of a kernel (results are then wrong on purpose) or adds per-workgroup phase stamps (9).  0 = the product.
@@ -1064,6 +1065,7 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
       for (int pc = 0; pc < 3; ++pc) bq[t0][3 * ks + pc] = wq[((t0 * 4 + 2 * ks) * 3 + pc) * 128];
   const float4 y4 = *(const float4*)(a.yin + rs * FD + 4 * tid);
   const float bias2 = (a.b2 + (long long)net * a.p_ns)[wave * 16 + j];
+  const float bcv = (a.bc + (long long)net * a.p_ns)[tid < K ? tid : 0];   // (needed by the very last statement: not behind the last barrier)
   // ... and what the head will want after conv2, so that its L2 round trips run under conv2's: the classifier rows of
   // the first 16 classes (wave w owns features [w F/4, (w+1) F/4) of the row, 5 per lane) and the dropout multipliers
   // of this thread's two float4 of the row (counter-based: they depend on nothing computed here)
@@ -1203,19 +1205,29 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   STAMP(0, 9);
   // logits: wave w takes the quarter [w*F4, (w+1)*F4) of the row for ALL classes (16 at a time), then the four
   // partial dot products meet in LDS
-  const float* bc = a.bc + (long long)net * a.p_ns;
   float* part = red + 4;                     // [4 waves][64 classes]
   float xr[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) xr[i] = row[fb + lane + 64 * i];
+  {
+    // all sixteen reductions in ONE basic block, step by step (the same sums as wave_sum): behind a `q < K` branch each
+    // class's six dependent cross-lane steps ran alone -- nine chains in a row, ~2 us of this sample's critical path
+    float t[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    if (q < K) {                             // uniform: no reduction for classes that do not exist
+    for (int q = 0; q < 16; ++q) {
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < 5; ++i) acc = fmaf(xr[i], wv0[q][i], acc);
-      const float t = wave_sum(acc);
-      if (lane == 0) part[wave * 64 + q] = t;
+      t[q] = acc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[q] += __shfl_xor(t[q], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (q < K) part[wave * 64 + q] = t[q];
     }
   }
   for (int kc = 16; kc < K; kc += 16) {      // more than 16 classes: further chunks
@@ -1228,19 +1240,26 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
 #pragma unroll
       for (int i = 0; i < 5; ++i) wv[q][i] = wr[64 * i];
     }
+    float t[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      if (kc + q < K) {                      // uniform: no reduction for classes that do not exist
-        float acc = 0.f;
+      float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc = fmaf(xr[i], wv[q][i], acc);
-        const float t = wave_sum(acc);
-        if (lane == 0) part[wave * 64 + kc + q] = t;
-      }
+      for (int i = 0; i < 5; ++i) acc = fmaf(xr[i], wv[q][i], acc);
+      t[q] = acc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[q] += __shfl_xor(t[q], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (kc + q < K) part[wave * 64 + kc + q] = t[q];
     }
   }
   __syncthreads();
-  if (tid < K) a.logits[rs * K + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bc[tid];
+  if (tid < K) a.logits[rs * K + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bcv;
 }
 
 // The first part of the backward pass of this workgroup's sample (S == 1), run in front of the conv1 data gradient:
@@ -1506,29 +1525,27 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
   constexpr int PS2 = 36;
   const int NPX2 = (H2 + 2) * PW2, PLN = NPX2 * PS2;
   uint32_t* pl = (uint32_t*)(smem + 2560);   // three bf16 planes [pixel][PS2 dwords]
+  float* xch = (float*)(pl + 3 * PLN);       // conv2's k-half exchange [4 channel groups][3 tiles][4][64] (behind the planes)
   const long long rs = (long long)net * a.n + sample;
-  const int cog = wave & 3, th = wave >> 2, NTL = (P4 + 3) >> 2;
+  // conv2: wave = (16 output channels cog = w & 3, k-step ksh = w >> 2 of every tap's two), ALL (up to three) 16-row tiles:
+  // a tap's three B fragments are loaded once and serve every tile; the two k-steps meet through LDS once, at the end
+  const int cog = wave & 3, ksh = wave >> 2;
   const int j = lane & 15, kg = lane >> 4;
-  const uint4* wq = (const uint4*)(a.w2f + (long long)net * a.w2f_ns) + ((kg >> 1) * 6 + (cog >> 1)) * 64 + (kg & 1) * 32 +
-                    16 * (cog & 1) + j;
-  constexpr int C2_AHEAD = 2;   // (three fragment sets: a fourth one spills -- 8-byte address spills around the tile loop)
-  uint4 bq[C2_AHEAD + 1][6];
-  auto prime_b = [&]() {
+  const uint4* wq = (const uint4*)(a.w2f + (long long)net * a.w2f_ns) + ((2 * ksh + (kg >> 1)) * 6 + (cog >> 1)) * 64 +
+                    (kg & 1) * 32 + 16 * (cog & 1) + j;
+  constexpr int C2_AHEAD = 3;
+  uint4 bq[C2_AHEAD + 1][3];
 #pragma unroll
-    for (int t0 = 0; t0 < C2_AHEAD; ++t0)
+  for (int t0 = 0; t0 < C2_AHEAD; ++t0)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) bq[t0][3 * ks + pc] = wq[((t0 * 4 + 2 * ks) * 3 + pc) * 128];
-  };
-  prime_b();
-  // ---- loads up front: the spectral row (threads 0..255), conv2's bias, this thread's dropout multipliers and the first
-  // eight classes' classifier weights of its 16-byte group
+    for (int pc = 0; pc < 3; ++pc) bq[t0][pc] = wq[((t0 * 4) * 3 + pc) * 128];
+  // ---- loads up front: the spectral row (threads 0..255), conv2's bias, this thread's dropout multipliers
   float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) y4 = *(const float4*)(a.yin + rs * FD + 4 * tid);
   const float bias2 = (a.b2 + (long long)net * a.p_ns)[cog * 16 + j];
+  const float bcv = (a.bc + (long long)net * a.p_ns)[tid < K ? tid : 0];
   const float* wc = a.wc + (long long)net * a.p_ns;
-  const bool grp = tid < F4;                 // this thread owns group tid of the row
+  const bool grp = tid < F4;                 // this thread owns the 16-byte group tid of the row
   const int f0 = 4 * (grp ? tid : 0);
   const int dmode = (!a.train || a.dropout_p <= 0.f) ? 0 : (a.dropmask != nullptr ? 1 : 2);
   const float keep_scale = 1.0f / (1.0f - a.dropout_p);
@@ -1573,72 +1590,88 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), cc, 0, 0, 0);
   };
   const int co = cog * 16 + j;
-#pragma unroll 1
-  for (int t = th; t < NTL; t += 2) {
-    // A row of this lane: sub-pixel (j & 3) of window 4 t + (j >> 2); windows past the map multiply a real pixel's
-    // operands (results dropped)
+  // A rows of this lane, window-major: sub-pixel (j & 3) of window 4 t + (j >> 2) of tile t; windows past the map
+  // multiply a real pixel's operands (results dropped)
+  const uint32_t* ap0[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
     const int wa = 4 * t + (j >> 2), wac = wa < P4 ? wa : 0;
     const int oh = 2 * (wac / W4) + ((j >> 1) & 1), ow = 2 * (wac % W4) + (j & 1);
-    const uint32_t* ap0 = pl + (size_t)((oh + 1) * PW2 + ow + 1) * PS2 + 4 * kg;
-    if (t != th) prime_b();
-    f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    uint4 af[2][6];
-    auto read_a = [&](int tap, uint4 (&x)[6]) {
-      const uint32_t* ap = ap0 + ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * PS2;
+    ap0[t] = pl + (size_t)((oh + 1) * PW2 + ow + 1) * PS2 + 4 * kg + 16 * ksh;
+  }
+  f32x4v acc0[3], acc1[3];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        x[3 * ks] = *(const uint4*)(ap + 16 * ks); x[3 * ks + 1] = *(const uint4*)(ap + PLN + 16 * ks);
-        x[3 * ks + 2] = *(const uint4*)(ap + 2 * PLN + 16 * ks);
-      }
-    };
-    read_a(0, af[0]);
+  for (int t = 0; t < 3; ++t) { acc0[t] = {0.f, 0.f, 0.f, 0.f}; acc1[t] = {0.f, 0.f, 0.f, 0.f}; }
+  uint4 af[2][9];
+  auto read_a = [&](int tap, uint4 (&x)[9]) {
+    const int toff = ((tap / 3 - 1) * PW2 + (tap % 3 - 1)) * PS2;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap + C2_AHEAD < 9) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
-            bq[(tap + C2_AHEAD) % (C2_AHEAD + 1)][3 * ks + pc] = wq[(((tap + C2_AHEAD) * 4 + 2 * ks) * 3 + pc) * 128];
-      }
-      if (tap + 1 < 9) read_a(tap + 1, af[(tap + 1) & 1]);
-      const uint4 (&bcur)[6] = bq[tap % (C2_AHEAD + 1)];
-      const uint4 (&acur)[6] = af[tap & 1];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const uint4 a1 = acur[3 * ks], a2 = acur[3 * ks + 1], a3 = acur[3 * ks + 2];
-        const uint4 b1 = bcur[3 * ks], b2 = bcur[3 * ks + 1], b3 = bcur[3 * ks + 2];
-        acc0 = mm(a1, b3, acc0); acc1 = mm(a2, b2, acc1); acc0 = mm(a3, b1, acc0);
-        acc1 = mm(a1, b2, acc1); acc0 = mm(a2, b1, acc0); acc1 = mm(a1, b1, acc1);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    for (int t = 0; t < 3; ++t) {            // (all three tiles whatever P4: straight-line code; a tile past the map costs 18 MFMAs)
+      const uint32_t* ap = ap0[t] + toff;
+      x[3 * t] = *(const uint4*)(ap); x[3 * t + 1] = *(const uint4*)(ap + PLN); x[3 * t + 2] = *(const uint4*)(ap + 2 * PLN);
     }
-    // epilogue: lane (co, kg) holds window 4 t + kg, registers = its four sub-pixels (dh, dw) = (r >> 1, r & 1)
-    const int win = 4 * t + kg;
-    if (win < P4) {
-      const int ph = win / W4, pw = win - ph * W4;
-      float r_[4];
+  };
+  read_a(0, af[0]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float res = img2[(size_t)((2 * ph + (r >> 1) + 1) * PW2 + 2 * pw + (r & 1) + 1) * CS + co];   // residual branch
-        r_[r] = relu_nan((acc0[r] + acc1[r]) + bias2 + res);
+  for (int tap = 0; tap < 9; ++tap) {
+    if (tap + C2_AHEAD < 9) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        bq[(tap + C2_AHEAD) % (C2_AHEAD + 1)][pc] = wq[(((tap + C2_AHEAD) * 4) * 3 + pc) * 128];
+    }
+    if (tap + 1 < 9) read_a(tap + 1, af[(tap + 1) & 1]);
+    const uint4 (&bcur)[3] = bq[tap % (C2_AHEAD + 1)];
+    const uint4 (&acur)[9] = af[tap & 1];
+    const uint4 b1 = bcur[0], b2 = bcur[1], b3 = bcur[2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const uint4 a1 = acur[3 * t], a2 = acur[3 * t + 1], a3 = acur[3 * t + 2];
+      acc0[t] = mm(a1, b3, acc0[t]); acc1[t] = mm(a2, b2, acc1[t]); acc0[t] = mm(a3, b1, acc0[t]);
+      acc1[t] = mm(a1, b2, acc1[t]); acc0[t] = mm(a2, b1, acc0[t]); acc1[t] = mm(a1, b1, acc1[t]);
+    }
+    // pin the order: this tap's loads and reads first, then its eighteen MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);    // VMEM reads (none in the last taps: the group is then empty)
+    __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);    // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);   // MFMA
+  }
+  STAMP(0, 8);
+  // first classes' classifier weights of this thread's group (their round trip runs under the fold and the epilogue)
+  constexpr int KC = 24;
+  float4 wv[KC];
+#pragma unroll
+  for (int q = 0; q < KC; ++q) wv[q] = *(const float4*)(wc + (long long)(q < K ? q : K - 1) * F + f0);
+  // fold the two k-steps: waves ksh = 1 hand (acc0 + acc1) of every tile to their partner
+  if (ksh == 1) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xch[((cog * 3 + t) * 4 + r) * 64 + lane] = acc0[t][r] + acc1[t][r];
+  }
+  __syncthreads();
+  if (ksh == 0) {
+    // epilogue: lane (co, kg) holds window 4 t + kg of tile t, registers = its four sub-pixels (dh, dw) = (r >> 1, r & 1)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int win = 4 * t + kg;
+      if (win < P4) {
+        const int ph = win / W4, pw = win - ph * W4;
+        float r_[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float res = img2[(size_t)((2 * ph + (r >> 1) + 1) * PW2 + 2 * pw + (r & 1) + 1) * CS + co];   // residual branch
+          r_[r] = relu_nan(((acc0[t][r] + acc1[t][r]) + xch[((cog * 3 + t) * 4 + r) * 64 + lane]) + bias2 + res);
+        }
+        const float o = ((r_[0] + r_[1]) + (r_[2] + r_[3])) * 0.25f;
+        const uint32_t nib = (relu_open(r_[0]) ? 1u : 0u) | (relu_open(r_[1]) ? 2u : 0u) | (relu_open(r_[2]) ? 4u : 0u) |
+                             (relu_open(r_[3]) ? 8u : 0u);
+        a.p2out[(rs * P4 + win) * 64 + co] = o;
+        a.m2out[(rs * P4 + win) * 64 + co] = (uint8_t)nib;
+        row[co * P4 + win] = o;              // canonical flatten order f = c * P4 + hw (x.view, models.py:141)
       }
-      const float o = ((r_[0] + r_[1]) + (r_[2] + r_[3])) * 0.25f;
-      const uint32_t nib = (relu_open(r_[0]) ? 1u : 0u) | (relu_open(r_[1]) ? 2u : 0u) | (relu_open(r_[2]) ? 4u : 0u) |
-                           (relu_open(r_[3]) ? 8u : 0u);
-      a.p2out[(rs * P4 + win) * 64 + co] = o;
-      a.m2out[(rs * P4 + win) * 64 + co] = (uint8_t)nib;
-      row[co * P4 + win] = o;                // canonical flatten order f = c * P4 + hw (x.view, models.py:141)
     }
   }
-  // (the first eight classes' classifier weights of this thread's group: requested here, not at kernel start -- the
-  //  conv2 loop's fragment rings leave no registers for them -- their round trip runs under the barrier and the row read)
-  float4 wv[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(q < K ? q : K - 1) * F + f0);
   __syncthreads();                           // row[0 .. SF) complete
+  STAMP(0, 9);
   const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
   if (tid == 0) a.ynorm[rs] = norm;
   if (tid < 256) {
@@ -1652,28 +1685,34 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
     if (dmode != 0) { x4.x *= dm4.x; x4.y *= dm4.y; x4.z *= dm4.z; x4.w *= dm4.w; }
     *(float4*)(a.catd + rs * F + f0) = x4;
   }
-  // logits: eight classes at a time, every weight of a chunk requested before the first is used
-  for (int kc = 0; kc < K; kc += 8) {
+  // logits: KC classes at a time, every weight of a chunk requested before the first is used
+  for (int kc = 0; kc < K; kc += KC) {
     if (kc > 0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(kc + q < K ? kc + q : K - 1) * F + f0);
+      for (int q = 0; q < KC; ++q) wv[q] = *(const float4*)(wc + (long long)(kc + q < K ? kc + q : K - 1) * F + f0);
+    }
+    float t[KC];                             // all reductions of a chunk in one basic block, step by step (see conv3_fwd_tail)
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+      const float acc = (x4.x * wv[q].x + x4.y * wv[q].y) + (x4.z * wv[q].z + x4.w * wv[q].w);
+      t[q] = grp ? acc : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (kc + q < K) {                      // uniform
-        float acc = (x4.x * wv[q].x + x4.y * wv[q].y) + (x4.z * wv[q].z + x4.w * wv[q].w);
-        acc = wave_sum(grp ? acc : 0.f);
-        if (lane == 0) part[wave * 64 + kc + q] = acc;
-      }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < KC; ++q) t[q] += __shfl_xor(t[q], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < KC; ++q)
+        if (kc + q < K) part[wave * 64 + kc + q] = t[q];
     }
   }
   __syncthreads();
   if (tid < K) {
-    const float* bc = a.bc + (long long)net * a.p_ns;
     float sacc = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) sacc += part[w * 64 + tid];
-    a.logits[rs * K + tid] = sacc + bc[tid];
+    a.logits[rs * K + tid] = sacc + bcv;
   }
 }
 
@@ -1706,13 +1745,6 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
   }
   const uint4* wq = (const uint4*)(a.w2d + (long long)net * a.w2d_ns) + lane;
   constexpr int C2_AHEAD = 3;
-  uint4 bq[C2_AHEAD + 1][6];
-#pragma unroll
-  for (int t0 = 0; t0 < C2_AHEAD; ++t0)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) bq[t0][3 * q + pc] = wq[(size_t)t0 * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
   if (tid < 64) dls[tid] = (tid < K) ? a.dlogits[rs * K + tid] : 0.f;
   const bool grp = tid < F4;
   const int f0 = 4 * (grp ? tid : 0);
@@ -1728,9 +1760,10 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
   const float* wc = a.wc + (long long)net * a.p_ns;
   float4 dm4 = make_float4(1.f, 1.f, 1.f, 1.f);
   if (a.hmask != nullptr && grp) dm4 = *(const float4*)(a.hmask + rs * F + f0);
-  float4 wv[8];
+  constexpr int KC = 24;                                            // classes per chunk: every weight of a chunk in flight at once
+  float4 wv[KC];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(q < K ? q : K - 1) * F + f0);
+  for (int q = 0; q < KC; ++q) wv[q] = *(const float4*)(wc + (long long)(q < K ? q : K - 1) * F + f0);
   {  // while those loads fly: zero-bordered dz2 image, conv1 image zero fill, output-pixel LUT
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < WBUF / 4; i += NT) ((float4*)img2)[i] = z4;
@@ -1749,13 +1782,13 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
   __syncthreads();
   dot = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
   float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int kc = 0; kc < K; kc += 8) {
+  for (int kc = 0; kc < K; kc += KC) {
     if (kc > 0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) wv[q] = *(const float4*)(wc + (long long)(kc + q < K ? kc + q : K - 1) * F + f0);
+      for (int q = 0; q < KC; ++q) wv[q] = *(const float4*)(wc + (long long)(kc + q < K ? kc + q : K - 1) * F + f0);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < KC; ++q) {
       const float dl = (kc + q < K) ? dls[kc + q] : 0.f;
       dc.x = fmaf(dl, wv[q].x, dc.x); dc.y = fmaf(dl, wv[q].y, dc.y);
       dc.z = fmaf(dl, wv[q].z, dc.z); dc.w = fmaf(dl, wv[q].w, dc.w);
@@ -1783,6 +1816,16 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
       *(float4*)(a.dy + rs * FD + j0) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
+  STAMP(1, 10);
+  // the conv2 data gradient's first fragment sets (requested here: their round trip runs under the dz2 staging and its
+  // barriers; at kernel start they would sit in registers through the head's arithmetic)
+  uint4 bq[C2_AHEAD + 1][6];
+#pragma unroll
+  for (int t0 = 0; t0 < C2_AHEAD; ++t0)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bq[t0][3 * q + pc] = wq[(size_t)t0 * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
   __syncthreads();                                                 // dp2s complete, img2 zeroed
   if (tid < P4 * 16) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
     const int c4 = tid & 15, pp = tid >> 4, ph = pp / W4, pw = pp - ph * W4;
@@ -1872,6 +1915,7 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
     }
   }
   __syncthreads();                                                 // dp1s complete; img2 (= wbuf) is free again
+  STAMP(1, 11);
   return dp1s;
 }
 
@@ -2093,6 +2137,87 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
       // dW0 tile of this wave on the split-bf16 MFMA: k-steps of 16 pixels; lane (row = band c, half h) takes pixels
       // 16 kq + 8h .. + 7 of its slab row, lane (col = co, half h) the same pixels of da0; both are split in registers
       // (132 VALU instructions per 12 MFMAs).  Pixels >= HW of the last step read the zero row behind da0.
+      if constexpr (BIG) {
+        // Eight waves, up to eight band tiles -- but BASELINE configs[4] has 48 bands: with wave = band tile six waves
+        // would idle while two walk fifteen k-steps.  By the band tiles of this pass (uniform):
+        //   <= 2 tiles: wave = (band tile w >> 2, co tile (w >> 1) & 1, k-steps of parity w & 1), the two parities meet in LDS
+        //   <= 4 tiles: wave = (band tile w >> 1, co tile w & 1)
+        //   else      : wave = band tile, both co tiles
+        const int NBT = (nb + 31) >> 5;
+        const int NS = (HWl + 15) >> 4;
+        float* xw = dal + (size_t)(HWl + 1) * 64;           // [8 waves][16][64] + [8][64]: the k-parity exchange (behind da0)
+        auto wtile = [&](auto nct_c, int btile, int cn0, int kq0, int kqs, bool pair) {
+          constexpr int NCT = decltype(nct_c)::value;
+          const bool has_tile = btile * 32 < nb;
+          const bool has_db = cb == 0 && btile == 0;        // the waves of band tile 0 also sum the bias gradient of their co tile(s)
+          f32x16 g[NCT];
+#pragma unroll
+          for (int i = 0; i < NCT; ++i) g[i] = zero16();
+          float dbacc[NCT];
+#pragma unroll
+          for (int i = 0; i < NCT; ++i) dbacc[i] = 0.f;
+          if (has_tile || has_db) {
+            const int crow = btile * 32 + l31;
+            const float* ap = slab + (size_t)crow * HWl + 8 * hh;
+            const float* bp = dal + 32 * cn0 + l31;
+#pragma unroll 1
+            for (int kq = kq0; kq < NS; kq += kqs) {        // (rolled: three variants of sixteen unrolled k-steps spilled addresses)
+              {
+                float ra[8], rb[NCT][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int k = kq * 16 + 8 * hh + j;
+                  const int kc = k < HWl ? k : HWl;         // the zero row
+                  ra[j] = ap[kq * 16 + j];
+#pragma unroll
+                  for (int i = 0; i < NCT; ++i) rb[i][j] = bp[kc * 64 + 32 * i];
+                }
+                uint4 A1, A2, A3, P1, P2, P3;
+                a_split(make_float4(ra[0], ra[1], ra[2], ra[3]), make_float4(ra[4], ra[5], ra[6], ra[7]), A1, A2, A3);
+#pragma unroll
+                for (int i = 0; i < NCT; ++i) {
+                  a_split(make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]), make_float4(rb[i][4], rb[i][5], rb[i][6], rb[i][7]), P1, P2, P3);
+                  g[i] = mfma_b3(A1, A2, A3, P1, P2, P3, g[i]);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) dbacc[i] += rb[i][j];
+                }
+              }
+            }
+          }
+          if (pair) {                                       // (uniform; NCT == 1) odd k-parity hands its tile and bias sum to the even one
+            if (wave & 1) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) xw[(wave * 16 + r) * 64 + lane] = g[0][r];
+              xw[8 * 1024 + wave * 64 + lane] = dbacc[0];
+            }
+            __syncthreads();
+            if (wave & 1) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[0][r] += xw[((wave + 1) * 16 + r) * 64 + lane];
+            dbacc[0] += xw[8 * 1024 + (wave + 1) * 64 + lane];
+          }
+          if (has_tile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int cc = btile * 32 + acc_row(r, lane);
+              if (cc < nb || (C <= BP && cc < Cw)) {
+#pragma unroll
+                for (int i = 0; i < NCT; ++i) pp[(size_t)(cb + cc) * 64 + 32 * (cn0 + i) + l31] = g[i][r];
+              }
+            }
+          }
+          if (has_db) {
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) {
+              const float tot = dbacc[i] + __shfl_xor(dbacc[i], 32, 64);
+              if (hh == 0) pp[(size_t)Cw * 64 + 32 * (cn0 + i) + l31] = tot;
+            }
+          }
+        };
+        if (NBT <= 2) wtile(std::integral_constant<int, 1>(), wave >> 2, (wave >> 1) & 1, wave & 1, 2, true);
+        else if (NBT <= 4) wtile(std::integral_constant<int, 1>(), wave >> 1, wave & 1, 0, 1, false);
+        else wtile(std::integral_constant<int, 2>(), wave, 0, 0, 1, false);
+      } else {
       // four waves: wave = band tile, both co tiles; eight waves: wave = (band tile, co tile)
       const int btile = (TPW == 2) ? wave : (wave >> 1), cn0 = (TPW == 2) ? 0 : (wave & 1);
       const bool has_tile = btile * 32 < nb;              // uniform: this wave's band tile exists in this pass
@@ -2144,6 +2269,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
           const float tot = dbacc + __shfl_xor(dbacc, 32, 64);
           if (hh == 0) pp[(size_t)Cw * 64 + wave * 32 + l31] = tot;
         }
+      }
       }
     }
   } else {
@@ -2361,7 +2487,7 @@ static bool conv3_big_geom(int H, int W, BigGeom* g) {
   if (switches().fuse_big == 0 || switches().fuse_conv0 == 0 || switches().fuse_tail == 0) return false;
   if (g->HW <= 128 || g->HW > 256 || g->P2 > 64 || g->P4 < 1 || g->P4 > 12) return false;
   if ((size_t)g->NPX2 * CS > WBUF) return false;                                  // the pooled map / dz2 image in the tap-weight buffer
-  if ((size_t)2560 + 3 * (size_t)g->NPX2 * 36 > (size_t)g->IMG * CS) return false;   // head row + partials + bf16 planes in the dead image
+  if ((size_t)2560 + 3 * (size_t)g->NPX2 * 36 + 3072 > (size_t)g->IMG * CS) return false;   // head row + partials + bf16 planes + conv2's exchange in the dead image
   for (int m = 0; m < 256; ++m)                                                   // the magic-number divide of the kernel
     if (((m * ((65536 + W - 1) / W)) >> 16) != m / W) return false;
   return true;
@@ -2384,7 +2510,8 @@ static int conv3_big_bp(const BigGeom& g, int C) {
 static size_t conv3_big_bwd_lds(const BigGeom& g, int C) {
   const int bp = conv3_big_bp(g, C);
   const size_t rows = (size_t)((bp + 31) / 32) * 32;                               // band rows a partial tile reads (garbage rows are dropped)
-  const size_t slab = (size_t)bp * g.HW + (size_t)(g.HW + 1) * 64, reach = rows * g.HW + 256;
+  const size_t slab = (size_t)bp * g.HW + (size_t)(g.HW + 1) * 64 + 8 * 1024 + 8 * 64,      // + the conv0 weight gradient's k-parity exchange
+               reach = rows * g.HW + 256;
   const size_t need = (slab > reach ? slab : reach) * 4, plain = conv3_big_plain(g);
   return need > plain ? need : plain;
 }

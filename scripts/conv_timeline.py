@@ -10,11 +10,12 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 103          # bands: 103 = B2, 2
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 BT = int(sys.argv[3]) if len(sys.argv) > 3 else 128          # rows per network: 64 64 = a rank's shard of configs[2] at 8 GPUs
 BTU = int(sys.argv[4]) if len(sys.argv) > 4 else 128
-shape = NetShape(C, 11, 11, C, K)
+WIN = int(os.environ.get("CMLPL_TL_WIN", "11"))           # window side: 11 = B2 / B4, 15 = B5
+shape = NetShape(C, WIN, WIN, C, K)
 eng = TrainEngine(shape, BT, BTU, HyperParams(), device="cuda:0", seed=1)
 g = torch.Generator(device="cuda:0").manual_seed(0)
-XPl = torch.randn(BT, C, 11, 11, device="cuda:0", generator=g)
-XPu = torch.randn(BTU, C, 11, 11, device="cuda:0", generator=g)
+XPl = torch.randn(BT, C, WIN, WIN, device="cuda:0", generator=g)
+XPu = torch.randn(BTU, C, WIN, WIN, device="cuda:0", generator=g)
 Xl = torch.randn(BT, C, device="cuda:0", generator=g)
 Xu = torch.randn(BTU, C, device="cuda:0", generator=g)
 Y = torch.randint(0, K, (BT,), device="cuda:0", generator=g)

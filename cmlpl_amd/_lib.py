@@ -31,7 +31,7 @@ EXPORTS = (
     "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
     "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g", "cmlpl_memobank_loss",
     "cmlpl_source_hash", "cmlpl_dyn_adam", "cmlpl_step_graph_create", "cmlpl_step_graph_launch",
-    "cmlpl_step_graph_destroy",
+    "cmlpl_step_graph_destroy", "cmlpl_infer_workspace_bytes", "cmlpl_infer_cube",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -179,6 +179,9 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_loss_workspace_bytes.restype = sz
     lib.cmlpl_dist_unpack.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.cmlpl_extract_patches.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp]
+    lib.cmlpl_infer_workspace_bytes.argtypes = [vp, i32]
+    lib.cmlpl_infer_workspace_bytes.restype = C.c_size_t
+    lib.cmlpl_infer_cube.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.c_int64, i32, vp, vp, vp, C.c_size_t, vp]
     lib.cmlpl_ntxent_workspace_bytes.argtypes = [i32, i32]
     lib.cmlpl_ntxent_workspace_bytes.restype = sz
     lib.cmlpl_ntxent_fwd_bwd.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp, sz, vp]
@@ -204,7 +207,7 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_timing_end.argtypes = [C.POINTER(C.c_double), C.POINTER(i64)]
     for s in EXPORTS[1:]:
         if hasattr(lib, s) and s not in ("cmlpl_workspace_bytes", "cmlpl_loss_workspace_bytes", "cmlpl_ntxent_workspace_bytes",
-                     "cmlpl_unsup_workspace_bytes", "cmlpl_source_hash"):
+                     "cmlpl_unsup_workspace_bytes", "cmlpl_source_hash", "cmlpl_infer_workspace_bytes"):
             getattr(lib, s).restype = i32
     if lib.cmlpl_abi_version() != ABI_VERSION:
         raise CmlplLibraryError(f"ABI version mismatch: library {lib.cmlpl_abi_version()}, binding {ABI_VERSION}")

@@ -822,6 +822,39 @@ int cmlpl_extract_patches(const float* d_cube, int rows, int cols, int C, int w,
                                     (hipStream_t)stream));
 }
 
+size_t cmlpl_infer_workspace_bytes(const cmlpl_shape* shape, int n) {
+  Dims d;
+  if (!make_dims(shape, &d) || n < 1 || !conv3_infer_ok(d.H, d.W, d.C, d.K)) return 0;   // 0: not a shape cmlpl_infer_cube takes
+  return up256((size_t)n * 1024 * 4);                       // y = relu(feat_spe(spectrum)) of the launch's pixels
+}
+
+int cmlpl_infer_cube(const cmlpl_shape* shape, const float* d_params, const float* d_packed, const float* d_cube,
+                     int rows, int cols, const float* d_spectra, int64_t pixel0, int n, int64_t* d_labels,
+                     float* d_logits, void* d_workspace, size_t workspace_bytes, void* stream) {
+  Dims d;
+  cmlpl_layout_t L;
+  if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
+  if (!d_params || !d_packed || !d_cube || !d_spectra || !d_labels || !d_workspace || rows < 1 || cols < 1 || n < 1 ||
+      pixel0 < 0 || pixel0 + n > (int64_t)rows * cols)
+    return CMLPL_E_ARG;
+  if (!conv3_infer_ok(d.H, d.W, d.C, d.K)) return CMLPL_E_SHAPE;
+  if (cmlpl_infer_workspace_bytes(shape, n) > workspace_bytes) return CMLPL_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* y = (float*)d_workspace;
+  int rc;
+  // spectral branch of the range's pixels (plain rows, canonical weight)
+  if ((rc = chk(launch_spe_fwd(1, n, d.bands, d_spectra + (long long)pixel0 * d.bands, d_params + L.param_off[6],
+                               d_params + L.param_off[7], L.param_total, y, st)))) return rc;
+  FwdTail t;
+  memset(&t, 0, sizeof(t));
+  t.w2f = d_packed + pack_off_b3(d.C, d.bands, 2); t.b2 = d_params + L.param_off[5];
+  t.wc = d_params + L.param_off[8]; t.bc = d_params + L.param_off[9];
+  t.y = y; t.logits = d_logits; t.K = d.K;
+  return chk(launch_conv3_infer(n, d.C, d.H, d.W, d_cube, rows, cols, pixel0, d_packed + pack_off_w0b3(d.C, d.bands),
+                                d_params + L.param_off[1], d_packed + pack_off_b3(d.C, d.bands, 0),
+                                d_params + L.param_off[3], t, (long long*)d_labels, st));
+}
+
 size_t cmlpl_ntxent_workspace_bytes(int B, int D) { return (B < 1 || D < 1) ? 0 : ntxent_ws_floats(B, D) * 4; }
 
 int cmlpl_ntxent_fwd_bwd(const float* d_emb_i, const float* d_emb_j, int B, int D, float temperature, float* d_loss,

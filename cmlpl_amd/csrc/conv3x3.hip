@@ -20,6 +20,7 @@
 // so the 9 taps are pure address offsets.  Weights are kept re-packed by the optimizer (kernels.hpp, PACK_*) as
 // ready-made split-bf16 B fragments [tap][k16][piece][n tile][lane][8 bf16]: a fragment is one 16-byte read.
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 // Ablation / timeline builds (scripts/conv_timeline.py): -DCMLPL_ABL=n removes one ingredient
@@ -144,12 +145,25 @@ struct Conv3Args {
   const float* dlogits; const float* dfeat; const float* hmask;   // hmask: dropout multiplier rows or null
   const float* ynrm; const uint8_t* m2in; const float* w2d; long long w2d_ns;
   float* dy; float* dp2out; float* dp1out;
+  // INFER (forward, TAIL == 2): whole-image inference straight from the scene cube (tools/hyper_tools.py:226-243,416-437):
+  // sample s is pixel pix0 + s (row-major) of the band-last cube [crows][ccols][C]; its H x W window is gathered through
+  // the mirror index of ExtractPatches while the slab chunks are staged -- no patch tensor exists; the argmax goes to
+  // labels_out[s] (logits optional)
+  const float* cube; int crows, ccols; long long pix0; long long* labels_out;
 };
 
 // Workgroup -> (network, first sample).  (Measured, round 3: numbering the workgroups so that the two a CU holds belong
 // to the same network -- hoping their weight-fragment streams would meet in L1 -- changed nothing: 0.2129 vs 0.2128 ms.)
 __device__ __forceinline__ void wg_decode(const Conv3Args& a, int& net, int& s0) {
   net = (int)blockIdx.y; s0 = (int)blockIdx.x * a.S;
+}
+// Inference from the cube: workgroup b takes pixel (b % 8) * ceil(n / 8) + b / 8 of the launch's range, so that each XCD
+// (own L2, workgroups dealt round-robin) walks one contiguous eighth in raster order and overlapping windows are re-read
+// from ITS L2 (what made raster-ordered patch extraction 25-30 % faster, augment.hip); -1: past the range.
+__device__ __forceinline__ int wg_infer_sample(const Conv3Args& a) {
+  const int b = (int)blockIdx.x, per = (a.n + 7) >> 3;
+  const int s = (b & 7) * per + (b >> 3);
+  return ((b >> 3) < per && s < a.n) ? s : -1;
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -617,15 +631,17 @@ struct Conv3Ctx {
 
 // NW = waves of the workgroup: 4 (every MODE), or 8 for the per-sample kernels (MODE >= 2) when one workgroup has a CU
 // to itself (see ks_unit); NT = its threads, TPW = M tiles per wave in the tap loop.
-template <int MODE, int NW = 4, int TPW = 8 / NW>
+template <int MODE, int NW = 4, int TPW = 8 / NW, bool CUBE = false>
 __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c,
                                             const float* dp_lds = nullptr, const uint32_t* mpre = nullptr) {
   constexpr int NT = 64 * NW;
+  static_assert(!CUBE || MODE == 2, "the cube source feeds the fused forward");
   static_assert(NW == 4 || (NW == 8 && MODE >= 2), "eight waves: per-sample kernels only");
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int net, s0;
   wg_decode(a, net, s0);
+  if constexpr (CUBE) s0 = wg_infer_sample(a);          // (>= 0: the kernel returned otherwise)
   const int H = a.H, W = a.W, HW = H * W, PW = W + 2, IMG = (H + 2) * PW;
   const int H2 = H >> 1, W2 = W >> 1, P2 = H2 * W2;
   const int RO = !(MODE & 1) ? 2 * H2 : H, CO = !(MODE & 1) ? 2 * W2 : W;
@@ -679,9 +695,9 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     float* slab = smem;                                   // [SLAB_RING][SLOT], aliases img | wbuf | lut
     // wave = pixel tile (32 pixels), BOTH output-channel tiles: the band values of a pixel are split into bf16 pieces
     // once (not once per output-channel tile, as with wave = (channel tile, pixel half))
-    const int nfl = C * HW, nf4 = nfl >> 2, rem = nfl & 3;
-    const float* xrow = xsrc_row(a.xs, net, s0, nfl);
-    const float sigma = a.xs.sigma;
+    const int nfl = C * HW, nf4 = CUBE ? (1 << 30) : (nfl >> 2), rem = CUBE ? 0 : (nfl & 3);
+    const float* xrow = CUBE ? a.cube : xsrc_row(a.xs, net, s0, nfl);
+    const float sigma = CUBE ? 0.f : a.xs.sigma;
     const float* nzrow = (sigma != 0.f) ? xsrc_noise_row(a.xs, net, s0, nfl) : nullptr;
     const uint64_t gsample = xsrc_global_sample(a.xs, s0);
     const uint64_t rstep = xsrc_step(a.xs);               // counter of the random streams (launch argument, or the device-side row)
@@ -733,21 +749,51 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) b[3 * nt + pc] = wq0[((kp * 3 + pc) * 2 + nt0 + nt) * 64];
       };
+      // CUBE: item g of a chunk = (window pixel g >> 2, bands 16 kq + 4 (g & 3) ..): four consecutive bands of ONE cube
+      // pixel (the cube is band-last), found through the mirror index of ExtractPatches; cofs = that pixel's float offset
+      int cofs[TPW];
+      if constexpr (CUBE) {
+        const long long pix = a.pix0 + s0;
+        const int pr = (int)(pix / a.ccols), pc = (int)(pix - (long long)pr * a.ccols), hwin = W >> 1;
+        const int magicp = (65536 + W - 1) / W;
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+          const int g = (wave + NW * k) * 64 + lane, pw = (g < CH4l ? g : 0) >> 2;
+          const int wi = (pw * magicp) >> 16, wj = pw - wi * W;
+          int rr = pr + wi - (H >> 1), cc = pc + wj - hwin;
+          rr = rr < 0 ? -rr - 1 : (rr >= a.crows ? 2 * a.crows - 1 - rr : rr);
+          cc = cc < 0 ? -cc - 1 : (cc >= a.ccols ? 2 * a.ccols - 1 - cc : cc);
+          cofs[k] = (rr * a.ccols + cc) * C + 4 * (g & 3);
+        }
+      }
       // this lane's float4 k of chunk kq: local index g inside the chunk, global index gg inside the slab
       auto fetch_d = [&](int kq, float4 (&d)[TPW]) {
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
           const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
-          const bool ok = k < PPW && g < CH4l && gg < nf4;
-          const float4 v = *(const float4*)(xrow + 4 * (ok ? gg : 0));
-          d[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (CUBE) {       // four 4-byte loads, each clamped (bands past C read as zero: their weights are zero, the values must be finite)
+            const bool ok = k < PPW && g < CH4l;
+            const int b0 = 16 * pch(kq) + 4 * (g & 3);
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool v = ok && b0 + e < C;
+              const float t = xrow[v ? cofs[k] + 16 * pch(kq) + e : 0];
+              x[e] = v ? t : 0.f;
+            }
+            d[k] = make_float4(x[0], x[1], x[2], x[3]);
+          } else {
+            const bool ok = k < PPW && g < CH4l && gg < nf4;
+            const float4 v = *(const float4*)(xrow + 4 * (ok ? gg : 0));
+            d[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
       };
 #pragma unroll
       for (int kq = 0; kq < 2; ++kq) if (kq < nch) fetch_b(kq, bw[kq]);
 #pragma unroll
       for (int kq = 0; kq < SLAB_WIN; ++kq) if (kq < nch) fetch_d(kq, dv[kq]);
-      if (c0 + nch == KQ0) {
+      if (!CUBE && c0 + nch == KQ0) {
         // the bands beyond C of the last chunk meet zero weights, but must be finite
         const int used = nfl - (KQ0 - 1) * 16 * HWl;
         float* sl = slab + (nch - 1) * SLOT;
@@ -790,6 +836,13 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
           const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+          if constexpr (CUBE) {     // (band quad, pixel) -> four rows of the slot [16 bands][HW]
+            if (k < PPW && g < CH4l) {
+              const float4 v = dv[kq % SLAB_WIN][k];
+              float* d4 = sl + (4 * (g & 3)) * HWl + (g >> 2);
+              d4[0] = v.x; d4[HWl] = v.y; d4[2 * HWl] = v.z; d4[3 * HWl] = v.w;
+            }
+          } else
           if (k < PPW && g < CH4l && gg < nf4) {
             float4 v = dv[kq % SLAB_WIN][k];
             if (sigma != 0.f) {
@@ -955,10 +1008,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 }
 
 // avgpool2 + ReLU-mask epilogue shared by the forward kernels (img holds relu(z) at the pixel centres)
-template <int NT = 256>
+template <int NT = 256, bool STORE = true>
 __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c, float* img2 = nullptr) {
-  float* out = a.out + (long long)c.net * a.out_ns;
-  uint8_t* mo = a.mask_out + (long long)c.net * a.mask_out_ns;
+  float* out = STORE ? a.out + (long long)c.net * a.out_ns : nullptr;
+  uint8_t* mo = STORE ? a.mask_out + (long long)c.net * a.mask_out_ns : nullptr;
   // one (pooled pixel, 4 channels) item per thread and pass: four ds_read_b128, one 16-B and one 4-B store
   const int tot = c.S * c.P2 * 16;
   for (int idx = c.tid; idx < tot; idx += NT) {
@@ -975,14 +1028,14 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
       o.y = (v00.y + v01.y + v10.y + v11.y) * 0.25f;
       o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
       o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
-      *(float4*)(out + g) = o;
+      if constexpr (STORE) *(float4*)(out + g) = o;
       // fused tail: the pooled map also becomes the zero-bordered conv2 input image, in LDS
       if (img2 != nullptr) *(float4*)(img2 + (size_t)((ph + 1) * (c.W2 + 2) + pw + 1) * CS + c4 * 4) = o;
 #define CMLPL_NIB(A, B, C, D) ((uint32_t)((relu_open(A) ? 1 : 0) | (relu_open(B) ? 2 : 0) | (relu_open(C) ? 4 : 0) | (relu_open(D) ? 8 : 0)))
       const uint32_t m = CMLPL_NIB(v00.x, v01.x, v10.x, v11.x) | (CMLPL_NIB(v00.y, v01.y, v10.y, v11.y) << 8) |
                          (CMLPL_NIB(v00.z, v01.z, v10.z, v11.z) << 16) | (CMLPL_NIB(v00.w, v01.w, v10.w, v11.w) << 24);
 #undef CMLPL_NIB
-      *(uint32_t*)(mo + g) = m;
+      if constexpr (STORE) *(uint32_t*)(mo + g) = m;
     }
   }
 }
@@ -1002,7 +1055,19 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
 // Eight-wave workgroups: conv2 and the head stay on waves 0..3 (their chains are one sample's latency, not issue
 // slots); waves 4..7 share the strided LDS passes and keep the barriers' company (the same number of barriers on both
 // paths: s_barrier counts arrivals).
-template <int NW = 4>
+// argmax of a logits row held in LDS (torch.max(outputs, 1), hyper_tools.py:430: the first index of the maximum; a NaN is
+// the maximum and the first one wins), one thread
+__device__ __forceinline__ long long logits_argmax(const float* v, int K) {
+  int best = 0;
+  float bv = v[0];
+  for (int k = 1; k < K; ++k) {
+    const float x = v[k];
+    if (bv == bv && (x != x || x > bv)) { best = k; bv = x; }
+  }
+  return (long long)best;
+}
+
+template <int NW = 4, bool INFER = false>
 __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ctx& c, float* smem) {
   constexpr int NT = 64 * NW;
   const int tid = c.tid, lane = c.lane, wave = c.wave, net = c.net, sample = c.s0;
@@ -1037,6 +1102,7 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
       *(uint2*)(d + 2 * PLN) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
     }
   };
+  static_assert(!(INFER && NW == 8), "inference from the cube: four-wave or eight-tile kernels");
   if (NW == 8 && wave >= 4) {                // (uniform) the barriers of the path below, one for one
     __syncthreads();
     split_planes();
@@ -1168,10 +1234,12 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
     if (dh == 0) {
       const int ph = kg >> 1;
       const float o0 = t0 * 0.25f, o1 = t1 * 0.25f;
-      float* p2 = a.p2out + (rs * 4 + ph * 2) * 64 + co;
-      uint8_t* m2 = a.m2out + (rs * 4 + ph * 2) * 64 + co;
-      p2[0] = o0; p2[64] = o1;
-      m2[0] = (uint8_t)n0; m2[64] = (uint8_t)n1;
+      if constexpr (!INFER) {
+        float* p2 = a.p2out + (rs * 4 + ph * 2) * 64 + co;
+        uint8_t* m2 = a.m2out + (rs * 4 + ph * 2) * 64 + co;
+        p2[0] = o0; p2[64] = o1;
+        m2[0] = (uint8_t)n0; m2[64] = (uint8_t)n1;
+      }
       row[co * 4 + ph * 2] = o0;             // canonical flatten order f = c * HW4 + hw (x.view, models.py:141)
       row[co * 4 + ph * 2 + 1] = o1;
     }
@@ -1183,22 +1251,24 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   if (lane == 0) red[wave] = ss;
   __syncthreads();                           // row[0..256) complete, red[] written
   if (CMLPL_ABL == 25) STAMP(0, 13);
-  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-  if (tid == 0) a.ynorm[rs] = norm;
-  {
-    float4 o = y4;
-    o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
-    *(float4*)(a.feat + rs * FD + 4 * tid) = o;
-  }
-  float* catd = a.catd + rs * F;
+  if constexpr (!INFER) {
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) a.ynorm[rs] = norm;
+    {
+      float4 o = y4;
+      o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
+      *(float4*)(a.feat + rs * FD + 4 * tid) = o;
+    }
+    float* catd = a.catd + rs * F;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int f0 = 1024 * q + 4 * tid;
-    if (f0 < F) {
-      float4 x = *(const float4*)(row + f0);
-      if (dmode != 0) { x.x *= dm4[q].x; x.y *= dm4[q].y; x.z *= dm4[q].z; x.w *= dm4[q].w; }
-      *(float4*)(catd + f0) = x;
-      *(float4*)(row + f0) = x;              // same thread re-writes what it read
+    for (int q = 0; q < 2; ++q) {
+      const int f0 = 1024 * q + 4 * tid;
+      if (f0 < F) {
+        float4 x = *(const float4*)(row + f0);
+        if (dmode != 0) { x.x *= dm4[q].x; x.y *= dm4[q].y; x.z *= dm4[q].z; x.w *= dm4[q].w; }
+        *(float4*)(catd + f0) = x;
+        *(float4*)(row + f0) = x;            // same thread re-writes what it read
+      }
     }
   }
   __syncthreads();
@@ -1259,7 +1329,17 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
     }
   }
   __syncthreads();
-  if (tid < K) a.logits[rs * K + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bcv;
+  if constexpr (INFER) {     // inference: the label (and, when asked for, the logits) of pixel pix0 + sample
+    if (tid < K) {
+      const float lg = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bcv;
+      part[256 + tid] = lg;
+      if (a.logits != nullptr) a.logits[rs * K + tid] = lg;
+    }
+    __syncthreads();
+    if (tid == 0) a.labels_out[rs] = logits_argmax(part + 256, K);
+  } else {
+    if (tid < K) a.logits[rs * K + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + bcv;
+  }
 }
 
 // The first part of the backward pass of this workgroup's sample (S == 1), run in front of the conv1 data gradient:
@@ -1513,6 +1593,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
 // w & 3, tiles (w >> 2), (w >> 2) + 2, ..).  Then flatten / concat / dropout / classifier / L2-norm (models.py:141-152):
 // thread t owns the 16-byte group t of the head row (its dropout multipliers, its classifier weights), the eight waves'
 // partial logits meet in LDS.
+template <bool INFER = false>
 __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3Ctx& c, float* smem) {
   constexpr int NT = 512;
   const int tid = c.tid, lane = c.lane, wave = c.wave, net = c.net, sample = c.s0;
@@ -1664,26 +1745,30 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
         const float o = ((r_[0] + r_[1]) + (r_[2] + r_[3])) * 0.25f;
         const uint32_t nib = (relu_open(r_[0]) ? 1u : 0u) | (relu_open(r_[1]) ? 2u : 0u) | (relu_open(r_[2]) ? 4u : 0u) |
                              (relu_open(r_[3]) ? 8u : 0u);
-        a.p2out[(rs * P4 + win) * 64 + co] = o;
-        a.m2out[(rs * P4 + win) * 64 + co] = (uint8_t)nib;
+        if constexpr (!INFER) {
+          a.p2out[(rs * P4 + win) * 64 + co] = o;
+          a.m2out[(rs * P4 + win) * 64 + co] = (uint8_t)nib;
+        }
         row[co * P4 + win] = o;              // canonical flatten order f = c * P4 + hw (x.view, models.py:141)
       }
     }
   }
   __syncthreads();                           // row[0 .. SF) complete
   STAMP(0, 9);
-  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-  if (tid == 0) a.ynorm[rs] = norm;
-  if (tid < 256) {
-    float4 o = y4;
-    o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
-    *(float4*)(a.feat + rs * FD + 4 * tid) = o;
+  if constexpr (!INFER) {
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) a.ynorm[rs] = norm;
+    if (tid < 256) {
+      float4 o = y4;
+      o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
+      *(float4*)(a.feat + rs * FD + 4 * tid) = o;
+    }
   }
   float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (grp) {
     x4 = *(const float4*)(row + f0);
     if (dmode != 0) { x4.x *= dm4.x; x4.y *= dm4.y; x4.z *= dm4.z; x4.w *= dm4.w; }
-    *(float4*)(a.catd + rs * F + f0) = x4;
+    if constexpr (!INFER) *(float4*)(a.catd + rs * F + f0) = x4;
   }
   // logits: KC classes at a time, every weight of a chunk requested before the first is used
   for (int kc = 0; kc < K; kc += KC) {
@@ -1712,7 +1797,13 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
     float sacc = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) sacc += part[w * 64 + tid];
-    a.logits[rs * K + tid] = sacc + bcv;
+    const float lg = sacc + bcv;
+    if (!INFER || a.logits != nullptr) a.logits[rs * K + tid] = lg;
+    if constexpr (INFER) red[520 + tid] = lg;                         // (behind the partials: red[8 + 512 ..])
+  }
+  if constexpr (INFER) {
+    __syncthreads();
+    if (tid == 0) a.labels_out[rs] = logits_argmax(red + 520, K);
   }
 }
 
@@ -1930,6 +2021,8 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
   constexpr int KMT = NW * TPW / 2;        // pixel tiles of the per-sample kernels
   constexpr int LUTN = (MODE >= 2) ? KMT * 32 : MTW * 128;
   constexpr bool BIG = (KMT == 8);         // the generalised tail / head (final maps up to 12 pooled pixels)
+  constexpr bool INFER = (MODE == 2 && TAIL == 2);   // forward from the scene cube, eval, argmax out: nothing kept for a backward
+  if constexpr (INFER) { if (wg_infer_sample(a) < 0) return; }
   if (CMLPL_ABL == 26) return;             // ablation: the launch itself (grid, LDS allocation, end of kernel) and nothing else
   Conv3Ctx c;
   STAMP(MODE & 1, 0);
@@ -1939,7 +2032,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     if constexpr (BIG) dp_lds = conv3_bwd_head_g(a, smem, mpre);
     else dp_lds = conv3_bwd_head<NW>(a, smem, mpre);
   }
-  conv3_stage<MODE, NW, TPW>(a, smem, LUTN, c, dp_lds, mpre);
+  conv3_stage<MODE, NW, TPW, INFER>(a, smem, LUTN, c, dp_lds, mpre);
   STAMP(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
@@ -1979,7 +2072,10 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
 
   // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
   STAMP(MODE & 1, 14);
-  if (MODE == 2) {
+  if constexpr (INFER) {
+    if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active);
+    else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
+  } else if (MODE == 2) {
     // a0 goes to HBM (the backward pass reads it) from the LDS image itself, which is read-only during the tap
     // loop: tap s copies items NT s + tid (pixel, 16-byte channel chunk) -- coalesced 16-byte stores, no registers
     // held across the loop.
@@ -2070,11 +2166,11 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     STAMP(0, 10);
     __syncthreads();
     STAMP(0, 11);
-    conv3_pool_store<NT>(a, c, TAIL ? wbuf : nullptr);
+    conv3_pool_store<NT, !INFER>(a, c, TAIL ? wbuf : nullptr);
     STAMP(0, 7);
     if constexpr (TAIL != 0) {
-      if constexpr (BIG) conv3_fwd_tail_g(a, c, smem);
-      else conv3_fwd_tail<NW>(a, c, smem);
+      if constexpr (BIG) conv3_fwd_tail_g<INFER>(a, c, smem);
+      else conv3_fwd_tail<NW, INFER>(a, c, smem);
     }
   } else if (MODE == 3) {
     // conv0 weight gradient fused in (S == 1, MTW == 1):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
@@ -2590,6 +2686,53 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
     return hipGetLastError();
   }
   return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
+}
+
+// Whole-image inference from the scene cube (cmlpl_infer_cube): the fused eval forward with the cube gather as its slab
+// source -- n consecutive pixels from pix0, one network; y = relu(feat_spe(spectrum)) of the same pixels comes from the
+// spectral launch in front.  Shapes: whatever the per-sample forward with its tail takes (four-wave kernels up to 128
+// window pixels, eight-tile kernels up to 256).
+// (one sample per workgroup whatever the training planner would pick for this window at this batch: its S > 1 choices
+//  are a throughput trade for the multi-sample kernels, not a limit of the per-sample one)
+static bool conv3_infer_small_ok(int H, int W, int C, size_t* lds) {
+  const int H2 = H / 2, W2 = W / 2;
+  if (switches().fuse_conv0 == 0 || switches().fuse_tail == 0 || C < 1 || H * W > 128 || H < 8 || W < 8) return false;
+  if (H2 / 2 != 2 || W2 / 2 != 2 || (H2 + 2) * (W2 + 2) * CS > 4096) return false;
+  for (int m = 0; m < 128; ++m)
+    if (((m * ((65536 + W - 1) / W)) >> 16) != m / W) return false;
+  *lds = conv3_fused_lds(H, W, C, conv3_lds(1, H, W, 1));
+  return 2 * *lds <= LDS_MAX;
+}
+bool conv3_infer_ok(int H, int W, int C, int K) {
+  BigGeom bg;
+  size_t lds;
+  return H == W && K >= 1 && K <= 64 && (conv3_big_fwd_ok(H, W, C, &bg) || conv3_infer_small_ok(H, W, C, &lds));
+}
+
+hipError_t launch_conv3_infer(int n, int C, int H, int W, const float* cube, int crows, int ccols, long long pix0,
+                              const float* w0t, const float* b0, const float* wpk, const float* bias, const FwdTail& t,
+                              long long* labels_out, hipStream_t st) {
+  if (!conv3_infer_ok(H, W, C, t.K) || n < 1 || !cube || !labels_out) return hipErrorInvalidValue;
+  if ((long long)crows * ccols * C >= (1LL << 31) || W / 2 > crows || W / 2 > ccols) return hipErrorInvalidValue;   // (32-bit offsets; one mirror fold)
+  BigGeom bg;
+  const bool big = conv3_big_fwd_ok(H, W, C, &bg);
+  size_t lds_small = 0;
+  if (!big && !conv3_infer_small_ok(H, W, C, &lds_small)) return hipErrorInvalidValue;
+  Conv3Args a;
+  memset(&a, 0, sizeof(a));
+  a.wpk = wpk; a.bias = bias;
+  a.n = n; a.H = H; a.W = W; a.S = 1;
+  a.w0t = w0t; a.b0 = b0; a.C = C;
+  a.w2f = t.w2f; a.b2 = t.b2; a.wc = t.wc; a.bc = t.bc; a.yin = t.y; a.logits = t.logits; a.K = t.K;
+  a.train = 0; a.dropout_p = 0.f;
+  a.cube = cube; a.crows = crows; a.ccols = ccols; a.pix0 = pix0; a.labels_out = labels_out;
+  static DevOnce attr_once;
+  hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 2>, conv3x3_kernel<2, 1, 2, 8, 2>);
+  if (e != hipSuccess) return e;
+  const dim3 grid(8 * ((n + 7) / 8), 1);
+  if (big) hipLaunchKernelGGL((conv3x3_kernel<2, 1, 2, 8, 2>), grid, dim3(512), conv3_big_fwd_lds(bg, C), st, a);
+  else hipLaunchKernelGGL((conv3x3_kernel<2, 1, 2>), grid, dim3(256), lds_small, st, a);
+  return hipGetLastError();
 }
 
 // conv0 weight gradient fused into the conv1 data gradient (MODE 3): same shape conditions as the fused forward, and

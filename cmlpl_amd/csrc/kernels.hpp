@@ -96,6 +96,10 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
                               const float* b0, long long b0_ns, float* a0out, const float* wpk, long long wpk_ns,
                               const float* bias, long long bias_ns, float* out, uint8_t* mask_out,
                               const FwdTail* tail /* or null */, hipStream_t st, float* xn_out = nullptr);
+bool conv3_infer_ok(int H, int W, int C, int K);
+hipError_t launch_conv3_infer(int n, int C, int H, int W, const float* cube, int crows, int ccols, long long pix0,
+                              const float* w0t, const float* b0, const float* wpk, const float* bias, const FwdTail& t,
+                              long long* labels_out, hipStream_t st);
 bool conv3_fused_bwd_ok(int H, int W, int C, int rows);
 // the head / conv2 part of the backward in the same per-sample workgroup: see conv3_bwd_head
 struct BwdHead {

@@ -1,0 +1,75 @@
+"""Whole-image inference straight from the scene cube (reference tools/hyper_tools.py:416-437 ``test_whole`` over the
+patches of :226-243 ``ExtractPatches``; train.py:291-294).  The reference materialises every pixel's window (19.9 GB
+for PaviaU) and streams it through a DataLoader; here the z-scored / PCA'd cube [rows, cols, C] and the spectra
+[rows * cols, bands] stay resident in HBM and ``cmlpl_infer_cube`` gathers each window through the mirror index while
+the fused forward stages its input slab -- no patch tensor exists, the argmax is written on the device."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+
+
+class CubeSource(NamedTuple):
+    """what ``tools.hyper_tools.test_whole`` takes instead of a DataLoader of patches"""
+    cube: torch.Tensor          # [rows, cols, C] float32 cuda, band-last (the scene the patches are cut from)
+    spectra: torch.Tensor       # [rows * cols, bands] float32 cuda (row-major pixel order)
+
+
+def _net_buffers(net):
+    """(shape struct, flat parameters, packed weights) of ONE network: a cmlpl_amd.models.BaseNet2 module, or a
+    (TrainEngine, net index) pair."""
+    if isinstance(net, tuple):
+        eng, i = net
+        eng._ensure_packed(C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream))
+        return eng.cshape, eng.params[i], eng.packed[i]
+    flat, packed = net._flat_params(net._live_params())
+    return net._cshape, flat, packed
+
+
+def infer_supported(shape) -> bool:
+    """does ``cmlpl_infer_cube`` take this window shape?  (square windows of 8 x 8 up to 256 pixels whose final pooled map
+    the per-sample fused forward covers; asked of the library: its workspace size is 0 otherwise)"""
+    lib = _lib.load()
+    cs = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
+    return lib.cmlpl_infer_workspace_bytes(C.byref(cs), 8) > 0
+
+
+@torch.no_grad()
+def infer_cube(net, cube: torch.Tensor, spectra: torch.Tensor, pixel0: int = 0, n: Optional[int] = None,
+               chunk: int = 65536, want_logits: bool = False):
+    """argmax labels (int64 cuda [n]) of pixels pixel0 .. pixel0 + n - 1 (row-major; default: the whole scene), and the
+    logits [n, K] when asked for.  Asynchronous; raises CmlplError(CMLPL_E_SHAPE) for window shapes the per-sample
+    forward does not take."""
+    if not (cube.is_cuda and cube.dtype == torch.float32 and cube.is_contiguous() and cube.dim() == 3):
+        raise ValueError("cube: need contiguous float32 cuda tensor [rows, cols, C]")
+    rows, cols, Cc = cube.shape
+    if not (spectra.is_cuda and spectra.dtype == torch.float32 and spectra.is_contiguous() and spectra.dim() == 2
+            and spectra.shape[0] == rows * cols):
+        raise ValueError("spectra: need contiguous float32 cuda tensor [rows * cols, bands]")
+    cs, flat, packed = _net_buffers(net)
+    if Cc != cs.C or spectra.shape[1] != cs.bands:
+        raise ValueError(f"cube has {Cc} channels / spectra {spectra.shape[1]} bands, the network wants {cs.C} / {cs.bands}")
+    n = rows * cols - pixel0 if n is None else int(n)
+    if pixel0 < 0 or n < 1 or pixel0 + n > rows * cols:
+        raise ValueError("pixel range outside the scene")
+    lib = _lib.load()
+    dev = cube.device
+    labels = torch.empty(n, dtype=torch.int64, device=dev)
+    logits = torch.empty(n, cs.K, dtype=torch.float32, device=dev) if want_logits else None
+    chunk = max(8, min(int(chunk), n))
+    need = lib.cmlpl_infer_workspace_bytes(C.byref(cs), chunk)
+    if need == 0:
+        raise _lib.CmlplError("cmlpl_infer_cube", -2)      # CMLPL_E_SHAPE: not a window the per-sample forward takes
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        _lib.check("cmlpl_infer_cube", lib.cmlpl_infer_cube(
+            C.byref(cs), flat.data_ptr(), packed.data_ptr(), cube.data_ptr(), rows, cols, spectra.data_ptr(),
+            pixel0 + o, m, labels.data_ptr() + 8 * o, None if logits is None else logits.data_ptr() + 4 * cs.K * o,
+            ws.data_ptr(), ws.numel(), st))
+    return (labels, logits) if want_logits else labels

@@ -9,6 +9,7 @@ import torch
 from torch.utils import data
 
 _ROOTS = {1: './dataset/PaviaU/', 2: './dataset/Salinas/', 3: './dataset/Houston/', 4: './dataset/Indian_pines/'}
+_SCENES = {1: (610, 340), 2: (512, 217), 3: (349, 1905), 4: (145, 145)}       # rows, cols of the scenes train.py:75-90 names
 
 
 def _tile_to(arr, max_iters):
@@ -51,6 +52,32 @@ class HSIDataSet(data.Dataset):
         Y = None if self.Y is None else torch.from_numpy(np.asarray(self.Y, dtype=np.int64)).to(device)
         return XP, X, Y
 
+    def cube_source(self, device, scene=None, dataID=None):
+        """The 'wholeset' as the scene it was cut from, for whole-image inference without the materialised patches
+        (tools.hyper_tools.test_whole): ``cube.npy`` ([rows, cols, C]) next to XP.npy when sample_generation kept it,
+        else rebuilt from the centre pixels of the patches (ExtractPatches walks the pixels row by row,
+        hyper_tools.py:226-243: patch k is pixel k and its centre is the pixel itself).  None when the scene's size
+        is not known or does not match."""
+        import os
+        from cmlpl_amd.infer import CubeSource
+        if self.setindex != 'wholeset':
+            raise ValueError("cube_source() is for the 'wholeset'")
+        if scene is None and dataID is not None:
+            scene = _SCENES.get(int(dataID))
+        path = self.root + 'cube.npy'
+        if os.path.exists(path):
+            cube = np.load(path, mmap_mode='r')
+        else:
+            if scene is None or scene[0] * scene[1] != len(self.XP):
+                return None
+            hw = self.XP.shape[2] // 2
+            cube = np.asarray(self.XP[:, :, hw, hw]).reshape(scene[0], scene[1], self.XP.shape[1])
+        cube = torch.from_numpy(np.ascontiguousarray(cube, dtype=np.float32)).to(device)
+        X = torch.from_numpy(np.ascontiguousarray(self.X, dtype=np.float32)).to(device)
+        if cube.shape[0] * cube.shape[1] != X.shape[0]:
+            return None
+        return CubeSource(cube, X)
+
 
 class SyntheticHSIDataSet(data.Dataset):
     """Seeded stand-in with the same item tuples; class-dependent mean so that training has signal."""
@@ -76,3 +103,26 @@ class SyntheticHSIDataSet(data.Dataset):
 
     def device_arrays(self, device):
         return self.XP.to(device), self.X.to(device), self.Y.to(device)
+
+
+class SyntheticScene:
+    """A seeded synthetic scene for whole-image inference: a cube [rows, cols, C] and spectra [rows * cols, bands] whose
+    pixels carry the class-dependent means of ``SyntheticHSIDataSet`` (same prototypes), plus the per-pixel labels."""
+
+    def __init__(self, shape, rows, cols, seed=3, separable=1.0):
+        C, H, W, bands, K = shape
+        g = torch.Generator().manual_seed(seed)
+        proto_g = torch.Generator().manual_seed(4242)
+        self.rows, self.cols, self.window = int(rows), int(cols), H
+        self.Y = torch.randint(0, K, (rows * cols,), generator=g)
+        proto_p = torch.randn(K, C, 1, 1, generator=proto_g) * separable
+        proto_x = torch.randn(K, bands, generator=proto_g) * separable
+        self.cube = (torch.randn(rows * cols, C, generator=g) + proto_p[self.Y].view(-1, C)).view(rows, cols, C)
+        self.X = torch.randn(rows * cols, bands, generator=g) + proto_x[self.Y]
+
+    def __len__(self):
+        return self.rows * self.cols
+
+    def cube_source(self, device):
+        from cmlpl_amd.infer import CubeSource
+        return CubeSource(self.cube.to(device).contiguous(), self.X.to(device).contiguous())

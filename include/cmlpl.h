@@ -331,6 +331,22 @@ int cmlpl_step_graph_destroy(void* graph);
 int cmlpl_extract_patches(const float* d_cube, int rows, int cols, int C, int w,
                           const int64_t* d_pixel_idx, int n, float* d_out, void* stream);
 
+/* Caller-side rows N1 x N3 joined: whole-image inference straight from the scene cube
+ * (tools/hyper_tools.py:416-437 test_whole over the patches of :226-243 ExtractPatches; train.py:291-294).  One network,
+ * eval mode (no dropout): pixels pixel0 .. pixel0 + n - 1 (row-major) of d_cube [rows][cols][C] f32 (band-last, the
+ * z-scored / PCA'd scene) with window shape->H == shape->W, their spectra d_spectra [rows * cols][bands] (row pixel0 + i
+ * is read for pixel i).  The fused forward gathers each window through the mirror index while it stages its slab: no
+ * patch tensor exists in HBM.  d_labels [n] int64 = argmax of the logits (first maximum, NaN first: torch.max);
+ * d_logits [n][K] optional (null: not written).  d_params / d_packed: ONE network's flat parameters and packed weights
+ * (cmlpl_layout / cmlpl_pack_weights with nets = 1).  Workspace: cmlpl_infer_workspace_bytes(shape, n) -- which is 0 for
+ * a shape this entry point does not take.
+ * Returns CMLPL_E_SHAPE for windows the per-sample forward does not take (more than 256 window pixels, final pooled
+ * maps of more than 12 pixels: extract patches and use cmlpl_basenet2_fwd there). */
+size_t cmlpl_infer_workspace_bytes(const cmlpl_shape* shape, int n);
+int cmlpl_infer_cube(const cmlpl_shape* shape, const float* d_params, const float* d_packed, const float* d_cube,
+                     int rows, int cols, const float* d_spectra, int64_t pixel0, int n, int64_t* d_labels,
+                     float* d_logits, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Caller-side row N4: tools.models.ContrastiveLoss (tools/models.py:14-39) -- NT-Xent over the
  * pairwise cosine similarity of the 2B normalised embeddings, forward + analytic backward.
  * d_emb_i, d_emb_j [B][D]; d_loss [1]; d_grad_i, d_grad_j [B][D] = dLoss/d emb. */

@@ -7,9 +7,15 @@ import torch
 
 @torch.no_grad()
 def test_whole(model, data_loader, print_per_batches=10):
-    """argmax prediction for every pixel of the scene; ``data_loader`` yields (XP, X) batches.
-    (The reference forgets no_grad here; the result is the same.)"""
+    """argmax prediction for every pixel of the scene (reference hyper_tools.py:416-437).  ``data_loader`` yields
+    (XP, X) batches of materialised patches, as in the reference -- or is a ``cmlpl_amd.infer.CubeSource`` (the scene
+    cube [rows, cols, C] and the spectra, resident in HBM): the windows are then gathered on the device inside the
+    forward kernel (cmlpl_infer_cube), no patch tensor and no DataLoader.  (The reference forgets no_grad here; the result
+    is the same.)"""
     model.eval()
+    from cmlpl_amd.infer import CubeSource, infer_cube
+    if isinstance(data_loader, CubeSource):
+        return infer_cube(model, data_loader.cube, data_loader.spectra).cpu().numpy()
     out = []
     for batch_idx, (XP, X) in enumerate(data_loader):
         logits, _ = model(XP.cuda(non_blocking=True), X.cuda(non_blocking=True))

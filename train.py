@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from cmlpl_amd import HyperParams, NetShape
-from hsi_loader import HSIDataSet, SyntheticHSIDataSet
+from hsi_loader import HSIDataSet, SyntheticHSIDataSet, SyntheticScene
 from tools.hyper_tools import CalAccuracy, test_whole
 from tools.models import BaseNet2
 
@@ -87,7 +87,7 @@ def main(args, make_engine=None, device=None):
         labeled = SyntheticHSIDataSet(shape, args.num_unlabel, 'label', seed=1)
         unlabeled = SyntheticHSIDataSet(shape, args.num_unlabel, 'unlabel', seed=2)
         if not args.no_eval:
-            whole = SyntheticHSIDataSet(shape, 4096, 'wholeset', seed=3)
+            whole = SyntheticScene(shape, 64, 64, seed=3)                  # a 64 x 64 scene cube, every pixel a test pixel
             Y_test, test_array = whole.Y.numpy(), np.arange(len(whole))
     else:
         num_classes, num_features = DATASETS[int(args.dataID)]
@@ -201,9 +201,24 @@ def main(args, make_engine=None, device=None):
             model = BaseNet2(num_features=num_features, dropout=args.dropout, num_classes=num_classes,
                              in_channels=shape[0], window=shape[1]).to(device)
             model.load_state_dict(eng.state_dict(net))
-            loader = torch.utils.data.DataLoader(whole, batch_size=args.val_batch_size, shuffle=False)
+            # The scene stays in HBM as its cube and the forward gathers the windows itself (cmlpl_infer_cube): no
+            # 19.9 GB patch tensor, no DataLoader (train.py:291-294 streams the materialised patches).  Window shapes the
+            # per-sample forward does not take, or a patch file without a known scene size, fall back to the loader.
+            from cmlpl_amd.infer import infer_supported
+            source = None
+            if infer_supported(NetShape(*shape)):
+                source = whole.cube_source(device) if args.synthetic else whole.cube_source(device, dataID=args.dataID)
+            if source is None:
+                if args.synthetic:      # (cut the scene's windows on the device, then the reference's loader path)
+                    from cmlpl_amd.patches import extract_patches
+                    cs = whole.cube_source(device)
+                    XPw = extract_patches(cs.cube, torch.arange(len(whole), device=device), shape[1]).cpu()
+                    source = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(XPw, whole.X),
+                                                         batch_size=args.val_batch_size, shuffle=False)
+                else:
+                    source = torch.utils.data.DataLoader(whole, batch_size=args.val_batch_size, shuffle=False)
             t1 = time.time()
-            pred = test_whole(model, loader, print_per_batches=10 ** 9)
+            pred = test_whole(model, source, print_per_batches=10 ** 9)
             OA, Kappa, producerA = CalAccuracy(pred[test_array], Y_test)
             tag = '' if net == 0 else '1'
             print('inference time == %.3f s' % (time.time() - t1))

@@ -31,7 +31,7 @@ EXPORTS = (
     "cmlpl_memobank_enqueue", "cmlpl_memobank_push", "cmlpl_memobank_infonce", "cmlpl_memobank_sum",
     "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g", "cmlpl_memobank_loss",
     "cmlpl_source_hash", "cmlpl_dyn_adam", "cmlpl_step_graph_create", "cmlpl_step_graph_launch",
-    "cmlpl_step_graph_destroy", "cmlpl_infer_workspace_bytes", "cmlpl_infer_cube",
+    "cmlpl_step_graph_destroy", "cmlpl_infer_workspace_bytes", "cmlpl_infer_cube", "cmlpl_dist_stage_graph_create",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -127,6 +127,24 @@ class StepIO(C.Structure):
     ]
 
 
+class DistIO(C.Structure):
+    """cmlpl_dist_io: what the five captured stages of the sharded step read and write"""
+    _fields_ = [
+        ("batch", Batch), ("shard", Shard), ("gathered", Gathered), ("banks", Banks),
+        ("d_params", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_packed", C.c_void_p),
+        ("d_grads", C.c_void_p), ("grad_stride", C.c_int64),
+        ("d_logits_l", C.c_void_p), ("d_feat_l", C.c_void_p), ("d_labels_f", C.c_void_p),
+        ("d_dlogits", C.c_void_p), ("d_dfeat", C.c_void_p),
+        ("d_probs_l", C.c_void_p), ("d_probs_g", C.c_void_p), ("probs_shard_rows", C.c_int32), ("reserved", C.c_int32),
+        ("d_scalars", C.c_void_p), ("d_dfeat_w_partial", C.c_void_p),
+        ("d_workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("d_loss_workspace", C.c_void_p), ("loss_workspace_bytes", C.c_size_t),
+        ("seed", C.c_uint64), ("d_dyn_table", C.c_void_p), ("d_dyn_cursor", C.c_void_p),
+    ]
+
+
+STAGE_IDS = {"forward": 0, "phase1": 1, "phase2": 2, "backward": 3, "update": 4}
+
 _lib = None
 
 
@@ -200,6 +218,7 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_train_step.argtypes = [SP, HP, C.POINTER(StepIO), vp]
     lib.cmlpl_dyn_adam.argtypes = [HP, i64, C.POINTER(f32), C.POINTER(f32)]
     lib.cmlpl_step_graph_create.argtypes = [SP, HP, C.POINTER(StepIO), vp, C.POINTER(vp)]
+    lib.cmlpl_dist_stage_graph_create.argtypes = [SP, HP, C.POINTER(DistIO), i32, vp, C.POINTER(vp)]
     lib.cmlpl_step_graph_launch.argtypes = [vp, vp]
     lib.cmlpl_step_graph_destroy.argtypes = [vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]

@@ -800,6 +800,79 @@ int cmlpl_step_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, c
   return 0;
 }
 
+// one stage of the sharded step, every per-step scalar from the device table (see cmlpl_dist_io)
+static int dist_stage_run(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_dist_io* io, int stage, void* stream) {
+  Dims d;
+  cmlpl_layout_t L;
+  if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
+  DynRef dyn;
+  dyn.table = io->d_dyn_table; dyn.cursor = io->d_dyn_cursor;
+  const int train = 1;
+  switch (stage) {
+    case CMLPL_STAGE_FORWARD:
+      return forward_impl(shape, hp, &io->batch, &io->shard, io->d_params, io->d_packed, nullptr, train, io->seed, 0,
+                          io->d_logits_l, io->d_feat_l, io->d_labels_f, io->d_workspace, io->workspace_bytes, stream, dyn);
+    case CMLPL_STAGE_PHASE1: {
+      LossArgs a;
+      RowSel sel = RowSel();
+      sel.dyn = dyn;
+      int rc = fill_loss_args(d, &io->shard, nullptr, nullptr, nullptr, &io->banks, 1, 0.f, hp, io->d_loss_workspace,
+                              io->loss_workspace_bytes, &a, &io->gathered, &sel);
+      if (rc) return rc;
+      if (!io->d_dlogits || !io->d_dfeat || !io->d_probs_l) return CMLPL_E_ARG;
+      a.dlogits = io->d_dlogits; a.dfeat = io->d_dfeat; a.probs_l = io->d_probs_l;
+      return chk(launch_loss_phase1(a, (hipStream_t)stream));
+    }
+    case CMLPL_STAGE_PHASE2: {
+      LossArgs a;
+      RowSel sel = RowSel();
+      sel.dyn = dyn;
+      int rc = fill_loss_args(d, &io->shard, nullptr, nullptr, nullptr, &io->banks, 1, 0.f, hp, io->d_loss_workspace,
+                              io->loss_workspace_bytes, &a, &io->gathered, &sel);
+      if (rc) return rc;
+      if (!io->d_probs_g || !io->d_scalars || !io->d_dfeat || !io->d_dfeat_w_partial || io->probs_shard_rows < 1 ||
+          io->shard.btu_g % io->probs_shard_rows != 0)
+        return CMLPL_E_ARG;
+      a.probs_g = io->d_probs_g; a.pshard = io->probs_shard_rows; a.scalars = io->d_scalars; a.dfeat = io->d_dfeat;
+      a.dfw_part = io->d_dfeat_w_partial;
+      if ((rc = chk(launch_loss_graph(a, (hipStream_t)stream)))) return rc;
+      return chk(launch_loss_dfeat(a, (hipStream_t)stream));
+    }
+    case CMLPL_STAGE_BACKWARD:
+      return backward_impl(shape, hp, &io->batch, &io->shard, io->d_params, io->d_packed, nullptr, train, io->seed, 0,
+                           io->d_dlogits, io->d_dfeat, io->d_grads, io->grad_stride, io->d_workspace, io->workspace_bytes,
+                           stream, dyn, io->d_dyn_cursor);
+    case CMLPL_STAGE_UPDATE:
+      return adam_impl(shape, 2, io->d_params, L.param_total, io->d_grads, io->grad_stride, io->d_m, io->d_v, 1, hp,
+                       io->d_packed, stream, dyn);
+    default:
+      return CMLPL_E_ARG;
+  }
+}
+
+int cmlpl_dist_stage_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_dist_io* io, int stage,
+                                  void* stream, void** graph_out) {
+  if (!shape || !hp || !io || !graph_out || !io->d_dyn_table || !io->d_dyn_cursor || !io->batch.d_lab_idx ||
+      !io->batch.d_unl_idx || io->batch.noise8 != nullptr)
+    return CMLPL_E_ARG;
+  if (g_timing.on) return CMLPL_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = loss_prepare_capture();
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return (int)e;
+  const int rc = dist_stage_run(shape, hp, io, stage, stream);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(st, &g);
+  if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return (int)e;
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); return (int)e; }
+  *graph_out = new StepGraph{g, ex};
+  return 0;
+}
+
 int cmlpl_step_graph_launch(void* graph, void* stream) {
   if (!graph) return CMLPL_E_ARG;
   return chk(hipGraphLaunch(((StepGraph*)graph)->exec, (hipStream_t)stream));

@@ -241,11 +241,14 @@ class DistTrainEngine(TrainEngine):
     STAGES = ("forward", "phase1", "phase2", "backward", "update")
 
     def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
-                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, comm=None, hist_rows: int = 1):
+                 hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, comm=None, hist_rows: int = 1,
+                 alias_single: bool = True):
+        """``alias_single=False`` keeps the REAL collectives at world size 1 (separate send / receive buffers, four
+        torch.distributed calls per step): what scripts/dist_overhead.py measures the host cost of the calls with."""
         if comm is None:
             import torch.distributed as dist
             comm = TorchDistComm() if (dist.is_available() and dist.is_initialized()) else NoOpComm()
-        if comm.world == 1 and isinstance(comm, (TorchDistComm, SingleComm)):
+        if comm.world == 1 and alias_single and isinstance(comm, (TorchDistComm, SingleComm)):
             comm = NoOpComm()      # identity collectives: alias instead of launching RCCL copies
         self.comm = comm
         W = self.world = comm.world
@@ -311,18 +314,26 @@ class DistTrainEngine(TrainEngine):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _banks(self) -> _lib.Banks:
-        b = _lib.Banks()
-        for i in range(2):
-            b.d_feats[i] = self.bank_feats[i].data_ptr()
-            b.d_probs[i] = self.bank_probs[i].data_ptr()
-            b.ptr[i] = self.ptr[i]
-        b.Q = self.Q
+        # (one record, kept: only the two pointers change from step to step -- rebuilding the structs of a stage call
+        #  on every step was a third of the sharded step's host time)
+        b = self.__dict__.get("_c_banks")
+        if b is None:
+            b = self._c_banks = _lib.Banks()
+            for i in range(2):
+                b.d_feats[i] = self.bank_feats[i].data_ptr()
+                b.d_probs[i] = self.bank_probs[i].data_ptr()
+            b.Q = self.Q
+        b.ptr[0], b.ptr[1] = self.ptr
         return b
 
     # ------------------------------------------------------------------ stages (no communication inside)
     def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True,
                       lab_idx=None, unl_idx=None):
         s, lib = self.shape, self.lib
+        g = self._graph() if self._graph is not None else None
+        if g is not None and g.pending > 0:
+            raise RuntimeError(f"{g.pending} programmed graph replays are pending: launch them (or program() anew) "
+                               "before an eager step")
         # (lab_idx / unl_idx: THIS rank's rows as indices into the resident splits, see TrainEngine.step)
         bt_l, btu_l = self._check_rows(XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
         if btu_l > self.btu_max:
@@ -356,7 +367,11 @@ class DistTrainEngine(TrainEngine):
             self.workspace.numel(), st))     # logits | feat | labels land directly in the packed exchange buffer
 
     def _gathered(self) -> _lib.Gathered:
-        return _lib.Gathered(self.recv.data_ptr(), self.world, self.bt_l, self.btu_l)
+        g = self.__dict__.get("_c_gathered")
+        if g is None or self._c_gathered_for != self._bound:
+            g = self._c_gathered = _lib.Gathered(self.recv.data_ptr(), self.world, self.bt_l, self.btu_l)
+            self._c_gathered_for = self._bound
+        return g
 
     def stage_phase1(self):
         # the loss kernels read the global rows where the all-gather left them (rank-major blocks): no re-ordering copy
@@ -419,9 +434,11 @@ class DistTrainEngine(TrainEngine):
         drive_step(self, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update,
                    lab_idx=lab_idx, unl_idx=unl_idx)
 
-    def capture(self, *a, **k):
-        raise RuntimeError("the sharded step cannot be captured as one graph: its collectives run between the launches "
-                           "(replay is a single-GPU feature; run sharded steps eagerly)")
+    def capture(self, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt: int, btu: int, capacity: int = 1024) -> "DistStepGraph":
+        """The sharded step as FIVE captured graphs, one per stage, with the four collectives eager between them
+        (cmlpl_dist_stage_graph_create); ``bt`` / ``btu`` are THIS rank's rows, ``lab_idx`` / ``unl_idx`` the resident
+        index buffers the step offsets point into.  See DistStepGraph."""
+        return DistStepGraph(self, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu, capacity)
 
     def outputs(self):
         """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..], in global row order [labelled of all
@@ -448,3 +465,124 @@ class DistTrainEngine(TrainEngine):
         rows = rows.contiguous()
         self.comm.all_reduce(rows)          # one collective per printed window
         return rows
+
+
+class DistStepGraph:
+    """The sharded training step replayed from five hipGraphs (forward | phase 1 | phase 2 | backward | update) with the
+    step's four collectives -- all-gather of the exchange buffer, all-gather of the smoothed probabilities,
+    reduce-scatter of the column-side feature gradient, all-reduce of the gradient bucket -- issued eagerly between them,
+    exactly where ``drive_step`` issues them.  Everything that changes from step to step comes from the same device
+    table as the single-GPU ``StepGraph`` (``program()``: (epoch, batch_index, lab_off, unl_off) with THIS rank's
+    offsets into the index buffers); a replay costs the host five graph launches and four torch.distributed calls
+    instead of five marshalled stage calls (scripts/dist_overhead.py).  Bit-identical to the eager sharded step."""
+
+    def __init__(self, eng: "DistTrainEngine", XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt: int, btu: int, capacity: int = 1024):
+        import numpy as np
+        self.eng, self.bt, self.btu, self.capacity = eng, int(bt), int(btu), int(capacity)
+        if lab_idx is None or unl_idx is None:
+            raise ValueError("a captured step reads its rows through index buffers")
+        for name, t in (("lab_idx", lab_idx), ("unl_idx", unl_idx)):
+            if t.dtype != torch.int64 or t.dim() != 1 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError(f"{name}: need a contiguous int64 cuda vector")
+        if lab_idx.shape[0] < bt or unl_idx.shape[0] < btu:
+            raise ValueError("index buffers shorter than one shard")
+        if eng.step_count == 0:
+            raise RuntimeError("run one eager DistTrainEngine.step() before capturing (kernel attributes are set lazily)")
+        eng._check_rows(XPl, Xl, Y, XPu, Xu, lab_idx[:bt], unl_idx[:btu])
+        TrainEngine.check_index_range(lab_idx, XPl.shape[0], "lab_idx")
+        TrainEngine.check_index_range(unl_idx, XPu.shape[0], "unl_idx")
+        eng._bind(self.bt, self.btu)
+        self._keep = (XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx)
+        self.n_lab_idx, self.n_unl_idx = int(lab_idx.shape[0]), int(unl_idx.shape[0])
+        dev = eng.device
+        self.table = torch.zeros((self.capacity + 2) * 64, dtype=torch.uint8, device=dev)
+        self.cursor = torch.ones(1, dtype=torch.int32, device=dev)
+        self.host = torch.zeros((self.capacity + 2) * 64, dtype=torch.uint8).pin_memory()
+        self.rows = self.host.numpy().view(np.dtype(_lib.DYN_DTYPE))[1:]
+        self.pending = 0
+        st = eng._stream()
+        eng._ensure_packed(st)
+        io = _lib.DistIO()
+        io.batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), Y.data_ptr(), None, self.bt, self.btu,
+                              lab_idx.data_ptr(), unl_idx.data_ptr())
+        io.shard = eng.cshard
+        io.gathered = eng._gathered()
+        io.banks = eng._banks()
+        io.d_params, io.d_m, io.d_v, io.d_packed = eng.params.data_ptr(), eng.m.data_ptr(), eng.v.data_ptr(), eng.packed.data_ptr()
+        io.d_grads, io.grad_stride = eng.grads.data_ptr(), eng.live
+        io.d_logits_l, io.d_feat_l, io.d_labels_f = eng.logits_l.data_ptr(), eng.feat_l.data_ptr(), eng.labels_f.data_ptr()
+        io.d_dlogits, io.d_dfeat = eng.dlogits_l.data_ptr(), eng.dfeat_l.data_ptr()
+        io.d_probs_l, io.d_probs_g, io.probs_shard_rows = eng.probs_l.data_ptr(), eng.probs_g.data_ptr(), self.btu
+        io.d_scalars = eng.scalar_hist.data_ptr()
+        io.d_dfeat_w_partial = eng.dfw_part.data_ptr()
+        io.d_workspace, io.workspace_bytes = eng.workspace.data_ptr(), eng.workspace.numel()
+        io.d_loss_workspace, io.loss_workspace_bytes = eng.loss_ws.data_ptr(), eng.loss_ws.numel()
+        io.seed = eng.seed
+        io.d_dyn_table, io.d_dyn_cursor = self.table.data_ptr(), self.cursor.data_ptr()
+        self._io = io
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        self.handles = {}
+        with torch.cuda.stream(cap):
+            for name in eng.STAGES:
+                h = C.c_void_p()
+                _lib.check("cmlpl_dist_stage_graph_create", eng.lib.cmlpl_dist_stage_graph_create(
+                    C.byref(eng.cshape), C.byref(eng._chp), C.byref(io), _lib.STAGE_IDS[name], C.c_void_p(cap.cuda_stream),
+                    C.byref(h)))
+                self.handles[name] = h
+        torch.cuda.current_stream(dev).wait_stream(cap)
+
+    def validate_indices(self) -> None:
+        """range check of the two index buffers (synchronising): after the caller re-filled them in place"""
+        XPl, _, _, XPu, _, lab_idx, unl_idx = self._keep
+        TrainEngine.check_index_range(lab_idx, XPl.shape[0], "lab_idx")
+        TrainEngine.check_index_range(unl_idx, XPu.shape[0], "unl_idx")
+
+    def program(self, steps) -> None:
+        """as StepGraph.program: (epoch, batch_index, lab_off, unl_off) of the next replays, offsets = this rank's"""
+        from .engine import StepGraph
+        StepGraph.program(self, steps)
+
+    def launch_stage(self, name: str) -> None:
+        """enqueue ONE stage's graph (the lockstep test harness performs the exchanges itself; ``launch`` is the product path)"""
+        eng = self.eng
+        if self.pending < 1:
+            raise RuntimeError("no programmed step left: call program() first")
+        if name == "forward":
+            eng._bind(self.bt, self.btu)      # (an eager short batch in between re-bound the views; same pointers for the same shard)
+            eng._ensure_packed(eng._stream())
+            eng._cur_row = eng.step_count % eng.hist_rows
+            eng._unpacked = False
+        _lib.check("cmlpl_step_graph_launch", eng.lib.cmlpl_step_graph_launch(self.handles[name], eng._stream()))
+        if name == "update":                  # host copy of the step bookkeeping (train.py:234,237)
+            eng.adam_t += 1
+            p0 = (eng.ptr[0] + eng.hp.bank_step) % eng.Q
+            eng.ptr = [p0, (p0 + eng.hp.bank_step) % eng.Q]
+            eng.step_count += 1
+            eng._last_n = self.bt + self.btu
+            self.pending -= 1
+
+    def launch(self) -> None:
+        """one replay = one sharded training step (asynchronous): five graph launches, four collectives"""
+        eng = self.eng
+        for name in eng.STAGES:
+            self.launch_stage(name)
+            for kind, out, inp in eng.exchange_after(name):
+                if kind == "all_gather":
+                    eng.comm.all_gather(out, inp)
+                elif kind == "reduce_scatter":
+                    eng.comm.reduce_scatter(out, inp)
+                else:
+                    eng.comm.all_reduce(out)
+
+    def close(self) -> None:
+        for name, h in list(self.handles.items()):
+            if h:
+                self.eng.lib.cmlpl_step_graph_destroy(h)
+        self.handles = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

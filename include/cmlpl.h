@@ -323,6 +323,35 @@ int cmlpl_step_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, c
 int cmlpl_step_graph_launch(void* graph, void* stream);
 int cmlpl_step_graph_destroy(void* graph);
 
+/* The five stages of the SHARDED step (forward | loss phase 1 | loss phase 2 | backward | update; the four collectives
+ * run between them, in the caller's hands) as replayable hipGraphs: what cmlpl_forward, cmlpl_loss_phase1_g,
+ * cmlpl_loss_phase2_g, cmlpl_backward and cmlpl_adam_step launch, captured once per stage with every per-step scalar
+ * read from the cmlpl_dyn table (as a captured cmlpl_train_step does) -- the host then enqueues five graph launches and
+ * four collectives per step instead of marshalling five calls.  The backward stage advances the cursor (its reduce
+ * launch), the update stage reads the finished step's row.  Batches by index only (d_lab_idx / d_unl_idx: this rank's
+ * slice starts at the row's lab_off / unl_off); in-kernel random streams only.  Launch / destroy a stage's graph with
+ * cmlpl_step_graph_launch / cmlpl_step_graph_destroy. */
+typedef struct cmlpl_dist_io {
+  cmlpl_batch batch;            /* this rank's rows (bt, btu PER RANK), by index                                   */
+  cmlpl_shard shard;            /* this rank's place in the global batch                                           */
+  cmlpl_gathered gathered;      /* the all-gathered exchange buffer the loss phases read                           */
+  cmlpl_banks banks;            /* (ptr[] unused: the table carries the pointers)                                  */
+  float* d_params; float* d_m; float* d_v; float* d_packed;   /* [2][param_total] / [2][packed_total]              */
+  float* d_grads; int64_t grad_stride;                         /* the gradient bucket, [2][grad_stride]             */
+  float* d_logits_l; float* d_feat_l; float* d_labels_f;       /* this rank's block of the exchange buffer          */
+  float* d_dlogits; float* d_dfeat;                            /* [2][n_l][K], [2][n_l][1024]                        */
+  float* d_probs_l; const float* d_probs_g; int32_t probs_shard_rows; int32_t reserved;
+  float* d_scalars;             /* ring base [hist_rows][16]: the row comes from the table                          */
+  float* d_dfeat_w_partial;     /* [btu_g][1024]                                                                    */
+  void* d_workspace; size_t workspace_bytes;                   /* cmlpl_workspace_bytes(shape, 2, n_l, Q)           */
+  void* d_loss_workspace; size_t loss_workspace_bytes;         /* cmlpl_loss_workspace_bytes                        */
+  uint64_t seed;
+  cmlpl_dyn* d_dyn_table; int32_t* d_dyn_cursor;
+} cmlpl_dist_io;
+enum { CMLPL_STAGE_FORWARD = 0, CMLPL_STAGE_PHASE1 = 1, CMLPL_STAGE_PHASE2 = 2, CMLPL_STAGE_BACKWARD = 3, CMLPL_STAGE_UPDATE = 4 };
+int cmlpl_dist_stage_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_dist_io* io, int stage,
+                                  void* stream, void** graph_out);
+
 /* Caller-side row N3: w x w patch windows gathered on device from the z-scored / PCA'd
  * scene cube instead of materialising XP.npy (tools/hyper_tools.py:35-55 MirrowCut, :226-243
  * ExtractPatches; for PaviaU that tensor is 19.9 GB).  d_cube [rows][cols][C] f32, d_pixel_idx int64 [n]

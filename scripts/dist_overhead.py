@@ -1,8 +1,11 @@
-"""What does the staged data-parallel step cost before any wire time?  DistTrainEngine at world size 1 (RCCL initialised,
-the four collectives of a step being identities) against TrainEngine on the same batch: host enqueue time and wall time
-per step.  Round 1: +24 % (a re-ordering copy of the gathered buffer, a label copy, RCCL's identity copies).  Now the
-loss kernels read the gathered blocks in place, the labels are written into the exchange buffer by the forward, and
-one-rank collectives alias their buffers:
+"""What does the staged data-parallel step cost before any wire time, and what do its four torch.distributed calls cost
+the HOST?  At world size 1 on one GPU (RCCL initialised):
+  TrainEngine                      one C call per step (the single-GPU engine)
+  DistTrainEngine, aliased         five stage calls, the one-rank collectives aliased away (NoOpComm)
+  DistTrainEngine, real calls      the same with the four REAL collectives per step (all_gather_into_tensor x 2,
+                                   reduce_scatter_tensor, all_reduce through TorchDistComm; separate send / receive buffers)
+host enqueue = wall time to ENQUEUE a step; wall = steps including the final synchronisation; plus the host time of each
+collective call alone.  Sizes: the headline batch and the per-rank shards of BASELINE configs[2] / configs[4] at 8 GPUs.
     python scripts/dist_overhead.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,25 +16,62 @@ os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", device_id=dev)
 from cmlpl_amd import NetShape, HyperParams, TrainEngine
-from cmlpl_amd.distributed import DistTrainEngine
+from cmlpl_amd.distributed import DistTrainEngine, TorchDistComm
 from bench import synth, WORKLOADS
-shape = WORKLOADS["B2"]
-for cls in (TrainEngine, DistTrainEngine):
-    eng = cls(NetShape(*shape), 128, 128, HyperParams(), device=dev, seed=1088)
-    eng.init_params_default(1088)
-    b = synth(shape, 128, 128, 1, dev)
+
+K = 200
+for wl, bt, btu in (("B2", 128, 128), ("B2", 64, 64), ("B5", 8, 64)):
+    shape = WORKLOADS[wl]
+    b = synth(shape, bt, btu, 1, dev)
+    print(f"{wl} {bt}+{btu} rows")
+    walls = []
+    for name, make in (("TrainEngine", lambda: TrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088)),
+                       ("DistTrainEngine aliased", lambda: DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088)),
+                       ("DistTrainEngine real calls", lambda: DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088,
+                                                                               comm=TorchDistComm(), alias_single=False))):
+        eng = make()
+        eng.init_params_default(1088)
+        for i in range(20):
+            eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, 20 + i)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        walls.append(t2 - t0)
+        print(f"  {name:28s} host enqueue {1e6 * (t1 - t0) / K:7.1f} us/step   wall {1e6 * (t2 - t0) / K:7.1f} us/step", flush=True)
+    print(f"  real calls / TrainEngine wall: {walls[2] / walls[0]:.3f}")
+    # ... and the same engine replaying its five stage graphs (DistStepGraph), the four real calls eager between them
+    li, ui = torch.arange(bt, device=dev), torch.arange(btu, device=dev)
+    gr = eng.capture(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], li, ui, bt, btu, capacity=K + 20)
+    gr.program([(1, 300 + i, 0, 0) for i in range(K + 20)])
     for i in range(20):
-        eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, i)
+        gr.launch()
     torch.cuda.synchronize()
-    K = 200
     t0 = time.perf_counter()
     for i in range(K):
-        eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, 20 + i)
+        gr.launch()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"{cls.__name__:16s} host enqueue {1e6 * (t1 - t0) / K:7.1f} us/step   wall {1e6 * (t2 - t0) / K:7.1f} us/step", flush=True)
-    walls = globals().setdefault("walls", [])
-    walls.append(t2 - t0)
-print(f"DistTrainEngine / TrainEngine wall time at world size 1: {walls[1] / walls[0]:.3f}")
+    print(f"  {'DistStepGraph + real calls':28s} host enqueue {1e6 * (t1 - t0) / K:7.1f} us/step   wall {1e6 * (t2 - t0) / K:7.1f} us/step"
+          f"   (host / device = {(t1 - t0) / (t2 - t0):.2f})", flush=True)
+    gr.close()
+    # the four calls alone (host time of the call, device idle)
+    comm = TorchDistComm()
+    for kind, out, inp in eng.exchange_after("forward") + eng.exchange_after("phase1") + eng.exchange_after("phase2") + eng.exchange_after("backward"):
+        f = {"all_gather": lambda: comm.all_gather(out, inp), "reduce_scatter": lambda: comm.reduce_scatter(out, inp),
+             "all_reduce": lambda: comm.all_reduce(out)}[kind]
+        for _ in range(20):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            f()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"    {kind:15s} {out.numel() * 4 / 1e6:6.2f} MB: host {1e6 * (t1 - t0) / K:6.1f} us/call, back to back {1e6 * (t2 - t0) / K:6.1f} us/call")
 dist.destroy_process_group()

@@ -284,3 +284,90 @@ def test_eight_rank_baseline_configs_match_the_oracle(cfg):
                 report_params(f"param[{net}] {k}", sd[k], st.params[net][k], steps, hp.lr)
     for e in engines[1:]:
         assert torch.equal(e.params, engines[0].params)       # replicas stay bit-identical
+
+
+def _exchange(engines, stage):
+    W = len(engines)
+    specs = [e.exchange_after(stage) for e in engines]
+    for k in range(len(specs[0])):
+        kind = specs[0][k][0]
+        if kind == "all_gather":
+            full = torch.cat([specs[r][k][2].reshape(-1) for r in range(W)])
+            for r in range(W):
+                specs[r][k][1].view(-1).copy_(full)
+        elif kind == "reduce_scatter":
+            tot = sum(specs[r][k][2] for r in range(W))
+            for r, chunk in enumerate(tot.chunk(W, dim=0)):
+                specs[r][k][1].copy_(chunk)
+        else:
+            tot = sum(specs[r][k][1] for r in range(W))
+            for r in range(W):
+                specs[r][k][1].copy_(tot)
+
+
+def _dist_state(e):
+    return [e.params.clone(), e.m.clone(), e.v.clone(), e.grads.clone(), e.bank_feats.clone(), e.bank_probs.clone(),
+            e.scalar_hist.clone()]
+
+
+@pytest.mark.parametrize("W,name,bt_l,btu_l", [(1, "B2", 64, 64), (2, "B2", 24, 40), (2, "B5", 8, 64), (1, "P", 16, 16)])
+def test_replayed_stage_graphs_are_bit_identical_to_the_eager_sharded_step(W, name, bt_l, btu_l):
+    """DistStepGraph -- the five stages of the sharded step as captured graphs, every per-step scalar from the device
+    table, the exchanges in between -- against the eager sharded step by index: parameters, Adam moments, gradient
+    bucket, banks and logged rows BIT-identical on every rank over a schedule that crosses the smoothing gate (batch 17
+    -> 18 of epoch 0) and two epoch boundaries (W ranks in lockstep on this GPU; W = 1: the aliased one-rank engine)."""
+    from cmlpl_amd import HyperParams, NetShape
+    from cmlpl_amd.distributed import DistTrainEngine, NoOpComm
+    shapes = {"B2": (103, 11, 11, 103, 9), "B5": (48, 15, 15, 48, 20), "P": (60, 20, 20, 103, 9)}
+    C, H, Wd, bands, K = shapes[name]
+    g = torch.Generator().manual_seed(17)
+    NL, NU = 4 * bt_l * W + 3, 4 * btu_l * W + 5
+    XP = torch.randn(NL, C, H, Wd, generator=g).to(DEV); X = torch.randn(NL, bands, generator=g).to(DEV)
+    Y = torch.randint(0, K, (NL,), generator=g).to(DEV)
+    XPu = torch.randn(NU, C, H, Wd, generator=g).to(DEV); Xu = torch.randn(NU, bands, generator=g).to(DEV)
+    lab_perm = torch.randperm(NL, generator=g).to(DEV); unl_perm = torch.randperm(NU, generator=g).to(DEV)
+    sched = [(0, 16), (0, 17), (0, 18), (0, 19), (1, 0), (1, 1), (2, 0)]
+    offs = [((k % 4) * bt_l * W, (k % 4) * btu_l * W) for k in range(len(sched))]     # global offsets of step k's batch
+
+    def make():
+        es = [DistTrainEngine(NetShape(*shapes[name]), bt_l, btu_l, HyperParams(), device=DEV, seed=1088,
+                              comm=(NoOpComm() if W == 1 else FakeComm(W, r)), hist_rows=8) for r in range(W)]
+        for e in es:
+            e.init_params_default(1088)
+        return es
+
+    def eager(es, k):
+        ep, bi = sched[k]
+        for r, e in enumerate(es):
+            lo, uo = offs[k][0] + r * bt_l, offs[k][1] + r * btu_l
+            e.stage_forward(XP, X, Y, XPu, Xu, ep, bi, lab_idx=lab_perm[lo:lo + bt_l], unl_idx=unl_perm[uo:uo + btu_l])
+        for stage in es[0].STAGES:
+            if stage != "forward":
+                for e in es:
+                    getattr(e, "stage_" + stage)()
+            if W > 1:
+                _exchange(es, stage)
+
+    ea, eb = make(), make()
+    for k in range(len(sched)):
+        eager(ea, k)
+    eager(eb, 0)                                                     # warm-up step, then everything from the graphs
+    graphs = [e.capture(XP, X, Y, XPu, Xu, lab_perm, unl_perm, bt_l, btu_l, capacity=8) for e in eb]
+    for r, gr in enumerate(graphs):
+        gr.program([(sched[k][0], sched[k][1], offs[k][0] + r * bt_l, offs[k][1] + r * btu_l) for k in range(1, len(sched))])
+    for k in range(1, len(sched)):
+        for stage in eb[0].STAGES:
+            for gr in graphs:
+                gr.launch_stage(stage)
+            if W > 1:
+                _exchange(eb, stage)
+    torch.cuda.synchronize()
+    for r in range(W):
+        assert ea[r].ptr == eb[r].ptr and ea[r].adam_t == eb[r].adam_t and ea[r].step_count == eb[r].step_count
+        for i, (x, y) in enumerate(zip(_dist_state(ea[r]), _dist_state(eb[r]))):
+            assert torch.equal(x, y), f"rank {r}: state tensor {i} differs, max |d| = {(x - y).abs().max().item():.3e}"
+    assert torch.isfinite(eb[0].scalar_hist[:len(sched)]).all()
+    with pytest.raises(RuntimeError):
+        graphs[0].launch_stage("forward")                            # nothing programmed
+    for gr in graphs:
+        gr.close()

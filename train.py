@@ -132,8 +132,10 @@ def main(args, make_engine=None, device=None):
             loss_hist[pending] = eng.loss_window(len(pending))
             pending.clear()
     by_index = getattr(eng, "takes_indices", False)
-    # (a split smaller than one batch has no full batch to replay: such a run stays eager)
-    use_graph = bool(args.graph) and world == 1 and by_index and len(lab_loader.X) >= bt and len(unl_loader.X) >= btu
+    # (a split smaller than one batch has no full batch to replay: such a run stays eager.  Several GPUs: the sharded
+    #  step is replayed stage by stage, its collectives eager in between -- DistStepGraph; offsets are this rank's)
+    use_graph = bool(args.graph) and by_index and hasattr(eng, "capture") and len(lab_loader.X) >= bt and len(unl_loader.X) >= btu
+    gbt, gbtu = bt // world, btu // world                              # rows of a replayed step on this rank
     graph = None
     t_start = time.time()
     t_warm, steps_warm = t_start, 0
@@ -141,7 +143,7 @@ def main(args, make_engine=None, device=None):
         batches = list(zip(lab_loader, unl_loader))                  # (offset, size) pairs; draws this epoch's permutations
         if use_graph and graph is not None:
             # the whole epoch's per-step scalars go to the device table at once; full batches are replays
-            graph.program([(epoch, bi, lo, uo) for bi, ((lo, ls), (uo, us)) in enumerate(batches)
+            graph.program([(epoch, bi, lo + rank * gbt, uo + rank * gbtu) for bi, ((lo, ls), (uo, us)) in enumerate(batches)
                            if ls == bt and us == btu])
         for batch_index, ((lo, ls), (uo, us)) in enumerate(batches):
             index_i += 1                                             # train.py:150
@@ -166,8 +168,8 @@ def main(args, make_engine=None, device=None):
                 # the first step ran eagerly (it sets the kernels' attributes); capture now and hand the rest of this
                 # epoch's full batches to the graph
                 graph = eng.capture(lab_loader.XP, lab_loader.X, lab_loader.Y, unl_loader.XP, unl_loader.X,
-                                    lab_loader.perm, unl_loader.perm, bt, btu, capacity=max(num_batches, 1))
-                rest = [(epoch, bi, lo2, uo2) for bi, ((lo2, ls2), (uo2, us2)) in enumerate(batches)
+                                    lab_loader.perm, unl_loader.perm, gbt, gbtu, capacity=max(num_batches, 1))
+                rest = [(epoch, bi, lo2 + rank * gbt, uo2 + rank * gbtu) for bi, ((lo2, ls2), (uo2, us2)) in enumerate(batches)
                         if bi > batch_index and ls2 == bt and us2 == btu]
                 if rest:
                     graph.program(rest)

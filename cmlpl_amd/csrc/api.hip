@@ -1080,6 +1080,10 @@ int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* na
       {"da0", w.da0, N * d.HW * 256}};
   for (auto& t : tab)
     if (!strcmp(t.nm, name)) { *byte_offset = (size_t)((const char*)t.p - base); *bytes = t.b; return 0; }
+  if (!strcmp(name, "xn") && nets == 2) {   // the step's augmented patch rows [2][n][C*H*W] (cmlpl_forward keeps them for cmlpl_backward)
+    *byte_offset = w.bytes; *bytes = (size_t)2 * n * d.C * d.HW * 4;
+    return 0;
+  }
   return CMLPL_E_ARG;
 }
 

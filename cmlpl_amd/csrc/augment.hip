@@ -64,9 +64,14 @@ __global__ void augment_kernel(AugArgs a) {
       z0 = *(const float4*)((lab ? a.noise[t] : a.noise[4 + t]) + (long long)sl * per + base);
       if (two) z1 = *(const float4*)((lab ? a.noise[2 + t] : a.noise[6 + t]) + (long long)sl * per + base);
     } else if (need_noise) {
-      const uint32_t stream = (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X);
-      z0 = noise_normal4(a.seed, rstep, stream, noise_ctr(gs, (uint32_t)(base >> 2)));
-      if (two) z1 = noise_normal4(a.seed, rstep, stream + 1, noise_ctr(gs, (uint32_t)(base >> 2)));
+      // (patches: the eight-normals-per-hash generator of the fused forward, one group of a pair here; spectra: four per hash)
+      if (t == 0) {
+        z0 = noise_normal4p(a.seed, rstep, STREAM_NOISE_XP, gs, (uint32_t)(base >> 2));
+        if (two) z1 = noise_normal4p(a.seed, rstep, STREAM_NOISE_XP + 1, gs, (uint32_t)(base >> 2));
+      } else {
+        z0 = noise_normal4(a.seed, rstep, STREAM_NOISE_X, noise_ctr(gs, (uint32_t)(base >> 2)));
+        if (two) z1 = noise_normal4(a.seed, rstep, STREAM_NOISE_X + 1, noise_ctr(gs, (uint32_t)(base >> 2)));
+      }
     }
     float4 v0 = xv, v1 = xv;
     if (need_noise) {
@@ -88,8 +93,8 @@ __global__ void augment_kernel(AugArgs a) {
     float* dst = a.dst[t] + ((long long)net * n_all + s) * per;
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (need_noise && !a.explicit_noise) {
-      const float4 nz = noise_normal4(a.seed, rstep, (t == 0 ? STREAM_NOISE_XP : STREAM_NOISE_X) + net,
-                                       noise_ctr(gs, (uint32_t)(base >> 2)));
+      const float4 nz = (t == 0) ? noise_normal4p(a.seed, rstep, STREAM_NOISE_XP + net, gs, (uint32_t)(base >> 2))
+                                 : noise_normal4(a.seed, rstep, STREAM_NOISE_X + net, noise_ctr(gs, (uint32_t)(base >> 2)));
       z[0] = nz.x; z[1] = nz.y; z[2] = nz.z; z[3] = nz.w;
     } else if (need_noise) {
       const float* nptr = (lab ? a.noise[2 * net + t] : a.noise[4 + 2 * net + t]) + (long long)sl * per;

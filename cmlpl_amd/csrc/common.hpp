@@ -177,6 +177,40 @@ __device__ __forceinline__ uint64_t noise_ctr(uint64_t global_sample, uint32_t g
   return (global_sample << 24) | (uint64_t)group;
 }
 
+// The PATCH noise (12,463 normals per sample-net at B2: the largest vector-bound item of the fused forward) takes EIGHT
+// normals from one hash call: each 32-bit hash word gives a 16-bit radius uniform u = (hi16 + 1) / 2^16 in (0, 1] and a
+// 16-bit angle lo16 / 2^16 revolutions, i.e. two normals per word -- half the hash multiplies per normal and no more
+// transcendentals than before.  |z| <= sqrt(2 ln 2^16) = 4.71 (the mass beyond is 2.5e-6: ~16 of a step's 6.4 M draws
+// land on the last radius instead of further out); 65,536 radii x 65,536 angles per pair.  The unit is the PAIR of
+// 16-byte groups 2c, 2c + 1 of a sample (elements 8c .. 8c + 7), keyed like noise_normal4: counter (global sample, c).
+__device__ __forceinline__ void bm16(uint32_t w, float& c, float& s) {
+  const float k16 = 1.52587890625e-05f;     // 2^-16
+  const float u = fmaf((float)(w >> 16), k16, k16);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
+  const float a = (float)(w & 0xffffu) * k16;
+  c = r * __builtin_amdgcn_cosf(a); s = r * __builtin_amdgcn_sinf(a);
+}
+__device__ __forceinline__ uint4 noise_hash(uint64_t seed, uint64_t step, uint32_t stream, uint64_t ctr) {
+  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  return pcg4d(make_uint4((uint32_t)ctr ^ s0, (uint32_t)(ctr >> 32) ^ s1,
+                          (stream * 0x9E3779B9u) ^ (uint32_t)(step >> 32) ^ (s1 * 0x85EBCA6Bu),
+                          (uint32_t)step ^ (s0 * 0xC2B2AE35u)));
+}
+// both groups of pair c = gidx >> 1 (gidx even): lo = elements 8c .. 8c + 3, hi = 8c + 4 .. 8c + 7
+__device__ __forceinline__ void noise_normal8(uint64_t seed, uint64_t step, uint32_t stream, uint64_t gsample, uint32_t pair,
+                                              float4& lo, float4& hi) {
+  const uint4 r = noise_hash(seed, step, stream, noise_ctr(gsample, pair));
+  bm16(r.x, lo.x, lo.y); bm16(r.y, lo.z, lo.w); bm16(r.z, hi.x, hi.y); bm16(r.w, hi.z, hi.w);
+}
+// ONE group (gidx) of its pair: the whole hash, half of the Box-Muller work (callers whose two groups are not neighbours)
+__device__ __forceinline__ float4 noise_normal4p(uint64_t seed, uint64_t step, uint32_t stream, uint64_t gsample, uint32_t gidx) {
+  const uint4 r = noise_hash(seed, step, stream, noise_ctr(gsample, gidx >> 1));
+  const bool odd = (gidx & 1u) != 0;
+  float4 o;
+  bm16(odd ? r.z : r.x, o.x, o.y); bm16(odd ? r.w : r.y, o.z, o.w);
+  return o;
+}
+
 // Where the patch rows of one network come from (train.py:157-174,181-184): local rows [0, nlab) are rows of
 // `lab`, rows [nlab, n) rows of `unl` (the concat is an index computation, not a copy); the augmentation
 // x + sigma * N(0,1) is applied on the fly -- from explicit noise tensors (parity mode: the reference's draws)

@@ -714,7 +714,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         float zt;
         if (nzrow != nullptr) zt = nzrow[4 * nf4 + tid];
         else {
-          const float4 t = noise_normal4(a.xs.seed, rstep, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)nf4));
+          const float4 t = noise_normal4p(a.xs.seed, rstep, STREAM_NOISE_XP + net, gsample, (uint32_t)nf4);
           zt = tid == 0 ? t.x : tid == 1 ? t.y : t.z;
         }
         tailv = fmaf(zt, sigma, tailv);
@@ -735,6 +735,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       int CH4l = CH4;
       asm volatile("" : "+s"(CH4l));
       const int HWl = CH4l >> 2;
+      // item k of this lane inside a chunk (16-byte group index): two neighbouring groups where a lane has two (TPW == 2),
+      // so that one eight-normal hash call serves both; item_g0 = the wave's first group (uniform)
+      auto item_g = [&](int k) { return TPW == 2 ? 2 * (wave * 64 + lane) + k : wave * 64 + lane; };
+      auto item_g0 = [&](int k) { return TPW == 2 ? 2 * wave * 64 + k : wave * 64; };
       if (c0 > 0) __syncthreads();                        // every wave is done reading the previous pass's slots
       uint4 bw[2][3 * C0N];                               // conv0 weight fragments of two chunks (window): [n tile][piece]
       float4 dv[SLAB_WIN][TPW], nzv[SLAB_RING][TPW];      // (a lane's float4 pieces of a chunk: TPW = 512 / NT at most)
@@ -758,7 +762,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         const int magicp = (65536 + W - 1) / W;
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
-          const int g = (wave + NW * k) * 64 + lane, pw = (g < CH4l ? g : 0) >> 2;
+          const int g = item_g(k), pw = (g < CH4l ? g : 0) >> 2;
           const int wi = (pw * magicp) >> 16, wj = pw - wi * W;
           int rr = pr + wi - (H >> 1), cc = pc + wj - hwin;
           rr = rr < 0 ? -rr - 1 : (rr >= a.crows ? 2 * a.crows - 1 - rr : rr);
@@ -770,9 +774,9 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       auto fetch_d = [&](int kq, float4 (&d)[TPW]) {
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
-          const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+          const int g = item_g(k), gg = pch(kq) * CH4l + g;
           if constexpr (CUBE) {       // four 4-byte loads, each clamped (bands past C read as zero: their weights are zero, the values must be finite)
-            const bool ok = k < PPW && g < CH4l;
+            const bool ok = g < CH4l;
             const int b0 = 16 * pch(kq) + 4 * (g & 3);
             float x[4];
 #pragma unroll
@@ -783,7 +787,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             }
             d[k] = make_float4(x[0], x[1], x[2], x[3]);
           } else {
-            const bool ok = k < PPW && g < CH4l && gg < nf4;
+            const bool ok = g < CH4l && gg < nf4;
             const float4 v = *(const float4*)(xrow + 4 * (ok ? gg : 0));
             d[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
           }
@@ -805,27 +809,35 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
       // (Two bodies behind ONE uniform branch, not a branch per piece: with "load the reference's draw OR generate" inside
       // one lambda both paths write the same registers, and the compiler guards the generated values' write with a
       // vmcnt(0) against the possibly outstanding load -- which also waits for every chunk load in flight, 14 times.)
-      auto noise_live = [&](int kq, int k) { return sigma != 0.f && kq < nch && k < PPW && (wave + NW * k) * 64 < CH4l; };   // uniform
+      auto noise_live = [&](int kq, int k) { return sigma != 0.f && kq < nch && item_g0(k) < CH4l; };   // uniform
       if (nzrow != nullptr) {                             // parity mode: the reference's own draws
 #pragma unroll
         for (int kq = 0; kq < SLAB_NUP; ++kq)
 #pragma unroll
           for (int k = 0; k < TPW; ++k) {
-            const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+            const int g = item_g(k), gg = pch(kq) * CH4l + g;
             float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             if (noise_live(kq, k)) z = *(const float4*)(nzrow + 4 * ((g < CH4l && gg < nf4) ? gg : 0));
             nzv[kq][k] = z;
           }
+      } else if constexpr (TPW == 2) {
+        // a lane's two items are NEIGHBOURS (groups gg, gg + 1 with gg even: CH4 is even): one hash call gives both
+        // (noise_normal8: eight normals per call)
+#pragma unroll
+        for (int kq = 0; kq < SLAB_NUP; ++kq) {
+          const int gg = pch(kq) * CH4l + item_g(0);
+          float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f), z1 = z0;
+          if (noise_live(kq, 0)) noise_normal8(a.xs.seed, rstep, STREAM_NOISE_XP + net, gsample, (uint32_t)gg >> 1, z0, z1);
+          nzv[kq][0] = z0; nzv[kq][1] = z1;
+        }
       } else {
 #pragma unroll
-        for (int kq = 0; kq < SLAB_NUP; ++kq)
-#pragma unroll
-          for (int k = 0; k < TPW; ++k) {
-            const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
-            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (noise_live(kq, k)) z = noise_normal4(a.xs.seed, rstep, STREAM_NOISE_XP + net, noise_ctr(gsample, (uint32_t)gg));
-            nzv[kq][k] = z;
-          }
+        for (int kq = 0; kq < SLAB_NUP; ++kq) {
+          const int gg = pch(kq) * CH4l + item_g(0);
+          float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (noise_live(kq, 0)) z = noise_normal4p(a.xs.seed, rstep, STREAM_NOISE_XP + net, gsample, (uint32_t)gg);
+          nzv[kq][0] = z;
+        }
       }
       if (c0 == 0 && CMLPL_ABL != 25) STAMP(0, 4);
       // One chunk AHEAD: chunk kq + 1 is put into LDS (noise added) and published before the MFMAs of chunk kq are
@@ -835,15 +847,15 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         float* sl = slab + kq * SLOT;
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
-          const int g = (wave + NW * k) * 64 + lane, gg = pch(kq) * CH4l + g;
+          const int g = item_g(k), gg = pch(kq) * CH4l + g;
           if constexpr (CUBE) {     // (band quad, pixel) -> four rows of the slot [16 bands][HW]
-            if (k < PPW && g < CH4l) {
+            if (g < CH4l) {
               const float4 v = dv[kq % SLAB_WIN][k];
               float* d4 = sl + (4 * (g & 3)) * HWl + (g >> 2);
               d4[0] = v.x; d4[HWl] = v.y; d4[2 * HWl] = v.z; d4[3 * HWl] = v.w;
             }
           } else
-          if (k < PPW && g < CH4l && gg < nf4) {
+          if (g < CH4l && gg < nf4) {
             float4 v = dv[kq % SLAB_WIN][k];
             if (sigma != 0.f) {
               v.x = fmaf(nzv[kq][k].x, sigma, v.x); v.y = fmaf(nzv[kq][k].y, sigma, v.y);

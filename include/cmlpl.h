@@ -473,7 +473,8 @@ int cmlpl_timing_end(double* ms_sum /*[CMLPL_K_COUNT]*/, int64_t* launches /*[CM
  * [nets][n][H*W][64] f32; "p1"/"p2" pooled stage outputs [nets][n][P][64] f32; "m1"/"m2" ReLU
  * masks [nets][n][P][64] u8 (bit (h&1)*2+(w&1) = relu(z) > 0 at that pixel of the 2x2 pool
  * window); "y" spectral ReLU output [nets][n][1024] f32; "catd","dropgen" [nets][n][cls_in];
- * "dy","dp2","dp1","da0" backward intermediates.  Returns CMLPL_E_ARG for an unknown name. */
+ * "dy","dp2","dp1","da0" backward intermediates; with nets = 2 also "xn": the augmented patch rows [2][n][C*H*W] a
+ * step's forward keeps for its backward (cmlpl_forward / cmlpl_train_step).  Returns CMLPL_E_ARG for an unknown name. */
 int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* name,
                        size_t* byte_offset, size_t* bytes);
 

@@ -297,12 +297,14 @@ def test_philox_noise_statistics():
 
 def test_device_noise_is_the_documented_generator():
     """The augmentation noise of the kernels, value by value, against the numpy restatement of pcg4d + Box-Muller in
-    tests/test_noise_generator_math.py (counter = (global sample << 24) | element group, stream 0x100 + network for the
-    patches): zero inputs and sigma = 1 make cmlpl_augment return the noise itself.  Tolerance 2e-5 absolute: the
-    kernel takes log2 / sin / cos from the hardware's approximations."""
+    tests/test_noise_generator_math.py: zero inputs and sigma = 1 make cmlpl_augment return the noise itself.  Patches:
+    noise_normal8 (eight normals per hash call, counter = (global sample << 24) | pair of 16-byte groups, stream 0x100 +
+    network); spectra: noise_normal4 (counter = .. | group, stream 0x200 + network).  The fused forward forms the SAME
+    patch values (it leaves the rows it augmented in the workspace: checked below through a training step with zero
+    patches).  Tolerance 2e-5 absolute: the kernel takes log2 / sin / cos from the hardware's approximations."""
     import ctypes as C
     from cmlpl_amd import _lib
-    from tests.test_noise_generator_math import noise_normal4, _ctr
+    from tests.test_noise_generator_math import noise_normal4, noise_normal8, _ctr
     lib = _lib.load()
     shape = O.NetShape(103, 11, 11, 103, 9)
     cs = _lib.Shape(shape.C, shape.H, shape.W, shape.bands, shape.K)
@@ -316,12 +318,30 @@ def test_device_noise_is_the_documented_generator():
     assert lib.cmlpl_augment(C.byref(cs), 2, bt, btu, xpl.data_ptr(), xl.data_ptr(), xpu.data_ptr(), xu.data_ptr(),
                              None, 1.0, seed, step, None, xn.data_ptr(), sn.data_ptr(), None, st) == 0
     torch.cuda.synchronize()
-    groups = np.arange((per + 3) // 4)
+    pairs = np.arange((per + 7) // 8)
+    sgroups = np.arange((103 + 3) // 4)
     for net in range(2):
         for row in (0, 3, 5):                      # rows 0..3 labelled (global sample = row), 4..7 unlabelled (bt + i)
-            want = noise_normal4(seed, step, 0x100 + net, _ctr(row, groups)).T.reshape(-1)[:per]
+            want = noise_normal8(seed, step, 0x100 + net, _ctr(row, pairs)).T.reshape(-1)[:per]
             got = xn[net, row].cpu().numpy()
             assert np.abs(got - want).max() < 2e-5, (net, row, np.abs(got - want).max())
+            wants = noise_normal4(seed, step, 0x200 + net, _ctr(row, sgroups)).T.reshape(-1)[:103]
+            assert np.abs(sn[net, row].cpu().numpy() - wants).max() < 2e-5
+    # the fused per-sample forward forms the SAME patch values: zero patches and sigma = 1 -> the rows it keeps for the
+    # backward ARE its noise (160 + 160 rows: the four-wave kernels; 24 + 24: the eight-wave ones, one workgroup per CU)
+    from cmlpl_amd import HyperParams, NetShape, TrainEngine
+    for bt2 in (160, 24):
+        eng = TrainEngine(NetShape(103, 11, 11, 103, 9), bt2, bt2, HyperParams(noise=1.0), device=DEV, seed=seed)
+        eng.init_params_default(1)
+        z = lambda *sh: torch.zeros(*sh, device=DEV)
+        eng.step(z(bt2, 103, 11, 11), z(bt2, 103), torch.zeros(bt2, dtype=torch.int64, device=DEV), z(bt2, 103, 11, 11),
+                 z(bt2, 103), 0, 0)
+        torch.cuda.synchronize()
+        rows = eng.debug_region("xn").view(2, 2 * bt2, per)
+        for net in range(2):
+            for row in (0, bt2 - 1, bt2, 2 * bt2 - 1):          # global sample = row (labelled rows first, then bt + i)
+                want = noise_normal8(seed, 0, 0x100 + net, _ctr(row, pairs)).T.reshape(-1)[:per]
+                assert np.abs(rows[net, row].cpu().numpy() - want).max() < 2e-5, (bt2, net, row)
 
 
 @pytest.mark.parametrize("win,C", [(9, 30), (8, 103)])

@@ -373,13 +373,21 @@ def run_rank(args):
         labels["conv1_dgrad"] = ("conv3x3_kernel<DGRAD0> (conv1 data gradient + conv0 weight gradient fused, "
                                  "both networks)")
     conv2_flops = 2.0 * 2 * n_local * (shape[1] // 2) * (shape[2] // 2) * 64 * 576    # dense 3x3 on the pooled map
+    # which instantiation of the per-sample kernels this launch takes (conv3x3.hip): <MODE, 1, 1, waves, tiles per wave> --
+    # eight waves x two tiles for windows of 129..256 pixels, eight waves x one tile when the grid fits the CUs, else four x two
+    if shape[1] * shape[2] > 128:
+        kvar = "8,2"
+    elif 2 * n_local <= 256 and os.environ.get("CMLPL_KS8", "-1") != "0" or os.environ.get("CMLPL_KS8") == "1":
+        kvar = "8,1"
+    else:
+        kvar = "4,2"
     if tail_fwd:
         kseg["conv1_fwd"]["split"] += conv2_flops                                       # tail: split-bf16 too (16x16x32 MFMA)
-        labels["conv1_fwd"] = ("conv3x3_kernel<2,1,1> (per-sample fused forward: augmentation + conv0 1x1 + conv1 3x3 + "
+        labels["conv1_fwd"] = (f"conv3x3_kernel<2,1,1,{kvar}> (per-sample fused forward: augmentation + conv0 1x1 + conv1 3x3 + "
                                "ReLU/pool + conv2 3x3 + ReLU/pool + concat/dropout/classifier/L2-norm, both networks)")
     if head_bwd:
         kseg["conv1_dgrad"]["split"] += conv2_flops
-        labels["conv1_dgrad"] = ("conv3x3_kernel<3,1,1> (per-sample fused backward: head + conv2 data gradient + conv1 "
+        labels["conv1_dgrad"] = (f"conv3x3_kernel<3,1,1,{kvar}> (per-sample fused backward: head + conv2 data gradient + conv1 "
                                  "data gradient + conv0 weight gradient, both networks)")
     if wgrad_pair:
         key = "split" if wgrad_split else "f32"

@@ -106,3 +106,37 @@ def test_graph_needs_a_warm_engine_and_index_buffers():
         eng.capture(XP, X, Y, XPu, Xu, None, None, 16, 16)
     with pytest.raises(ValueError):
         eng.step(XP, X, Y, XPu, Xu, 0, 1, lab_idx=idx[:16])          # one index list without the other
+
+
+def test_index_lists_are_checked_and_pending_replays_block_eager_steps():
+    """(1) the fast path of the row check (same resident splits as last call) refuses a strided index view
+    like the slow path does; (2) index values are range-checked where lists are filled (capture, validate_indices) and
+    on request (check_index_range); (3) an eager step while programmed replays are pending raises -- their table rows were
+    formed from the state before it; (4) launch() refreshes the packed weights after load_state_dict."""
+    shape = SHAPES["B2"]
+    XP, X, Y, XPu, Xu = _data(shape, 64, 64, 2)
+    eng = _engine(shape, 16, 16)
+    idx = torch.arange(64, device=DEV)
+    eng.step(XP, X, Y, XPu, Xu, 0, 0, lab_idx=idx[:16], unl_idx=idx[:16])
+    with pytest.raises(ValueError):
+        eng.step(XP, X, Y, XPu, Xu, 0, 1, lab_idx=idx[::2][:16], unl_idx=idx[:16])      # strided view, fast path
+    with pytest.raises(ValueError):
+        TrainEngine.check_index_range(torch.tensor([0, 64], device=DEV), 64, "lab_idx")
+    with pytest.raises(ValueError):
+        TrainEngine.check_index_range(torch.tensor([-1, 3], device=DEV), 64, "lab_idx")
+    bad = idx.clone(); bad[5] = 999
+    with pytest.raises(ValueError):
+        eng.capture(XP, X, Y, XPu, Xu, bad, idx, 16, 16)
+    graph = eng.capture(XP, X, Y, XPu, Xu, idx, idx, 16, 16, capacity=4)
+    graph.program([(0, 1, 0, 0), (0, 2, 16, 16)])
+    with pytest.raises(RuntimeError):
+        eng.step(XP, X, Y, XPu, Xu, 0, 1, lab_idx=idx[:16], unl_idx=idx[:16])             # replays pending
+    graph.launch()
+    eng.load_state_dict(0, {k: v * 1.0 for k, v in eng.state_dict(0).items()})               # marks the packed copies stale
+    assert eng._packed_dirty
+    graph.launch()
+    assert not eng._packed_dirty                                                             # launch() re-packed them
+    eng.step(XP, X, Y, XPu, Xu, 0, 3, lab_idx=idx[:16], unl_idx=idx[:16])                 # nothing pending: fine
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.scalar_hist).all()
+    graph.close()

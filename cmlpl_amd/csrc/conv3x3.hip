@@ -242,6 +242,18 @@ __device__ __forceinline__ void tap_put(float4* wl, const TapRegs& t, int tid) {
   wl[tid + 1280] = t.w5;
 }
 
+// the same for 512-thread workgroups: three 16-byte pieces per thread
+struct TapRegs8 { float4 w0, w1, w2; };
+__device__ __forceinline__ TapRegs8 tap_fetch8(const float4* wg, int tap, int tid) {
+  TapRegs8 t;
+  const float4* wn = wg + tap * TAPW + tid;
+  t.w0 = wn[0]; t.w1 = wn[512]; t.w2 = wn[1024];
+  return t;
+}
+__device__ __forceinline__ void tap_put8(float4* wl, const TapRegs8& t, int tid) {
+  wl[tid] = t.w0; wl[tid + 512] = t.w1; wl[tid + 1024] = t.w2;
+}
+
 // The 9-tap main loop: 36 k-steps of 16 input channels.  NTA = number of this wave's M tiles that carry real pixels
 // (wave-uniform, so the loop body is branch-free).  Tap weights go global -> registers (prefetched one tap ahead)
 // -> LDS.  The steps are software-pipelined across the taps:
@@ -343,9 +355,10 @@ __device__ __forceinline__ void tap_step(const float* __restrict__ img, const ui
 
 // `side(s)` runs once per tap right after the tap's weights are queued: the fused forward drains its deferred
 // a0 stores there, two rows per tap, instead of bursting them in front of the loop.
-template <int MTW, int NTA, class Side = NoSide, int UNR = 1>
+// (W = TapRegs: 256 threads, six 16-byte pieces each; TapRegs8: 512 threads, three each -- the eight-wave general kernels)
+template <int MTW, int NTA, class Side = NoSide, int UNR = 1, class W = TapRegs>
 __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float* __restrict__ wbuf,
-                                           const float4* __restrict__ wg, TapRegs w, const int (&abase)[MTW],
+                                           const float4* __restrict__ wg, W w, const int (&abase)[MTW],
                                            f32x16 (&acc)[MTW][2], int PW, int tid, int lane, Side side = Side()) {
   float4* wl = (float4*)wbuf;
   const uint4* bl = (const uint4*)wbuf + lane;
@@ -358,9 +371,15 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
     if (s == 0) {
 #endif
     __syncthreads();  // everyone done with wbuf of tap s-1 (and, for s == 0, the staged image is complete)
-    tap_put(wl, w, tid);
-    __syncthreads();
-    if (s + 1 < 9) w = tap_fetch(wg, s + 1, tid);
+    if constexpr (sizeof(W) == sizeof(TapRegs)) {
+      tap_put(wl, w, tid);
+      __syncthreads();
+      if (s + 1 < 9) w = tap_fetch(wg, s + 1, tid);
+    } else {
+      tap_put8(wl, w, tid);
+      __syncthreads();
+      if (s + 1 < 9) w = tap_fetch8(wg, s + 1, tid);
+    }
 #if CMLPL_ABL == 20
     }
 #endif
@@ -485,17 +504,6 @@ __device__ __forceinline__ void conv3_taps_ks(const float* __restrict__ img, con
 // workgroups could not afford: every tap's 24 KiB of fragments go global -> registers -> LDS ONCE per workgroup (three
 // 16-byte pieces per thread, requested two taps ahead), double-buffered (the tap-weight buffer and the fold's exchange
 // region), ONE barrier per tap; a wave reads a k-step's six fragments a unit ahead of their MFMAs.
-struct TapRegs8 { float4 w0, w1, w2; };
-__device__ __forceinline__ TapRegs8 tap_fetch8(const float4* wg, int tap, int tid) {
-  TapRegs8 t;
-  const float4* wn = wg + tap * TAPW + tid;
-  t.w0 = wn[0]; t.w1 = wn[512]; t.w2 = wn[1024];
-  return t;
-}
-__device__ __forceinline__ void tap_put8(float4* wl, const TapRegs8& t, int tid) {
-  wl[tid] = t.w0; wl[tid + 512] = t.w1; wl[tid + 1024] = t.w2;
-}
-
 // one unit (tile t = I % TPW, k-step q = I / TPW) with this unit's six fragments in `b`; on exit `b` holds the next
 // unit's (read from this tap's LDS copy when the k-step changes inside the tap)
 template <int I, int TPW>
@@ -636,7 +644,6 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
                                             const float* dp_lds = nullptr, const uint32_t* mpre = nullptr) {
   constexpr int NT = 64 * NW;
   static_assert(!CUBE || MODE == 2, "the cube source feeds the fused forward");
-  static_assert(NW == 4 || (NW == 8 && MODE >= 2), "eight waves: per-sample kernels only");
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int net, s0;
@@ -654,10 +661,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* p = (float4*)img;
     const int tot = S * IMG * (CS / 4);
-    for (int i = tid; i < tot; i += 256) p[i] = z;
+    for (int i = tid; i < tot; i += NT) p[i] = z;
   }
   if (MODE != 2 && dp_lds == nullptr) {
-    for (int m = tid; m < lut_entries; m += 256) {
+    for (int m = tid; m < lut_entries; m += NT) {
       const int mm = (m < npx) ? m : 0;
       const int s = mm / PX, rem = mm - s * PX, r = rem / CO, c = rem - r * CO;
       lut[m] = s * IMG + (r + 1) * PW + (c + 1);
@@ -665,8 +672,8 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   }
   const float4* wg = (const float4*)(a.wpk + (long long)net * a.wpk_ns);
   // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
-  if (MODE < 2) c.wp = tap_fetch(wg, 0, tid);   // (the four-wave per-sample kernels fetch their fragments themselves)
-  if constexpr (NW == 8 && MODE == 3) c.wp8 = tap_fetch8(wg, 0, tid);
+  if constexpr (MODE < 2 && NW == 4) c.wp = tap_fetch(wg, 0, tid);   // (the four-wave per-sample kernels fetch their fragments themselves)
+  if constexpr (NW == 8 && (MODE == 3 || MODE < 2)) c.wp8 = tap_fetch8(wg, 0, tid);
   __syncthreads();
 
   if (MODE == 2) {
@@ -946,7 +953,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     __syncthreads();                                      // the LUT (and the image) are complete
   } else if (MODE == 0) {
     const float* src = a.in + (long long)net * a.in_ns;
-    staged_copy<8, float4>(S * HW * 16, tid,
+    staged_copy<8, float4, NT>(S * HW * 16, tid,
         [&](int idx) {
           const int c4 = idx & 15, p = idx >> 4, s = p / HW, pix = p - s * HW, sample = s0 + s;
           const bool ok = sample < a.n;
@@ -988,7 +995,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const uint8_t* mk = a.mask_in + (long long)net * a.mask_in_ns;
     struct DM { float4 d; uint32_t m; };
     // one (pooled pixel, 4 channels) item feeds the 4 full-resolution positions of its 2x2 window
-    staged_copy<8, DM>(S * P2 * 16, tid,
+    staged_copy<8, DM, NT>(S * P2 * 16, tid,
         [&](int idx) {
           const int c4 = idx & 15, pp = idx >> 4, s = pp / P2, q = pp - s * P2, sample = s0 + s;
           const bool ok = sample < a.n;
@@ -2031,7 +2038,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 64 * NW;
   constexpr int KMT = NW * TPW / 2;        // pixel tiles of the per-sample kernels
-  constexpr int LUTN = (MODE >= 2) ? KMT * 32 : MTW * 128;
+  constexpr int LUTN = (MODE >= 2) ? KMT * 32 : MTW * NW * 32;
   constexpr bool BIG = (KMT == 8);         // the generalised tail / head (final maps up to 12 pooled pixels)
   constexpr bool INFER = (MODE == 2 && TAIL == 2);   // forward from the scene cube, eval, argmax out: nothing kept for a backward
   if constexpr (INFER) { if (wg_infer_sample(a) < 0) return; }
@@ -2058,7 +2065,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
   if constexpr (!KS) {
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
-      abase[t] = lut[(wave + 4 * t) * 32 + l31] * CS + 8 * hh;
+      abase[t] = lut[(wave + NW * t) * 32 + l31] * CS + 8 * hh;
       acc[t][0] = zero16();
       acc[t][1] = zero16();
     }
@@ -2107,6 +2114,10 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active);
     else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
   }
+  else if constexpr (NW == 8) {   // the general kernels with eight waves (one workgroup per CU: 20 x 20 windows): two waves per SIMD
+    if (wave + NW * (MTW - 1) < MT) conv3_taps<MTW, MTW, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+    else                            conv3_taps<MTW, MTW - 1, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+  }
   else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   STAMP(MODE & 1, 15);
@@ -2147,7 +2158,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     } else {
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
-      const int tile = wave + 4 * t;
+      const int tile = wave + NW * t;
       if (tile < MT) {
         // three passes -- positions, residual reads, writes -- so that the 16 rows' LDS round trips overlap
         // (a row-by-row loop is a chain of dependent lut -> read -> write trips: 6 us per workgroup here)
@@ -2385,7 +2396,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     const int nvalid = (a.n - s0 < S ? a.n - s0 : S) * PX;  // rows that map to real samples
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
-      const int tile = wave + 4 * t;
+      const int tile = wave + NW * t;
       if (tile < MT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -2486,8 +2497,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(Conv3Args a) {
   }
 }
 
-static size_t conv3_lds(int S, int H, int W, int MTW) {
-  return ((size_t)S * (H + 2) * (W + 2) * CS + WBUF + (size_t)MTW * 128) * 4;
+static size_t conv3_lds(int S, int H, int W, int MTW, int NW = 4) {
+  return ((size_t)S * (H + 2) * (W + 2) * CS + WBUF + (size_t)MTW * NW * 32) * 4;
 }
 
 // Pick samples-per-workgroup S.  Cost model: MFMA tile-times queued on the busiest SIMD (workgroups
@@ -2513,20 +2524,27 @@ bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
     const double overhead = 0.45 * (double)waves_deep + (resident > 1 ? 0.0 : 0.15 * MTW);
     const double cost = mfma + overhead;
     if (force_s ? (S == force_s) : (cost < best - 1e-9)) {
-      best = cost; p->S = S; p->MTW = split ? 0 : MTW; p->lds = lds; ok = true;
+      best = cost; p->S = S; p->MTW = split ? 0 : MTW; p->lds = lds; p->nw = 4; ok = true;
+      // One workgroup per CU and several tiles per wave (20 x 20 windows: a 131 KB image, 13 pixel tiles): EIGHT waves
+      // -- two per SIMD, so that a wave's LDS reads, barriers and stores have something to hide under (round 5;
+      // CMLPL_CONV3_NW8=0: four waves as before)
+      const size_t lds8 = conv3_lds(S, H, W, (MT + 7) / 8, 8);
+      if (!split && resident == 1 && MTW >= 2 && lds8 <= LDS_MAX && switches().conv3_nw8 != 0) {
+        p->nw = 8; p->MTW = (MT + 7) / 8; p->lds = lds8;
+      }
     }
   }
   return ok;
 }
 
-template <int MODE, int MTW>
+template <int MODE, int MTW, int NW = 4>
 static hipError_t launch_conv3_t(const Conv3Args& a, dim3 grid, size_t lds, hipStream_t st) {
   static DevOnce attr_once;
   {
-    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<MODE, MTW>);
+    hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<MODE, MTW, 0, NW>);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<MODE, MTW>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<MODE, MTW, 0, NW>), grid, dim3(64 * NW), lds, st, a);
   return hipGetLastError();
 }
 
@@ -2545,6 +2563,11 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
+  if (pl.nw == 8) {   // (MTW 1 .. 2: at most 16 pixel tiles in a 160 KB image)
+    if (pl.MTW > 2) return hipErrorInvalidValue;
+    if (mode == 0) return pl.MTW == 1 ? launch_conv3_t<0, 1, 8>(a, grid, pl.lds, st) : launch_conv3_t<0, 2, 8>(a, grid, pl.lds, st);
+    return pl.MTW == 1 ? launch_conv3_t<1, 1, 8>(a, grid, pl.lds, st) : launch_conv3_t<1, 2, 8>(a, grid, pl.lds, st);
+  }
 #define CMLPL_DISPATCH(M)                                                      \
   switch (pl.MTW) {                                                            \
     case 0: {                                                                  \

@@ -77,7 +77,7 @@ hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, 
 // ---- conv3x3.hip
 hipError_t launch_pack_weights(int nets, const float* params, long long pstride, const PackInfo& pi, float* packed,
                                hipStream_t st);
-struct Conv3Plan { int S, MTW; size_t lds; };
+struct Conv3Plan { int S, MTW; size_t lds; int nw; };   // nw: waves of the workgroup (4, or 8: one workgroup per CU, several tiles per wave)
 bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p);
 // mode 0: out = avgpool2(relu(conv(in)+bias+in)), mask_out = relu bits; in [nets][n][H*W][64]
 // mode 1: in = dpool [nets][n][(H/2)*(W/2)][64] + mask_in; out = dgrad(dz) + dz, [nets][n][H*W][64]
@@ -177,6 +177,7 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
 struct Switches {
   int fuse_conv0, fuse_conv0_bwd, fuse_tail, fuse_spe;        // CMLPL_FUSE_*: 0 = the unfused round-1 kernels (default 1)
   int fuse_big;                                               // CMLPL_FUSE_BIG: 0 = windows of 129 .. 256 pixels on the general kernels (default 1: eight-tile per-sample kernels)
+  int conv3_nw8;                                              // CMLPL_CONV3_NW8: 0 = the general 3x3 kernels always with four waves (default 1)
   int ks8;                                                    // CMLPL_KS8: eight-wave per-sample workgroups never (0) / always (1) / when the grid fits the CUs (-1)
   int conv3_s, conv0_dma, conv0_ps;                           // CMLPL_CONV3_S (0 = planner), CMLPL_CONV0_DMA (default 1), CMLPL_CONV0_PS (0 = planner)
   int wgrad3_u, wgrad3_cspl, wgrad3_r, wgrad3_ru, wgrad3_rg, wgrad3_pg1, wgrad3_pg2, wgrad3_b3, wgrad3_pair;   // CMLPL_WGRAD3_*
@@ -190,7 +191,7 @@ inline const Switches& switches() {
     Switches w;
     w.fuse_conv0 = env("CMLPL_FUSE_CONV0", 1); w.fuse_conv0_bwd = env("CMLPL_FUSE_CONV0_BWD", 1);
     w.fuse_tail = env("CMLPL_FUSE_TAIL", 1); w.fuse_spe = env("CMLPL_FUSE_SPE", 1);
-    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1);
+    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1); w.conv3_nw8 = env("CMLPL_CONV3_NW8", 1);
     w.conv3_s = env("CMLPL_CONV3_S", 0); w.conv0_dma = env("CMLPL_CONV0_DMA", 1); w.conv0_ps = env("CMLPL_CONV0_PS", 0);
     w.wgrad3_u = env("CMLPL_WGRAD3_U", 0); w.wgrad3_cspl = env("CMLPL_WGRAD3_CSPL", 0); w.wgrad3_r = env("CMLPL_WGRAD3_R", 1);
     w.wgrad3_ru = env("CMLPL_WGRAD3_RU", 0); w.wgrad3_rg = env("CMLPL_WGRAD3_RG", 0);

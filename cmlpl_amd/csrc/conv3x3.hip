@@ -107,13 +107,18 @@ hipError_t launch_pack_weights(int nets, const float* params, long long pstride,
 #if CMLPL_ABL == 9 || (CMLPL_ABL >= 20 && CMLPL_ABL != 26)
 // phase timeline instrumentation (ablation build only): constant-rate 100 MHz stamps per workgroup
 __device__ unsigned long long g_stamps[3][2048][16];
+#ifndef CMLPL_STAMP_MIN_H             // launches on maps of fewer rows leave no stamps (conv1 of the general path is followed
+#define CMLPL_STAMP_MIN_H 0           // by conv2 on the pooled map): ABL_FLAGS=-DCMLPL_STAMP_MIN_H=20 bash scripts/build_abl.sh 9
+#endif
 #define STAMP(MODE_, i) do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) \
     g_stamps[MODE_][blockIdx.x + gridDim.x * blockIdx.y][i] = wall_clock64(); } while (0)
+#define STAMPG(MODE_, i) do { if (MODE >= 2 || CMLPL_STAMP_MIN_H == 0 || a.H >= CMLPL_STAMP_MIN_H) STAMP(MODE_, i); } while (0)
 extern "C" int cmlpl_abl_read_stamps(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
 #else
 #define STAMP(MODE_, i) do {} while (0)
+#define STAMPG(MODE_, i) do {} while (0)
 #endif
 
 struct Conv3Args {
@@ -273,7 +278,9 @@ __device__ __forceinline__ int tap_step_off(int step, int PW) {
 
 // one k-step (KQ = its position inside the tap) for NTA tiles
 
-template <int NTA, int KQ, int MTW>
+// HALF (several tiles per wave only): 1 / 2 = the wave's LAST active tile is computed for output-channel tile 0 / 1 only
+// (its other half belongs to another wave: see the eight-wave general kernels' tile assignment in conv3x3_kernel)
+template <int NTA, int KQ, int MTW, int HALF = 0>
 __device__ __forceinline__ void tap_step(const float* __restrict__ img, const uint4* __restrict__ bl,
                                          const int (&abase)[MTW], f32x16 (&acc)[MTW][2], ASplit (&cur)[NTA],
                                          float4 (&rn0)[NTA], float4 (&rn1)[NTA], uint4 (&b)[6], int step, int PW) {
@@ -305,15 +312,16 @@ __device__ __forceinline__ void tap_step(const float* __restrict__ img, const ui
     // instructions sit in front of its twelve MFMAs and the matrix pipe idles meanwhile: 110 us for conv1's forward at
     // 20 x 20 against a matrix-pipe floor of 52; sched_group_barrier patterns, what the one-tile waves use, take
     // minutes to compile at this many groups.)  Same MFMAs in the same order per accumulator: bit-identical results.
+#define CMLPL_SPLIT1(j) { u0[j] = __float_as_uint(v[j]); const float r1_ = v[j] - __uint_as_float(u0[j] & 0xffff0000u); \
+                          u1[j] = __float_as_uint(r1_); u2[j] = __float_as_uint(r1_ - __uint_as_float(u1[j] & 0xffff0000u)); }
+#define CMLPL_FENCE __builtin_amdgcn_sched_barrier(0);
+    constexpr int NFULL = NTA - (HALF != 0 ? 1 : 0);
 #pragma unroll
-    for (int t = 0; t < NTA; ++t) {
+    for (int t = 0; t < NFULL; ++t) {
       const uint4 A1 = cur[t].p1, A2 = cur[t].p2, A3 = cur[t].p3;
       const float v[8] = {rn0[t].x, rn0[t].y, rn0[t].z, rn0[t].w, rn1[t].x, rn1[t].y, rn1[t].z, rn1[t].w};
       uint32_t u0[8], u1[8], u2[8];
       f32x16 c0 = acc[t][0], c1 = acc[t][1];
-#define CMLPL_SPLIT1(j) { u0[j] = __float_as_uint(v[j]); const float r1_ = v[j] - __uint_as_float(u0[j] & 0xffff0000u); \
-                          u1[j] = __float_as_uint(r1_); u2[j] = __float_as_uint(r1_ - __uint_as_float(u1[j] & 0xffff0000u)); }
-#define CMLPL_FENCE __builtin_amdgcn_sched_barrier(0);
       CMLPL_FENCE
       c0 = mfma_b16(A1, b[4], c0); CMLPL_FENCE CMLPL_SPLIT1(0) CMLPL_FENCE
       c0 = mfma_b16(A2, b[2], c0); CMLPL_FENCE CMLPL_SPLIT1(1) CMLPL_FENCE
@@ -333,10 +341,30 @@ __device__ __forceinline__ void tap_step(const float* __restrict__ img, const ui
       nxt[t].p3 = make_uint4(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]), hi_pair(u2[4], u2[5]), hi_pair(u2[6], u2[7]));
       CMLPL_FENCE
       c1 = mfma_b16(A1, b[1], c1); CMLPL_FENCE
-#undef CMLPL_SPLIT1
-#undef CMLPL_FENCE
       acc[t][0] = c0; acc[t][1] = c1;
     }
+    if constexpr (HALF != 0) {   // the shared tile: six MFMAs of ONE channel tile, in the order a full tile runs them
+      constexpr int t = NTA - 1, h = HALF == 2 ? 1 : 0;
+      const uint4 A1 = cur[t].p1, A2 = cur[t].p2, A3 = cur[t].p3;
+      const float v[8] = {rn0[t].x, rn0[t].y, rn0[t].z, rn0[t].w, rn1[t].x, rn1[t].y, rn1[t].z, rn1[t].w};
+      uint32_t u0[8], u1[8], u2[8];
+      f32x16 ch = acc[t][h];
+      CMLPL_FENCE
+      ch = mfma_b16(A1, b[4 + h], ch); CMLPL_FENCE CMLPL_SPLIT1(0) CMLPL_SPLIT1(1) CMLPL_FENCE
+      ch = mfma_b16(A2, b[2 + h], ch); CMLPL_FENCE CMLPL_SPLIT1(2) CMLPL_SPLIT1(3) CMLPL_FENCE
+      ch = mfma_b16(A3, b[0 + h], ch); CMLPL_FENCE CMLPL_SPLIT1(4) CMLPL_SPLIT1(5) CMLPL_FENCE
+      ch = mfma_b16(A1, b[2 + h], ch); CMLPL_FENCE CMLPL_SPLIT1(6) CMLPL_SPLIT1(7) CMLPL_FENCE
+      ch = mfma_b16(A2, b[0 + h], ch); CMLPL_FENCE
+      nxt[t].p1 = make_uint4(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]), hi_pair(u0[4], u0[5]), hi_pair(u0[6], u0[7]));
+      nxt[t].p2 = make_uint4(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]), hi_pair(u1[4], u1[5]), hi_pair(u1[6], u1[7]));
+      CMLPL_FENCE
+      ch = mfma_b16(A1, b[0 + h], ch); CMLPL_FENCE
+      nxt[t].p3 = make_uint4(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]), hi_pair(u2[4], u2[5]), hi_pair(u2[6], u2[7]));
+      CMLPL_FENCE
+      acc[t][h] = ch;
+    }
+#undef CMLPL_SPLIT1
+#undef CMLPL_FENCE
   }
   // pin the interleave: the reads first, four MFMAs while they (and nothing else) are outstanding, then one MFMA
   // per six split instructions
@@ -356,7 +384,7 @@ __device__ __forceinline__ void tap_step(const float* __restrict__ img, const ui
 // `side(s)` runs once per tap right after the tap's weights are queued: the fused forward drains its deferred
 // a0 stores there, two rows per tap, instead of bursting them in front of the loop.
 // (W = TapRegs: 256 threads, six 16-byte pieces each; TapRegs8: 512 threads, three each -- the eight-wave general kernels)
-template <int MTW, int NTA, class Side = NoSide, int UNR = 1, class W = TapRegs>
+template <int MTW, int NTA, class Side = NoSide, int UNR = 1, class W = TapRegs, int HALF = 0>
 __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float* __restrict__ wbuf,
                                            const float4* __restrict__ wg, W w, const int (&abase)[MTW],
                                            f32x16 (&acc)[MTW][2], int PW, int tid, int lane, Side side = Side()) {
@@ -397,10 +425,10 @@ __device__ __forceinline__ void conv3_taps(const float* __restrict__ img, float*
           rn0[t] = *(const float4*)p1; rn1[t] = *(const float4*)(p1 + 4);
         }
       }
-      tap_step<NTA, 0>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 0, PW);
-      tap_step<NTA, 1>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 1, PW);
-      tap_step<NTA, 2>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 2, PW);
-      tap_step<NTA, 3>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 3, PW);
+      tap_step<NTA, 0, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 0, PW);
+      tap_step<NTA, 1, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 1, PW);
+      tap_step<NTA, 2, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 2, PW);
+      tap_step<NTA, 3, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 3, PW);
     }
   }
 }
@@ -2044,7 +2072,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
   if constexpr (INFER) { if (wg_infer_sample(a) < 0) return; }
   if (CMLPL_ABL == 26) return;             // ablation: the launch itself (grid, LDS allocation, end of kernel) and nothing else
   Conv3Ctx c;
-  STAMP(MODE & 1, 0);
+  STAMPG(MODE & 1, 0);
   const float* dp_lds = nullptr;
   uint32_t mpre[2] = {0u, 0u};
   if constexpr (MODE == 3 && TAIL) {
@@ -2052,7 +2080,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     else dp_lds = conv3_bwd_head<NW>(a, smem, mpre);
   }
   conv3_stage<MODE, NW, TPW, INFER>(a, smem, LUTN, c, dp_lds, mpre);
-  STAMP(MODE & 1, 1);
+  STAMPG(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
   float* img = c.img; float* wbuf = c.wbuf; int* lut = c.lut; const float4* wg = c.wg;
@@ -2062,10 +2090,20 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
   f32x16 acc[MTW][2];
   // per-sample fused kernels (S == 1, MTW == 1): the barrier-free tap loop, see conv3_taps_ks
   constexpr bool KS = (MODE >= 2);
+  // General kernels: slot t of wave w holds pixel tile w + NW t.  Eight waves sit two to a SIMD (w and w + 4), so when
+  // the last round has 1 or 5 tiles, SIMD 0 carries one tile more than the others (20 x 20 windows: 13 tiles = 4, 3, 3,
+  // 3): that round's last tile is then SHARED by its wave (output-channel tile 0) and the next wave (channel tile 1, in
+  // the slot that would be empty) -- 3.5, 3.5, 3, 3.  nmask = which channel tiles of the last slot this wave computes.
+  const int RL = MT - NW * (MTW - 1);
+  const bool nsplit = !KS && NW == 8 && MTW >= 2 && (RL == 1 || RL == 5);
+  int last_tile = wave + NW * (MTW - 1), nmask = 3;
+  if (nsplit && wave == RL - 1) nmask = 1;
+  else if (nsplit && wave == RL) { last_tile = MT - 1; nmask = 2; }
+  auto slot_tile = [&](int t) { return t == MTW - 1 ? last_tile : wave + NW * t; };
   if constexpr (!KS) {
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
-      abase[t] = lut[(wave + NW * t) * 32 + l31] * CS + 8 * hh;
+      abase[t] = lut[slot_tile(t) * 32 + l31] * CS + 8 * hh;
       acc[t][0] = zero16();
       acc[t][1] = zero16();
     }
@@ -2090,7 +2128,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
   f32x16 own[TPW];
 
   // tiles t <= MTW-2 are always active; only the last one may be missing for some waves (wave-uniform)
-  STAMP(MODE & 1, 14);
+  STAMPG(MODE & 1, 14);
   if constexpr (INFER) {
     if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active);
     else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
@@ -2115,18 +2153,22 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
   }
   else if constexpr (NW == 8) {   // the general kernels with eight waves (one workgroup per CU: 20 x 20 windows): two waves per SIMD
-    if (wave + NW * (MTW - 1) < MT) conv3_taps<MTW, MTW, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
-    else                            conv3_taps<MTW, MTW - 1, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+    if (last_tile >= MT) conv3_taps<MTW, MTW - 1, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+    else if (nmask == 3) conv3_taps<MTW, MTW, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+    else if constexpr (MTW >= 2) {
+      if (nmask == 1) conv3_taps<MTW, MTW, NoSide, 1, TapRegs8, 1>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+      else            conv3_taps<MTW, MTW, NoSide, 1, TapRegs8, 2>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+    }
   }
   else if (wave + 4 * (MTW - 1) < MT) conv3_taps<MTW, MTW>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
   else                           conv3_taps<MTW, MTW - 1>(img, wbuf, wg, wp, abase, acc, PW, tid, lane);
-  STAMP(MODE & 1, 15);
+  STAMPG(MODE & 1, 15);
   __syncthreads();  // all MFMA reads of img are done; the epilogue overwrites it in place
   // (eight waves: the exchange needs [8][16][64] floats = 32 KiB, more than the tap-weight buffer: its own region behind
   //  the LUT -- where the backward's head kept its hand-off buffers, dead since the staging; one workgroup per CU, LDS
   //  is plentiful: conv3_ks8_lds)
   if constexpr (KS) conv3_ks_fold<TPW>(acc2, own, NW == 8 ? x8 : wbuf, wave, lane);
-  STAMP(MODE & 1, 2);
+  STAMPG(MODE & 1, 2);
 
   if (!(MODE & 1)) {
     const float* bias = a.bias + (long long)net * a.bias_ns;
@@ -2158,7 +2200,8 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     } else {
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
-      const int tile = wave + NW * t;
+      const int tile = slot_tile(t);
+      const int nm = (t == MTW - 1) ? nmask : 3;
       if (tile < MT) {
         // three passes -- positions, residual reads, writes -- so that the 16 rows' LDS round trips overlap
         // (a row-by-row loop is a chain of dependent lut -> read -> write trips: 6 us per workgroup here)
@@ -2175,8 +2218,8 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
         for (int r = 0; r < 16; ++r) {
           const int m = tile * 32 + acc_row(r, lane);
           if (m < npx) {
-            img[pos[r] + l31] = relu_nan(acc[t][0][r] + bv0 + x0[r]);
-            img[pos[r] + 32 + l31] = relu_nan(acc[t][1][r] + bv1 + x1[r]);
+            if (nm & 1) img[pos[r] + l31] = relu_nan(acc[t][0][r] + bv0 + x0[r]);
+            if (nm & 2) img[pos[r] + 32 + l31] = relu_nan(acc[t][1][r] + bv1 + x1[r]);
           }
         }
       }
@@ -2396,7 +2439,8 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
     const int nvalid = (a.n - s0 < S ? a.n - s0 : S) * PX;  // rows that map to real samples
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
-      const int tile = wave + NW * t;
+      const int tile = slot_tile(t);
+      const int nm = (t == MTW - 1) ? nmask : 3;
       if (tile < MT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -2404,14 +2448,14 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
           if (m < nvalid) {
             const float* p = img + (size_t)lut[m] * CS;
             float* o = out + ((size_t)s0 * HW + m) * 64;
-            o[l31] = acc[t][0][r] + p[l31];
-            o[32 + l31] = acc[t][1][r] + p[32 + l31];
+            if (nm & 1) o[l31] = acc[t][0][r] + p[l31];
+            if (nm & 2) o[32 + l31] = acc[t][1][r] + p[32 + l31];
           }
         }
       }
     }
   }
-  STAMP(MODE & 1, 3);
+  STAMPG(MODE & 1, 3);
 }
 
 

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../cmlpl_amd"
 HASH=$(cd .. && python3 -c "from cmlpl_amd.build_ext import source_hash; print(source_hash())")
 mkdir -p build_abl$N
 for f in api augment conv0 conv3x3 dense head loss memobank ntxent optim wgrad3x3; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DCMLPL_ABL=$N -DCMLPL_SOURCE_HASH=\"$HASH\" -c csrc/$f.hip -o build_abl$N/$f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DCMLPL_ABL=$N $ABL_FLAGS -DCMLPL_SOURCE_HASH=\"$HASH\" -c csrc/$f.hip -o build_abl$N/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libabl$N.so build_abl$N/*.o

@@ -19,10 +19,12 @@ XPu = torch.randn(BTU, C, WIN, WIN, device="cuda:0", generator=g)
 Xl = torch.randn(BT, C, device="cuda:0", generator=g)
 Xu = torch.randn(BTU, C, device="cuda:0", generator=g)
 Y = torch.randint(0, K, (BT,), device="cuda:0", generator=g)
+lib = _lib.load()
+# (general path, e.g. 20x20 windows: build the library with ABL_FLAGS=-DCMLPL_STAMP_MIN_H=20 to see conv1's launches
+#  instead of conv2's on the pooled map, which come later and overwrite the slots)
 for i in range(20):
     eng.step(XPl, Xl, Y, XPu, Xu, 1, i)
 torch.cuda.synchronize()
-lib = _lib.load()
 from cmlpl_amd.build_ext import embedded_hash, source_hash
 _h = embedded_hash(os.environ.get("CMLPL_LIB"))
 print(f"timeline library built from sources {_h}; sources here {source_hash()}" + ("" if _h == source_hash() else "   ** STALE BUILD: run scripts/build_abl.sh 9 **"))

@@ -11,7 +11,7 @@ from cmlpl_amd import HyperParams, NetShape, TrainEngine  # noqa: E402
 
 dev = "cuda:0"
 SHAPES = {"B2": (103, 11, 11, 103, 9), "B4": (200, 11, 11, 200, 16), "W8": (40, 8, 8, 40, 5), "W10": (64, 10, 11, 64, 33),
-          "P": (60, 20, 20, 60, 16)}
+          "P": (60, 20, 20, 60, 16), "W12": (5, 12, 12, 9, 3)}
 shp = SHAPES[sys.argv[1]] if len(sys.argv) > 1 else SHAPES["B2"]
 bt = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 btu = int(sys.argv[3]) if len(sys.argv) > 3 else 64

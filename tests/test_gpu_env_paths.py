@@ -125,14 +125,18 @@ def test_eight_wave_per_sample_kernels_are_bit_identical_to_the_four_wave_ones(s
     assert outs[0][-1].startswith("sha ") and outs[0] == outs[1], (outs[0][-2:], outs[1][-2:])
 
 
-def test_eight_wave_general_kernels_are_bit_identical_to_the_four_wave_plan():
+@pytest.mark.parametrize("shape,bt,btu,extra", [("P", 32, 48, {}),
+                                                 ("W12", 20, 30, {"CMLPL_FUSE_BIG": "0", "CMLPL_CONV3_S": "2"})])
+def test_eight_wave_general_kernels_are_bit_identical_to_the_four_wave_plan(shape, bt, btu, extra):
     """conv3x3_kernel<0 / 1, MTW, 0, 8, 1> (general 3x3 kernels with eight waves: what plan_conv3 picks where one workgroup
     fills a CU and a wave would carry two or more pixel tiles -- the reference's own 20x20x60 windows) against the
-    four-wave plan (CMLPL_CONV3_NW8=0): the same tiles on other waves, so three steps agree bit for bit."""
+    four-wave plan (CMLPL_CONV3_NW8=0): the same tiles on other waves, the odd tile of a last round of 1 or 5 tiles shared
+    by two waves (one output-channel tile each: 13 tiles at 20x20, 9 at two 12x12 windows per workgroup), every
+    accumulator fed in the same order -- three steps agree bit for bit."""
     outs = []
     for nw8 in ("0", "1"):
-        env = dict(os.environ, CMLPL_CONV3_NW8=nw8)
-        r = subprocess.run([sys.executable, "tests/_philox_traj_child.py", "P", "32", "48"], cwd=ROOT, env=env,
+        env = dict(os.environ, CMLPL_CONV3_NW8=nw8, **extra)
+        r = subprocess.run([sys.executable, "tests/_philox_traj_child.py", shape, str(bt), str(btu)], cwd=ROOT, env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines())

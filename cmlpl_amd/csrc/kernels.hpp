@@ -184,6 +184,7 @@ struct Switches {
   int pair_wide, pair_nbw, pair_mb, pair16, pair_tall;        // CMLPL_PAIR_WIDE / _TALL (-1 = planner), _NBW / _MB (0 = planner), CMLPL_PAIR16 (default 1)
   int dfeat_lds;                                              // CMLPL_DFEAT_LDS (-1 = wherever the operands allow, 0 = never)
   int mb_fast, unsup_onewg, unsup_3l, ntx_mfma;               // CMLPL_MB_FAST, CMLPL_UNSUP_ONEWG, CMLPL_UNSUP_3L, CMLPL_NTX_MFMA (default 1)
+  int ntx_ncw;                                                // CMLPL_NTX_NCW: 1 / 2 / 4 = 64 / 128 / 256 embedding columns per workgroup of the NT-Xent gradient (0 = planner)
 };
 inline const Switches& switches() {
   static const Switches sw = [] {
@@ -201,7 +202,7 @@ inline const Switches& switches() {
     w.pair16 = env("CMLPL_PAIR16", 1); w.pair_tall = env("CMLPL_PAIR_TALL", -1);
     w.dfeat_lds = env("CMLPL_DFEAT_LDS", -1);
     w.mb_fast = env("CMLPL_MB_FAST", 1); w.unsup_onewg = env("CMLPL_UNSUP_ONEWG", 1); w.unsup_3l = env("CMLPL_UNSUP_3L", 1);
-    w.ntx_mfma = env("CMLPL_NTX_MFMA", 1);
+    w.ntx_mfma = env("CMLPL_NTX_MFMA", 1); w.ntx_ncw = env("CMLPL_NTX_NCW", 0);
     return w;
   }();
   return sw;

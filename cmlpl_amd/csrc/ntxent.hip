@@ -265,51 +265,66 @@ __global__ __launch_bounds__(256) void ntx_grad_kernel(NtxArgs a, int CT) {
 // multiply -- and only the embedding rows are staged: chunks of 64 rows x 64 columns in 16-byte pieces, two chunks in
 // flight in registers, double-buffered in LDS, one barrier per chunk; wave w owns columns 16 w .. 16 w + 15 on
 // v_mfma_f32_16x16x4_f32.
-constexpr int NTG_R = 16, NTG_KC = 64, NTG_BS = 80;      // rows per workgroup; chunk rows; LDS row stride of a chunk (64 + 16)
+// NCW = 16-column tiles per wave (a workgroup takes 64 NCW embedding columns), KC = embedding rows per staged chunk.  The
+// prologue (denominators of ALL rows, the workgroup's sixteen rows of W) is the same for every column slice of a row
+// group, so at large batches the slices are made wide: B = 512 with NCW = 1 ran 64 x 16 workgroups, every one folding
+// 32 k denominator partials and forming 16 k exponentials for 2 MFLOP of product, four rounds of one workgroup per CU
+// (126 us); NCW = 4 is ONE round of 256 workgroups, W formed four times instead of sixteen (launch_ntxent picks the
+// widest slice that still leaves a workgroup per CU).  (Also built and measured, round 5: 64 x 64 tiles in both launches --
+// ntx_sim64 / ntx_grad64, W formed chunk by chunk beside the embedding rows, a quarter of the L2 traffic -- 44.9 + 74.7 us
+// at 2B = 1024 against 43.1 + 65.4: one four-wave workgroup per CU exposes every stall of its chunk loop; removed.)
+constexpr int NTG_R = 16;                                  // rows per workgroup
+__host__ __device__ constexpr int ntg_bs(int NCW) { return 64 * NCW + 16; }     // LDS row stride of a chunk
 
-__global__ __launch_bounds__(256) void ntx_grad_mfma_kernel(NtxArgs a, int CT) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // iden[N2] | inrm[N2] | red[64] | Wt[N2p][16] | xs[2][KC][BS]
+// NW = waves: 8 where the slice is 256 columns wide (ONE workgroup per CU: two waves per SIMD, two column tiles each)
+template <int NCW, int KC, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void ntx_grad_mfma_kernel(NtxArgs a, int CT) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // iden[N2] | inrm[N2] | red[128] | Wt[N2p][16] | xs[2][KC][BS]
+  constexpr int BS = ntg_bs(NCW), WC = 64 * NCW;               // columns per workgroup
+  constexpr int NT = 64 * NW, TW = 4 * NCW / NW;              // threads; 16-column tiles per wave
+  constexpr int NP = KC * (WC / 4) / NT;                      // 16-byte pieces per thread and chunk
+  constexpr int RSTEP = NT / (WC / 4);                        // chunk rows between a thread's pieces
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N2 = 2 * a.B, D = a.D, B = a.B;
-  const int N2p = ((N2 + NTG_KC - 1) / NTG_KC) * NTG_KC;            // rows of Wt, padded to whole chunks (zeros)
-  const int r0 = blockIdx.x * NTG_R, d0 = blockIdx.y * 64;
+  const int N2p = ((N2 + 63) / 64) * 64;                          // rows of Wt, padded to whole chunks of either size (zeros)
+  const int r0 = blockIdx.x * NTG_R, d0 = blockIdx.y * WC;
   float* iden = sm;
   float* inrm = iden + N2;
   float* red = inrm + N2;
-  float* Wt = sm + (((2 * N2 + 64) + 3) & ~3);                       // [N2p][16], 16-byte aligned
-  float* xs = Wt + (size_t)N2p * NTG_R;                             // [2][NTG_KC][NTG_BS]
+  float* Wt = sm + (((2 * N2 + 128) + 3) & ~3);                       // [N2p][16], 16-byte aligned
+  float* xs = Wt + (size_t)N2p * NTG_R;                             // [2][KC][BS]
   const float invT = 1.f / a.T, sc = 1.f / (a.T * (float)N2);
   // ---- the first two chunks of embedding rows are requested before anything else
-  const int rb = tid >> 4, cb = (tid & 15) * 4;                     // piece q: row rb + 16 q of the chunk, floats cb .. cb + 3
+  const int rb = tid / (WC / 4), cb = (tid % (WC / 4)) * 4;         // piece q: row rb + RSTEP q of the chunk, floats cb .. cb + 3
   const bool b_ok = d0 + cb < D;
-  auto fetch = [&](int k0, float4 (&v)[4]) {
+  auto fetch = [&](int k0, float4 (&v)[NP]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = k0 + rb + 16 * q;
+    for (int q = 0; q < NP; ++q) {
+      const int r = k0 + rb + RSTEP * q;
       const float4 y = *(const float4*)(ntx_row(a, r < N2 ? r : 0) + (b_ok ? d0 + cb : 0));
       v[q] = (r < N2 && b_ok) ? y : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto stage = [&](int buf, const float4 (&v)[4]) {
+  auto stage = [&](int buf, const float4 (&v)[NP]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *(float4*)(xs + (size_t)buf * NTG_KC * NTG_BS + (rb + 16 * q) * NTG_BS + cb) = make_float4(v[q].x, v[q].y, v[q].z, v[q].w);
+    for (int q = 0; q < NP; ++q)
+      *(float4*)(xs + (size_t)buf * KC * BS + (rb + RSTEP * q) * BS + cb) = make_float4(v[q].x, v[q].y, v[q].z, v[q].w);
   };
-  const int NC = N2p / NTG_KC;
-  float4 v0[4], v1[4];
+  const int NC = N2p / KC;
+  float4 v0[NP], v1[NP];
   fetch(0, v0);
-  if (NC > 1) fetch(NTG_KC, v1);
+  if (NC > 1) fetch(KC, v1);
   // ---- denominators of all rows (column tiles summed in index order), and the loss (workgroup (0, 0))
   float lsum = 0.f;
-  for (int b = tid; b < N2; b += 256) {
+  for (int b = tid; b < N2; b += NT) {
     float den = 0.f;
-    for (int c0 = 0; c0 < CT; c0 += 8) {               // eight partials requested together, added in index order
-      float pv[8];
+    for (int c0 = 0; c0 < CT; c0 += 32) {              // thirty-two partials requested together, added in index order
+      float pv[32];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) pv[q] = a.rs_part[(long long)(c0 + q < CT ? c0 + q : CT - 1) * N2 + b];
+      for (int q = 0; q < 32; ++q) pv[q] = a.rs_part[(long long)(c0 + q < CT ? c0 + q : CT - 1) * N2 + b];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) den += (c0 + q < CT) ? pv[q] : 0.f;
+      for (int q = 0; q < 32; ++q) den += (c0 + q < CT) ? pv[q] : 0.f;
     }
     iden[b] = 1.f / den;
     inrm[b] = 1.f / a.nrm[b];
@@ -322,18 +337,28 @@ __global__ __launch_bounds__(256) void ntx_grad_mfma_kernel(NtxArgs a, int CT) {
     lsum = wave_sum(lsum);
     if (lane == 0) red[wave] = lsum;
   }
+  // the sixteen similarities of this thread's first column b (unconditional loads, in flight across the barrier)
+  auto load_s = [&](int b, float (&sv)[NTG_R]) {
+#pragma unroll
+    for (int i = 0; i < NTG_R; ++i) sv[i] = a.S[(long long)(r0 + i < N2 ? r0 + i : N2 - 1) * N2 + (b < N2 ? b : 0)];
+  };
+  float sv[NTG_R];
+  load_s(tid, sv);
   __syncthreads();
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)N2;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    float l = (red[0] + red[1]) + (red[2] + red[3]);
+    if (NW == 8) l += (red[4] + red[5]) + (red[6] + red[7]);
+    a.loss[0] = l / (float)N2;
+  }
   // ---- this workgroup's rows of W = G + G^T (transposed, scaled by 1 / |x_b|), and z_a . dz_a = sum_b W[a][b] S[a][b]
   float dotp[NTG_R];
 #pragma unroll
   for (int i = 0; i < NTG_R; ++i) dotp[i] = 0.f;
-  for (int b = tid; b < N2p; b += 256) {
+  for (int b = tid; b < N2p; b += NT) {
     const bool bv = b < N2;
     const float idb = bv ? iden[b] : 0.f, inb = bv ? inrm[b] : 0.f;
-    float sv[NTG_R];                                     // the sixteen similarities first (unconditional loads)
-#pragma unroll
-    for (int i = 0; i < NTG_R; ++i) sv[i] = a.S[(long long)(r0 + i < N2 ? r0 + i : N2 - 1) * N2 + (bv ? b : 0)];
+    float sn[NTG_R];                                     // the next column's similarities while this one's exponentials run
+    if (b + NT < N2p) load_s(b + NT, sn);
     float wr[NTG_R];
 #pragma unroll
     for (int i = 0; i < NTG_R; ++i) {
@@ -347,6 +372,10 @@ __global__ __launch_bounds__(256) void ntx_grad_mfma_kernel(NtxArgs a, int CT) {
     }
 #pragma unroll
     for (int i = 0; i < NTG_R; i += 4) *(float4*)(Wt + (size_t)b * NTG_R + i) = make_float4(wr[i], wr[i + 1], wr[i + 2], wr[i + 3]);
+    if (b + NT < N2p) {
+#pragma unroll
+      for (int i = 0; i < NTG_R; ++i) sv[i] = sn[i];
+    }
   }
   __syncthreads();                               // (also: red[] has been read)
 #pragma unroll
@@ -354,38 +383,51 @@ __global__ __launch_bounds__(256) void ntx_grad_mfma_kernel(NtxArgs a, int CT) {
     const float v = wave_sum(dotp[i]);
     if (lane == 0) red[wave * 16 + i] = v;
   }
-  // ---- dz[a][d] = sum_b Wt[b][a] x[b][d]
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  // ---- dz[a][d] = sum_b Wt[b][a] x[b][d]: wave w owns column tiles TW w .. TW w + TW - 1 of the slice
+  f32x4 acc[TW], acc2[TW];
+#pragma unroll
+  for (int j = 0; j < TW; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   stage(0, v0);
-  if (NC > 2) fetch(2 * NTG_KC, v0);
+  if (NC > 2) fetch(2 * KC, v0);
   for (int c = 0; c < NC; ++c) {
     __syncthreads();                             // chunk c staged (and, c = 0: Wt, red complete); the other buffer is free
     if (c + 1 < NC) {
-      if ((c & 1) == 0) { stage(1, v1); if (c + 3 < NC) fetch((c + 3) * NTG_KC, v1); }
-      else              { stage(0, v0); if (c + 3 < NC) fetch((c + 3) * NTG_KC, v0); }
+      if ((c & 1) == 0) { stage(1, v1); if (c + 3 < NC) fetch((c + 3) * KC, v1); }
+      else              { stage(0, v0); if (c + 3 < NC) fetch((c + 3) * KC, v0); }
     }
-    const float* as = Wt + (size_t)(c * NTG_KC + kq) * NTG_R + l16;
-    const float* bs = xs + (size_t)(c & 1) * NTG_KC * NTG_BS + kq * NTG_BS + wave * 16 + l16;
-    float av[NTG_KC / 4], bv[NTG_KC / 4];
+    const float* as = Wt + (size_t)(c * KC + kq) * NTG_R + l16;
+    const float* bs = xs + (size_t)(c & 1) * KC * BS + kq * BS + wave * (16 * TW) + l16;
+    float av[KC / 4];
 #pragma unroll
-    for (int k4 = 0; k4 < NTG_KC / 4; ++k4) { av[k4] = as[(4 * k4) * NTG_R]; bv[k4] = bs[(4 * k4) * NTG_BS]; }
+    for (int k4 = 0; k4 < KC / 4; ++k4) av[k4] = as[(4 * k4) * NTG_R];
 #pragma unroll
-    for (int k4 = 0; k4 < NTG_KC / 4; k4 += 2) {
-      acc  = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4], bv[k4], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4 + 1], bv[k4 + 1], acc2, 0, 0, 0);
+    for (int j = 0; j < TW; ++j) {
+      float bv[KC / 4];
+#pragma unroll
+      for (int k4 = 0; k4 < KC / 4; ++k4) bv[k4] = bs[(4 * k4) * BS + 16 * j];
+#pragma unroll
+      for (int k4 = 0; k4 < KC / 4; k4 += 2) {
+        acc[j]  = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4], bv[k4], acc[j], 0, 0, 0);
+        acc2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k4 + 1], bv[k4 + 1], acc2[j], 0, 0, 0);
+      }
     }
   }
   // ---- backward of x / max(|x|, eps): D register r of lane l is row 4 (l >> 4) + r, column l & 15
-  const int d = d0 + wave * 16 + l16;
-  if (d >= D) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = 4 * kq + r, ra = r0 + i;
-    if (ra < N2) {
-      const float n = a.nrm[ra], z = ntx_row(a, ra)[d] * inrm[ra];
-      const float dot = (red[i] + red[16 + i]) + (red[32 + i] + red[48 + i]);
-      float* g = (ra < B) ? a.gi + (long long)ra * D : a.gj + (long long)(ra - B) * D;
-      g[d] = ((acc[r] + acc2[r]) - z * dot) / n;
+  for (int j = 0; j < TW; ++j) {
+    const int d = d0 + wave * (16 * TW) + 16 * j + l16;
+    if (d < D) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * kq + r, ra = r0 + i;
+        if (ra < N2) {
+          const float n = a.nrm[ra], z = ntx_row(a, ra)[d] * inrm[ra];
+          float dot = (red[i] + red[16 + i]) + (red[32 + i] + red[48 + i]);
+          if (NW == 8) dot += (red[64 + i] + red[80 + i]) + (red[96 + i] + red[112 + i]);
+          float* g = (ra < B) ? a.gi + (long long)ra * D : a.gj + (long long)(ra - B) * D;
+          g[d] = ((acc[j][r] + acc2[j][r]) - z * dot) / n;
+        }
+      }
     }
   }
 }
@@ -405,19 +447,42 @@ hipError_t launch_ntxent(const float* ei, const float* ej, int B, int D, float T
   a.S = ws; ws += N2 * N2;
   a.rs_part = ws; ws += (size_t)CT * N2;
   a.nrm = ws;
+  const bool aligned = D % 4 == 0 && (((uintptr_t)ei | (uintptr_t)ej) & 15) == 0;
   hipLaunchKernelGGL(ntx_sim_kernel, dim3(CT, (unsigned)((N2 + 15) / 16)), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  // the MFMA gradient wherever the rows are whole 16-byte pieces (CMLPL_NTX_MFMA=0: the vector kernel always)
-  const size_t N2p = ((N2 + NTG_KC - 1) / NTG_KC) * NTG_KC;
-  const size_t lds_m = ((((2 * N2 + 64) + 3) & ~(size_t)3) + N2p * NTG_R + 2 * (size_t)NTG_KC * NTG_BS) * 4;
-  const bool aligned = D % 4 == 0 && (((uintptr_t)ei | (uintptr_t)ej) & 15) == 0;
-  if (aligned && switches().ntx_mfma != 0 && lds_m <= LDS_MAX) {
-    static DevOnce once;
-    if ((e = ensure_max_lds(once, ntx_grad_mfma_kernel)) != hipSuccess) return e;
-    hipLaunchKernelGGL(ntx_grad_mfma_kernel, dim3((unsigned)((N2 + NTG_R - 1) / NTG_R), (unsigned)((D + 63) / 64)), dim3(256),
-                       lds_m, st, a, CT);
-    return hipGetLastError();
+  // the MFMA gradient wherever the rows are whole 16-byte pieces (CMLPL_NTX_MFMA=0: the vector kernel always); the widest
+  // column slice (64 NCW columns per workgroup) that still gives every CU a workgroup and fits LDS
+  const size_t N2p = ((N2 + 63) / 64) * 64;
+  if (aligned && switches().ntx_mfma != 0) {
+    const unsigned rg = (unsigned)((N2 + NTG_R - 1) / NTG_R);
+    auto lds_of = [&](int ncw, int kc) { return ((((2 * N2 + 128) + 3) & ~(size_t)3) + N2p * NTG_R + 2 * (size_t)kc * ntg_bs(ncw)) * 4; };
+    auto wgs_of = [&](int ncw) { return (size_t)rg * (size_t)((D + 64 * ncw - 1) / (64 * ncw)); };
+    const int force = switches().ntx_ncw;
+    int ncw = 1;
+    if (force == 2 || force == 4) ncw = force;
+    else if (force == 0) {
+      if (wgs_of(2) >= 256 && lds_of(2, 64) <= LDS_MAX) ncw = 2;
+      if (wgs_of(4) >= 256 && lds_of(4, 32) <= LDS_MAX) ncw = 4;
+    }
+    const size_t lds_m = lds_of(ncw, ncw == 4 ? 32 : 64);
+    if (lds_m <= LDS_MAX) {
+      const dim3 grid(rg, (unsigned)((D + 64 * ncw - 1) / (64 * ncw)));
+      if (ncw == 4) {
+        static DevOnce once;
+        if ((e = ensure_max_lds(once, ntx_grad_mfma_kernel<4, 32, 8>)) != hipSuccess) return e;
+        hipLaunchKernelGGL((ntx_grad_mfma_kernel<4, 32, 8>), grid, dim3(512), lds_m, st, a, CT);
+      } else if (ncw == 2) {
+        static DevOnce once;
+        if ((e = ensure_max_lds(once, ntx_grad_mfma_kernel<2, 64>)) != hipSuccess) return e;
+        hipLaunchKernelGGL((ntx_grad_mfma_kernel<2, 64>), grid, dim3(256), lds_m, st, a, CT);
+      } else {
+        static DevOnce once;
+        if ((e = ensure_max_lds(once, ntx_grad_mfma_kernel<1, 64>)) != hipSuccess) return e;
+        hipLaunchKernelGGL((ntx_grad_mfma_kernel<1, 64>), grid, dim3(256), lds_m, st, a, CT);
+      }
+      return hipGetLastError();
+    }
   }
   const size_t lds = (2 * N2 + (size_t)NTX_R * N2 + 64) * 4;
   if (lds > 64 * 1024) return hipErrorInvalidValue;        // 2B <= 1600 rows

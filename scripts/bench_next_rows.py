@@ -56,7 +56,7 @@ def n3():
 
 def n4():
     from tools.models import ContrastiveLoss
-    for B, D in ((128, 1024), (512, 1024)):
+    for B, D in ((128, 1024), (256, 1024), (512, 1024)):
         ei = torch.randn(B, D, device=DEV, requires_grad=True)
         ej = torch.randn(B, D, device=DEV, requires_grad=True)
         crit = ContrastiveLoss(B, device="cuda", temperature=0.5)

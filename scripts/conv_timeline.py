@@ -50,8 +50,9 @@ for mode, name, nwg in ((0, "fwd", NWG), (1, "dgrad", NWG), (2, "wgrad(conv1 wor
               f"done {f[:,9].mean():.2f}  end {f[:,3].mean():.2f}")
     elif mode == 0 and full[:, 4].max() > 0:
         f = (full - full[:, :1]) / 100.0
+        c3 = f"{f[:,13].mean():.2f}" if full[:, 13].min() > 0 else "n/a (fewer than four 16-band chunks)"
         print(f"fwd fused prologue (us from workgroup start): loads issued + noise formed {f[:,4].mean():.2f}  chunk 0 in LDS "
-              f"{f[:,12].mean():.2f}  chunk 3 in LDS {f[:,13].mean():.2f}  conv0 MFMAs done {f[:,5].mean():.2f}  "
+              f"{f[:,12].mean():.2f}  chunk 3 in LDS {c3}  conv0 MFMAs done {f[:,5].mean():.2f}  "
               f"image zeroed {f[:,6].mean():.2f}  a0 written / stage end {f[:,1].mean():.2f}")
     if mode == 0 and full[:, 9].max() > 0:
         f = (full - full[:, :1]) / 100.0

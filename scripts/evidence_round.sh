@@ -18,6 +18,8 @@ CMLPL_LIB=cmlpl_amd/libabl9.so python3 scripts/conv_timeline.py 2>&1 | grep -av 
 (for k in 0 1; do CMLPL_KS8=$k CMLPL_LIB=cmlpl_amd/libabl9.so python3 scripts/conv_timeline.py 103 9 64 64 2>&1 | grep -av "amdgpu.ids\|wgrad"; done
  CMLPL_TL_WIN=15 CMLPL_LIB=cmlpl_amd/libabl9.so python3 scripts/conv_timeline.py 48 20 8 64 2>&1 | grep -av "amdgpu.ids\|wgrad"
  CMLPL_TL_WIN=15 CMLPL_LIB=cmlpl_amd/libabl9.so python3 scripts/conv_timeline.py 48 20 128 128 2>&1 | grep -av "amdgpu.ids\|wgrad") > $OUT/${TAG}_timeline_shards.txt
+# the general path's conv1 launches at the reference's own 20 x 20 x 60 windows (library built with CMLPL_STAMP_MIN_H=20)
+[ -f cmlpl_amd/libabl9p.so ] && CMLPL_TL_WIN=20 CMLPL_LIB=cmlpl_amd/libabl9p.so python3 scripts/conv_timeline.py 60 16 128 128 2>&1 | grep -av amdgpu.ids > $OUT/${TAG}_timeline_p.txt
 # whole-image inference from the cube (PaviaU-sized scene) + its kernel stats
 (python3 scripts/bench_infer.py B2; python3 scripts/bench_infer.py B5) 2>&1 | grep -av amdgpu.ids > $OUT/${TAG}_infer.txt
 (cd /tmp && export TMPDIR=/tmp && rm -rf $OLDPWD/$OUT/${TAG}_infer_ks && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/${TAG}_infer_ks -o t -- python3 $OLDPWD/scripts/bench_infer.py B2 > /dev/null 2>&1)

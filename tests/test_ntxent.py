@@ -34,7 +34,7 @@ def test_oracle_matches_reference_contrastive_loss():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,D,T", [(8, 16, 0.5), (32, 128, 0.3), (64, 1024, 0.5), (128, 1024, 0.5), (20, 100, 0.2), (9, 37, 0.4),
-                                   (150, 300, 0.5)])
+                                   (150, 300, 0.5), (256, 1024, 0.5), (512, 1024, 0.5), (512, 200, 0.3), (300, 516, 0.4)])
 def test_hip_contrastive_loss_matches_oracle(B, D, T):
     from tools.models import ContrastiveLoss
     ei, ej = _emb(B, D, 70 + B)

@@ -19,4 +19,6 @@ cd $ROOT
 cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 python3 scripts/pmc_summary.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write --json $OUT/${TAG}_pmc_traffic.json --workload $WL --n-local 256 --profile profiles/${TAG}_pmc_hbm_traffic.txt > $OUT/${TAG}_pmc_hbm_traffic.txt
 python3 scripts/pmc_sq_summary.py $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_sq2 > $OUT/${TAG}_pmc_mfma.txt || true
+# the traffic record bench.py quotes (it carries the source hash): in place before the bench line of this round is taken
+[ "$WL" = B2 ] && cp $OUT/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
 python3 bench.py --workload $WL --steps 200 > $OUT/${TAG}_bench.json 2> /dev/null

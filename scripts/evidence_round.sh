@@ -3,7 +3,7 @@
 #   bash scripts/evidence_round.sh r02_final
 TAG=${1:-rXX}
 OUT=gpurun_out
-python3 bench.py --steps 200 > $OUT/${TAG}_bench.json 2> /dev/null
+# (the round's bench line, ${TAG}_bench.json, is taken by scripts/profile_round.sh right after it has put the traffic record in place)
 python3 scripts/bench_next_rows.py > $OUT/${TAG}_next_rows.txt 2>&1
 for w in 1 2 4 8; do python3 scripts/rank_cost.py $w 2>&1 | grep -av amdgpu.ids | tail -14; done > $OUT/${TAG}_rank_cost.txt
 python3 scripts/dist_overhead.py > $OUT/${TAG}_dist_overhead.txt 2>&1

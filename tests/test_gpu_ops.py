@@ -202,6 +202,35 @@ def test_basenet2_eval_matches_oracle_and_state_dict_keys():
     assert torch.equal(lo.argmax(1).cpu(), lo_ref.argmax(1))
 
 
+@pytest.mark.parametrize("name", ["B2", "P"])
+def test_non_finite_input_stays_in_its_own_sample(name):
+    """An Inf / NaN pixel: the three-piece bf16 split turns +-Inf into NaN (Inf - Inf in the remainder), the
+    reference would carry Inf into sums of mixed-sign products, i.e. NaN one layer later.  Either way the damaged sample's
+    logits are not finite in the oracle AND on the device, and every other sample of the batch is untouched (the
+    per-sample kernels share nothing across samples; the general kernels' tiles may hold several samples)."""
+    shape = SHAPES[name]
+    params = O.closed_form_params(shape, 3)
+    net = _module(shape, params, dropout=0.8)
+    net.eval()
+    g = torch.Generator().manual_seed(11)
+    n = 19
+    x = torch.randn(n, shape.C, shape.H, shape.W, generator=g)
+    y = torch.randn(n, shape.bands, generator=g)
+    x[3, 5, 2, 2] = float("inf")
+    x[11, 0, 0, 0] = float("nan")
+    x[17, shape.C - 1, shape.H - 1, shape.W - 1] = float("-inf")
+    with torch.no_grad():
+        lo, fe = net(x.to(DEV), y.to(DEV))
+    lo_ref, fe_ref = O.basenet2_forward(params, x, y, None)
+    bad = [3, 11, 17]
+    good = [i for i in range(n) if i not in bad]
+    for i in bad:
+        assert not torch.isfinite(lo_ref[i]).all(), i                     # the reference arithmetic does not survive it either
+        assert not torch.isfinite(lo[i].cpu()).all(), i
+    report("logits of the undamaged samples", lo[good], lo_ref[good], 1e-4, 2e-5)
+    report("features of the undamaged samples", fe[good], fe_ref[good], 1e-5, 1e-6)
+
+
 def test_dropout_philox_statistics():
     shape = SHAPES["B2"]
     net = _module(shape, O.closed_form_params(shape, 3), dropout=0.8)

@@ -1528,6 +1528,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   }
   STAMP(1, 10);
   __syncthreads();                                                 // dp2s complete, img2 zeroed
+  STAMP(1, 4);
   if (tid < 64) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
     const int c4 = tid & 15, pp = tid >> 4, ph = pp >> 1, pw = pp & 1;
     const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
@@ -1544,11 +1545,16 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     }
   }
   __syncthreads();
+  STAMP(1, 5);
   // ---- conv2 data gradient, split-bf16 on the 32x32x16 MFMA: the P2 <= 32 output pixels are ONE tile (row p = l31,
   // rows >= P2 read the zero corner); this wave multiplies its half of the input channels of every tap into its
   // output-channel tile.  Nothing is shared between the waves, so the B fragments go L2 -> registers directly
   // (six 1 KiB loads per tap, the next tap's in flight) and the loop has no barrier.
-  const int posA = l31 < P2 ? ((l31 / W2) + 1) * PW2 + (l31 % W2) + 1 : 0;
+  // (p / W2 by multiplication: a 32-bit division by a run-time value is ~40 vector instructions, and the fold below did
+  //  sixteen of them per lane)
+  const int mg2 = (65536 + W2 - 1) / W2;                           // p / W2 == (p * mg2) >> 16 for p < 4096 / W2 ... (p W2 < 65536)
+  const int phA = (l31 * mg2) >> 16;
+  const int posA = l31 < P2 ? (phA + 1) * PW2 + (l31 - phA * W2) + 1 : 0;
   const float* ap = img2 + (size_t)posA * CS + kh2 * 32 + hh * 8;
   f32x16 acc = zero16();
   // Units u = (tap, k-step q) of 16 input channels, software-pipelined as in ks_unit: unit u's two ds_read_b128 are
@@ -1593,6 +1599,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     SchedInterleave<6>::run();                             // (6 VALU, 1 MFMA) x 6; the rest of the split behind them
     cur = nxt; rn0 = rnn0; rn1 = rnn1;
   }
+  STAMP(1, 6);
   // ---- fold the two channel halves through LDS (the dz2 image region, once every wave is done reading it) and
   // finish: lane (ci = 32 nt + l31) holds pixels p = acc_row(r); the residual branch adds dz2 itself
   {
@@ -1600,16 +1607,18 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     float res[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int p = acc_row(r, lane);
-      res[r] = (kh2 == 0 && p < P2) ? img2[(size_t)(((p / W2) + 1) * PW2 + (p % W2) + 1) * CS + ci] : 0.f;
+      const int p = acc_row(r, lane), ph = (p * mg2) >> 16;
+      res[r] = (kh2 == 0 && p < P2) ? img2[(size_t)((ph + 1) * PW2 + (p - ph * W2) + 1) * CS + ci] : 0.f;
     }
     __syncthreads();                                               // every wave has finished reading img2
+    STAMP(1, 7);
     float* xch = img2 + nt * 1024;                                 // [16][64] per output-channel tile
     if (kh2 == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
     }
     __syncthreads();
+    STAMP(1, 8);
     if (kh2 == 0) {
       float* dp1g = a.dp1out + rs * (long long)P2 * 64;
 #pragma unroll
@@ -1724,7 +1733,8 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int wa = 4 * t + (j >> 2), wac = wa < P4 ? wa : 0;
-    const int oh = 2 * (wac / W4) + ((j >> 1) & 1), ow = 2 * (wac % W4) + (j & 1);
+    const int wph = (wac * ((65536 + W4 - 1) / W4)) >> 16;          // wac / W4 (a 32-bit division costs ~40 instructions)
+    const int oh = 2 * wph + ((j >> 1) & 1), ow = 2 * (wac - wph * W4) + (j & 1);
     ap0[t] = pl + (size_t)((oh + 1) * PW2 + ow + 1) * PS2 + 4 * kg + 16 * ksh;
   }
   f32x4v acc0[3], acc1[3];
@@ -1782,7 +1792,7 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
     for (int t = 0; t < 3; ++t) {
       const int win = 4 * t + kg;
       if (win < P4) {
-        const int ph = win / W4, pw = win - ph * W4;
+        const int ph = (win * ((65536 + W4 - 1) / W4)) >> 16, pw = win - ph * W4;
         float r_[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1938,7 +1948,7 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
       float* dp2g = a.dp2out + rs * SF;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int f = f0 + e, cc = f / P4, hw = f - cc * P4;
+        const int f = f0 + e, cc = (f * ((65536 + P4 - 1) / P4)) >> 16, hw = f - cc * P4;    // f / P4, f < 64 P4 <= 768
         dp2s[hw * 64 + cc] = d[e];
         dp2g[hw * 64 + cc] = d[e];
       }
@@ -1965,6 +1975,7 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) bq[t0][3 * q + pc] = wq[(size_t)t0 * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
   __syncthreads();                                                 // dp2s complete, img2 zeroed
+  STAMP(1, 4);
   if (tid < P4 * 16) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
     const int c4 = tid & 15, pp = tid >> 4, ph = pp / W4, pw = pp - ph * W4;
     const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
@@ -1981,9 +1992,12 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
     }
   }
   __syncthreads();
+  STAMP(1, 5);
   // ---- conv2 data gradient (split-bf16, 32x32x16): this wave's pixel tile x input-channel tile x output-channel half
   const int pA = mtile * 32 + l31;
-  const int posA = pA < P2 ? ((pA / W2) + 1) * PW2 + (pA % W2) + 1 : 0;
+  const int mg2 = (65536 + W2 - 1) / W2;                           // p / W2 == (p * mg2) >> 16 (p W2 < 65536)
+  const int phA = (pA * mg2) >> 16;
+  const int posA = pA < P2 ? (phA + 1) * PW2 + (pA - phA * W2) + 1 : 0;
   const float* ap = img2 + (size_t)posA * CS + kh2 * 32 + hh * 8;
   f32x16 acc = zero16();
   auto raw_ptr = [&](int u) {
@@ -2024,21 +2038,24 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
     SchedInterleave<6>::run();
     cur = nxt; rn0 = rnn0; rn1 = rnn1;
   }
+  STAMP(1, 6);
   {
     const int ci = nt * 32 + l31;
     float res[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int p = mtile * 32 + acc_row(r, lane);
-      res[r] = (kh2 == 0 && p < P2) ? img2[(size_t)(((p / W2) + 1) * PW2 + (p % W2) + 1) * CS + ci] : 0.f;
+      const int p = mtile * 32 + acc_row(r, lane), ph = (p * mg2) >> 16;
+      res[r] = (kh2 == 0 && p < P2) ? img2[(size_t)((ph + 1) * PW2 + (p - ph * W2) + 1) * CS + ci] : 0.f;
     }
     __syncthreads();                                               // every wave has finished reading img2
+    STAMP(1, 7);
     float* xch = img2 + (mtile * 2 + nt) * 1024;                   // [16][64] per (pixel tile, channel tile)
     if (kh2 == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
     }
     __syncthreads();
+    STAMP(1, 8);
     if (kh2 == 0) {
       float* dp1g = a.dp1out + rs * (long long)P2 * 64;
 #pragma unroll

@@ -67,6 +67,11 @@ for mode, name, nwg in ((0, "fwd", NWG), (1, "dgrad", NWG), (2, "wgrad(conv1 wor
         print(f"bwd head (us from workgroup start): head done {f[:,10].mean():.2f}  conv2 dgrad done {f[:,11].mean():.2f}  stage end "
               f"{f[:,1].mean():.2f}  taps end {f[:,2].mean():.2f}  slab issued+da0 {f[:,12].mean():.2f}  noise+landed {f[:,13].mean():.2f}  "
               f"end {f[:,3].mean():.2f}")
+    if mode == 1 and full[:, 5].max() > 0:
+        f = (full - full[:, :1]) / 100.0
+        print(f"bwd conv2 data gradient (us from workgroup start): head done {f[:,10].mean():.2f}  barrier passed {f[:,4].mean():.2f}  dz2 staged + "
+              f"barrier {f[:,5].mean():.2f}  MFMA loop done {f[:,6].mean():.2f}  residual read + barrier {f[:,7].mean():.2f}  exchange + barrier "
+              f"{f[:,8].mean():.2f}  dp1 written + barrier {f[:,11].mean():.2f}")
     t0 = t[:, 0].min()
     us = (t - t0) / 100.0
     print(f"{name}: start skew  mean {us[:,0].mean():.2f}  max {us[:,0].max():.2f} us")

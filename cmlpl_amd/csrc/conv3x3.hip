@@ -155,7 +155,19 @@ struct Conv3Args {
   // the mirror index of ExtractPatches while the slab chunks are staged -- no patch tensor exists; the argmax goes to
   // labels_out[s] (logits optional)
   const float* cube; int crows, ccols; long long pix0; long long* labels_out;
+  // x / d for the per-item index arithmetic of the staging and pooling loops, as one multiply (fdiv below): d = H W, W,
+  // (H / 2)(W / 2), W / 2 -- a 32-bit division by a run-time value is ~40 vector instructions, and those loops did two to
+  // four of them per 16-byte item (set by conv3_set_magics on the host)
+  uint32_t mg_hw, mg_w, mg_p2, mg_w2;
 };
+
+// x / d == umulhi(x, ceil(2^32 / d)) for x d < 2^32 (every index here is below 2^16); d = 1 is flagged by 0
+static inline uint32_t fdiv_magic(int d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ULL + (uint32_t)d - 1) / (uint32_t)d); }
+__device__ __forceinline__ int fdiv(int x, uint32_t mg) { return mg == 0u ? x : (int)__umulhi((uint32_t)x, mg); }
+static inline void conv3_set_magics(Conv3Args& a) {
+  const int H2 = a.H >> 1, W2 = a.W >> 1;
+  a.mg_hw = fdiv_magic(a.H * a.W); a.mg_w = fdiv_magic(a.W); a.mg_p2 = fdiv_magic(H2 * W2); a.mg_w2 = fdiv_magic(W2);
+}
 
 // Workgroup -> (network, first sample).  (Measured, round 3: numbering the workgroups so that the two a CU holds belong
 // to the same network -- hoping their weight-fragment streams would meet in L1 -- changed nothing: 0.2129 vs 0.2128 ms.)
@@ -983,13 +995,13 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const float* src = a.in + (long long)net * a.in_ns;
     staged_copy<8, float4, NT>(S * HW * 16, tid,
         [&](int idx) {
-          const int c4 = idx & 15, p = idx >> 4, s = p / HW, pix = p - s * HW, sample = s0 + s;
+          const int c4 = idx & 15, p = idx >> 4, s = fdiv(p, a.mg_hw), pix = p - s * HW, sample = s0 + s;
           const bool ok = sample < a.n;
           const float4 v = *(const float4*)(src + ((size_t)(ok ? sample : s0) * HW + pix) * 64 + c4 * 4);
           return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         },
         [&](int idx, float4 v) {
-          const int c4 = idx & 15, p = idx >> 4, s = p / HW, pix = p - s * HW, h = pix / W, w = pix - h * W;
+          const int c4 = idx & 15, p = idx >> 4, s = fdiv(p, a.mg_hw), pix = p - s * HW, h = fdiv(pix, a.mg_w), w = pix - h * W;
           *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
         });
   } else if (dp_lds != nullptr) {
@@ -999,7 +1011,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     for (int q = 0; q < 2; ++q) {
       const int idx = tid + NT * q;
       if (idx < P2 * 16) {
-        const int c4 = idx & 15, pp = idx >> 4, ph = pp / W2, pw = pp - ph * W2;
+        const int c4 = idx & 15, pp = idx >> 4, ph = fdiv(pp, a.mg_w2), pw = pp - ph * W2;
         const float4 d = *(const float4*)(dp_lds + pp * 64 + c4 * 4);
         const uint32_t m = mpre[q];
 #pragma unroll
@@ -1025,7 +1037,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     // one (pooled pixel, 4 channels) item feeds the 4 full-resolution positions of its 2x2 window
     staged_copy<8, DM, NT>(S * P2 * 16, tid,
         [&](int idx) {
-          const int c4 = idx & 15, pp = idx >> 4, s = pp / P2, q = pp - s * P2, sample = s0 + s;
+          const int c4 = idx & 15, pp = idx >> 4, s = fdiv(pp, a.mg_p2), q = pp - s * P2, sample = s0 + s;
           const bool ok = sample < a.n;
           const size_t g = ((size_t)(ok ? sample : s0) * P2 + q) * 64 + c4 * 4;
           DM r;
@@ -1034,7 +1046,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           return r;
         },
         [&](int idx, DM r) {
-          const int c4 = idx & 15, pp = idx >> 4, s = pp / P2, q = pp - s * P2, ph = q / W2, pw = q - ph * W2;
+          const int c4 = idx & 15, pp = idx >> 4, s = fdiv(pp, a.mg_p2), q = pp - s * P2, ph = fdiv(q, a.mg_w2), pw = q - ph * W2;
 #pragma unroll
           for (int sub = 0; sub < 4; ++sub) {
             float4 v;
@@ -1063,7 +1075,7 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
   const int tot = c.S * c.P2 * 16;
   for (int idx = c.tid; idx < tot; idx += NT) {
     const int c4 = idx & 15, pp = idx >> 4;
-    const int s = pp / c.P2, q = pp - s * c.P2, ph = q / c.W2, pw = q - ph * c.W2;
+    const int s = fdiv(pp, a.mg_p2), q = pp - s * c.P2, ph = fdiv(q, a.mg_w2), pw = q - ph * c.W2;
     const int sample = c.s0 + s;
     if (sample < a.n) {
       const float* p = c.img + (size_t)(s * c.IMG + (2 * ph + 1) * c.PW + 2 * pw + 1) * CS + c4 * 4;
@@ -2621,6 +2633,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   if (mode == 0) { a.in_ns = (long long)n * HW * 64; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns; a.mask_in_ns = 0; }
   else           { a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = (long long)n * HW * 64; a.mask_out_ns = 0; }
   a.n = n; a.H = H; a.W = W; a.S = pl.S;
+  conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
@@ -2755,6 +2768,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   a.wpk_ns = wpk_ns; a.bias_ns = bias_ns;
   a.in_ns = 0; a.mask_in_ns = 0; a.out_ns = (long long)n * P2 * 64; a.mask_out_ns = a.out_ns;
   a.n = n; a.H = H; a.W = W; a.S = 1;
+  conv3_set_magics(a);
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   (void)HW;
@@ -2818,6 +2832,7 @@ hipError_t launch_conv3_infer(int n, int C, int H, int W, const float* cube, int
   memset(&a, 0, sizeof(a));
   a.wpk = wpk; a.bias = bias;
   a.n = n; a.H = H; a.W = W; a.S = 1;
+  conv3_set_magics(a);
   a.w0t = w0t; a.b0 = b0; a.C = C;
   a.w2f = t.w2f; a.b2 = t.b2; a.wc = t.wc; a.bc = t.bc; a.yin = t.y; a.logits = t.logits; a.K = t.K;
   a.train = 0; a.dropout_p = 0.f;
@@ -2895,6 +2910,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   a.wpk_ns = wpk_ns; a.bias_ns = 0;
   a.in_ns = (long long)n * P2 * 64; a.mask_in_ns = a.in_ns; a.out_ns = 0; a.mask_out_ns = 0;
   a.n = n; a.H = H; a.W = W; a.S = 1;
+  conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
   if (head != nullptr) {

@@ -32,6 +32,7 @@ EXPORTS = (
     "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g", "cmlpl_memobank_loss",
     "cmlpl_source_hash", "cmlpl_dyn_adam", "cmlpl_step_graph_create", "cmlpl_step_graph_launch",
     "cmlpl_step_graph_destroy", "cmlpl_infer_workspace_bytes", "cmlpl_infer_cube", "cmlpl_dist_stage_graph_create",
+    "cmlpl_debug_reload_switches",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -157,6 +158,10 @@ def load(path: str = LIB_PATH):
         raise CmlplLibraryError(
             f"{path} not found: build it with `python -m cmlpl_amd.build_ext` (hipcc, gfx950). "
             "cmlpl_amd has no CPU fallback.")
+    # torch FIRST: it brings its own libamdhip64, and the library must bind to THAT runtime (the one that owns the
+    # tensors' memory and streams).  Loaded before torch, the library pulls in /opt/rocm's copy, torch then loads its
+    # own, and the process holds two HIP runtimes: every launch fails with hipErrorNoDevice (100).
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(path)
     except OSError as e:  # e.g. libamdhip64 missing

@@ -1087,4 +1087,9 @@ int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* na
   return CMLPL_E_ARG;
 }
 
+int cmlpl_debug_reload_switches(void) {
+  switches_table() = read_switches();
+  return 0;
+}
+
 }  // extern "C"

@@ -755,7 +755,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const uint4* wq0 = (const uint4*)(a.w0t + (long long)net * a.w0t_ns) + lane;
     // the last, partial float4 group of the slab (C * HW need not be a multiple of 4): threads 0 .. rem-1
     float tailv = 0.f;
-    if (tid < rem) {
+    if constexpr (!CUBE) if (tid < rem) {
       tailv = xrow[4 * nf4 + tid];
       if (sigma != 0.f) {
         float zt;
@@ -912,7 +912,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             if (xnrow != nullptr) *(float4*)(xnrow + 4 * gg) = v;
           }
         }
-        if (pch(kq) == KQ0 - 1 && tid < rem) {
+        if constexpr (!CUBE) if (pch(kq) == KQ0 - 1 && tid < rem) {
           sl[4 * nf4 - (KQ0 - 1) * 16 * HWl + tid] = tailv;
           if (xnrow != nullptr) xnrow[4 * nf4 + tid] = tailv;
         }

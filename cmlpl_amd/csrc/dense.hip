@@ -39,7 +39,6 @@ __global__ __launch_bounds__(256) void spe_fwd_kernel(const float* __restrict__ 
   const float* ar = As + l31 * BP + hh;
   const float* br = Bs + (wave * 32 + l31) * BP + hh;
   const int KK = (bands + 1) >> 1;
-#pragma unroll 4
   for (int kk = 0; kk < KK; ++kk) acc = mfma32(ar[2 * kk], br[2 * kk], acc);
   const int o = o0 + wave * 32 + l31;
   const float bv = b[(long long)net * pstride + o];

@@ -172,7 +172,8 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
                            float* dy, float* dp2, hipStream_t st);
 
 // ---- loss.hip   (row-sharded: see the header of loss.hip)
-// Planner / path switches: environment variables, read ONCE per process, all of them here.
+// Planner / path switches: environment variables, read once per process (and again only on
+// cmlpl_debug_reload_switches), all of them here.
 // -1 / 0 = "not set" where the comment says so; every default is the product path.
 struct Switches {
   int fuse_conv0, fuse_conv0_bwd, fuse_tail, fuse_spe;        // CMLPL_FUSE_*: 0 = the unfused round-1 kernels (default 1)
@@ -186,8 +187,7 @@ struct Switches {
   int mb_fast, unsup_onewg, unsup_3l, ntx_mfma;               // CMLPL_MB_FAST, CMLPL_UNSUP_ONEWG, CMLPL_UNSUP_3L, CMLPL_NTX_MFMA (default 1)
   int ntx_ncw;                                                // CMLPL_NTX_NCW: 1 / 2 / 4 = 64 / 128 / 256 embedding columns per workgroup of the NT-Xent gradient (0 = planner)
 };
-inline const Switches& switches() {
-  static const Switches sw = [] {
+inline Switches read_switches() {
     auto env = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
     Switches w;
     w.fuse_conv0 = env("CMLPL_FUSE_CONV0", 1); w.fuse_conv0_bwd = env("CMLPL_FUSE_CONV0_BWD", 1);
@@ -204,9 +204,14 @@ inline const Switches& switches() {
     w.mb_fast = env("CMLPL_MB_FAST", 1); w.unsup_onewg = env("CMLPL_UNSUP_ONEWG", 1); w.unsup_3l = env("CMLPL_UNSUP_3L", 1);
     w.ntx_mfma = env("CMLPL_NTX_MFMA", 1); w.ntx_ncw = env("CMLPL_NTX_NCW", 0);
     return w;
-  }();
+}
+// the process's table: filled on first use; cmlpl_debug_reload_switches (tests: one process walks several settings)
+// reads the environment again -- between calls, never while a launch is being planned on another thread
+inline Switches& switches_table() {
+  static Switches sw = read_switches();
   return sw;
 }
+inline const Switches& switches() { return switches_table(); }
 
 // compute units of the current device (cached per device: the pair launch shares them between its two maps; a
 // host without a device -- the library loaded for its symbols only -- plans for a full MI355X)

@@ -478,6 +478,12 @@ int cmlpl_timing_end(double* ms_sum /*[CMLPL_K_COUNT]*/, int64_t* launches /*[CM
 int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* name,
                        size_t* byte_offset, size_t* bytes);
 
+/* Test aid: read the CMLPL_* planner switches from the environment again (they are otherwise read once per
+ * process).  Lets ONE test process walk several kernel variants; call it between library calls only -- objects
+ * created under the old settings (captured graphs, engines with cached plans) must not be used afterwards.
+ * The reference has no counterpart (it has no native code). */
+int cmlpl_debug_reload_switches(void);
+
 #ifdef __cplusplus
 }
 #endif

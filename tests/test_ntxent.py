@@ -37,16 +37,21 @@ def test_oracle_matches_reference_contrastive_loss():
                                    (150, 300, 0.5), (256, 1024, 0.5), (512, 1024, 0.5), (512, 200, 0.3), (300, 516, 0.4)])
 def test_hip_contrastive_loss_matches_oracle(B, D, T):
     from tools.models import ContrastiveLoss
+    from tests.memo import memo
     ei, ej = _emb(B, D, 70 + B)
-    ri, rj = ei.clone().requires_grad_(True), ej.clone().requires_grad_(True)
-    ref = O.ntxent_loss(ri, rj, T)
-    ref.backward()
+
+    def oracle():          # (the reference's [2B, 2B, D] broadcast: 17 s at B = 512; the kernel variants share one evaluation)
+        ri, rj = ei.clone().requires_grad_(True), ej.clone().requires_grad_(True)
+        ref = O.ntxent_loss(ri, rj, T)
+        ref.backward()
+        return ref.detach(), ri.grad, rj.grad
+    ref, ri_grad, rj_grad = memo(f"ntxent-{B}-{D}-{T}-seed{70 + B}", oracle)
     gi, gj = ei.cuda().requires_grad_(True), ej.cuda().requires_grad_(True)
     crit = ContrastiveLoss(B, device="cuda", temperature=T)
     loss = crit(gi, gj)
     loss.backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()), (loss.item(), ref.item())
-    for got, want in ((gi.grad, ri.grad), (gj.grad, rj.grad)):
+    for got, want in ((gi.grad, ri_grad), (gj.grad, rj_grad)):
         err = (got.cpu() - want).abs().max().item()
         assert err <= 2e-4 * want.abs().max().item() + 1e-9, (err, want.abs().max().item())

@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMLPL_LIB") or os.path.join(HERE, "libcmlpl_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_TENSORS = 16
 NUM_LIVE = 10
 
@@ -32,7 +32,8 @@ EXPORTS = (
     "cmlpl_forward", "cmlpl_backward", "cmlpl_loss_phase1_g", "cmlpl_loss_phase2_g", "cmlpl_memobank_loss",
     "cmlpl_source_hash", "cmlpl_dyn_adam", "cmlpl_step_graph_create", "cmlpl_step_graph_launch",
     "cmlpl_step_graph_destroy", "cmlpl_infer_workspace_bytes", "cmlpl_infer_cube", "cmlpl_dist_stage_graph_create",
-    "cmlpl_debug_reload_switches",
+    "cmlpl_debug_reload_switches", "cmlpl_forward_spectral", "cmlpl_forward_spatial", "cmlpl_backward_data",
+    "cmlpl_backward_weights",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -103,7 +104,8 @@ class MemobankCall(C.Structure):
 
 
 class Gathered(C.Structure):
-    _fields_ = [("d_recv", C.c_void_p), ("world", C.c_int32), ("bt_local", C.c_int32), ("btu_local", C.c_int32)]
+    _fields_ = [("d_recv_feat", C.c_void_p), ("d_logits_local", C.c_void_p), ("world", C.c_int32), ("bt_local", C.c_int32),
+                ("btu_local", C.c_int32)]
 
 
 class Banks(C.Structure):
@@ -129,7 +131,7 @@ class StepIO(C.Structure):
 
 
 class DistIO(C.Structure):
-    """cmlpl_dist_io: what the five captured stages of the sharded step read and write"""
+    """cmlpl_dist_io: what the seven captured stages of the sharded step read and write"""
     _fields_ = [
         ("batch", Batch), ("shard", Shard), ("gathered", Gathered), ("banks", Banks),
         ("d_params", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_packed", C.c_void_p),
@@ -144,7 +146,7 @@ class DistIO(C.Structure):
     ]
 
 
-STAGE_IDS = {"forward": 0, "phase1": 1, "phase2": 2, "backward": 3, "update": 4}
+STAGE_IDS = {"spectral": 0, "spatial": 1, "phase1": 2, "phase2": 3, "backward_data": 4, "backward_weights": 5, "update": 6}
 
 _lib = None
 
@@ -200,7 +202,11 @@ def load(path: str = LIB_PATH):
                                       vp]
     lib.cmlpl_loss_workspace_bytes.argtypes = [SP, SH, i32]
     lib.cmlpl_loss_workspace_bytes.restype = sz
-    lib.cmlpl_dist_unpack.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.cmlpl_dist_unpack.argtypes = [SP, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.cmlpl_forward_spectral.argtypes = [SP, HP, BP, SH, vp, u64, u64, vp, vp, vp, sz, vp]
+    lib.cmlpl_forward_spatial.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, sz, vp]
+    lib.cmlpl_backward_data.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, sz, vp]
+    lib.cmlpl_backward_weights.argtypes = [SP, HP, BP, SH, vp, vp, vp, i32, u64, u64, vp, vp, vp, i64, vp, sz, vp]
     lib.cmlpl_extract_patches.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp]
     lib.cmlpl_infer_workspace_bytes.argtypes = [vp, i32]
     lib.cmlpl_infer_workspace_bytes.restype = C.c_size_t

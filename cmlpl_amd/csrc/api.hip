@@ -233,16 +233,21 @@ XSrc xsrc_raw(const cmlpl_batch* b, float sigma, uint64_t seed, uint64_t step, c
   x.seed = seed; x.step = step;
   return x;
 }
+// parts: bit 0 = the spectral branch (feat_spe + ReLU; with early_feat also the L2 normalisation -> d_feat, ynorm),
+//        bit 1 = the convolution stack + head (-> d_logits; d_feat / ynorm too unless early_feat)
 int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const XSrc* xspec, float* d_sn_out, const long long* d_labels, float* d_labels_f, const float* d_xn,
              const float* d_sn, const float* d_snT,
              const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
              const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st,
-             float* xn_save = nullptr);
+             float* xn_save = nullptr, int parts = 3, bool early_feat = false);
+// parts: bit 0 = the data-gradient chain + the 3x3 weight-gradient partials (needs d_dlogits; d_dfeat only when parts == 3),
+//        bit 1 = partial reduction + classifier / feat_spe weight gradients (parts == 2: dy first takes its d_dfeat part)
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor = nullptr, cmlpl_dyn* dyn_table = nullptr);
+             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor = nullptr, cmlpl_dyn* dyn_table = nullptr,
+             int parts = 3);
 }  // namespace
 
 int cmlpl_basenet2_fwd(const cmlpl_shape* shape, int nets, int n, const float* d_params, int64_t param_stride,
@@ -270,10 +275,10 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
              const float* d_sn, const float* d_snT,
              const float* d_dropmask, float dropout_p, int train, uint64_t seed, uint64_t step,
              const cmlpl_shard* shard, float* d_logits, float* d_feat, const NetWs& w, hipStream_t st,
-             float* xn_save) {
+             float* xn_save, int parts, bool early_feat) {
   int rc;
   const long long pk_ns = L.packed_total;
-  {  // spectral branch (feat_spe + ReLU)
+  if (parts & 1) {  // spectral branch (feat_spe + ReLU)
     if (xspec != nullptr) {
       // raw spectra: augmentation + GEMM + bias + ReLU in one launch (also writes the augmented rows for the
       // weight gradient)
@@ -285,7 +290,13 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
       if ((rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_spe_fwd(nets, n, d.bands, d_sn, d_params + L.param_off[6],
                                    d_params + L.param_off[7], param_stride, w.y, st))))) return rc;
     }
+    // the embeddings right here (they depend on nothing the convolutions compute, tools/models.py:142-146)
+    // (timed with the spectral branch it belongs to)
+    if (early_feat && (rc = TIMED(CMLPL_K_SPE_FWD, chk(launch_feat_norm(nets, n, w.y, w.ynorm, d_feat, (long long)n * 1024, st)))))
+      return rc;
   }
+  if (!(parts & 2)) return 0;
+  if (early_feat) d_feat = nullptr;           // the head skips its own normalisation
   if (shard && shard->nlab + shard->nunl != n) return CMLPL_E_ARG;
   if (conv3_fused_tail_ok(d.H, d.W, d.C, nets * n, d.K)) {
     // the whole spatial forward + head of a sample in one workgroup: conv0 + conv1 + pool + conv2 + pool + flatten /
@@ -345,10 +356,13 @@ namespace {
 int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const float* d_params, int64_t param_stride,
              const float* d_packed, const XSrc& xs, const float* d_xn, const float* d_sn, const float* d_dropmask,
              float dropout_p, int train, const float* d_dlogits, const float* d_dfeat, float* d_grads,
-             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor, cmlpl_dyn* dyn_table) {
+             int64_t grad_stride, const NetWs& w, hipStream_t st, int* dyn_cursor, cmlpl_dyn* dyn_table, int parts) {
   const float* mask = (!train || dropout_p <= 0.f) ? nullptr : (d_dropmask ? d_dropmask : w.dropgen);
   int rc;
   const bool fused_head = conv3_fused_head_ok(d.H, d.W, d.C, nets * n, d.K);
+  // in two parts the head runs WITHOUT the feature gradients (dy is linear in them; launch_dy_fixup adds their share
+  // in front of the feat_spe weight-gradient GEMM, bit-identically)
+  const float* d_dfeat_head = (parts == 3) ? d_dfeat : nullptr;
   GemmTN gw_cls, gw_spe;
   {
     GemmTN& g = gw_cls;
@@ -367,12 +381,13 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     h.C = d_grads + L.param_off[6]; h.ldc = d.bands;
     h.bias = d_grads + L.param_off[7];
   }
-  if (fused_head) {
+  if (!(parts & 1)) {
+  } else if (fused_head) {
     // ONE per-sample launch for the whole data-gradient chain: head backward -> conv2 data gradient -> conv1 data
     // gradient -> conv0 weight-gradient partial.  dp2 / dp1 / dy still go to HBM for the weight-gradient kernels
     // that follow; da0 and the pooled-gradient hand-offs stay on chip.
     BwdHead hd;
-    hd.dlogits = d_dlogits; hd.dfeat = d_dfeat; hd.mask = mask; hd.wc = d_params + L.param_off[8]; hd.p_ns = param_stride;
+    hd.dlogits = d_dlogits; hd.dfeat = d_dfeat_head; hd.mask = mask; hd.wc = d_params + L.param_off[8]; hd.p_ns = param_stride;
     hd.y = w.y; hd.ynorm = w.ynorm; hd.m2 = w.m2; hd.w2d = d_packed + pack_off_b3(d.C, d.bands, 3); hd.w2d_ns = L.packed_total;
     hd.dy = w.dy; hd.dp2 = w.dp2; hd.dp1 = w.dp1; hd.K = d.K;
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
@@ -389,7 +404,7 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // produces conv1's pooled gradient), and the classifier / feat_spe weight-gradient GEMMs ride in the reduce launch --
     // 17 launches where there were 19; the forked side streams of round 1 are gone (they never paid: DESIGN.md section 7).
     // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
-    if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat, mask,
+    if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat_head, mask,
                                   d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
     if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + pack_off_b3(d.C, d.bands, 3),
                                L.packed_total, nullptr, 0, w.dp1, nullptr, st))))) return rc;
@@ -409,6 +424,11 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
       if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
         return rc;
     }
+  }
+  if (!(parts & 2)) return 0;
+  if (parts == 2) {
+    if (!d_dfeat) return CMLPL_E_ARG;
+    if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_dy_fixup(nets, n, w.y, w.ynorm, d_dfeat, w.dy, st))))) return rc;
   }
   // one launch folds the per-workgroup partials of all three convolutions into the flat gradient
   ReduceTable rt;
@@ -438,11 +458,15 @@ namespace {
 int forward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
                  const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
                  uint64_t step, float* d_logits, float* d_feat, float* d_labels_f, void* d_workspace,
-                 size_t workspace_bytes, void* stream, DynRef dyn) {
+                 size_t workspace_bytes, void* stream, DynRef dyn, int parts = 3) {
   Dims d;
   cmlpl_layout_t L;
   if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
-  if (!hp || !check_batch(batch) || !d_params || !d_packed || !d_logits || !d_feat || !d_workspace) return CMLPL_E_ARG;
+  // in two parts (the sharded step) the spectral part forms the embeddings itself: early_feat
+  const bool early_feat = parts != 3;
+  if (!hp || !check_batch(batch) || !d_params || !d_workspace || ((parts & 2) && (!d_packed || !d_logits)) ||
+      ((parts & 1 || !early_feat) && !d_feat))
+    return CMLPL_E_ARG;
   if (d_labels_f && !batch->d_labels) return CMLPL_E_ARG;
   if (hp->dropout_p < 0.f || hp->dropout_p >= 1.f) return CMLPL_E_ARG;
   const int n = batch->bt + batch->btu;
@@ -460,7 +484,8 @@ int forward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_
   // falls back to the unfused kernels, the spectra when the fused spectral kernel does not apply, and the label
   // conversion for the data-parallel exchange buffer
   const bool spe_fused = spe_fused_ok(d.bands);
-  const int which = (copy ? 1 : 0) | (spe_fused ? 0 : 2);
+  const int which = ((parts & 2) && copy ? 1 : 0) | ((parts & 1) && !spe_fused ? 2 : 0);
+  if (!(parts & 1)) d_labels_f = nullptr;     // (the labels travel with the spectral part)
   const RowSel sel = batch_sel(batch, dyn);
   if (which &&
       (rc = TIMED(CMLPL_K_AUGMENT, chk(launch_augment(which, 2, batch->bt, batch->btu, d.C * d.HW, d.bands, lab0,
@@ -478,10 +503,23 @@ int forward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_
                   spe_fused ? &xspec : nullptr, sw.sn, (const long long*)batch->d_labels, d_labels_f,
                   copy ? sw.xn : nullptr, sw.sn, nullptr, d_dropmask, hp->dropout_p,
                   train, seed, step, shard, d_logits, d_feat, nw, st,
-                  !copy ? sw.xn : nullptr);
+                  !copy ? sw.xn : nullptr, parts, early_feat);
 }
 }  // namespace
 extern "C" {
+int cmlpl_forward_spectral(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                           const cmlpl_shard* shard, const float* d_params, uint64_t seed, uint64_t step, float* d_feat,
+                           float* d_labels_f, void* d_workspace, size_t workspace_bytes, void* stream) {
+  return forward_impl(shape, hp, batch, shard, d_params, nullptr, nullptr, 1, seed, step, nullptr, d_feat, d_labels_f,
+                      d_workspace, workspace_bytes, stream, DynRef(), 1);
+}
+int cmlpl_forward_spatial(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                          const cmlpl_shard* shard, const float* d_params, const float* d_packed, const float* d_dropmask,
+                          int train, uint64_t seed, uint64_t step, float* d_logits, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
+  return forward_impl(shape, hp, batch, shard, d_params, d_packed, d_dropmask, train, seed, step, d_logits, nullptr, nullptr,
+                      d_workspace, workspace_bytes, stream, DynRef(), 2);
+}
 int cmlpl_forward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
                   const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
                   uint64_t step, float* d_logits, float* d_feat, float* d_labels_f, void* d_workspace,
@@ -494,9 +532,23 @@ namespace {
 int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
                   const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
                   uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
-                  void* d_workspace, size_t workspace_bytes, void* stream, DynRef dyn, int* dyn_cursor);
+                  void* d_workspace, size_t workspace_bytes, void* stream, DynRef dyn, int* dyn_cursor, int parts = 3);
 }  // namespace
 extern "C" {
+
+int cmlpl_backward_data(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
+                        const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
+                        uint64_t step, const float* d_dlogits, void* d_workspace, size_t workspace_bytes, void* stream) {
+  return backward_impl(shape, hp, batch, shard, d_params, d_packed, d_dropmask, train, seed, step, d_dlogits, nullptr,
+                       nullptr, 0, d_workspace, workspace_bytes, stream, DynRef(), nullptr, 1);
+}
+int cmlpl_backward_weights(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                           const cmlpl_shard* shard, const float* d_params, const float* d_packed, const float* d_dropmask,
+                           int train, uint64_t seed, uint64_t step, const float* d_dlogits, const float* d_dfeat,
+                           float* d_grads, int64_t grad_stride, void* d_workspace, size_t workspace_bytes, void* stream) {
+  return backward_impl(shape, hp, batch, shard, d_params, d_packed, d_dropmask, train, seed, step, d_dlogits, d_dfeat,
+                       d_grads, grad_stride, d_workspace, workspace_bytes, stream, DynRef(), nullptr, 2);
+}
 
 int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
                    const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
@@ -510,11 +562,12 @@ namespace {
 int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch, const cmlpl_shard* shard,
                   const float* d_params, const float* d_packed, const float* d_dropmask, int train, uint64_t seed,
                   uint64_t step, const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
-                  void* d_workspace, size_t workspace_bytes, void* stream, DynRef dyn, int* dyn_cursor) {
+                  void* d_workspace, size_t workspace_bytes, void* stream, DynRef dyn, int* dyn_cursor, int parts) {
   Dims d;
   cmlpl_layout_t L;
   if (!make_dims(shape, &d) || cmlpl_layout(shape, &L)) return CMLPL_E_SHAPE;
-  if (!hp || !check_batch(batch) || !d_params || !d_packed || !d_dlogits || !d_grads || !d_workspace) return CMLPL_E_ARG;
+  if (!hp || !check_batch(batch) || !d_params || !d_packed || !d_dlogits || ((parts & 2) && !d_grads) || !d_workspace)
+    return CMLPL_E_ARG;
   const int n = batch->bt + batch->btu;
   NetWs nw;
   if (!carve_net(d, 2, n, (char*)d_workspace, &nw)) return CMLPL_E_SHAPE;
@@ -530,7 +583,7 @@ int backward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl
   const XSrc xs = xsrc_plain(sw.xn, 2, n, (long long)d.C * d.HW, seed, step, shard, dyn);
   return bwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xs,
                   copy ? sw.xn : nullptr, sw.sn, d_dropmask, hp->dropout_p, train, d_dlogits, d_dfeat, d_grads,
-                  grad_stride, nw, (hipStream_t)stream, dyn_cursor, dyn_cursor ? (cmlpl_dyn*)dyn.table : nullptr);
+                  grad_stride, nw, (hipStream_t)stream, dyn_cursor, dyn_cursor ? (cmlpl_dyn*)dyn.table : nullptr, parts);
 }
 }  // namespace
 extern "C" {
@@ -542,7 +595,7 @@ int fill_loss_args(const Dims& d, const cmlpl_shard* sh, const float* d_logits, 
                    const cmlpl_gathered* gth = nullptr, const RowSel* sel = nullptr) {
   if (!sh || !banks || !hp || !ws) return CMLPL_E_ARG;
   if (gth == nullptr && (!d_logits || !d_feat || !d_labels)) return CMLPL_E_ARG;
-  if (gth != nullptr && (!gth->d_recv || gth->world < 1 || gth->bt_local < 1 || gth->btu_local < 1 ||
+  if (gth != nullptr && (!gth->d_recv_feat || !gth->d_logits_local || gth->world < 1 || gth->bt_local < 1 || gth->btu_local < 1 ||
                          gth->world * gth->bt_local != sh->bt_g || gth->world * gth->btu_local != sh->btu_g ||
                          sh->nunl != gth->btu_local || sh->unl0 % gth->btu_local != 0 ||
                          (sh->nlab != 0 && (sh->nlab != gth->bt_local || sh->lab0 % gth->bt_local != 0))))
@@ -560,8 +613,9 @@ int fill_loss_args(const Dims& d, const cmlpl_shard* sh, const float* d_logits, 
   if (sel != nullptr) a.sel = *sel;
   if (gth != nullptr) {
     const long long n_l = gth->bt_local + gth->btu_local;
-    a.recv = gth->d_recv; a.bt_l = gth->bt_local; a.btu_l = gth->btu_local;
-    a.pack = 2 * n_l * d.K + 2 * n_l * 1024 + gth->bt_local;
+    a.recv_f = gth->d_recv_feat; a.bt_l = gth->bt_local; a.btu_l = gth->btu_local;
+    a.pack_f = 2 * n_l * 1024 + gth->bt_local;
+    a.logits_loc = gth->d_logits_local;
   }
   for (int i = 0; i < 2; ++i) {
     a.bank_f[i] = banks->d_feats[i]; a.bank_p[i] = banks->d_probs[i];
@@ -696,13 +750,14 @@ int cmlpl_loss_fwd_bwd(const cmlpl_shape* shape, int bt, int btu, const float* d
                    d_dfeat, d_probs, d_workspace, workspace_bytes, stream, nullptr);
 }
 
-int cmlpl_dist_unpack(const cmlpl_shape* shape, int world, int bt_local, int btu_local, const float* d_gathered,
-                      float* d_logits_g, float* d_feat_g, int64_t* d_labels_g, void* stream) {
+int cmlpl_dist_unpack(const cmlpl_shape* shape, int world, int bt_local, int btu_local, const float* d_gathered_feat,
+                      const float* d_gathered_logits, float* d_logits_g, float* d_feat_g, int64_t* d_labels_g, void* stream) {
   Dims d;
   if (!make_dims(shape, &d)) return CMLPL_E_SHAPE;
-  if (world < 1 || bt_local < 1 || btu_local < 1 || !d_gathered || !d_logits_g || !d_feat_g || !d_labels_g)
+  if (world < 1 || bt_local < 1 || btu_local < 1 || !d_gathered_feat || !d_gathered_logits || !d_logits_g || !d_feat_g ||
+      !d_labels_g)
     return CMLPL_E_ARG;
-  return chk(launch_dist_unpack(d_gathered, world, bt_local, btu_local, d.K, d_logits_g, d_feat_g,
+  return chk(launch_dist_unpack(d_gathered_feat, d_gathered_logits, world, bt_local, btu_local, d.K, d_logits_g, d_feat_g,
                                 (long long*)d_labels_g, (hipStream_t)stream));
 }
 
@@ -809,9 +864,12 @@ static int dist_stage_run(const cmlpl_shape* shape, const cmlpl_hparams* hp, con
   dyn.table = io->d_dyn_table; dyn.cursor = io->d_dyn_cursor;
   const int train = 1;
   switch (stage) {
-    case CMLPL_STAGE_FORWARD:
+    case CMLPL_STAGE_SPECTRAL:
       return forward_impl(shape, hp, &io->batch, &io->shard, io->d_params, io->d_packed, nullptr, train, io->seed, 0,
-                          io->d_logits_l, io->d_feat_l, io->d_labels_f, io->d_workspace, io->workspace_bytes, stream, dyn);
+                          nullptr, io->d_feat_l, io->d_labels_f, io->d_workspace, io->workspace_bytes, stream, dyn, 1);
+    case CMLPL_STAGE_SPATIAL:
+      return forward_impl(shape, hp, &io->batch, &io->shard, io->d_params, io->d_packed, nullptr, train, io->seed, 0,
+                          io->d_logits_l, nullptr, nullptr, io->d_workspace, io->workspace_bytes, stream, dyn, 2);
     case CMLPL_STAGE_PHASE1: {
       LossArgs a;
       RowSel sel = RowSel();
@@ -838,10 +896,13 @@ static int dist_stage_run(const cmlpl_shape* shape, const cmlpl_hparams* hp, con
       if ((rc = chk(launch_loss_graph(a, (hipStream_t)stream)))) return rc;
       return chk(launch_loss_dfeat(a, (hipStream_t)stream));
     }
-    case CMLPL_STAGE_BACKWARD:
+    case CMLPL_STAGE_BACKWARD_DATA:
+      return backward_impl(shape, hp, &io->batch, &io->shard, io->d_params, io->d_packed, nullptr, train, io->seed, 0,
+                           io->d_dlogits, nullptr, nullptr, 0, io->d_workspace, io->workspace_bytes, stream, dyn, nullptr, 1);
+    case CMLPL_STAGE_BACKWARD_WEIGHTS:      // (the reduce launch of this part advances the table's cursor)
       return backward_impl(shape, hp, &io->batch, &io->shard, io->d_params, io->d_packed, nullptr, train, io->seed, 0,
                            io->d_dlogits, io->d_dfeat, io->d_grads, io->grad_stride, io->d_workspace, io->workspace_bytes,
-                           stream, dyn, io->d_dyn_cursor);
+                           stream, dyn, io->d_dyn_cursor, 2);
     case CMLPL_STAGE_UPDATE:
       return adam_impl(shape, 2, io->d_params, L.param_total, io->d_grads, io->grad_stride, io->d_m, io->d_v, 1, hp,
                        io->d_packed, stream, dyn);

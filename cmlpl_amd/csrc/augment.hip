@@ -6,7 +6,7 @@
 // the same noise no matter how the batch is sharded over GPUs.
 // HBM-bound elementwise kernel: reads each source once, writes one noisy copy per network.
 //
-// dist_unpack_kernel: re-orders the all-gathered per-rank [logits | feat | labels] blocks into the
+// dist_unpack_kernel: re-orders gathered per-rank [feat | labels] and [logits] blocks into the
 // global row order [labelled of all ranks ; unlabelled of all ranks] the loss kernels expect.
 #ifndef CMLPL_ABL
 #define CMLPL_ABL 0
@@ -138,12 +138,12 @@ hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int 
   return hipGetLastError();
 }
 
-// recv: [W][ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels-as-float ], n_l = bt_l + btu_l
-__global__ void dist_unpack_kernel(const float* __restrict__ recv, int W, int bt_l, int btu_l, int K,
-                                   float* __restrict__ logits_g, float* __restrict__ feat_g,
+// recv_f: [W][ 2*n_l*1024 feat | bt_l labels-as-float ], recv_z: [W][2*n_l*K logits], n_l = bt_l + btu_l
+__global__ void dist_unpack_kernel(const float* __restrict__ recv_f, const float* __restrict__ recv_z, int W, int bt_l,
+                                   int btu_l, int K, float* __restrict__ logits_g, float* __restrict__ feat_g,
                                    long long* __restrict__ labels_g) {
   const int n_l = bt_l + btu_l, bt_g = W * bt_l, n_g = W * n_l;
-  const long long pack = 2LL * n_l * K + 2LL * n_l * FD + bt_l;
+  const long long pack_f = 2LL * n_l * FD + bt_l, pack_z = 2LL * n_l * K;
   const long long nfeat4 = 2LL * n_g * (FD / 4), nlog = 2LL * n_g * K;
   const long long total = nfeat4 + nlog + bt_g;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -153,7 +153,7 @@ __global__ void dist_unpack_kernel(const float* __restrict__ recv, int W, int bt
       const int net = (int)(row / n_g), g = (int)(row - (long long)net * n_g);
       const int rank = (g < bt_g) ? g / bt_l : (g - bt_g) / btu_l;
       const int loc = (g < bt_g) ? g - rank * bt_l : bt_l + (g - bt_g) - rank * btu_l;
-      const float* src = recv + rank * pack + 2LL * n_l * K + ((long long)net * n_l + loc) * FD;
+      const float* src = recv_f + rank * pack_f + ((long long)net * n_l + loc) * FD;
       ((float4*)feat_g)[i] = ((const float4*)src)[c4];
     } else if (i < nfeat4 + nlog) {
       const long long j = i - nfeat4;
@@ -162,18 +162,18 @@ __global__ void dist_unpack_kernel(const float* __restrict__ recv, int W, int bt
       const int net = (int)(row / n_g), g = (int)(row - (long long)net * n_g);
       const int rank = (g < bt_g) ? g / bt_l : (g - bt_g) / btu_l;
       const int loc = (g < bt_g) ? g - rank * bt_l : bt_l + (g - bt_g) - rank * btu_l;
-      logits_g[j] = recv[rank * pack + ((long long)net * n_l + loc) * K + k];
+      logits_g[j] = recv_z[rank * pack_z + ((long long)net * n_l + loc) * K + k];
     } else {
       const int g = (int)(i - nfeat4 - nlog);
       const int rank = g / bt_l, loc = g - rank * bt_l;
-      labels_g[g] = (long long)(recv[rank * pack + 2LL * n_l * K + 2LL * n_l * FD + loc] + 0.5f);
+      labels_g[g] = (long long)(recv_f[rank * pack_f + 2LL * n_l * FD + loc] + 0.5f);
     }
   }
 }
 
-hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
-                              long long* labels_g, hipStream_t st) {
-  hipLaunchKernelGGL(dist_unpack_kernel, dim3(512), dim3(256), 0, st, recv, W, bt_l, btu_l, K, logits_g, feat_g,
+hipError_t launch_dist_unpack(const float* recv_f, const float* recv_z, int W, int bt_l, int btu_l, int K, float* logits_g,
+                              float* feat_g, long long* labels_g, hipStream_t st) {
+  hipLaunchKernelGGL(dist_unpack_kernel, dim3(512), dim3(256), 0, st, recv_f, recv_z, W, bt_l, btu_l, K, logits_g, feat_g,
                      labels_g);
   return hipGetLastError();
 }

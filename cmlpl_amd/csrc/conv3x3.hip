@@ -1311,9 +1311,9 @@ __device__ __forceinline__ void conv3_fwd_tail(const Conv3Args& a, const Conv3Ct
   __syncthreads();                           // row[0..256) complete, red[] written
   if (CMLPL_ABL == 25) STAMP(0, 13);
   if constexpr (!INFER) {
-    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-    if (tid == 0) a.ynorm[rs] = norm;
-    {
+    if (a.feat != nullptr) {                 // (null: feat_norm_kernel formed the embeddings behind the spectral branch)
+      const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+      if (tid == 0) a.ynorm[rs] = norm;
       float4 o = y4;
       o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
       *(float4*)(a.feat + rs * FD + 4 * tid) = o;
@@ -1825,12 +1825,14 @@ __device__ __forceinline__ void conv3_fwd_tail_g(const Conv3Args& a, const Conv3
   __syncthreads();                           // row[0 .. SF) complete
   STAMP(0, 9);
   if constexpr (!INFER) {
-    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-    if (tid == 0) a.ynorm[rs] = norm;
-    if (tid < 256) {
-      float4 o = y4;
-      o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
-      *(float4*)(a.feat + rs * FD + 4 * tid) = o;
+    if (a.feat != nullptr) {                 // (null: feat_norm_kernel formed the embeddings behind the spectral branch)
+      const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+      if (tid == 0) a.ynorm[rs] = norm;
+      if (tid < 256) {
+        float4 o = y4;
+        o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
+        *(float4*)(a.feat + rs * FD + 4 * tid) = o;
+      }
     }
   }
   float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -206,6 +206,36 @@ hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const fl
   return hipGetLastError();
 }
 
+// L2 normalisation of the spectral feature in a launch of its own (Normalize, tools/models.py:87-90,145-146: no epsilon,
+// an all-zero row gives 0 / 0 = NaN as in the reference): feat = y / ||y||, ynorm = ||y||, one workgroup per (network,
+// row).  The embeddings depend on the spectral branch alone, so a step that wants them EARLY -- the similarity products
+// beside the convolutions, the all-gather of a sharded step under them -- forms them here, right behind spe_fused_kernel;
+// the per-sample forward then skips its own normalisation (FwdTail::feat == null).  Same arithmetic, element for
+// element, as conv3_fwd_tail: thread t squares elements 4t .. 4t+3 as (x^2 + y^2) + (z^2 + w^2), lanes folded by
+// wave_sum, waves as (0 + 1) + (2 + 3) -- the two producers of `feat` are bit-identical.
+__global__ __launch_bounds__(256) void feat_norm_kernel(const float* __restrict__ y, float* __restrict__ ynorm,
+                                                        float* __restrict__ feat, long long feat_ns, int n) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int net = blockIdx.y, row = blockIdx.x;
+  const long long rs = (long long)net * n + row;
+  const float4 y4 = *(const float4*)(y + rs * FD + 4 * tid);
+  float ss = (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  if (tid == 0) ynorm[rs] = norm;
+  float4 o = y4;
+  o.x /= norm; o.y /= norm; o.z /= norm; o.w /= norm;
+  *(float4*)(feat + (long long)net * feat_ns + (long long)row * FD + 4 * tid) = o;
+}
+
+hipError_t launch_feat_norm(int nets, int n, const float* y, float* ynorm, float* feat, long long feat_ns, hipStream_t st) {
+  hipLaunchKernelGGL(feat_norm_kernel, dim3(n, nets), dim3(256), 0, st, y, ynorm, feat, feat_ns, n);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN2 t) {
   __shared__ GemmTNShared sh;
   gemm_tn_block(t, (int)blockIdx.x, sh);

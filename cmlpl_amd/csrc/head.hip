@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   ss = wave_sum(ss);
   if (lane == 0) red[wave] = ss;
   __syncthreads();
-  const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-  if (tid == 0) a.ynorm[rs] = norm;
-  float* feat = a.feat + rs * FD;
-  {  // the spectral part of this thread's slice is still in v[] (pre-dropout)
+  if (a.feat != nullptr) {     // (null: feat_norm_kernel formed the embeddings and the norm behind the spectral branch)
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) a.ynorm[rs] = norm;
+    float* feat = a.feat + rs * FD;
+    // the spectral part of this thread's slice is still in v[] (pre-dropout)
 #pragma unroll
     for (int q = 0; q < HEAD_MAXQ4; ++q) {
       const int f0 = 1024 * q + 4 * tid;
@@ -253,6 +254,49 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
   a.dlogits = dlogits; a.dfeat = dfeat; a.dropmask = dropmask; a.wc = wc; a.pstride = pstride;
   a.y = y; a.ynorm = ynorm; a.dy = dy; a.dp2 = dp2; a.n = n; a.HW4 = HW4; a.K = K;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(n, nets), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// The feature-gradient part of dy, added behind a backward head that ran WITHOUT it (dfeat == null):
+//   dy += relu'(y) * (dfeat - feat <feat, dfeat>) / ||y||          (the L2 normalisation's backward, models.py:145-146)
+// dy is linear in dfeat, so the head can run as soon as dlogits exist -- the convolution backward needs nothing else
+// (tools/models.py:144-150) -- while the contrastive feature gradients are still being formed (on a second stream) or
+// reduce-scattered (data parallelism); this launch joins them in front of feat_spe's weight-gradient GEMM.  Element for
+// element the arithmetic of conv3_bwd_head / head_bwd_kernel (thread t: elements t + 256 q, dot by fmaf over q, lanes by
+// wave_sum, waves as (0 + 1) + (2 + 3)); the sum d + x is rounded once either way, so head + fix-up equals the head that
+// was handed dfeat bit for bit.  Every row is visited (labelled rows carry dfeat = 0: a NaN row then spreads exactly as
+// 0 * NaN does in the reference's autograd).
+__global__ __launch_bounds__(256) void dy_fixup_kernel(const float* __restrict__ y, const float* __restrict__ ynorm,
+                                                       const float* __restrict__ dfeat, float* __restrict__ dy, int n) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long rs = (long long)blockIdx.y * n + blockIdx.x;
+  const float norm = ynorm[rs];
+  float yv[4], dv[4], dyv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    yv[q] = y[rs * FD + tid + 256 * q];
+    dv[q] = dfeat[rs * FD + tid + 256 * q];
+    dyv[q] = dy[rs * FD + tid + 256 * q];
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dot = fmaf(yv[q] / norm, dv[q], dot);
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // (a closed ReLU holds dy = 0 whatever arrives; an open one -- NaN included -- takes the sum)
+    const float g = dyv[q] + (dv[q] - (yv[q] / norm) * dot) / norm;
+    dy[rs * FD + tid + 256 * q] = relu_open(yv[q]) ? g : 0.f;
+  }
+}
+
+hipError_t launch_dy_fixup(int nets, int n, const float* y, const float* ynorm, const float* dfeat, float* dy,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(dy_fixup_kernel, dim3(n, nets), dim3(256), 0, st, y, ynorm, dfeat, dy, n);
   return hipGetLastError();
 }
 

@@ -68,8 +68,8 @@ hipError_t launch_augment(int which, int nets, int bt, int btu, int per_xp, int 
                           const float* const* noise8, float sigma, uint64_t seed, uint64_t step,
                           float* xn, float* sn, float* snT, hipStream_t st,
                           const long long* labels = nullptr, float* labels_f = nullptr, const RowSel* sel = nullptr);
-hipError_t launch_dist_unpack(const float* recv, int W, int bt_l, int btu_l, int K, float* logits_g, float* feat_g,
-                              long long* labels_g, hipStream_t st);
+hipError_t launch_dist_unpack(const float* recv_f, const float* recv_z, int W, int bt_l, int btu_l, int K, float* logits_g,
+                              float* feat_g, long long* labels_g, hipStream_t st);
 
 hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, int w, const long long* idx, int n,
                                   float* out, hipStream_t st);
@@ -147,6 +147,8 @@ hipError_t launch_spe_fused(int nets, int n, int bands, const XSrc& xs, const fl
                             float* labels_f, int bt, hipStream_t st);
 hipError_t launch_spe_fwd(int nets, int n, int bands, const float* sn, const float* w, const float* b,
                           long long pstride, float* y, hipStream_t st);
+// feat = y / ||y||, ynorm = ||y|| in a launch of its own (bit-identical to the per-sample forward's tail); feat_ns: per-net stride of `feat`
+hipError_t launch_feat_norm(int nets, int n, const float* y, float* ynorm, float* feat, long long feat_ns, hipStream_t st);
 // C[b][i][j] = scale * sum_r A[b][r][i] * B[b][r][j]  (+ optional colsum of A into bias[b][i])
 struct GemmTN {
   const float* A; const float* B; float* C; float* bias;
@@ -170,6 +172,9 @@ hipError_t launch_head_bwd(int nets, int n, int HW4, int K, const float* dlogits
                            const float* dropmask, const float* wc, long long pstride,
                            const float* y, const float* ynorm,
                            float* dy, float* dp2, hipStream_t st);
+// dy += relu'(y) * (dfeat - feat <feat, dfeat>) / ||y|| behind a head that ran with dfeat == null (bit-identical to the head with dfeat)
+hipError_t launch_dy_fixup(int nets, int n, const float* y, const float* ynorm, const float* dfeat, float* dy,
+                           hipStream_t st);
 
 // ---- loss.hip   (row-sharded: see the header of loss.hip)
 // Planner / path switches: environment variables, read once per process (and again only on
@@ -230,9 +235,13 @@ inline int device_cus() {
 
 struct LossArgs {
   const float* logits; const float* feat; const int64_t* labels;   // GLOBAL [2][n][K], [2][n][1024], [bt]  (plain mode)
-  // packed mode (recv != null): the global rows are read where the all-gather left them, rank-major blocks
-  // [W][ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels as float ] with per-rank rows [labelled ; unlabelled]
-  const float* recv; long long pack; int bt_l, btu_l;
+  // packed mode (recv_f != null; the sharded step): the GLOBAL embeddings and labels are read where the all-gather left
+  // them, rank-major blocks [W][ 2*n_l*1024 feat | bt_l labels as float ] with per-rank rows [labelled ; unlabelled] --
+  // they depend on the spectral branch alone and are gathered under the convolutions; the logits stay LOCAL
+  // (logits_loc [2][n_l][K], this shard's rows: only they are read -- the bank write takes the un-smoothed probabilities
+  // of the other ranks' rows from the gathered probabilities, which carry them anyway)
+  const float* recv_f; long long pack_f; int bt_l, btu_l;
+  const float* logits_loc;
   const float* bank_f[2]; const float* bank_p[2];
   float* bank_fw[2]; float* bank_pw[2];
   int Q, ptr0, ptr1;
@@ -253,6 +262,8 @@ struct LossArgs {
 };
 size_t loss_ws_floats(int nlab, int nunl, int btu_g, int K, int Q);
 void loss_ws_carve(LossArgs& a, float* ws);
+// phase 1 = pair_exp (embeddings and banks only) + the row kernel (this shard's logits); plain mode: the row launch also
+// writes the banks.  Packed mode: the bank write rides with phase 2's graph launch (it needs every rank's probabilities).
 hipError_t launch_loss_phase1(const LossArgs& a, hipStream_t st);
 hipError_t loss_prepare_capture();   // kernel attributes a captured step may need for the first time
 hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st);

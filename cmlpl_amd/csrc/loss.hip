@@ -65,29 +65,28 @@ __device__ __forceinline__ const float* prob_row(const LossArgs& a, int which, i
 // Global rows by (network, labelled/unlabelled, index): one buffer in plain mode, or the rank-major blocks of the
 // all-gather in packed mode (no re-ordering copy: the block of rank r holds that rank's rows [labelled ; unlabelled]).
 __device__ __forceinline__ const float* feat_lab(const LossArgs& a, int net, int g) {
-  if (a.recv == nullptr) return a.feat + ((long long)net * (a.bt + a.btu) + g) * FD;
+  if (a.recv_f == nullptr) return a.feat + ((long long)net * (a.bt + a.btu) + g) * FD;
   const int r = g / a.bt_l, i = g - r * a.bt_l, n_l = a.bt_l + a.btu_l;
-  return a.recv + r * a.pack + 2LL * n_l * a.K + ((long long)net * n_l + i) * FD;
+  return a.recv_f + r * a.pack_f + ((long long)net * n_l + i) * FD;
 }
 __device__ __forceinline__ const float* feat_unl(const LossArgs& a, int net, int g) {
-  if (a.recv == nullptr) return a.feat + ((long long)net * (a.bt + a.btu) + a.bt + g) * FD;
+  if (a.recv_f == nullptr) return a.feat + ((long long)net * (a.bt + a.btu) + a.bt + g) * FD;
   const int r = g / a.btu_l, i = g - r * a.btu_l, n_l = a.bt_l + a.btu_l;
-  return a.recv + r * a.pack + 2LL * n_l * a.K + ((long long)net * n_l + a.bt_l + i) * FD;
+  return a.recv_f + r * a.pack_f + ((long long)net * n_l + a.bt_l + i) * FD;
 }
+// logits: every reader asks for rows of THIS shard only (packed mode keeps them local: g - lab0 / g - unl0 is the local row)
 __device__ __forceinline__ const float* logit_lab(const LossArgs& a, int net, int g) {
-  if (a.recv == nullptr) return a.logits + ((long long)net * (a.bt + a.btu) + g) * a.K;
-  const int r = g / a.bt_l, i = g - r * a.bt_l, n_l = a.bt_l + a.btu_l;
-  return a.recv + r * a.pack + ((long long)net * n_l + i) * a.K;
+  if (a.recv_f == nullptr) return a.logits + ((long long)net * (a.bt + a.btu) + g) * a.K;
+  return a.logits_loc + ((long long)net * (a.bt_l + a.btu_l) + (g - a.lab0)) * a.K;
 }
 __device__ __forceinline__ const float* logit_unl(const LossArgs& a, int net, int g) {
-  if (a.recv == nullptr) return a.logits + ((long long)net * (a.bt + a.btu) + a.bt + g) * a.K;
-  const int r = g / a.btu_l, i = g - r * a.btu_l, n_l = a.bt_l + a.btu_l;
-  return a.recv + r * a.pack + ((long long)net * n_l + a.bt_l + i) * a.K;
+  if (a.recv_f == nullptr) return a.logits + ((long long)net * (a.bt + a.btu) + a.bt + g) * a.K;
+  return a.logits_loc + ((long long)net * (a.bt_l + a.btu_l) + a.bt_l + (g - a.unl0)) * a.K;
 }
 __device__ __forceinline__ int label_of(const LossArgs& a, int g) {
-  if (a.recv == nullptr) return (int)a.labels[rowsel_index(a.sel, true, g)];
+  if (a.recv_f == nullptr) return (int)a.labels[rowsel_index(a.sel, true, g)];
   const int r = g / a.bt_l, i = g - r * a.bt_l, n_l = a.bt_l + a.btu_l;
-  return (int)(a.recv[r * a.pack + 2LL * n_l * a.K + 2LL * n_l * FD + i] + 0.5f);
+  return (int)(a.recv_f[r * a.pack_f + 2LL * n_l * FD + i] + 0.5f);
 }
 
 // the step scalars of the loss block: launch arguments, or the device-side row (graph replay)
@@ -818,15 +817,24 @@ __device__ __forceinline__ void bank_write_block(const LossArgs& a, int r) {
   const bool kv = lane < K;
   float zs = NEG, zw = NEG;
   int yl = -1;
+  // packed mode (the sharded step): the logits of other ranks' rows are not here, but their un-smoothed probabilities
+  // are -- the row kernel wrote p_w0 / p_s0 (the same instructions as below) into the gathered probabilities
+  const bool from_probs = a.recv_f != nullptr;
   if (tid < 64) {                                          // requested before the feature stores, not behind them
-    if (r < btu) { if (kv) { zs = logit_unl(a, 0, r)[lane]; zw = logit_unl(a, 1, r)[lane]; } }
-    else yl = label_of(a, r - btu);
+    if (r < btu) {
+      if (kv) {
+        if (from_probs) { zw = prob_row(a, 2, r)[lane]; zs = prob_row(a, 3, r)[lane]; }
+        else { zs = logit_unl(a, 0, r)[lane]; zw = logit_unl(a, 1, r)[lane]; }
+      }
+    } else yl = label_of(a, r - btu);
   }
   ((float4*)(a.bank_fw[0] + (long long)d0 * FD))[tid] = v0;
   ((float4*)(a.bank_fw[1] + (long long)d1 * FD))[tid] = v1;
   if (tid < 64) {
     float q0, q1;
-    if (r < btu) {
+    if (r < btu && from_probs) {
+      q0 = zw; q1 = zs;
+    } else if (r < btu) {
       const float mxs = wave_max(zs), mxw = wave_max(zw);
       const float es = kv ? expf(zs - mxs) : 0.f, ew = kv ? expf(zw - mxw) : 0.f;
       const float ses = wave_sum(es), sew = wave_sum(ew);
@@ -999,6 +1007,7 @@ __global__ __launch_bounds__(256) void graph_loss_kernel(LossArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // gq[btu], pp[btu]
   __shared__ float red[32];
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.nunl) { bank_write_block(a, (int)blockIdx.x - a.nunl); return; }   // (packed mode: see launch_loss_graph)
   const int btu = a.btu, K = a.K, i = blockIdx.x;               // local row
   const int ig = a.unl0 + i;                                    // global row (diagonal position)
   const int RL = a.nlab > a.nunl ? a.nlab : a.nunl;
@@ -1286,15 +1295,17 @@ hipError_t launch_loss_phase1(const LossArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(pair_exp_kernel, g1, dim3(256), 0, st, a);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  // + one workgroup per row of the global batch for the bank write
-  hipLaunchKernelGGL(loss_rows_kernel, dim3((nl + 3) / 4 + a.bt + a.btu), dim3(256), 0, st, a);
+  // + one workgroup per row of the global batch for the bank write (plain mode; packed mode: with the graph launch)
+  hipLaunchKernelGGL(loss_rows_kernel, dim3((nl + 3) / 4 + (a.recv_f == nullptr ? a.bt + a.btu : 0)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_loss_graph(const LossArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * a.btu * 4;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(graph_loss_kernel, dim3(a.nunl), dim3(256), lds, st, a);
+  // packed mode: + one workgroup per row of the global batch for the bank write (every rank's probabilities are here now;
+  // pair_exp, the last reader of the banks, ran a launch earlier)
+  hipLaunchKernelGGL(graph_loss_kernel, dim3(a.nunl + (a.recv_f != nullptr ? a.bt + a.btu : 0)), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -1305,12 +1316,12 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   GemmTN g;
   g.A = a.GT; g.lda = a.nunl; g.M = a.nunl; g.R = btu;
   g.b_seg_rows = 0; g.b_seg_stride = 0;
-  if (a.recv == nullptr) {
+  if (a.recv_f == nullptr) {
     g.B = a.feat + ((long long)n + bt) * FD;
   } else {   // fU_w of all ranks, read from the rank-major blocks: row r -> block r / btu_l
     const long long n_l = a.bt_l + a.btu_l;
-    g.B = a.recv + 2 * n_l * a.K + (n_l + a.bt_l) * FD;
-    g.b_seg_rows = a.btu_l; g.b_seg_stride = a.pack;
+    g.B = a.recv_f + (n_l + a.bt_l) * FD;
+    g.b_seg_rows = a.btu_l; g.b_seg_stride = a.pack_f;
   }
   g.ldb = FD; g.N = FD;
   g.C = a.dfeat + (long long)a.nlab * FD; g.ldc = FD;
@@ -1320,12 +1331,11 @@ hipError_t launch_loss_dfeat(const LossArgs& a, hipStream_t st) {
   GemmTN h = g;
   h.b_seg_rows = 0; h.b_seg_stride = 0;
   h.A = a.G; h.lda = btu; h.M = btu; h.R = a.nunl;
-  if (a.recv == nullptr) {
+  if (a.recv_f == nullptr) {
     h.B = a.feat + ((long long)bt + a.unl0) * FD;
   } else {   // this rank's fU_s rows: one block, contiguous
-    const long long n_l = a.bt_l + a.btu_l;
     const int r = a.unl0 / a.btu_l, i0 = a.unl0 - r * a.btu_l;
-    h.B = a.recv + r * a.pack + 2 * n_l * a.K + (a.bt_l + i0) * FD;
+    h.B = a.recv_f + r * a.pack_f + (a.bt_l + i0) * FD;
   }
   h.C = a.dfw_part;
   (void)e;

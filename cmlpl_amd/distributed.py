@@ -2,25 +2,32 @@
 
 The reference is single-process; this layer is the build's own design for one xGMI node:
 both networks and both memory banks are replicated, every rank takes bt/W labelled + btu/W unlabelled
-rows, and a step exchanges exactly what crosses samples:
+rows, and a step exchanges exactly what crosses samples -- staged by what depends on what in
+tools/models.py:130-152, so that only two small collectives sit on the critical path:
 
-  1. local augment + 2x BaseNet2 forward                          (no communication)
-  2. ALL-GATHER  one packed buffer [logits | feat | labels] per rank  -> global logits/feats/labels
-  3. loss phase 1 on the local rows (bank smoothing, CE, masks, mutual loss)
-  4. ALL-GATHER  the smoothed probabilities [4][btu/W][K]         (the pseudo-label graph Q0 = p_s.p_w^T
-                                                                   needs every key's probabilities)
-  5. loss phase 2: local rows x global keys contrastive loss, identical bank write on every rank
-  6. REDUCE-SCATTER the column-side gradient d fU_w [btu][1024]   (backward of gathering the keys)
-  7. local 2x backward
-  8. ALL-REDUCE(sum) one flat gradient bucket (both networks, 2 x 207,881 floats for PaviaU);
-     losses are normalised by GLOBAL counts inside the kernels, so the sum IS the global gradient
-  9. Adam on every rank (replicated, deterministic)
+  1. spectral    augmented spectra -> feat_spe + ReLU -> L2 norm: the EMBEDDINGS (they depend on nothing the
+                 convolutions compute, models.py:142-146)
+       ALL-GATHER (async) [feat | labels] of every rank  -> the keys of the contrastive terms, the bank rows
+  2. spatial     conv0 .. conv2 + head -> this rank's logits            ... the gather runs under it
+  3. phase 1     (waits for the gather) similarity tiles, per-row CE / softmax / smoothing / masks / mutual loss
+       ALL-GATHER the smoothed + un-smoothed probabilities [4][btu/W][K] (18 KB: the pseudo-label graph
+                  Q0 = p_s.p_w^T and the bank write need every row's)           <- exposed
+  4. phase 2     local rows x global keys contrastive loss, identical bank write on every rank
+       REDUCE-SCATTER (async) the column-side gradient d fU_w [btu][1024]  (backward of gathering the keys)
+  5. backward data     classifier / conv2 / conv1 data gradients, conv0 + 3x3 weight-gradient partials: needs
+                       dlogits ONLY (models.py:144-150)                 ... the reduce-scatter runs under it
+  6. backward weights  (waits for the reduce-scatter) dy takes its feature-gradient share, partials are
+                       reduced, classifier / feat_spe weight gradients
+       ALL-REDUCE(sum) one flat gradient bucket (both networks, 2 x 207,881 floats for PaviaU)   <- exposed
+                  losses are normalised by GLOBAL counts inside the kernels, so the sum IS the global gradient
+  7. update      Adam on every rank (replicated, deterministic)
 
-Four collectives per step (the gradient bucket is ONE buffer holding the live tensors of both
-networks), all NCCL(=RCCL)-over-xGMI through torch.distributed; message sizes are
-1-4 MB, i.e. latency-bound on 7 x 153 GB/s links, hence one packed bucket per exchange rather than
-one collective per tensor.  W-rank results equal the 1-rank results on the same global batch up to
-fp32 summation order (tests/test_distributed_*.py).
+Four collectives per step (the logits are never gathered: only this rank's rows are read, the bank takes
+the other rows' probabilities from collective 2), all NCCL(=RCCL)-over-xGMI through torch.distributed;
+message sizes are 18 KB - 4 MB, i.e. latency-bound on 7 x 153 GB/s links, hence one packed buffer per
+exchange rather than one collective per tensor.  Through round 5 all four ran synchronously between the
+stages; the two large ones now overlap the convolutions.  W-rank results equal the 1-rank results on the
+same global batch up to fp32 summation order (tests/test_distributed_*.py).
 """
 from __future__ import annotations
 
@@ -155,13 +162,35 @@ class TorchDistComm:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.debug = bool(int(os.environ.get("CMLPL_DIST_DEBUG", "0"))) if debug is None else bool(debug)
 
-    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
-        self.dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
+    class _Handle:
+        """an asynchronous collective in flight: wait() orders the CURRENT stream behind it (no host block on RCCL)
+        and runs the debug check of the finished exchange"""
+        def __init__(self, work, after=None):
+            self.work, self.after = work, after
+
+        def wait(self):
+            if self.work is not None:
+                self.work.wait()
+            if self.after is not None:
+                self.after()
+
+    def _finish(self, work, async_op, after):
+        if async_op:
+            return TorchDistComm._Handle(work, after)
+        if after is not None:
+            after()
+        return None
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        work = self.dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group, async_op=async_op)
+        after = None
         if self.debug:
-            n = inp.numel()
-            got = out.view(-1)[self.rank * n:(self.rank + 1) * n]
-            if not torch.equal(got.cpu(), inp.view(-1).cpu()):
-                raise RuntimeError(f"rank {self.rank}: all_gather did not deliver this rank's own block (stream order?)")
+            def after():
+                n = inp.numel()
+                got = out.view(-1)[self.rank * n:(self.rank + 1) * n]
+                if not torch.equal(got.cpu(), inp.view(-1).cpu()):
+                    raise RuntimeError(f"rank {self.rank}: all_gather did not deliver this rank's own block (stream order?)")
+        return self._finish(work, async_op, after)
 
     def _check(self, name, before, after):
         """debug: [sum, sum of |.|] over all ranks before and after a reduction must agree to fp32 summation error"""
@@ -176,30 +205,37 @@ class TorchDistComm:
         d = t.detach().double()
         return torch.stack([d.sum(), d.abs().sum()])
 
-    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor):
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         before = self._sums(inp) if self.debug else None
-        self.dist.reduce_scatter_tensor(out.view(-1), inp.view(-1), op=self.dist.ReduceOp.SUM, group=self.group)
+        work = self.dist.reduce_scatter_tensor(out.view(-1), inp.view(-1), op=self.dist.ReduceOp.SUM, group=self.group,
+                                               async_op=async_op)
+        after = None
         if self.debug:      # sum over ranks of the inputs == sum over ranks of the scattered outputs
-            after = self._sums(out)
-            after[1] = before[1]
-            self._check("reduce_scatter", before, after)
+            def after():
+                aft = self._sums(out)
+                aft[1] = before[1]
+                self._check("reduce_scatter", before, aft)
+        return self._finish(work, async_op, after)
 
-    def all_reduce(self, t: torch.Tensor):
+    def all_reduce(self, t: torch.Tensor, async_op: bool = False):
         before = self._sums(t) if self.debug else None
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        work = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        after = None
         if self.debug:      # every rank now holds the sum: W x (sum over ranks of the inputs) after the second reduction
-            after = self._sums(t) / self.world
-            after[1] = before[1]
-            self._check("all_reduce", before, after)
+            def after():
+                aft = self._sums(t) / self.world
+                aft[1] = before[1]
+                self._check("all_reduce", before, aft)
+        return self._finish(work, async_op, after)
 
 
 class SingleComm:
     """world size 1: every collective is a copy."""
     world, rank = 1, 0
 
-    def all_gather(self, out, inp): out.view(-1).copy_(inp.view(-1))
-    def reduce_scatter(self, out, inp): out.view(-1).copy_(inp.view(-1))
-    def all_reduce(self, t): pass
+    def all_gather(self, out, inp, async_op=False): out.view(-1).copy_(inp.view(-1))
+    def reduce_scatter(self, out, inp, async_op=False): out.view(-1).copy_(inp.view(-1))
+    def all_reduce(self, t, async_op=False): pass
 
 
 class NoOpComm:
@@ -207,28 +243,47 @@ class NoOpComm:
     (see DistTrainEngine._bind), so nothing is launched."""
     world, rank = 1, 0
 
-    def all_gather(self, out, inp): assert out.data_ptr() == inp.data_ptr()
-    def reduce_scatter(self, out, inp): assert out.data_ptr() == inp.data_ptr()
-    def all_reduce(self, t): pass
+    def all_gather(self, out, inp, async_op=False): assert out.data_ptr() == inp.data_ptr()
+    def reduce_scatter(self, out, inp, async_op=False): assert out.data_ptr() == inp.data_ptr()
+    def all_reduce(self, t, async_op=False): pass
+
+
+def issue_exchange(comm, spec):
+    """one exchange of a stage: spec = (kind, out, inp, key); key None = synchronous, else the handle (or None, when the
+    backend finished it on the spot) is returned for the stage that waits for it"""
+    kind, out, inp, key = spec
+    a = key is not None
+    if kind == "all_gather":
+        return comm.all_gather(out, inp, async_op=a)
+    if kind == "reduce_scatter":
+        return comm.reduce_scatter(out, inp, async_op=a)
+    if kind == "all_reduce":
+        return comm.all_reduce(out, async_op=a)
+    raise ValueError(kind)
 
 
 def drive_step(engine, comm, *fwd_args, **fwd_kw) -> None:
-    """Run the stages of one sharded step with the collective that follows each of them.  ``engine``
-    provides STAGES, stage_<name>() and exchange_after(name) -> [(kind, out, inp)] (DistTrainEngine, or the
-    CPU stand-in used by the gloo tests)."""
-    engine.stage_forward(*fwd_args, **fwd_kw)
-    for stage in engine.STAGES:
-        if stage != "forward":
+    """Run the stages of one sharded step with the collectives that follow them.  ``engine`` provides STAGES,
+    stage_<name>(), exchange_after(name) -> [(kind, out, inp, key)] and waits_before(name) -> [key]
+    (DistTrainEngine, or the CPU stand-in used by the gloo tests).  An exchange with a key is issued asynchronously
+    right behind the stage that produced its input and waited for in front of the first stage that reads its output:
+    the embedding all-gather overlaps the convolution forward, the column-gradient reduce-scatter the convolution
+    backward."""
+    pending = {}
+    for i, stage in enumerate(engine.STAGES):
+        for key in engine.waits_before(stage):
+            h = pending.pop(key)
+            if h is not None:
+                h.wait()
+        if i == 0:
+            getattr(engine, "stage_" + stage)(*fwd_args, **fwd_kw)
+        else:
             getattr(engine, "stage_" + stage)()
-        for kind, out, inp in engine.exchange_after(stage):
-            if kind == "all_gather":
-                comm.all_gather(out, inp)
-            elif kind == "reduce_scatter":
-                comm.reduce_scatter(out, inp)
-            elif kind == "all_reduce":
-                comm.all_reduce(out)
-            else:
-                raise ValueError(kind)
+        for spec in engine.exchange_after(stage):
+            h = issue_exchange(comm, spec)
+            if spec[3] is not None:
+                pending[spec[3]] = h
+    assert not pending, f"exchanges never waited for: {sorted(pending)}"
 
 
 class DistTrainEngine(TrainEngine):
@@ -238,7 +293,7 @@ class DistTrainEngine(TrainEngine):
     train.py:134 keeps it) as long as EVERY rank brings the same number: shards are equal by construction,
     which is what makes the sum of the ranks' shares the global mean."""
 
-    STAGES = ("forward", "phase1", "phase2", "backward", "update")
+    STAGES = ("spectral", "spatial", "phase1", "phase2", "backward_data", "backward_weights", "update")
 
     def __init__(self, shape: NetShape, labeled_batch_size: int, unlabeled_batch_size: int,
                  hp: Optional[HyperParams] = None, device="cuda:0", seed: int = 1088, comm=None, hist_rows: int = 1,
@@ -264,8 +319,10 @@ class DistTrainEngine(TrainEngine):
         self.live = int(self.layout.param_live)
         self.grads = z(2, self.live)
         # flat max-size buffers; a step's tensors are views of their heads (see _bind)
-        self._pack = z(2 * n_l * K + 2 * n_l * FEAT_DIM + bt_l)
+        self._pack = z(2 * n_l * FEAT_DIM + bt_l)              # this rank's block of the exchange buffer: [feat | labels]
         self._recv = z(W * self._pack.numel())
+        self._logits_loc = z(2 * n_l * K)                      # this rank's logits: never exchanged by the step
+        self._recv_z = z(W * 2 * n_l * K)                      # outputs(): the logits gathered on request
         self._logits_g, self._feat_g = z(2 * n_l * W * K), z(2 * n_l * W * FEAT_DIM)
         self._labels_g = torch.zeros(bt_l * W, dtype=torch.int64, device=dev)
         self._probs_l, self._probs_g = z(4 * btu_l * K), z(W * 4 * btu_l * K)
@@ -290,13 +347,13 @@ class DistTrainEngine(TrainEngine):
         self.bt_l, self.btu_l = bt_l, btu_l
         self.bt_g, self.btu_g, self.n_g = bt_l * W, btu_l * W, n_l * W
         nk, nf = 2 * n_l * K, 2 * n_l * FEAT_DIM
-        self.pack_len = nk + nf + bt_l
+        self.pack_len = nf + bt_l
         alias = isinstance(self.comm, NoOpComm)
         self.pack = self._pack[:self.pack_len]
         self.recv = self.pack if alias else self._recv[:W * self.pack_len]
-        self.logits_l = self.pack[:nk].view(2, n_l, K)
-        self.feat_l = self.pack[nk:nk + nf].view(2, n_l, FEAT_DIM)
-        self.labels_f = self.pack[nk + nf:]
+        self.logits_l = self._logits_loc[:nk].view(2, n_l, K)
+        self.feat_l = self.pack[:nf].view(2, n_l, FEAT_DIM)
+        self.labels_f = self.pack[nf:]
         self.logits_g = self._logits_g[:2 * self.n_g * K].view(2, self.n_g, K)
         self.feat_g = self._feat_g[:2 * self.n_g * FEAT_DIM].view(2, self.n_g, FEAT_DIM)
         self.labels_g = self._labels_g[:self.bt_g]
@@ -327,8 +384,8 @@ class DistTrainEngine(TrainEngine):
         return b
 
     # ------------------------------------------------------------------ stages (no communication inside)
-    def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True,
-                      lab_idx=None, unl_idx=None):
+    def stage_spectral(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True,
+                       lab_idx=None, unl_idx=None):
         s, lib = self.shape, self.lib
         g = self._graph() if self._graph is not None else None
         if g is not None and g.pending > 0:
@@ -358,18 +415,28 @@ class DistTrainEngine(TrainEngine):
                          smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
                          adap=float(self.hp.thr * self.hp.adap_thr(epoch)),
                          keep=(keep, XPl, Xl, Y, XPu, Xu, noise, lab_idx, unl_idx), batch=batch)
-        # augmentation + both forwards; the raw rows are handed over as they are (the fused forward leaves the
-        # augmented rows in the workspace for stage_backward: no other cmlpl_forward may use this workspace in between)
-        _lib.check("cmlpl_forward", lib.cmlpl_forward(
+        # the spectral branch of both networks: augmented spectra -> feat_spe -> ReLU -> L2 norm.  feat | labels land
+        # directly in this rank's block of the exchange buffer; their all-gather starts behind this stage
+        _lib.check("cmlpl_forward_spectral", lib.cmlpl_forward_spectral(
             C.byref(self.cshape), C.byref(self._chp), C.byref(batch), C.byref(self.cshard), self.params.data_ptr(),
-            self.packed.data_ptr(), None if dropmask is None else dropmask.data_ptr(), 1, self.seed, self.step_count,
-            self.logits_l.data_ptr(), self.feat_l.data_ptr(), self.labels_f.data_ptr(), self.workspace.data_ptr(),
-            self.workspace.numel(), st))     # logits | feat | labels land directly in the packed exchange buffer
+            self.seed, self.step_count, self.feat_l.data_ptr(), self.labels_f.data_ptr(), self.workspace.data_ptr(),
+            self.workspace.numel(), st))
+
+    def stage_spatial(self):
+        # augmentation of the patches + the convolution stack + head of both networks -> this rank's logits; the raw rows
+        # are handed over as they are (the fused forward leaves the augmented rows in the workspace for the backward
+        # stages: no other forward may use this workspace in between)
+        c, st = self._ctx, self._stream()
+        dm = c["dropmask"]
+        _lib.check("cmlpl_forward_spatial", self.lib.cmlpl_forward_spatial(
+            C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard), self.params.data_ptr(),
+            self.packed.data_ptr(), None if dm is None else dm.data_ptr(), 1, self.seed, self.step_count,
+            self.logits_l.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), st))
 
     def _gathered(self) -> _lib.Gathered:
         g = self.__dict__.get("_c_gathered")
         if g is None or self._c_gathered_for != self._bound:
-            g = self._c_gathered = _lib.Gathered(self.recv.data_ptr(), self.world, self.bt_l, self.btu_l)
+            g = self._c_gathered = _lib.Gathered(self.recv.data_ptr(), self.logits_l.data_ptr(), self.world, self.bt_l, self.btu_l)
             self._c_gathered_for = self._bound
         return g
 
@@ -391,11 +458,22 @@ class DistTrainEngine(TrainEngine):
             C.byref(self._chp), self.probs_g.data_ptr(), self.btu_l, self.scalars.data_ptr(), self.dfeat_l.data_ptr(),
             self.dfw_part.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
 
-    def stage_backward(self):
+    def stage_backward_data(self):
+        # everything of the backward that needs dlogits alone (the reduce-scatter of the column-side feature gradient is
+        # still in flight): data-gradient chain, conv0 and 3x3 weight-gradient partials
         c, st = self._ctx, self._stream()
-        n_l = self.bt_l + self.btu_l
         dm = c["dropmask"]
-        _lib.check("cmlpl_backward", self.lib.cmlpl_backward(
+        _lib.check("cmlpl_backward_data", self.lib.cmlpl_backward_data(
+            C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard), self.params.data_ptr(),
+            self.packed.data_ptr(), None if dm is None else dm.data_ptr(), 1, self.seed, self.step_count,
+            self.dlogits_l.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), st))
+
+    def stage_backward_weights(self):
+        # dfeat is complete (this rank's slice of the reduce-scatter has arrived): dy takes its share, partials are
+        # reduced, classifier / feat_spe weight gradients -> the gradient bucket
+        c, st = self._ctx, self._stream()
+        dm = c["dropmask"]
+        _lib.check("cmlpl_backward_weights", self.lib.cmlpl_backward_weights(
             C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard), self.params.data_ptr(),
             self.packed.data_ptr(), None if dm is None else dm.data_ptr(), 1, self.seed, self.step_count,
             self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.grads.data_ptr(), self.live,
@@ -414,16 +492,24 @@ class DistTrainEngine(TrainEngine):
         self._last_n = self.bt_l + self.btu_l
         self._ctx = None
 
-    # the collective that follows each stage: (output, input, kind)
+    # the collectives that follow a stage: (kind, output, input, key).  key None: synchronous (on the critical path);
+    # otherwise issued asynchronously and waited for in front of the stage that names the key in waits_before
     def exchange_after(self, stage: str):
-        if stage == "forward":
-            return [("all_gather", self.recv, self.pack)]
+        if stage == "spectral":         # the embeddings (+ labels) of every rank: runs under the convolution forward
+            return [("all_gather", self.recv, self.pack, "feat")]
         if stage == "phase1":
-            return [("all_gather", self.probs_g, self.probs_l)]
-        if stage == "phase2":   # backward of "gather the keys": sum the partials, keep this rank's rows
-            return [("reduce_scatter", self.dfeat_l[1, self.bt_l:], self.dfw_part)]
-        if stage == "backward":  # one flat bucket: the live tensors of both networks
-            return [("all_reduce", self.grads, None)]
+            return [("all_gather", self.probs_g, self.probs_l, None)]
+        if stage == "phase2":           # backward of "gather the keys": sum the partials, keep this rank's rows;
+            return [("reduce_scatter", self.dfeat_l[1, self.bt_l:], self.dfw_part, "dfw")]   # runs under the convolution backward
+        if stage == "backward_weights":  # one flat bucket: the live tensors of both networks
+            return [("all_reduce", self.grads, None, None)]
+        return []
+
+    def waits_before(self, stage: str):
+        if stage == "phase1":           # similarity tiles against every rank's keys, labels for the bank write
+            return ["feat"]
+        if stage == "backward_weights":  # dy's feature-gradient share, then feat_spe's weight gradient
+            return ["dfw"]
         return []
 
     # ------------------------------------------------------------------ the step
@@ -440,13 +526,23 @@ class DistTrainEngine(TrainEngine):
         index buffers the step offsets point into.  See DistStepGraph."""
         return DistStepGraph(self, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt, btu, capacity)
 
-    def outputs(self):
+    def outputs(self, gathered_logits=None):
         """(logits, feat) of the GLOBAL batch of the last step, [2][n_g][..], in global row order [labelled of all
         ranks ; unlabelled of all ranks] (re-ordered on demand from the gathered blocks; the step itself never
-        makes this copy)."""
+        makes this copy and never gathers the logits: they are gathered HERE, a collective every rank must join --
+        or handed in as ``gathered_logits``, the ranks' logits_l back to back)."""
         if not getattr(self, "_unpacked", False):
+            nk = self.logits_l.numel()
+            if gathered_logits is not None:          # (a harness that moved the blocks itself: tests' lockstep ranks)
+                recv_z = gathered_logits.reshape(-1)
+                assert recv_z.numel() == self.world * nk
+            elif isinstance(self.comm, NoOpComm):
+                recv_z = self.logits_l
+            else:                                    # the step never gathers logits: do it for this call
+                recv_z = self._recv_z[:self.world * nk]
+                self.comm.all_gather(recv_z, self.logits_l)
             _lib.check("cmlpl_dist_unpack", self.lib.cmlpl_dist_unpack(
-                C.byref(self.cshape), self.world, self.bt_l, self.btu_l, self.recv.data_ptr(),
+                C.byref(self.cshape), self.world, self.bt_l, self.btu_l, self.recv.data_ptr(), recv_z.data_ptr(),
                 self._logits_g.data_ptr(), self._feat_g.data_ptr(), self._labels_g.data_ptr(), self._stream()))
             self._unpacked = True
         return self.logits_g, self.feat_g
@@ -468,13 +564,15 @@ class DistTrainEngine(TrainEngine):
 
 
 class DistStepGraph:
-    """The sharded training step replayed from five hipGraphs (forward | phase 1 | phase 2 | backward | update) with the
-    step's four collectives -- all-gather of the exchange buffer, all-gather of the smoothed probabilities,
-    reduce-scatter of the column-side feature gradient, all-reduce of the gradient bucket -- issued eagerly between them,
-    exactly where ``drive_step`` issues them.  Everything that changes from step to step comes from the same device
-    table as the single-GPU ``StepGraph`` (``program()``: (epoch, batch_index, lab_off, unl_off) with THIS rank's
-    offsets into the index buffers); a replay costs the host five graph launches and four torch.distributed calls
-    instead of five marshalled stage calls (scripts/dist_overhead.py).  Bit-identical to the eager sharded step."""
+    """The sharded training step replayed from seven hipGraphs (spectral | spatial | phase 1 | phase 2 | backward data |
+    backward weights | update) with the step's four collectives issued eagerly between them, exactly where and how
+    ``drive_step`` issues them: the embedding all-gather asynchronously behind the spectral stage (waited for in front of
+    phase 1), the probability all-gather, the reduce-scatter of the column-side feature gradient asynchronously behind
+    phase 2 (waited for in front of the backward-weights stage), the all-reduce of the gradient bucket.  Everything that
+    changes from step to step comes from the same device table as the single-GPU ``StepGraph`` (``program()``: (epoch,
+    batch_index, lab_off, unl_off) with THIS rank's offsets into the index buffers); a replay costs the host seven graph
+    launches and four torch.distributed calls instead of seven marshalled stage calls (scripts/dist_overhead.py).
+    Bit-identical to the eager sharded step."""
 
     def __init__(self, eng: "DistTrainEngine", XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt: int, btu: int, capacity: int = 1024):
         import numpy as np
@@ -548,7 +646,7 @@ class DistStepGraph:
         eng = self.eng
         if self.pending < 1:
             raise RuntimeError("no programmed step left: call program() first")
-        if name == "forward":
+        if name == eng.STAGES[0]:
             eng._bind(self.bt, self.btu)      # (an eager short batch in between re-bound the views; same pointers for the same shard)
             eng._ensure_packed(eng._stream())
             eng._cur_row = eng.step_count % eng.hist_rows
@@ -563,17 +661,21 @@ class DistStepGraph:
             self.pending -= 1
 
     def launch(self) -> None:
-        """one replay = one sharded training step (asynchronous): five graph launches, four collectives"""
+        """one replay = one sharded training step (asynchronous): seven graph launches, four collectives -- two of them
+        in flight under the convolution stages, as in drive_step"""
         eng = self.eng
+        pending = {}
         for name in eng.STAGES:
+            for key in eng.waits_before(name):
+                h = pending.pop(key)
+                if h is not None:
+                    h.wait()
             self.launch_stage(name)
-            for kind, out, inp in eng.exchange_after(name):
-                if kind == "all_gather":
-                    eng.comm.all_gather(out, inp)
-                elif kind == "reduce_scatter":
-                    eng.comm.reduce_scatter(out, inp)
-                else:
-                    eng.comm.all_reduce(out)
+            for spec in eng.exchange_after(name):
+                h = issue_exchange(eng.comm, spec)
+                if spec[3] is not None:
+                    pending[spec[3]] = h
+        assert not pending
 
     def close(self) -> None:
         for name, h in list(self.handles.items()):

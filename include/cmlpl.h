@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CMLPL_ABI_VERSION 3
+#define CMLPL_ABI_VERSION 4
 #define CMLPL_FEAT_DIM 1024 /* tools/models.py:119 */
 #define CMLPL_CONV_CH 64    /* tools/models.py:102-107 */
 
@@ -210,6 +210,37 @@ int cmlpl_backward(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlp
                    const float* d_dlogits, const float* d_dfeat, float* d_grads, int64_t grad_stride,
                    void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ABI 4: cmlpl_forward / cmlpl_backward in two parts each, for a step that exchanges data between them (the sharded step
+ * of cmlpl_amd/distributed.py).  The split follows what depends on what in tools/models.py:130-152:
+ *   cmlpl_forward_spectral : augmented spectra -> feat_spe + ReLU -> L2 normalisation (:142-146) -> d_feat [2][n][1024]
+ *                            (+ d_labels_f).  The embeddings depend on NOTHING the convolutions compute: a sharded step
+ *                            starts their all-gather here and lets it run under the spatial part.
+ *   cmlpl_forward_spatial  : conv0 .. conv2, pooling, concat / dropout / classifier (:132-141,144,147-150) -> d_logits.
+ *                            Same workspace, after the spectral part (it reads the spectral ReLU output there).
+ *   cmlpl_backward_data    : the data-gradient chain (classifier, conv2, conv1, conv0 partials) and the 3x3 weight-gradient
+ *                            partials -- needs d_dlogits ONLY (:144-150): the column-side feature gradient can still be
+ *                            in its reduce-scatter.
+ *   cmlpl_backward_weights : dy takes its feature-gradient share (through the normalisation's backward; bit-identical to
+ *                            the one-part head), partials are reduced, classifier / feat_spe weight gradients -> d_grads.
+ * Both halves of a pair take the same batch / seed / step / shard / workspace as the whole call would. */
+int cmlpl_forward_spectral(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                           const cmlpl_shard* shard, const float* d_params, uint64_t seed, uint64_t step,
+                           float* d_feat, float* d_labels_f /* optional [bt] */,
+                           void* d_workspace, size_t workspace_bytes, void* stream);
+int cmlpl_forward_spatial(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                          const cmlpl_shard* shard, const float* d_params, const float* d_packed,
+                          const float* d_dropmask, int train, uint64_t seed, uint64_t step, float* d_logits,
+                          void* d_workspace, size_t workspace_bytes, void* stream);
+int cmlpl_backward_data(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                        const cmlpl_shard* shard, const float* d_params, const float* d_packed,
+                        const float* d_dropmask, int train, uint64_t seed, uint64_t step, const float* d_dlogits,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
+int cmlpl_backward_weights(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_batch* batch,
+                           const cmlpl_shard* shard, const float* d_params, const float* d_packed,
+                           const float* d_dropmask, int train, uint64_t seed, uint64_t step, const float* d_dlogits,
+                           const float* d_dfeat, float* d_grads, int64_t grad_stride,
+                           void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* State of the two memory banks (train.py:138-145). */
 typedef struct cmlpl_banks {
   float* d_feats[2];  /* [Q][1024] queue_feats, queue_feats1 */
@@ -258,12 +289,16 @@ int cmlpl_loss_phase2(const cmlpl_shape* shape, const cmlpl_shard* shard,
                       float* d_scalars, float* d_dfeat, float* d_dfeat_w_partial,
                       void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* The loss phases reading the global rows WHERE THE ALL-GATHER LEFT THEM (no re-ordering copy): d_recv holds
- * `world` rank-major blocks [ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels as float ] (n_l = bt_local + btu_local,
- * per-rank rows [labelled ; unlabelled]) -- the buffer cmlpl_forward's outputs and d_labels_f are laid out for.
+/* The loss phases of the SHARDED step (ABI 4).  What crosses ranks is read WHERE THE ALL-GATHER LEFT IT (no re-ordering
+ * copy): d_recv_feat holds `world` rank-major blocks [ 2*n_l*1024 feat | bt_l labels as float ] (n_l = bt_local +
+ * btu_local, per-rank rows [labelled ; unlabelled]) -- the buffer cmlpl_forward_spectral's d_feat and d_labels_f are laid
+ * out for, gathered while the convolutions run.  The LOGITS are never gathered: d_logits_local [2][n_l][K] are this
+ * rank's rows (cmlpl_forward_spatial's output), the only ones phase 1 reads; the bank write needs the other ranks'
+ * un-smoothed probabilities and takes them from the gathered probabilities, so it rides with phase 2.
  * Otherwise identical to cmlpl_loss_phase1 / _phase2. */
 typedef struct cmlpl_gathered {
-  const float* d_recv;
+  const float* d_recv_feat;
+  const float* d_logits_local;
   int32_t world, bt_local, btu_local;
 } cmlpl_gathered;
 int cmlpl_loss_phase1_g(const cmlpl_shape* shape, const cmlpl_shard* shard, const cmlpl_gathered* gathered,
@@ -276,11 +311,12 @@ int cmlpl_loss_phase2_g(const cmlpl_shape* shape, const cmlpl_shard* shard, cons
                         float* d_scalars, float* d_dfeat, float* d_dfeat_w_partial,
                         void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* Re-order an all-gathered buffer [world][ 2*n_l*K logits | 2*n_l*1024 feat | bt_l labels as float ]
- * (n_l = bt_local + btu_local, per-rank rows [labelled ; unlabelled]) into the global row order. */
+/* Inspection aid: re-order gathered blocks into the global row order [labelled of all ranks ; unlabelled of all ranks]:
+ * d_gathered_feat = [world][ 2*n_l*1024 feat | bt_l labels as float ] (the step's exchange buffer), d_gathered_logits =
+ * [world][2*n_l*K] (the step does not gather logits: a caller that wants the global logits gathers them for this call). */
 int cmlpl_dist_unpack(const cmlpl_shape* shape, int world, int bt_local, int btu_local,
-                      const float* d_gathered, float* d_logits_g, float* d_feat_g, int64_t* d_labels_g,
-                      void* stream);
+                      const float* d_gathered_feat, const float* d_gathered_logits,
+                      float* d_logits_g, float* d_feat_g, int64_t* d_labels_g, void* stream);
 
 /* torch.optim.Adam.step for `nets` flat buffers (train.py:268,272); `t` is the 1-based
  * step count.  Also refreshes the packed conv weights when d_packed != NULL. */
@@ -323,22 +359,22 @@ int cmlpl_step_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, c
 int cmlpl_step_graph_launch(void* graph, void* stream);
 int cmlpl_step_graph_destroy(void* graph);
 
-/* The five stages of the SHARDED step (forward | loss phase 1 | loss phase 2 | backward | update; the four collectives
- * run between them, in the caller's hands) as replayable hipGraphs: what cmlpl_forward, cmlpl_loss_phase1_g,
- * cmlpl_loss_phase2_g, cmlpl_backward and cmlpl_adam_step launch, captured once per stage with every per-step scalar
- * read from the cmlpl_dyn table (as a captured cmlpl_train_step does) -- the host then enqueues five graph launches and
- * four collectives per step instead of marshalling five calls.  The backward stage advances the cursor (its reduce
- * launch), the update stage reads the finished step's row.  Batches by index only (d_lab_idx / d_unl_idx: this rank's
- * slice starts at the row's lab_off / unl_off); in-kernel random streams only.  Launch / destroy a stage's graph with
- * cmlpl_step_graph_launch / cmlpl_step_graph_destroy. */
+/* The seven stages of the SHARDED step (spectral | spatial | loss phase 1 | loss phase 2 | backward data | backward
+ * weights | update; the collectives run between them, in the caller's hands: cmlpl_amd/distributed.py) as replayable
+ * hipGraphs: what cmlpl_forward_spectral, cmlpl_forward_spatial, cmlpl_loss_phase1_g, cmlpl_loss_phase2_g,
+ * cmlpl_backward_data, cmlpl_backward_weights and cmlpl_adam_step launch, captured once per stage with every per-step
+ * scalar read from the cmlpl_dyn table (as a captured cmlpl_train_step does).  The backward-weights stage advances the
+ * cursor (its reduce launch), the update stage reads the finished step's row.  Batches by index only (d_lab_idx /
+ * d_unl_idx: this rank's slice starts at the row's lab_off / unl_off); in-kernel random streams only.  Launch / destroy a
+ * stage's graph with cmlpl_step_graph_launch / cmlpl_step_graph_destroy. */
 typedef struct cmlpl_dist_io {
   cmlpl_batch batch;            /* this rank's rows (bt, btu PER RANK), by index                                   */
   cmlpl_shard shard;            /* this rank's place in the global batch                                           */
-  cmlpl_gathered gathered;      /* the all-gathered exchange buffer the loss phases read                           */
+  cmlpl_gathered gathered;      /* the gathered embeddings / labels and this rank's logits                          */
   cmlpl_banks banks;            /* (ptr[] unused: the table carries the pointers)                                  */
   float* d_params; float* d_m; float* d_v; float* d_packed;   /* [2][param_total] / [2][packed_total]              */
   float* d_grads; int64_t grad_stride;                         /* the gradient bucket, [2][grad_stride]             */
-  float* d_logits_l; float* d_feat_l; float* d_labels_f;       /* this rank's block of the exchange buffer          */
+  float* d_logits_l; float* d_feat_l; float* d_labels_f;       /* this rank's logits; its block of the exchange buffer */
   float* d_dlogits; float* d_dfeat;                            /* [2][n_l][K], [2][n_l][1024]                        */
   float* d_probs_l; const float* d_probs_g; int32_t probs_shard_rows; int32_t reserved;
   float* d_scalars;             /* ring base [hist_rows][16]: the row comes from the table                          */
@@ -348,7 +384,8 @@ typedef struct cmlpl_dist_io {
   uint64_t seed;
   cmlpl_dyn* d_dyn_table; int32_t* d_dyn_cursor;
 } cmlpl_dist_io;
-enum { CMLPL_STAGE_FORWARD = 0, CMLPL_STAGE_PHASE1 = 1, CMLPL_STAGE_PHASE2 = 2, CMLPL_STAGE_BACKWARD = 3, CMLPL_STAGE_UPDATE = 4 };
+enum { CMLPL_STAGE_SPECTRAL = 0, CMLPL_STAGE_SPATIAL = 1, CMLPL_STAGE_PHASE1 = 2, CMLPL_STAGE_PHASE2 = 3,
+       CMLPL_STAGE_BACKWARD_DATA = 4, CMLPL_STAGE_BACKWARD_WEIGHTS = 5, CMLPL_STAGE_UPDATE = 6 };
 int cmlpl_dist_stage_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_dist_io* io, int stage,
                                   void* stream, void** graph_out);
 

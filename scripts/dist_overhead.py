@@ -1,7 +1,7 @@
 """What does the staged data-parallel step cost before any wire time, and what do its four torch.distributed calls cost
 the HOST?  At world size 1 on one GPU (RCCL initialised):
   TrainEngine                      one C call per step (the single-GPU engine)
-  DistTrainEngine, aliased         five stage calls, the one-rank collectives aliased away (NoOpComm)
+  DistTrainEngine, aliased         seven stage calls, the one-rank collectives aliased away (NoOpComm)
   DistTrainEngine, real calls      the same with the four REAL collectives per step (all_gather_into_tensor x 2,
                                    reduce_scatter_tensor, all_reduce through TorchDistComm; separate send / receive buffers)
 host enqueue = wall time to ENQUEUE a step; wall = steps including the final synchronisation; plus the host time of each
@@ -43,7 +43,7 @@ for wl, bt, btu in (("B2", 128, 128), ("B2", 64, 64), ("B5", 8, 64)):
         walls.append(t2 - t0)
         print(f"  {name:28s} host enqueue {1e6 * (t1 - t0) / K:7.1f} us/step   wall {1e6 * (t2 - t0) / K:7.1f} us/step", flush=True)
     print(f"  real calls / TrainEngine wall: {walls[2] / walls[0]:.3f}")
-    # ... and the same engine replaying its five stage graphs (DistStepGraph), the four real calls eager between them
+    # ... and the same engine replaying its seven stage graphs (DistStepGraph), the four real calls eager between them
     li, ui = torch.arange(bt, device=dev), torch.arange(btu, device=dev)
     gr = eng.capture(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], li, ui, bt, btu, capacity=K + 20)
     gr.program([(1, 300 + i, 0, 0) for i in range(K + 20)])
@@ -61,7 +61,7 @@ for wl, bt, btu in (("B2", 128, 128), ("B2", 64, 64), ("B5", 8, 64)):
     gr.close()
     # the four calls alone (host time of the call, device idle)
     comm = TorchDistComm()
-    for kind, out, inp in eng.exchange_after("forward") + eng.exchange_after("phase1") + eng.exchange_after("phase2") + eng.exchange_after("backward"):
+    for kind, out, inp, _key in [x for st in eng.STAGES for x in eng.exchange_after(st)]:
         f = {"all_gather": lambda: comm.all_gather(out, inp), "reduce_scatter": lambda: comm.reduce_scatter(out, inp),
              "all_reduce": lambda: comm.all_reduce(out)}[kind]
         for _ in range(20):

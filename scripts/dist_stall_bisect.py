@@ -34,6 +34,27 @@ def _gc_cb(phase, info):
 gc.callbacks.append(_gc_cb)
 
 
+def _cgroup_cpu():
+    """(nr_throttled, throttled time in us) of this container's CPU controller (cgroup v2, else v1), or None"""
+    for path, key_t in (("/sys/fs/cgroup/cpu.stat", "throttled_usec"), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time")):
+        try:
+            d = dict(ln.split() for ln in open(path).read().splitlines() if len(ln.split()) == 2)
+            t = int(d.get(key_t, 0))
+            return int(d.get("nr_throttled", 0)), (t // 1000 if key_t == "throttled_time" else t)
+        except OSError:
+            continue
+    return None
+
+
+def _sched():
+    """this thread: (ns on a CPU, ns runnable but waiting for one, voluntary, involuntary context switches)"""
+    import threading
+    tid = threading.get_native_id()
+    run, wait = (int(v) for v in open(f"/proc/self/task/{tid}/schedstat").read().split()[:2])
+    st = dict(ln.split(":\t") for ln in open(f"/proc/self/task/{tid}/status").read().splitlines() if ":\t" in ln)
+    return run, wait, int(st["voluntary_ctxt_switches"]), int(st["nonvoluntary_ctxt_switches"])
+
+
 class TimedComm(TorchDistComm):
     """real collectives, host time per call site; `copy` names call sites served by a plain copy instead"""
     def __init__(self, copy=()):
@@ -80,12 +101,21 @@ def run(wl, bt, btu, copy=()):
     st.clear(); comm.t.clear()
     per = []
     GC_LOG.clear()
+    cg0, worst = _cgroup_cpu(), (0.0, None)
     t0 = time.perf_counter()
     for i in range(K):
         comm.site = 0
+        s0 = _sched()
+        c0 = time.thread_time()
         ts = time.perf_counter()
         eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, 20 + i)
-        per.append(time.perf_counter() - ts)
+        dt = time.perf_counter() - ts
+        per.append(dt)
+        if dt > worst[0]:
+            s1 = _sched()
+            worst = (dt, dict(step=i, thread_cpu_ms=round(1e3 * (time.thread_time() - c0), 2), on_cpu_ms=round((s1[0] - s0[0]) / 1e6, 2),
+                              runnable_waiting_ms=round((s1[1] - s0[1]) / 1e6, 2), voluntary_switches=s1[2] - s0[2],
+                              involuntary_switches=s1[3] - s0[3]))
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -95,6 +125,10 @@ def run(wl, bt, btu, copy=()):
           f"p90 {1e6 * per[int(K * 0.9)]:.1f} max {1e6 * per[-1]:.1f}")
     print("    stages      " + "  ".join(f"{k} {1e6 * v / K:.1f}" for k, v in st.items()))
     print("    collectives " + "  ".join(f"{k} {1e6 * v / K:.1f}" for k, v in comm.t.items()))
+    cg1 = _cgroup_cpu()
+    print(f"    slowest step {1e3 * worst[0]:.2f} ms: {worst[1]}   cgroup throttling during the run: "
+          + (f"{cg1[0] - cg0[0]} periods, {(cg1[1] - cg0[1]) / 1e3:.1f} ms" if cg0 and cg1 else "n/a")
+          + f"   threads {len(os.listdir('/proc/self/task'))}")
     print("    garbage collections during the timed steps: " +
           (", ".join(f"gen{g} {1e3 * t:.1f} ms" for g, t in GC_LOG) or "none") + f"   (gc enabled: {gc.isenabled()})", flush=True)
     del eng

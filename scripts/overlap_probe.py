@@ -3,7 +3,7 @@
 Timing probe only (results of the overlapped variants are meaningless: the side stream reads the PREVIOUS step's
 features / logits).  The stages of the sharded step at world size 1 are separate C calls that take a stream, so they can
 be placed freely:
-  seq            forward | phase1 | phase2 | backward | update on one stream (= the product's order)
+  seq            the stages of the sharded step on one stream (= the product's order)
   fwd||p1        phase 1 (pair_exp + loss_rows) on stream B beside the forward (spe_fused + fused forward) on stream A
   bwd||p2        phase 2 (graph_loss + loss_dfeat) on stream B beside the backward on stream A
   both
@@ -33,22 +33,22 @@ def step(mode, sB, i):
     A = torch.cuda.current_stream(dev)
     if mode in ("fwd||p1", "both"):
         sB.wait_stream(A)
-        eng.stage_forward(*args, 1, i)
+        eng.stage_spectral(*args, 1, i); eng.stage_spatial()
         with torch.cuda.stream(sB):
             eng.stage_phase1()
         A.wait_stream(sB)
     else:
-        eng.stage_forward(*args, 1, i)
+        eng.stage_spectral(*args, 1, i); eng.stage_spatial()
         eng.stage_phase1()
     if mode in ("bwd||p2", "both"):
         sB.wait_stream(A)
         with torch.cuda.stream(sB):
             eng.stage_phase2()
-        eng.stage_backward()
+        eng.stage_backward_data(); eng.stage_backward_weights()
         A.wait_stream(sB)
     else:
         eng.stage_phase2()
-        eng.stage_backward()
+        eng.stage_backward_data(); eng.stage_backward_weights()
     eng.stage_update()
 
 

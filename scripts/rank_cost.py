@@ -26,9 +26,9 @@ class FakeComm:
 
 def step(e, b, i):
     W = e.comm.world
-    e.stage_forward(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, i)
+    e.stage_spectral(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, i)
     for stage in e.STAGES:
-        if stage != "forward":
+        if stage != "spectral":
             getattr(e, "stage_" + stage)()
         for spec in e.exchange_after(stage):
             kind = spec[0]

@@ -22,6 +22,46 @@ shape = O.NetShape(103, 11, 11, 103, 9)
 bt, btu, steps = (int(os.environ.get(k, v)) for k, v in (("CMLPL_TEST_BT", 32), ("CMLPL_TEST_BTU", 64), ("CMLPL_TEST_STEPS", 3)))
 hp = HyperParams()
 p0, p1 = O.closed_form_params(shape, 51), O.closed_form_params(shape, 52)
+if os.environ.get("CMLPL_TEST_GRAPH") == "1":
+    # DistStepGraph.launch() itself -- seven graph launches with the REAL collectives between them, two of them asynchronous
+    # (what `train.py --graph` runs on several GPUs) -- against the eager drive_step on the same process group: bit for bit
+    bl, bul = bt // W, btu // W
+    g = torch.Generator().manual_seed(9)
+    NL, NU = 4 * bt, 4 * btu
+    d = lambda t: t.to(dev).contiguous()
+    XP, X, Y = d(torch.randn(NL, 103, 11, 11, generator=g)), d(torch.randn(NL, 103, generator=g)), d(torch.randint(0, 9, (NL,), generator=g))
+    XPu, Xu = d(torch.randn(NU, 103, 11, 11, generator=g)), d(torch.randn(NU, 103, generator=g))
+    lp, up = d(torch.randperm(NL, generator=g)), d(torch.randperm(NU, generator=g))
+    sched = [(0, 16), (0, 17), (0, 18), (1, 0), (1, 1)]          # crosses the smoothing gate and an epoch boundary
+    offs = [((k % 4) * bt + rank * bl, (k % 4) * btu + rank * bul) for k in range(len(sched))]
+    engs = []
+    for _ in range(2):
+        e = DistTrainEngine(NetShape(103, 11, 11, 103, 9), bl, bul, hp, device=dev, seed=5, hist_rows=8)
+        e.load_state_dict(0, p0); e.load_state_dict(1, p1)
+        engs.append(e)
+    ea, eb = engs
+    def eager(e, k):
+        lo, uo = offs[k]
+        e.step(XP, X, Y, XPu, Xu, sched[k][0], sched[k][1], lab_idx=lp[lo:lo + bl], unl_idx=up[uo:uo + bul])
+    for k in range(len(sched)):
+        eager(ea, k)
+    eager(eb, 0)
+    gr = eb.capture(XP, X, Y, XPu, Xu, lp, up, bl, bul, capacity=8)
+    gr.program([(sched[k][0], sched[k][1], offs[k][0], offs[k][1]) for k in range(1, len(sched))])
+    for k in range(1, len(sched)):
+        gr.launch()
+    torch.cuda.synchronize()
+    for name in ("params", "m", "v", "grads", "bank_feats", "bank_probs", "scalar_hist"):
+        x, y = getattr(ea, name), getattr(eb, name)
+        assert torch.equal(x, y), f"rank {rank}: {name} differs, max |d| = {(x - y).abs().max().item():.3e}"
+    assert ea.ptr == eb.ptr and ea.adam_t == eb.adam_t and ea.step_count == eb.step_count
+    assert torch.isfinite(eb.scalar_hist[:len(sched)]).all()
+    gr.close()
+    if rank == 0:
+        print(f"OK graph world={W} steps={len(sched)}")
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 eng = DistTrainEngine(NetShape(103, 11, 11, 103, 9), bt // W, btu // W, hp, device=dev, seed=5)
 eng.load_state_dict(0, p0); eng.load_state_dict(1, p1)
 ref = None

@@ -1,5 +1,5 @@
 """TEST-ONLY CPU stand-in for cmlpl_amd.distributed.DistTrainEngine: same stage protocol
-(STAGES / stage_* / exchange_after, same packed-buffer layouts), with the per-shard math written in
+(STAGES / stage_* / exchange_after / waits_before, same packed-buffer layouts), with the per-shard math written in
 PyTorch-CPU from the oracle's formulas.  It lets the multi-process wiring (drive_step + TorchDistComm
 over gloo) be exercised without a GPU, and doubles as an independent statement of the sharded algorithm."""
 import torch
@@ -11,7 +11,7 @@ FD = O.FEAT_DIM
 
 
 class CpuDistEngine:
-    STAGES = ("forward", "phase1", "phase2", "backward", "update")
+    STAGES = ("spectral", "spatial", "phase1", "phase2", "backward_data", "backward_weights", "update")
 
     def __init__(self, shape, bt_l, btu_l, hp, world, rank, params0, params1):
         self.shape, self.hp, self.world, self.rank = shape, hp, world, rank
@@ -36,54 +36,67 @@ class CpuDistEngine:
         self.bt_l, self.btu_l, self.n_l = bt_l, btu_l, bt_l + btu_l
         self.bt_g, self.btu_g, self.n_g = bt_l * W, btu_l * W, (bt_l + btu_l) * W
         n_l = self.n_l
-        self.pack_len = 2 * n_l * K + 2 * n_l * FD + bt_l
+        self.pack_len = 2 * n_l * FD + bt_l                  # this rank's block of the exchange buffer: [feat | labels]
         self.pack, self.recv = torch.zeros(self.pack_len), torch.zeros(W * self.pack_len)
+        self.logits_l = torch.zeros(2, n_l, K)               # never exchanged
         self.probs_l, self.probs_g = torch.zeros(4, btu_l, K), torch.zeros(W, 4, btu_l, K)
         self.dlogits_l, self.dfeat_l = torch.zeros(2, n_l, K), torch.zeros(2, n_l, FD)
         self.dfw_part = torch.zeros(self.btu_g, FD)
 
     # --------------------------------------------------------------
-    def stage_forward(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update=True):
+    def stage_spectral(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update=True):
+        """the embeddings from the spectral branch ALONE (tools/models.py:142-146): feat = l2norm(relu(feat_spe(x)))"""
         sg = self.hp.noise
-        xp = [torch.cat([XPl + noise[0] * sg, XPu + noise[4] * sg]), torch.cat([XPl + noise[2] * sg, XPu + noise[6] * sg])]
-        xs = [torch.cat([Xl + noise[1] * sg, Xu + noise[5] * sg]), torch.cat([Xl + noise[3] * sg, Xu + noise[7] * sg])]
+        self.xp = [torch.cat([XPl + noise[0] * sg, XPu + noise[4] * sg]), torch.cat([XPl + noise[2] * sg, XPu + noise[6] * sg])]
+        self.xs = [torch.cat([Xl + noise[1] * sg, Xu + noise[5] * sg]), torch.cat([Xl + noise[3] * sg, Xu + noise[7] * sg])]
+        self.dropmask = dropmask
         self.leaf = [{k: (v.clone().requires_grad_(True) if k in O.LIVE_KEYS else v) for k, v in p.items()}
                      for p in self.params]
-        self.fwd = [O.basenet2_forward(self.leaf[net], xp[net], xs[net], dropmask[net]) for net in range(2)]
-        K, n_l = self.shape.K, self.n_l
-        self.pack[:2 * n_l * K] = torch.stack([f[0].detach() for f in self.fwd]).reshape(-1)
-        self.pack[2 * n_l * K:2 * n_l * K + 2 * n_l * FD] = torch.stack([f[1].detach() for f in self.fwd]).reshape(-1)
-        self.pack[2 * n_l * K + 2 * n_l * FD:] = Y.float()
+        n_l = self.n_l
+        early = []
+        for net in range(2):
+            y = torch.relu(F.linear(self.xs[net], self.leaf[net]["feat_spe.weight"], self.leaf[net]["feat_spe.bias"]))
+            early.append((y / y.pow(2).sum(1, keepdim=True).sqrt()).detach())
+        self.feat_early = torch.stack(early)
+        self.pack[:2 * n_l * FD] = self.feat_early.reshape(-1)
+        self.pack[2 * n_l * FD:] = Y.float()
         self.ctx = dict(smooth=(epoch > 0) or (batch_index > self.hp.queue_batch),
                         adap=self.hp.thr * self.hp.adap_thr(epoch), apply_update=apply_update)
 
+    def stage_spatial(self):
+        """the whole forward (the logits need both branches); its embeddings must be the ones already sent"""
+        self.fwd = [O.basenet2_forward(self.leaf[net], self.xp[net], self.xs[net], self.dropmask[net]) for net in range(2)]
+        self.logits_l.copy_(torch.stack([f[0].detach() for f in self.fwd]))
+        late = torch.stack([f[1].detach() for f in self.fwd])
+        assert torch.allclose(late, self.feat_early, rtol=1e-6, atol=1e-7, equal_nan=True)
+
     def _unpack(self):
-        W, K, n_l, bt_l = self.world, self.shape.K, self.n_l, self.bt_l
+        W, n_l, bt_l = self.world, self.n_l, self.bt_l
         r = self.recv.view(W, self.pack_len)
-        lo = r[:, :2 * n_l * K].reshape(W, 2, n_l, K)
-        fe = r[:, 2 * n_l * K:2 * n_l * K + 2 * n_l * FD].reshape(W, 2, n_l, FD)
-        lab = r[:, 2 * n_l * K + 2 * n_l * FD:]
+        fe = r[:, :2 * n_l * FD].reshape(W, 2, n_l, FD)
+        lab = r[:, 2 * n_l * FD:]
         glob = lambda t, d: torch.cat([t[:, :, :bt_l].permute(1, 0, 2, 3).reshape(2, -1, d),
                                        t[:, :, bt_l:].permute(1, 0, 2, 3).reshape(2, -1, d)], dim=1)
-        self.logits_g, self.feat_g = glob(lo, K).contiguous(), glob(fe, FD).contiguous()
+        self.feat_g = glob(fe, FD).contiguous()
         self.labels_g = (lab.reshape(-1) + 0.5).long()
 
     def stage_phase1(self):
         self._unpack()
         hp, T = self.hp, self.hp.temperature
         bt_g, btu_g, bt_l, btu_l, r = self.bt_g, self.btu_g, self.bt_l, self.btu_l, self.rank
-        lab = slice(r * bt_l, (r + 1) * bt_l)
-        unl = slice(bt_g + r * btu_l, bt_g + (r + 1) * btu_l)
-        z = [self.logits_g[net].clone().requires_grad_(True) for net in range(2)]     # [s, w]
+        # only THIS rank's logits exist here (local rows [labelled ; unlabelled]); embeddings and labels are global
+        lab, unl = slice(0, bt_l), slice(bt_l, bt_l + btu_l)
+        gunl = slice(bt_g + r * btu_l, bt_g + (r + 1) * btu_l)
+        z = [self.logits_l[net].clone().requires_grad_(True) for net in range(2)]     # [s, w]
         f = self.feat_g
-        Yl = self.labels_g[lab]
+        Yl = self.labels_g[r * bt_l:(r + 1) * bt_l]
         with torch.no_grad():
             p_w0, p_s0 = torch.softmax(z[1][unl], 1), torch.softmax(z[0][unl], 1)
             p_w, p_s = p_w0.clone(), p_s0.clone()
             if self.ctx["smooth"]:
-                A = torch.exp(f[1][unl] @ self.bank_feats[0].t() / T); A = A / A.sum(1, keepdim=True)
+                A = torch.exp(f[1][gunl] @ self.bank_feats[0].t() / T); A = A / A.sum(1, keepdim=True)
                 p_w = hp.alpha * p_w + (1 - hp.alpha) * (A @ self.bank_probs[0])
-                A1 = torch.exp(f[0][unl] @ self.bank_feats[1].t() / T); A1 = A1 / A1.sum(1, keepdim=True)
+                A1 = torch.exp(f[0][gunl] @ self.bank_feats[1].t() / T); A1 = A1 / A1.sum(1, keepdim=True)
                 p_s = hp.alpha * p_s + (1 - hp.alpha) * (A1 @ self.bank_probs[1])
             m_w = (p_w.max(1)[0] >= torch.tensor(self.ctx["adap"], dtype=torch.float32)).float()
             m_s = (p_s.max(1)[0] >= torch.tensor(self.ctx["adap"], dtype=torch.float32)).float()
@@ -134,16 +147,22 @@ class CpuDistEngine:
             float(p1["cls"][1]) + hp.w_contrast * c + hp.w_mutual * float(p1["con"][1]), float(p1["cls"][1]),
             float(p1["con"][1]), c])
 
-    def stage_backward(self):
-        outs, gouts = [], []
-        for net in range(2):
-            outs += [self.fwd[net][0], self.fwd[net][1]]
-            gouts += [self.dlogits_l[net], self.dfeat_l[net]]
+    def _leaf_grads(self, outs, gouts, retain):
         leaves = [self.leaf[net][k] for net in range(2) for k in O.LIVE_KEYS]
-        gr = torch.autograd.grad(outs, leaves, grad_outputs=gouts)
+        gr = torch.autograd.grad(outs, leaves, grad_outputs=gouts, retain_graph=retain, allow_unused=True)
         nk = len(O.LIVE_KEYS)
-        for net in range(2):
-            self.grads[net] = torch.cat([g.reshape(-1) for g in gr[net * nk:(net + 1) * nk]])
+        return torch.stack([torch.cat([(g if g is not None else torch.zeros_like(l)).reshape(-1)
+                                       for g, l in zip(gr[net * nk:(net + 1) * nk], leaves[net * nk:(net + 1) * nk])])
+                            for net in range(2)])
+
+    def stage_backward_data(self):
+        """everything that flows back from the logits (needs dlogits only; the reduce-scatter is still in flight)"""
+        self.g_logits = self._leaf_grads([self.fwd[net][0] for net in range(2)], [self.dlogits_l[net] for net in range(2)], True)
+
+    def stage_backward_weights(self):
+        """+ what flows back from the embeddings (dfeat complete): the gradient is linear in the two"""
+        g_feat = self._leaf_grads([self.fwd[net][1] for net in range(2)], [self.dfeat_l[net] for net in range(2)], False)
+        self.grads.copy_(self.g_logits + g_feat)
 
     def stage_update(self):
         if self.ctx["apply_update"]:
@@ -160,15 +179,18 @@ class CpuDistEngine:
         self.ptr = [p0, (p0 + self.hp.bank_step) % q]
 
     def exchange_after(self, stage):
-        if stage == "forward":
-            return [("all_gather", self.recv, self.pack)]
+        if stage == "spectral":
+            return [("all_gather", self.recv, self.pack, "feat")]
         if stage == "phase1":
-            return [("all_gather", self.probs_g, self.probs_l)]
+            return [("all_gather", self.probs_g, self.probs_l, None)]
         if stage == "phase2":
-            return [("reduce_scatter", self.dfeat_l[1, self.bt_l:], self.dfw_part)]
-        if stage == "backward":
-            return [("all_reduce", self.grads, None)]
+            return [("reduce_scatter", self.dfeat_l[1, self.bt_l:], self.dfw_part, "dfw")]
+        if stage == "backward_weights":
+            return [("all_reduce", self.grads, None, None)]
         return []
+
+    def waits_before(self, stage):
+        return {"phase1": ["feat"], "backward_weights": ["dfw"]}.get(stage, [])
 
 
 class CpuLoopEngine:

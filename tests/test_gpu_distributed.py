@@ -21,29 +21,43 @@ class FakeComm:
         self.world, self.rank = world, rank
 
 
-def lockstep_step(engines, per_rank_inputs, epoch, batch_index, **kw):
+def _exchange(engines, stage):
+    """the collectives that follow `stage`, performed on the ranks' buffers right away (every rank's stage has been
+    enqueued on the one stream, so also an exchange the product issues asynchronously finds its input in stream order)"""
     W = len(engines)
+    specs = [e.exchange_after(stage) for e in engines]
+    for k in range(len(specs[0])):
+        kind = specs[0][k][0]
+        if kind == "all_gather":
+            full = torch.cat([specs[r][k][2].reshape(-1) for r in range(W)])
+            for r in range(W):
+                specs[r][k][1].view(-1).copy_(full)
+        elif kind == "reduce_scatter":
+            tot = sum(specs[r][k][2] for r in range(W))
+            for r, chunk in enumerate(tot.chunk(W, dim=0)):
+                specs[r][k][1].copy_(chunk)
+        else:
+            tot = sum(specs[r][k][1] for r in range(W))
+            for r in range(W):
+                specs[r][k][1].copy_(tot)
+
+
+def lockstep_step(engines, per_rank_inputs, epoch, batch_index, **kw):
+    first = engines[0].STAGES[0]
     for e, inp in zip(engines, per_rank_inputs):
-        e.stage_forward(*inp["args"], epoch, batch_index, noise=inp.get("noise"), dropmask=inp.get("dropmask"), **kw)
+        getattr(e, "stage_" + first)(*inp["args"], epoch, batch_index, noise=inp.get("noise"), dropmask=inp.get("dropmask"), **kw)
     for stage in engines[0].STAGES:
-        if stage != "forward":
+        if stage != first:
             for e in engines:
                 getattr(e, "stage_" + stage)()
-        specs = [e.exchange_after(stage) for e in engines]
-        for k in range(len(specs[0])):
-            kind = specs[0][k][0]
-            if kind == "all_gather":
-                full = torch.cat([specs[r][k][2].reshape(-1) for r in range(W)])
-                for r in range(W):
-                    specs[r][k][1].view(-1).copy_(full)
-            elif kind == "reduce_scatter":
-                tot = sum(specs[r][k][2] for r in range(W))
-                for r, chunk in enumerate(tot.chunk(W, dim=0)):
-                    specs[r][k][1].copy_(chunk)
-            else:
-                tot = sum(specs[r][k][1] for r in range(W))
-                for r in range(W):
-                    specs[r][k][1].copy_(tot)
+        _exchange(engines, stage)
+
+
+def global_outputs(engines, which):
+    """(logits, feat) of the global batch as rank `which` sees them; the step never gathers the logits, the harness hands
+    the ranks' blocks over"""
+    full = torch.cat([e.logits_l.reshape(-1) for e in engines])
+    return engines[which].outputs(gathered_logits=full)
 
 
 def shard_inputs(cb, W, bt, btu, cls_in, with_noise):
@@ -97,8 +111,8 @@ def test_sharded_step_equals_single_gpu_step(W, shape_name, bt, btu, explicit):
         assert [got[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")] == \
                [want[k] for k in ("n_mask_w", "n_mask_s", "n_pos", "n_neg")]
         lo, fe = ref.outputs()
-        report("logits_g", engines[0].outputs()[0], lo, 1e-5, 1e-5)     # same kernels; only the tile grouping differs
-        report("feat_g", engines[-1].outputs()[1], fe, 1e-5, 5e-6)     # after updates: fp32 reduction-order drift
+        report("logits_g", global_outputs(engines, 0)[0], lo, 1e-5, 1e-5)     # same kernels; only the tile grouping differs
+        report("feat_g", global_outputs(engines, -1)[1], fe, 1e-5, 5e-6)     # after updates: fp32 reduction-order drift
         for net in range(2):
             for k in O.LIVE_KEYS:
                 gr = ref.grad(net, k)
@@ -290,10 +304,10 @@ def test_eight_rank_baseline_configs_match_the_oracle(cfg):
             assert rel_err([got[k] for k in ("total_w", "cls_w", "con_w", "ctr_w")], z["extra"][0], 1e-7) < 1e-4
             assert [got["n_mask_w"], got["n_mask_s"], got["n_pos"], got["n_neg"]] == list(z["counts"][0])
             assert engines[0].ptr == [int(v) for v in z["ptr"][0]]
-            report("golden logits", engines[0].outputs()[0], z["s0_logits"], 2e-4, 5e-5)
+            report("golden logits", global_outputs(engines, 0)[0], z["s0_logits"], 2e-4, 5e-5)
         lo_ref = torch.stack(ref["logits"])
-        report("logits_g", engines[0].outputs()[0], lo_ref, 2e-4, 5e-6 * float(lo_ref.abs().max()) + 2e-5)
-        report("feat_g", engines[-1].outputs()[1], torch.stack(ref["feats"]), 1e-5, 3e-6)
+        report("logits_g", global_outputs(engines, 0)[0], lo_ref, 2e-4, 5e-6 * float(lo_ref.abs().max()) + 2e-5)
+        report("feat_g", global_outputs(engines, -1)[1], torch.stack(ref["feats"]), 1e-5, 3e-6)
         for r, e in enumerate(engines):      # every rank's masks sit on the oracle's signs (its own rows)
             rows = list(range(r * bt_l, (r + 1) * bt_l)) + list(range(bt + r * btu_l, bt + (r + 1) * btu_l))
             taps = [{k: v[rows] for k, v in ref["taps"][net].items()} for net in range(2)]
@@ -318,25 +332,6 @@ def test_eight_rank_baseline_configs_match_the_oracle(cfg):
                 report_params(f"param[{net}] {k}", sd[k], st.params[net][k], steps, hp.lr)
     for e in engines[1:]:
         assert torch.equal(e.params, engines[0].params)       # replicas stay bit-identical
-
-
-def _exchange(engines, stage):
-    W = len(engines)
-    specs = [e.exchange_after(stage) for e in engines]
-    for k in range(len(specs[0])):
-        kind = specs[0][k][0]
-        if kind == "all_gather":
-            full = torch.cat([specs[r][k][2].reshape(-1) for r in range(W)])
-            for r in range(W):
-                specs[r][k][1].view(-1).copy_(full)
-        elif kind == "reduce_scatter":
-            tot = sum(specs[r][k][2] for r in range(W))
-            for r, chunk in enumerate(tot.chunk(W, dim=0)):
-                specs[r][k][1].copy_(chunk)
-        else:
-            tot = sum(specs[r][k][1] for r in range(W))
-            for r in range(W):
-                specs[r][k][1].copy_(tot)
 
 
 def _dist_state(e):
@@ -374,9 +369,9 @@ def test_replayed_stage_graphs_are_bit_identical_to_the_eager_sharded_step(W, na
         ep, bi = sched[k]
         for r, e in enumerate(es):
             lo, uo = offs[k][0] + r * bt_l, offs[k][1] + r * btu_l
-            e.stage_forward(XP, X, Y, XPu, Xu, ep, bi, lab_idx=lab_perm[lo:lo + bt_l], unl_idx=unl_perm[uo:uo + btu_l])
+            e.stage_spectral(XP, X, Y, XPu, Xu, ep, bi, lab_idx=lab_perm[lo:lo + bt_l], unl_idx=unl_perm[uo:uo + btu_l])
         for stage in es[0].STAGES:
-            if stage != "forward":
+            if stage != "spectral":
                 for e in es:
                     getattr(e, "stage_" + stage)()
             if W > 1:
@@ -402,6 +397,6 @@ def test_replayed_stage_graphs_are_bit_identical_to_the_eager_sharded_step(W, na
             assert torch.equal(x, y), f"rank {r}: state tensor {i} differs, max |d| = {(x - y).abs().max().item():.3e}"
     assert torch.isfinite(eb[0].scalar_hist[:len(sched)]).all()
     with pytest.raises(RuntimeError):
-        graphs[0].launch_stage("forward")                            # nothing programmed
+        graphs[0].launch_stage("spectral")                           # nothing programmed
     for gr in graphs:
         gr.close()

@@ -41,3 +41,14 @@ def test_multiprocess_at_the_shard_size_of_configs2():
                           timeout=900)
     assert rc == 0, out
     assert "OK world=4" in out, out
+
+
+def test_multiprocess_replayed_stage_graphs_equal_the_eager_sharded_step():
+    """DistStepGraph.launch() -- the seven stage graphs with the real torch.distributed calls between them, the embedding
+    all-gather and the reduce-scatter issued asynchronously -- in two REAL processes, bit-identical to the eager
+    drive_step on the same process group (what `train.py --graph` runs under torch.distributed.run)."""
+    from cmlpl_amd.launch import spawn_ranks
+    rc, out = spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_child.py")],
+                          extra_env=dict(CMLPL_TEST_GRAPH="1", CMLPL_TEST_BT="32", CMLPL_TEST_BTU="48"), timeout=600)
+    assert rc == 0, out
+    assert "OK graph world=2" in out, out

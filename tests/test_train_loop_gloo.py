@@ -19,11 +19,7 @@ def _single_process(num_unlabel):
     import train
     from tests.cpu_dist_engine import CpuLoopEngine
 
-    class One:
-        world, rank = 1, 0
-        def all_gather(self, out, inp): out.view(-1).copy_(inp.view(-1))
-        def reduce_scatter(self, out, inp): out.view(-1).copy_(inp.view(-1))
-        def all_reduce(self, t): pass
+    from cmlpl_amd.distributed import SingleComm as One       # world size 1: every collective is a copy
 
     args = train.build_parser().parse_args([
         "--synthetic", "B2", "--num_unlabel", str(num_unlabel), "--labeled_batch_size", "8",

@@ -8,7 +8,8 @@ Differences from the reference that are deliberate, MI355X-first choices:
     (the epoch's permutation, also resident): the kernels read the rows where they lie, no batch tensor is gathered
     (the reference copies every batch over PCIe and draws noise on the CPU);
   * ``--graph``: the step is captured once as a hipGraph and replayed, one launch per step, its per-step scalars
-    coming from a device-side table filled once per epoch (single GPU);
+    coming from a device-side table filled once per epoch (several GPUs: one graph per stage of the sharded step,
+    the collectives eager between them -- cmlpl_amd.distributed.DistStepGraph);
   * noise and dropout come from in-kernel counter-based streams (PCG4D hash + Box-Muller for the augmentation noise,
     Philox4x32-10 for the dropout masks) seeded with the reference's seed 1088;
   * the five logged scalars of every step (loss_hist, train.py:136,274-278) are written by the step into a
@@ -262,7 +263,8 @@ def build_parser():
     parser.add_argument('--save_loss_hist', default=None, help='write loss_hist [num_steps,5] (train.py:136) as .npy')
     parser.add_argument('--no_eval', action='store_true', help='skip the whole-image inference after training')
     parser.add_argument('--graph', action='store_true',
-                        help='capture the training step once as a hipGraph and replay it (single GPU)')
+                        help='capture the training step once as a hipGraph and replay it (several GPUs: the sharded '
+                             'step as seven stage graphs, its collectives eager between them)')
     return parser
 
 

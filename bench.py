@@ -340,10 +340,12 @@ def run_rank(args):
     dom_name = max(calib, key=calib.get)
     dom_id = ids[dom_name]
     _lib.check("cmlpl_timing_begin", lib.cmlpl_timing_begin(1 << dom_id, args.steps + 8))
+    thr0 = cgroup_throttle()
     t0 = time.perf_counter()
     run(args.steps, args.warmup + calib_steps)
     barrier()
     dt = time.perf_counter() - t0
+    thr1 = cgroup_throttle()
     _lib.check("cmlpl_timing_end", lib.cmlpl_timing_end(ms, cnt))
     if dist is not None:
         t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -431,6 +433,10 @@ def run_rank(args):
              "traffic": traffic.get(k)}
             for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
+        # did the container's CPU quota freeze this process inside the timed region?  (a throttled period stops every
+        # thread for up to a CFS period, ~100 ms: profiles/r06_stall_rootcause.txt)  null where cpu.stat is not readable
+        "host_throttled": None if thr0 is None or thr1 is None else
+                          {"periods": thr1[0] - thr0[0], "ms": (thr1[1] - thr0[1]) / 1e3},
     }
 
     if args.breakdown:     # every rank runs the extra steps (they contain collectives); rank 0 prints
@@ -455,6 +461,18 @@ def run_rank(args):
         out["cpu_baseline"] = cpu_baseline(shape, bt, btu) if (world == 1 and not args.no_cpu_baseline) else None
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
+def cgroup_throttle():
+    """(throttled periods, throttled time in us) of this container's CPU controller (cgroup v2, else v1), or None"""
+    for path, key in (("/sys/fs/cgroup/cpu.stat", "throttled_usec"), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time")):
+        try:
+            d = dict(ln.split() for ln in open(path).read().splitlines() if len(ln.split()) == 2)
+            t = int(d.get(key, 0))
+            return int(d.get("nr_throttled", 0)), (t // 1000 if key == "throttled_time" else t)
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def main(argv=None):

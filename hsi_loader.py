@@ -54,24 +54,22 @@ class HSIDataSet(data.Dataset):
 
     def cube_source(self, device, scene=None, dataID=None):
         """The 'wholeset' as the scene it was cut from, for whole-image inference without the materialised patches
-        (tools.hyper_tools.test_whole): ``cube.npy`` ([rows, cols, C]) next to XP.npy when sample_generation kept it,
-        else rebuilt from the centre pixels of the patches (ExtractPatches walks the pixels row by row,
-        hyper_tools.py:226-243: patch k is pixel k and its centre is the pixel itself).  None when the scene's size
-        is not known or does not match."""
+        (tools.hyper_tools.test_whole): ``cube.npy`` ([rows, cols, C], the z-scored / PCA'd scene the patches were cut
+        from -- INTEGRATION.md says which line of the reference's preprocessing has it in hand) next to XP.npy.  None
+        when it is not there (the caller then streams the materialised patches, as the reference does): the cube is
+        NOT rebuilt from XP.npy -- that gather touches every page of a ~20 GB file to recover 0.25 % of it."""
         import os
         from cmlpl_amd.infer import CubeSource
         if self.setindex != 'wholeset':
             raise ValueError("cube_source() is for the 'wholeset'")
+        path = self.root + 'cube.npy'
+        if not os.path.exists(path):
+            return None
+        cube = np.load(path, mmap_mode='r')
         if scene is None and dataID is not None:
             scene = _SCENES.get(int(dataID))
-        path = self.root + 'cube.npy'
-        if os.path.exists(path):
-            cube = np.load(path, mmap_mode='r')
-        else:
-            if scene is None or scene[0] * scene[1] != len(self.XP):
-                return None
-            hw = self.XP.shape[2] // 2
-            cube = np.asarray(self.XP[:, :, hw, hw]).reshape(scene[0], scene[1], self.XP.shape[1])
+        if cube.ndim != 3 or (scene is not None and tuple(cube.shape[:2]) != tuple(scene)):
+            return None
         cube = torch.from_numpy(np.ascontiguousarray(cube, dtype=np.float32)).to(device)
         X = torch.from_numpy(np.ascontiguousarray(self.X, dtype=np.float32)).to(device)
         if cube.shape[0] * cube.shape[1] != X.shape[0]:
@@ -107,14 +105,20 @@ class SyntheticHSIDataSet(data.Dataset):
 
 class SyntheticScene:
     """A seeded synthetic scene for whole-image inference: a cube [rows, cols, C] and spectra [rows * cols, bands] whose
-    pixels carry the class-dependent means of ``SyntheticHSIDataSet`` (same prototypes), plus the per-pixel labels."""
+    pixels carry the class-dependent means of ``SyntheticHSIDataSet`` (same prototypes), plus the per-pixel labels.
+    The classes lie in square REGIONS one and a half windows wide (a real scene's fields and roofs; each region its own
+    seeded class), so that a window is mostly one class, like the training patches, which carry one class mean over the
+    whole window -- with a class per pixel the spatial branch met windows it never trained on."""
 
     def __init__(self, shape, rows, cols, seed=3, separable=1.0):
         C, H, W, bands, K = shape
         g = torch.Generator().manual_seed(seed)
         proto_g = torch.Generator().manual_seed(4242)
         self.rows, self.cols, self.window = int(rows), int(cols), H
-        self.Y = torch.randint(0, K, (rows * cols,), generator=g)
+        blk = max(1, (3 * H) // 2)
+        nbr, nbc = (rows + blk - 1) // blk, (cols + blk - 1) // blk
+        region = torch.randint(0, K, (nbr, nbc), generator=g)
+        self.Y = region.repeat_interleave(blk, 0)[:rows].repeat_interleave(blk, 1)[:, :cols].reshape(-1).contiguous()
         proto_p = torch.randn(K, C, 1, 1, generator=proto_g) * separable
         proto_x = torch.randn(K, bands, generator=proto_g) * separable
         self.cube = (torch.randn(rows * cols, C, generator=g) + proto_p[self.Y].view(-1, C)).view(rows, cols, C)

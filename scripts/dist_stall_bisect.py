@@ -46,6 +46,21 @@ def _cgroup_cpu():
     return None
 
 
+def _thread_cpu():
+    """{tid: (name, CPU seconds)} of every thread of this process"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    for t in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{t}/stat").read()
+            name = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            out[t] = (name, (int(rest[11]) + int(rest[12])) / tick)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def _sched():
     """this thread: (ns on a CPU, ns runnable but waiting for one, voluntary, involuntary context switches)"""
     import threading
@@ -67,16 +82,53 @@ class TimedComm(TorchDistComm):
         key = f"{self.site}:{name}"
         self.site += 1
         t0 = time.perf_counter()
+        h = None
         if key in self.copy:
             if inp is not None:
                 out.view(-1).copy_(inp.view(-1))
         else:
-            f()
+            h = f()
         self.t[key] = self.t.get(key, 0.0) + time.perf_counter() - t0
+        return h
 
-    def all_gather(self, out, inp): self._do("all_gather", lambda: TorchDistComm.all_gather(self, out, inp), out, inp)
-    def reduce_scatter(self, out, inp): self._do("reduce_scatter", lambda: TorchDistComm.reduce_scatter(self, out, inp), out, inp)
-    def all_reduce(self, t): self._do("all_reduce", lambda: TorchDistComm.all_reduce(self, t), t, None)
+    def all_gather(self, out, inp, async_op=False):
+        return self._do("all_gather", lambda: TorchDistComm.all_gather(self, out, inp, async_op), out, inp)
+
+    def reduce_scatter(self, out, inp, async_op=False):
+        return self._do("reduce_scatter", lambda: TorchDistComm.reduce_scatter(self, out, inp, async_op), out, inp)
+
+    def all_reduce(self, t, async_op=False):
+        return self._do("all_reduce", lambda: TorchDistComm.all_reduce(self, t, async_op), t, None)
+
+
+# A watcher thread: when the main thread has been inside one step for more than 5 ms, note what it is waiting in
+# (/proc/<tid>/wchan = the kernel function it sleeps in, /proc/<tid>/syscall = the system call and its arguments,
+# /proc/<tid>/stat field 3 = R running / S sleeping / D uninterruptible) -- once per stalled step.
+import threading
+MAIN_TID = threading.get_native_id()
+STEP_T0 = [0.0]
+WATCH = []
+
+
+def _watch():
+    seen = 0.0
+    while True:
+        time.sleep(0.001)
+        t0 = STEP_T0[0]
+        if t0 and t0 != seen and time.perf_counter() - t0 > 0.005:
+            seen = t0
+            rec = {}
+            for f in ("wchan", "syscall", "stat"):
+                try:
+                    v = open(f"/proc/self/task/{MAIN_TID}/{f}").read().strip()
+                    rec[f] = v.split()[2] if f == "stat" else v[:120]
+                except OSError as e:
+                    rec[f] = f"({e.errno})"
+            rec["after_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+            WATCH.append(rec)
+
+
+threading.Thread(target=_watch, daemon=True).start()
 
 
 def run(wl, bt, btu, copy=()):
@@ -101,6 +153,8 @@ def run(wl, bt, btu, copy=()):
     st.clear(); comm.t.clear()
     per = []
     GC_LOG.clear()
+    WATCH.clear()
+    tc0, tw0 = _thread_cpu(), time.perf_counter()
     cg0, worst = _cgroup_cpu(), (0.0, None)
     t0 = time.perf_counter()
     for i in range(K):
@@ -108,7 +162,9 @@ def run(wl, bt, btu, copy=()):
         s0 = _sched()
         c0 = time.thread_time()
         ts = time.perf_counter()
+        STEP_T0[0] = ts
         eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, 20 + i)
+        STEP_T0[0] = 0.0
         dt = time.perf_counter() - ts
         per.append(dt)
         if dt > worst[0]:
@@ -129,6 +185,13 @@ def run(wl, bt, btu, copy=()):
     print(f"    slowest step {1e3 * worst[0]:.2f} ms: {worst[1]}   cgroup throttling during the run: "
           + (f"{cg1[0] - cg0[0]} periods, {(cg1[1] - cg0[1]) / 1e3:.1f} ms" if cg0 and cg1 else "n/a")
           + f"   threads {len(os.listdir('/proc/self/task'))}")
+    tc1, tw = _thread_cpu(), time.perf_counter() - tw0
+    burn = sorted(((c - tc0.get(t, (n, 0.0))[1], n, t) for t, (n, c) in tc1.items()), reverse=True)
+    tot = sum(b[0] for b in burn)
+    print(f"    CPU burnt by this process's threads over the {1e3 * tw:.0f} ms of the run: {1e3 * tot:.0f} ms = {tot / tw:.1f} cores; top: "
+          + ", ".join(f"{n}[{t}] {1e3 * c:.0f} ms" for c, n, t in burn[:6]))
+    if WATCH:
+        print(f"    watcher (main thread inside a step for > 5 ms): {WATCH}")
     print("    garbage collections during the timed steps: " +
           (", ".join(f"gen{g} {1e3 * t:.1f} ms" for g, t in GC_LOG) or "none") + f"   (gc enabled: {gc.isenabled()})", flush=True)
     del eng
@@ -147,4 +210,13 @@ gc.collect(); gc.freeze(); gc.disable()
 for item in order.split(","):
     wl, bt, btu = item.split(":")
     run(wl, int(bt), int(btu))
+try:
+    print("cgroup cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip())
+except OSError:
+    try:
+        print("cgroup cfs quota / period (us):", open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read().strip(), "/",
+              open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+    except OSError:
+        print("cgroup cpu limits: not readable")
+print("online CPUs:", os.cpu_count(), " affinity:", len(os.sched_getaffinity(0)))
 dist.destroy_process_group()

@@ -199,27 +199,32 @@ def main(args, make_engine=None, device=None):
         if args.save_loss_hist:
             np.save(args.save_loss_hist, loss_hist)
     if rank == 0 and not args.no_eval:
-        # whole-image inference + accuracy (train.py:291-306)
+        # whole-image inference + accuracy (train.py:291-306).  The scene stays in HBM as its cube and the forward gathers
+        # the windows itself (cmlpl_infer_cube): no 19.9 GB patch tensor, no DataLoader (train.py:291-294 streams the
+        # materialised patches).  Window shapes the per-sample forward does not take, or a dataset directory without the
+        # cube, fall back to the loader.  The source is built ONCE for both networks, and its load time is printed
+        # (the reference's "inference time" includes streaming the data).
+        from cmlpl_amd.infer import infer_supported
+        t_src = time.time()
+        source = None
+        if infer_supported(NetShape(*shape)):
+            source = whole.cube_source(device) if args.synthetic else whole.cube_source(device, dataID=args.dataID)
+        if source is None:
+            if args.synthetic:      # (cut the scene's windows on the device, then the reference's loader path)
+                from cmlpl_amd.patches import extract_patches
+                cs = whole.cube_source(device)
+                XPw = extract_patches(cs.cube, torch.arange(len(whole), device=device), shape[1]).cpu()
+                source = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(XPw, whole.X),
+                                                     batch_size=args.val_batch_size, shuffle=False)
+            else:
+                source = torch.utils.data.DataLoader(whole, batch_size=args.val_batch_size, shuffle=False)
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        print('evaluation source ready in %.3f s' % (time.time() - t_src))
         for net in range(2):
             model = BaseNet2(num_features=num_features, dropout=args.dropout, num_classes=num_classes,
                              in_channels=shape[0], window=shape[1]).to(device)
             model.load_state_dict(eng.state_dict(net))
-            # The scene stays in HBM as its cube and the forward gathers the windows itself (cmlpl_infer_cube): no
-            # 19.9 GB patch tensor, no DataLoader (train.py:291-294 streams the materialised patches).  Window shapes the
-            # per-sample forward does not take, or a patch file without a known scene size, fall back to the loader.
-            from cmlpl_amd.infer import infer_supported
-            source = None
-            if infer_supported(NetShape(*shape)):
-                source = whole.cube_source(device) if args.synthetic else whole.cube_source(device, dataID=args.dataID)
-            if source is None:
-                if args.synthetic:      # (cut the scene's windows on the device, then the reference's loader path)
-                    from cmlpl_amd.patches import extract_patches
-                    cs = whole.cube_source(device)
-                    XPw = extract_patches(cs.cube, torch.arange(len(whole), device=device), shape[1]).cpu()
-                    source = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(XPw, whole.X),
-                                                         batch_size=args.val_batch_size, shuffle=False)
-                else:
-                    source = torch.utils.data.DataLoader(whole, batch_size=args.val_batch_size, shuffle=False)
             t1 = time.time()
             pred = test_whole(model, source, print_per_batches=10 ** 9)
             OA, Kappa, producerA = CalAccuracy(pred[test_array], Y_test)

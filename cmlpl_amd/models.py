@@ -149,25 +149,34 @@ class BaseNet2(nn.Module):
 
 
 class _NTXentFn(torch.autograd.Function):
+    """One C call forms the loss AND both gradients.  Host cost matters here (two launches of 13 us each at B = 128): the
+    workspace is kept per (B, D, device), the two gradients share one allocation, and the backward scales them with one
+    launch instead of two."""
+    _ws = {}
+
     @staticmethod
     def forward(ctx, emb_i, emb_j, temperature):
         lib = _lib.load()
         B, D = emb_i.shape
         dev = emb_i.device
-        loss = torch.empty(1, device=dev, dtype=torch.float32)
-        gi, gj = torch.empty_like(emb_i), torch.empty_like(emb_j)
-        ws = torch.empty(lib.cmlpl_ntxent_workspace_bytes(B, D), dtype=torch.uint8, device=dev)
+        key = (B, D, dev)
+        ws = _NTXentFn._ws.get(key)
+        if ws is None:     # (stream-ordered re-use: a later call's kernels run behind this one's on the same stream)
+            ws = _NTXentFn._ws[key] = torch.empty(lib.cmlpl_ntxent_workspace_bytes(B, D), dtype=torch.uint8, device=dev)
+        out = torch.empty(2 * B * D + 1, device=dev, dtype=torch.float32)        # [gi | gj | loss]
+        g2 = out[:2 * B * D].view(2, B, D)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        p = out.data_ptr()
         _lib.check("cmlpl_ntxent_fwd_bwd", lib.cmlpl_ntxent_fwd_bwd(
-            emb_i.data_ptr(), emb_j.data_ptr(), B, D, float(temperature), loss.data_ptr(), gi.data_ptr(),
-            gj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
-        ctx.save_for_backward(gi, gj)
-        return loss[0]
+            emb_i.data_ptr(), emb_j.data_ptr(), B, D, temperature, p + 8 * B * D, p, p + 4 * B * D,
+            ws.data_ptr(), ws.numel(), stream))
+        ctx.g2 = g2
+        return out[2 * B * D]
 
     @staticmethod
     def backward(ctx, g):
-        gi, gj = ctx.saved_tensors
-        return gi * g, gj * g, None
+        s = ctx.g2 * g
+        return s[0], s[1], None
 
 
 class ContrastiveLoss(nn.Module):

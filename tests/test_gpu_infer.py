@@ -30,11 +30,12 @@ def _module(shape, seed, scale=1.0):
 
 @pytest.mark.parametrize("name,shape,rows,cols", [("B2", (103, 11, 11, 103, 9), 64, 48), ("B4", (200, 11, 11, 200, 16), 20, 24),
                                                   ("B5", (48, 15, 15, 48, 20), 24, 40), ("W8", (30, 8, 8, 30, 5), 16, 16),
-                                                  ("W12", (16, 12, 12, 16, 7), 14, 19)])
+                                                  ("W12", (16, 12, 12, 16, 7), 14, 19), ("P", (60, 20, 20, 103, 9), 22, 26)])
 def test_infer_cube_matches_the_oracle(name, shape, rows, cols):
     """labels equal the oracle's extract_patches -> basenet2_forward -> argmax wherever the top two logits are further
     apart than the logits tolerance; logits within 1e-4 (relative to the row's largest); every pixel of the scene, i.e.
-    every kind of mirrored border."""
+    every kind of mirrored border.  P = the reference's own 20 x 20 x 60 window (tools/models.py:102,127): more pixels
+    than the fused forward takes, so infer_cube cuts the windows of a chunk on the device and runs the general forward."""
     from cmlpl_amd.infer import infer_cube
     s = O.NetShape(*shape)
     cube, X = _scene(rows, cols, s.C, s.bands, 99)
@@ -86,14 +87,11 @@ def test_infer_cube_equals_the_patch_path_and_test_whole_takes_a_cube():
 
 
 def test_infer_cube_refuses_what_it_cannot_take():
-    from cmlpl_amd import _lib
-    from cmlpl_amd.infer import infer_cube, infer_supported
+    from cmlpl_amd.infer import infer_cube, infer_fused, infer_supported
     s = O.NetShape(60, 20, 20, 103, 9)                   # the reference's own 20 x 20 window: 400 pixels
-    assert not infer_supported(s) and infer_supported(O.NetShape(103, 11, 11, 103, 9)) and infer_supported(O.NetShape(48, 15, 15, 48, 20))
-    net, _ = _module(s, 3)
+    assert not infer_fused(s) and infer_fused(O.NetShape(103, 11, 11, 103, 9)) and infer_fused(O.NetShape(48, 15, 15, 48, 20))
+    assert infer_supported(s) and infer_supported(O.NetShape(103, 11, 11, 103, 9))      # (by chunks of extracted windows)
     cube, X = _scene(24, 24, 60, 103, 1)
-    with pytest.raises(_lib.CmlplError):
-        infer_cube(net, torch.from_numpy(cube).to(DEV), torch.from_numpy(X).to(DEV))
     net2, _ = _module(O.NetShape(103, 11, 11, 103, 9), 3)
     with pytest.raises(ValueError):
         infer_cube(net2, torch.from_numpy(cube).to(DEV), torch.from_numpy(X).to(DEV))      # 60 channels into a 103-channel net

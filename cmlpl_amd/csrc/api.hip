@@ -318,9 +318,16 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
                                d_params + L.param_off[3], param_stride, w.p1, w.m1, nullptr, st, xn_save))))) return rc;
   } else {
-    if (!d_xn) return CMLPL_E_ARG;
-    if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
-                                   d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
+    if (conv0a_ok(d.C, d.HW) && (d_xn == nullptr || xs.sigma == 0.f)) {
+      // the general path: augmentation + conv0 in ONE launch on the split-bf16 MFMA, from the rows `xs` names (raw rows
+      // with their noise -> the augmented rows also go to xn_save for the backward; or a caller's pre-augmented tensor)
+      if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0a_fwd(nets, n, d.C, d.HW, xs, d_packed + pack_off_w0b3(d.C, d.bands), pk_ns,
+                                     d_params + L.param_off[1], param_stride, w.a0, xn_save, st))))) return rc;
+    } else {
+      if (!d_xn) return CMLPL_E_ARG;
+      if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
+                                     d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
+    }
     if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + pack_off_b3(d.C, d.bands, 0),
                                pk_ns, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
   }
@@ -484,7 +491,10 @@ int forward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_
   // falls back to the unfused kernels, the spectra when the fused spectral kernel does not apply, and the label
   // conversion for the data-parallel exchange buffer
   const bool spe_fused = spe_fused_ok(d.bands);
-  const int which = ((parts & 2) && copy ? 1 : 0) | ((parts & 1) && !spe_fused ? 2 : 0);
+  // (general path: the augmentation of the patches rides in conv0's launch where conv0a_fwd_kernel takes the window; it
+  //  leaves the augmented rows in sw.xn like the fused forward does)
+  const bool c0a = copy && !conv3_fused_ok(d.H, d.W, d.C, 2 * n) && conv0a_ok(d.C, d.HW);
+  const int which = ((parts & 2) && copy && !c0a ? 1 : 0) | ((parts & 1) && !spe_fused ? 2 : 0);
   if (!(parts & 1)) d_labels_f = nullptr;     // (the labels travel with the spectral part)
   const RowSel sel = batch_sel(batch, dyn);
   if (which &&
@@ -501,9 +511,9 @@ int forward_impl(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_
   // (fused per-sample kernels: the forward leaves the rows it saw in sw.xn for cmlpl_backward, which lands them by DMA)
   return fwd_core(d, L, 2, n, d_params, L.param_total, d_packed, xsrc_raw(batch, hp->noise_sigma, seed, step, shard, dyn),
                   spe_fused ? &xspec : nullptr, sw.sn, (const long long*)batch->d_labels, d_labels_f,
-                  copy ? sw.xn : nullptr, sw.sn, nullptr, d_dropmask, hp->dropout_p,
+                  (copy && !c0a) ? sw.xn : nullptr, sw.sn, nullptr, d_dropmask, hp->dropout_p,
                   train, seed, step, shard, d_logits, d_feat, nw, st,
-                  !copy ? sw.xn : nullptr, parts, early_feat);
+                  (!copy || c0a) ? sw.xn : nullptr, parts, early_feat);
 }
 }  // namespace
 extern "C" {

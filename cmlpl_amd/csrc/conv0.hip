@@ -83,6 +83,157 @@ hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, con
 }
 
 // ------------------------------------------------------------------------------------------
+// conv0a_fwd_kernel: the patch AUGMENTATION and conv0 in one launch, on the split-bf16 MFMA -- the general path's forward
+// for windows the per-sample fused kernels do not reach (the reference's own 20 x 20 x 60, tools/models.py:102,127,132;
+// train.py:157,163,170,181).  Round 5's general path ran augment_kernel (raw rows -> xn, 74 MB at 128 + 128 rows of P)
+// and conv0_fwd_kernel (xn -> a0 on the f32-input MFMA: 60 steps of 64 cycles per wave, 23 us of matrix pipe in a 38-us
+// launch) back to back: 53 us.  Here a workgroup takes 128 consecutive pixels of ONE sample (window sizes that are
+// multiples of 8 pixels, so that a pair of 16-byte groups -- the unit of the noise generator, elements 8c .. 8c + 7 of
+// the sample's [C][HW] block -- is eight pixels of one band):
+//   phase 1  every thread walks (band, 8-pixel pair) items of the tile: two 16-byte loads of the raw row, one
+//            eight-normal hash call (or the reference's own draws), the augmented values to LDS [band][132] and -- for
+//            conv0's weight gradient in the backward pass -- to xn in HBM, 16 bytes at a time;
+//   phase 2  wave w = pixel tile 32 w .. 32 w + 31, both output-channel tiles: per k-step of 16 bands eight ds_read_b32
+//            down the bands (consecutive lanes = consecutive pixels), the split into three bf16 pieces, twelve MFMAs
+//            against conv0's packed split fragments (kernels.hpp: pack_off_w0b3, the set the fused forward uses), read
+//            from L2 a step ahead;
+//   a0 + bias goes out pixel-major / channel-last.
+// Same element values as augment_kernel forms (same counters), same products as conv3_stage's conv0.
+// ------------------------------------------------------------------------------------------
+constexpr int C0A_SP = 132;     // LDS row stride in floats (128 pixels + 4: 16-byte aligned rows)
+struct Conv0aArgs {
+  XSrc xs; const float* w0b3; long long w0b3_ns; const float* b; long long pstride;
+  float* a0; float* xn;         // xn may be null (no backward follows: inference)
+  int n, C, HW;
+};
+
+template <int KQMAX>
+__global__ __launch_bounds__(256, KQMAX <= 4 ? 4 : 2) void conv0a_fwd_kernel(Conv0aArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];   // [16 KQ0][C0A_SP]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.y, net = blockIdx.z, p0 = blockIdx.x * 128;
+  const int C = a.C, HW = a.HW, KQ0 = (C + 15) >> 4;
+  const int npx = (HW - p0 < 128) ? HW - p0 : 128, np8 = npx >> 3;      // pixels of this tile (a multiple of 8)
+  const long long per = (long long)C * HW;
+  const float* xrow = xsrc_row(a.xs, net, s, per);
+  const float sigma = a.xs.sigma;
+  const float* nzrow = (sigma != 0.f) ? xsrc_noise_row(a.xs, net, s, per) : nullptr;
+  const uint64_t gs = xsrc_global_sample(a.xs, s), rstep = xsrc_step(a.xs);
+  float* xnrow = (a.xn != nullptr) ? a.xn + ((long long)net * a.n + s) * per : nullptr;
+  const uint4* wq = (const uint4*)(a.w0b3 + (long long)net * a.w0b3_ns) + lane;
+  // ---- phase 1: items it = tid, tid + 256, ...: (band c = it / np8, pair j = it % np8) -> pixels p0 + 8 j .. + 7
+  constexpr int NI = (KQMAX * 16 * 16 + 255) / 256;                   // items per thread at most (16 pairs per band)
+  const int items = C * np8;
+  const uint32_t mg = (np8 <= 1) ? 0u : (uint32_t)((0x100000000ULL + (uint32_t)np8 - 1) / (uint32_t)np8);
+  float4 v0[NI], v1[NI];
+  int cc[NI], jj[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int it = tid + 256 * q;
+    const int itc = it < items ? it : 0;
+    cc[q] = mg == 0u ? itc : (int)__umulhi((uint32_t)itc, mg);
+    jj[q] = itc - cc[q] * np8;
+    const float* src = xrow + (long long)cc[q] * HW + p0 + 8 * jj[q];
+    v0[q] = *(const float4*)src; v1[q] = *(const float4*)(src + 4);
+  }
+  if (sigma != 0.f) {
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const long long e = (long long)cc[q] * HW + p0 + 8 * jj[q];     // first element of the pair (a multiple of 8)
+      float4 z0, z1;
+      if (nzrow != nullptr) { z0 = *(const float4*)(nzrow + e); z1 = *(const float4*)(nzrow + e + 4); }
+      else noise_normal8(a.xs.seed, rstep, STREAM_NOISE_XP + net, gs, (uint32_t)(e >> 3), z0, z1);
+      v0[q].x = fmaf(z0.x, sigma, v0[q].x); v0[q].y = fmaf(z0.y, sigma, v0[q].y);
+      v0[q].z = fmaf(z0.z, sigma, v0[q].z); v0[q].w = fmaf(z0.w, sigma, v0[q].w);
+      v1[q].x = fmaf(z1.x, sigma, v1[q].x); v1[q].y = fmaf(z1.y, sigma, v1[q].y);
+      v1[q].z = fmaf(z1.z, sigma, v1[q].z); v1[q].w = fmaf(z1.w, sigma, v1[q].w);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    if (tid + 256 * q < items) {
+      float* d = slab + cc[q] * C0A_SP + 8 * jj[q];
+      *(float4*)d = v0[q]; *(float4*)(d + 4) = v1[q];
+      if (xnrow != nullptr) {
+        float* g = xnrow + (long long)cc[q] * HW + p0 + 8 * jj[q];
+        *(float4*)g = v0[q]; *(float4*)(g + 4) = v1[q];
+      }
+    }
+  }
+  // conv0's split fragments of the first two k-steps: requested here (the tile's values have left the registers), they
+  // land under the zero fill and the barrier -- requested at kernel start they cost 48 registers through phase 1 and the
+  // kernel one workgroup per SIMD pair less
+  uint4 bw[2][6];
+#pragma unroll
+  for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bw[kq][i] = wq[(((kq < KQ0 ? kq : 0) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
+  // bands C .. 16 KQ0 - 1 meet zero weights but must be finite; so must the pixels of a partial tile
+  for (int i = C * C0A_SP + tid; i < KQ0 * 16 * C0A_SP; i += 256) slab[i] = 0.f;
+  if (npx < 128)
+    for (int i = tid; i < C * (128 - npx); i += 256) { const int c = i / (128 - npx); slab[c * C0A_SP + npx + (i - c * (128 - npx))] = 0.f; }
+  __syncthreads();
+  // ---- phase 2
+  if (32 * wave >= npx) return;                                         // (uniform) a tile without pixels
+  f32x16 z0 = zero16(), z1 = zero16();
+  const float* ap = slab + 8 * hh * C0A_SP + 32 * wave + l31;
+  float rn[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rn[j] = ap[j * C0A_SP];
+#pragma unroll
+  for (int kq = 0; kq < KQMAX; ++kq) {
+    if (kq < KQ0) {                                                     // uniform
+      uint4 A1, A2, A3;
+      a_split(make_float4(rn[0], rn[1], rn[2], rn[3]), make_float4(rn[4], rn[5], rn[6], rn[7]), A1, A2, A3);
+      if (kq + 1 < KQ0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rn[j] = ap[((kq + 1) * 16 + j) * C0A_SP];
+      }
+      const uint4 (&b)[6] = bw[kq & 1];
+      z0 = mfma_b3(A1, A2, A3, b[0], b[2], b[4], z0);
+      z1 = mfma_b3(A1, A2, A3, b[1], b[3], b[5], z1);
+      if (kq + 2 < KQ0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bw[kq & 1][i] = wq[(((kq + 2) * 3 + (i >> 1)) * 2 + (i & 1)) * 64];
+      }
+    }
+  }
+  const float* bias = a.b + (long long)net * a.pstride;
+  const float bv0 = bias[l31], bv1 = bias[32 + l31];
+  float* out = a.a0 + (((long long)net * a.n + s) * HW + p0 + 32 * wave) * 64;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = acc_row(r, lane);
+    if (32 * wave + m < npx) {
+      out[(long long)m * 64 + l31] = z0[r] + bv0;
+      out[(long long)m * 64 + 32 + l31] = z1[r] + bv1;
+    }
+  }
+}
+
+bool conv0a_ok(int C, int HW) {
+  return switches().conv0a != 0 && C >= 1 && C <= 128 && (HW & 7) == 0 && HW >= 8;
+}
+
+hipError_t launch_conv0a_fwd(int nets, int n, int C, int HW, const XSrc& xs, const float* w0b3, long long w0b3_ns,
+                             const float* b, long long pstride, float* a0, float* xn, hipStream_t st) {
+  if (!conv0a_ok(C, HW)) return hipErrorInvalidValue;
+  Conv0aArgs a;
+  a.xs = xs; a.w0b3 = w0b3; a.w0b3_ns = w0b3_ns; a.b = b; a.pstride = pstride; a.a0 = a0; a.xn = xn;
+  a.n = n; a.C = C; a.HW = HW;
+  const int KQ0 = (C + 15) / 16;
+  const size_t lds = (size_t)KQ0 * 16 * C0A_SP * 4;
+  static DevOnce attr_once;
+  hipError_t e = ensure_max_lds(attr_once, conv0a_fwd_kernel<4>, conv0a_fwd_kernel<8>);
+  if (e != hipSuccess) return e;
+  dim3 grid((HW + 127) / 128, n, nets);
+  if (KQ0 <= 4) hipLaunchKernelGGL((conv0a_fwd_kernel<4>), grid, dim3(256), lds, st, a);
+  else          hipLaunchKernelGGL((conv0a_fwd_kernel<8>), grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // weight gradient.  One workgroup walks its samples; per sample the [C][HW] slab of xn is staged
 // in LDS (row stride odd => conflict-free column reads), da0 rows come straight from HBM/L2 in
 // double-buffered batches of 8 pixel pairs.

@@ -2092,8 +2092,13 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
 //  CU, or -- NW = 8 -- one eight-wave workgroup that has the CU to itself)
 //  TPW = pixel tiles per wave of the tap loop: NW * TPW / 2 tiles of 32 pixels -- 4 (windows up to 128 pixels: NW = 4 with
 //  TPW = 2, or NW = 8 with TPW = 1) or 8 (NW = 8, TPW = 2: windows up to 256 pixels, e.g. BASELINE configs[4]'s 15 x 15)
-template <int MODE, int MTW, int TAIL = 0, int NW = 4, int TPW = 8 / NW>
-__global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
+//  KSG (MODE 0 / 1, one sample per workgroup, at most four pixel tiles): the GENERAL forward / data-gradient kernel with
+//  the per-sample kernels' barrier-free tap loop (conv3_taps_ks: wave = (pixel half, channel half), fragments L2 ->
+//  registers a tap ahead, the halves folded through LDS) instead of the LDS-staged weights with two workgroup barriers
+//  per tap -- what conv2 takes on windows the fused kernels do not reach (the reference's 20 x 20: 10 x 10 maps).
+template <int MODE, int MTW, int TAIL = 0, int NW = 4, int TPW = 8 / NW, bool KSG = false>
+__global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
+  static_assert(!KSG || (MODE < 2 && MTW == 1 && TAIL == 0 && NW == 4 && TPW == 2), "KSG: four waves, S = 1, four tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 64 * NW;
   constexpr int KMT = NW * TPW / 2;        // pixel tiles of the per-sample kernels
@@ -2120,7 +2125,7 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
   int abase[MTW];
   f32x16 acc[MTW][2];
   // per-sample fused kernels (S == 1, MTW == 1): the barrier-free tap loop, see conv3_taps_ks
-  constexpr bool KS = (MODE >= 2);
+  constexpr bool KS = (MODE >= 2) || KSG;
   // General kernels: slot t of wave w holds pixel tile w + NW t.  Eight waves sit two to a SIMD (w and w + 4), so when
   // the last round has 1 or 5 tiles, SIMD 0 carries one tile more than the others (20 x 20 windows: 13 tiles = 4, 3, 3,
   // 3): that round's last tile is then SHARED by its wave (output-channel tile 0) and the next wave (channel tile 1, in
@@ -2465,6 +2470,21 @@ __global__ __launch_bounds__(64 * NW, (MODE >= 2 && NW == 4 ? 2 : 1)) void conv3
       }
       }
     }
+  } else if constexpr (KS) {      // (MODE 1 with the barrier-free tap loop: this wave's tile `ot`, both channel tiles, after the fold)
+    float* out = a.out + (long long)net * a.out_ns;
+    const int nvalid = (a.n - s0 < S ? a.n - s0 : S) * PX;
+    if (ot < MT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = ot * 32 + acc_row(r, lane);
+        if (m < nvalid) {
+          const float* p = img + (size_t)lut[m] * CS;
+          float* o = out + ((size_t)s0 * HW + m) * 64;
+#pragma unroll
+          for (int i = 0; i < TPW; ++i) o[32 * (nt0 + i) + l31] = own[i][r] + p[32 * (nt0 + i) + l31];
+        }
+      }
+    }
   } else {
     float* out = a.out + (long long)net * a.out_ns;
     const int nvalid = (a.n - s0 < S ? a.n - s0 : S) * PX;  // rows that map to real samples
@@ -2600,12 +2620,14 @@ bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p) {
     const double cost = mfma + overhead;
     if (force_s ? (S == force_s) : (cost < best - 1e-9)) {
       best = cost; p->S = S; p->MTW = split ? 0 : MTW; p->lds = lds; p->nw = 4; ok = true;
+      // one sample per workgroup, one tile per wave, two workgroups per CU: the barrier-free tap loop (KSG)
+      p->ks = (!split && S == 1 && MTW == 1 && resident >= 2 && switches().conv3_ks != 0) ? 1 : 0;
       // One workgroup per CU and several tiles per wave (20 x 20 windows: a 131 KB image, 13 pixel tiles): EIGHT waves
       // -- two per SIMD, so that a wave's LDS reads, barriers and stores have something to hide under (round 5;
       // CMLPL_CONV3_NW8=0: four waves as before)
       const size_t lds8 = conv3_lds(S, H, W, (MT + 7) / 8, 8);
       if (!split && resident == 1 && MTW >= 2 && lds8 <= LDS_MAX && switches().conv3_nw8 != 0) {
-        p->nw = 8; p->MTW = (MT + 7) / 8; p->lds = lds8;
+        p->nw = 8; p->MTW = (MT + 7) / 8; p->lds = lds8; p->ks = 0;
       }
     }
   }
@@ -2639,6 +2661,14 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
+  if (pl.ks) {
+    static DevOnce attr_ks;
+    hipError_t e = ensure_max_lds(attr_ks, conv3x3_kernel<0, 1, 0, 4, 2, true>, conv3x3_kernel<1, 1, 0, 4, 2, true>);
+    if (e != hipSuccess) return e;
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_kernel<0, 1, 0, 4, 2, true>), grid, dim3(256), pl.lds, st, a);
+    else           hipLaunchKernelGGL((conv3x3_kernel<1, 1, 0, 4, 2, true>), grid, dim3(256), pl.lds, st, a);
+    return hipGetLastError();
+  }
   if (pl.nw == 8) {   // (MTW 1 .. 2: at most 16 pixel tiles in a 160 KB image)
     if (pl.MTW > 2) return hipErrorInvalidValue;
     if (mode == 0) return pl.MTW == 1 ? launch_conv3_t<0, 1, 8>(a, grid, pl.lds, st) : launch_conv3_t<0, 2, 8>(a, grid, pl.lds, st);

@@ -77,7 +77,7 @@ hipError_t launch_extract_patches(const float* cube, int rows, int cols, int C, 
 // ---- conv3x3.hip
 hipError_t launch_pack_weights(int nets, const float* params, long long pstride, const PackInfo& pi, float* packed,
                                hipStream_t st);
-struct Conv3Plan { int S, MTW; size_t lds; int nw; };   // nw: waves of the workgroup (4, or 8: one workgroup per CU, several tiles per wave)
+struct Conv3Plan { int S, MTW; size_t lds; int nw; int ks; };   // nw: waves of the workgroup (4, or 8: one workgroup per CU, several tiles per wave); ks: the barrier-free tap loop (S = 1, one tile per wave)
 bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p);
 // mode 0: out = avgpool2(relu(conv(in)+bias+in)), mask_out = relu bits; in [nets][n][H*W][64]
 // mode 1: in = dpool [nets][n][(H/2)*(W/2)][64] + mask_in; out = dgrad(dz) + dz, [nets][n][H*W][64]
@@ -124,6 +124,11 @@ hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1,
 // ---- conv0.hip
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w0t, long long w0t_ns,
                             const float* b, long long pstride, float* a0, hipStream_t st);
+// augmentation + conv0 in one launch on the split-bf16 MFMA (general path; windows of a multiple of 8 pixels, C <= 128):
+// raw rows in (xs), a0 out, the augmented rows to xn (or null); w0b3 = the packed split fragments of conv0 (pack_off_w0b3)
+bool conv0a_ok(int C, int HW);
+hipError_t launch_conv0a_fwd(int nets, int n, int C, int HW, const XSrc& xs, const float* w0b3, long long w0b3_ns,
+                             const float* b, long long pstride, float* a0, float* xn, hipStream_t st);
 int plan_conv0_wgrad_G(int n, int C, int HW);
 // deterministic sum of per-workgroup weight-gradient partials, up to 3 tensors in one launch
 struct ReduceProb { const float* part; float* dW; float* db; int G, PS, mode, C, blk0, el; };
@@ -184,6 +189,8 @@ struct Switches {
   int fuse_conv0, fuse_conv0_bwd, fuse_tail, fuse_spe;        // CMLPL_FUSE_*: 0 = the unfused round-1 kernels (default 1)
   int fuse_big;                                               // CMLPL_FUSE_BIG: 0 = windows of 129 .. 256 pixels on the general kernels (default 1: eight-tile per-sample kernels)
   int conv3_nw8;                                              // CMLPL_CONV3_NW8: 0 = the general 3x3 kernels always with four waves (default 1)
+  int conv0a;                                                 // CMLPL_CONV0A: 0 = augment_kernel + conv0_fwd_kernel (f32 MFMA) on the general path (default 1: one fused split-bf16 launch)
+  int conv3_ks;                                               // CMLPL_CONV3_KS: 0 = the general 3x3 kernels always with LDS-staged tap weights (default 1: barrier-free loop at S = 1, one tile per wave)
   int ks8;                                                    // CMLPL_KS8: eight-wave per-sample workgroups never (0) / always (1) / when the grid fits the CUs (-1)
   int conv3_s, conv0_dma, conv0_ps;                           // CMLPL_CONV3_S (0 = planner), CMLPL_CONV0_DMA (default 1), CMLPL_CONV0_PS (0 = planner)
   int wgrad3_u, wgrad3_cspl, wgrad3_r, wgrad3_ru, wgrad3_rg, wgrad3_pg1, wgrad3_pg2, wgrad3_b3, wgrad3_pair;   // CMLPL_WGRAD3_*
@@ -197,7 +204,7 @@ inline Switches read_switches() {
     Switches w;
     w.fuse_conv0 = env("CMLPL_FUSE_CONV0", 1); w.fuse_conv0_bwd = env("CMLPL_FUSE_CONV0_BWD", 1);
     w.fuse_tail = env("CMLPL_FUSE_TAIL", 1); w.fuse_spe = env("CMLPL_FUSE_SPE", 1);
-    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1); w.conv3_nw8 = env("CMLPL_CONV3_NW8", 1);
+    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1); w.conv3_nw8 = env("CMLPL_CONV3_NW8", 1); w.conv3_ks = env("CMLPL_CONV3_KS", 1); w.conv0a = env("CMLPL_CONV0A", 1);
     w.conv3_s = env("CMLPL_CONV3_S", 0); w.conv0_dma = env("CMLPL_CONV0_DMA", 1); w.conv0_ps = env("CMLPL_CONV0_PS", 0);
     w.wgrad3_u = env("CMLPL_WGRAD3_U", 0); w.wgrad3_cspl = env("CMLPL_WGRAD3_CSPL", 0); w.wgrad3_r = env("CMLPL_WGRAD3_R", 1);
     w.wgrad3_ru = env("CMLPL_WGRAD3_RU", 0); w.wgrad3_rg = env("CMLPL_WGRAD3_RG", 0);

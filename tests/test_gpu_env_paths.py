@@ -177,6 +177,16 @@ def test_unfused_conv0_kernels_pass_on_a_fusable_shape():
 
 J_UNFSPE = _job("conv", "spe-unfused", {"CMLPL_FUSE_SPE": "0"}, ["tests/test_gpu_step.py", "-k", "b2_64 or b5"])
 
+J_GEN_R5 = _job("conv", "general-r5", {"CMLPL_CONV0A": "0", "CMLPL_CONV3_KS": "0"},
+                ["tests/test_gpu_ops.py", "tests/test_gpu_step.py", "-k", "(forward_backward and (P or W8 or W16)) or p_short or non_finite"])
+
+
+def test_round5_general_path_kernels_pass_parity():
+    """augment_kernel + conv0_fwd_kernel (f32-input MFMA: what windows that are not a multiple of 8 pixels, or more than
+    128 channels, still take) and the LDS-staged tap weights of the one-tile general 3x3 kernels, instead of round 6's
+    conv0a_fwd_kernel / barrier-free tap loop, on the reference's own 20 x 20 window and on 8 x 8 / 16 x 16 ones"""
+    _run(J_GEN_R5)
+
 
 def test_unfused_spectral_branch_passes_step_parity():
     _run(J_UNFSPE)

@@ -365,6 +365,7 @@ class DistTrainEngine(TrainEngine):
         self.dfw_part = self.dfeat_l[1, bt_l:] if alias else self._dfw_part[:self.btu_g * FEAT_DIM].view(self.btu_g, FEAT_DIM)
         self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
         self._bound = (bt_l, btu_l)
+        self._args = None           # the stage calls' ready-made argument tuples (see _stage_args)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -383,6 +384,44 @@ class DistTrainEngine(TrainEngine):
         b.ptr[0], b.ptr[1] = self.ptr
         return b
 
+    def _stage_args(self):
+        """The seven stage calls' argument tuples for the bound shard, built ONCE: every pointer into the engine's own
+        buffers as a ready-made ctypes instance (ctypes passes instances through without conversion), what changes from
+        step to step in small ctypes cells that the stages update in place.  Marshalling fourteen arguments per call,
+        seven calls per step, was 90 of the sharded step's ~175 us of host time -- more than the device leaves room for
+        at a rank's shard (profiles/r06_final_dist_overhead.txt)."""
+        vp, P = C.c_void_p, lambda t: C.c_void_p(t.data_ptr())
+        c = self._cells = dict(step=C.c_uint64(0), smooth=C.c_int(0), adap=C.c_float(0.0), dm=vp(None), st=vp(None),
+                               adam_t=C.c_int64(1), scal=vp(None), batch=_lib.Batch())
+        sh, hp, bt, sd = C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard)
+        banks, g = C.byref(self._banks()), C.byref(self._gathered())
+        ws, wsn = P(self.workspace), C.c_size_t(self.workspace.numel())
+        lws, lwsn = P(self.loss_ws), C.c_size_t(self.loss_ws.numel())
+        one, seed, live = C.c_int(1), C.c_uint64(self.seed), C.c_int64(self.live)
+        par, pk = P(self.params), P(self.packed)
+        lib = self.lib
+        self._args = dict(
+            spectral=(lib.cmlpl_forward_spectral, (sh, hp, bt, sd, par, seed, c["step"], P(self.feat_l), P(self.labels_f), ws, wsn, c["st"])),
+            spatial=(lib.cmlpl_forward_spatial, (sh, hp, bt, sd, par, pk, c["dm"], one, seed, c["step"], P(self.logits_l), ws, wsn, c["st"])),
+            phase1=(lib.cmlpl_loss_phase1_g, (sh, sd, g, banks, c["smooth"], c["adap"], hp, P(self.dlogits_l), P(self.dfeat_l),
+                                              P(self.probs_l), lws, lwsn, c["st"])),
+            phase2=(lib.cmlpl_loss_phase2_g, (sh, sd, g, banks, c["smooth"], c["adap"], hp, P(self.probs_g), C.c_int(self.btu_l),
+                                              c["scal"], P(self.dfeat_l), P(self.dfw_part), lws, lwsn, c["st"])),
+            backward_data=(lib.cmlpl_backward_data, (sh, hp, bt, sd, par, pk, c["dm"], one, seed, c["step"], P(self.dlogits_l),
+                                                     ws, wsn, c["st"])),
+            backward_weights=(lib.cmlpl_backward_weights, (sh, hp, bt, sd, par, pk, c["dm"], one, seed, c["step"], P(self.dlogits_l),
+                                                           P(self.dfeat_l), P(self.grads), live, ws, wsn, c["st"])),
+            update=(lib.cmlpl_adam_step, (sh, C.c_int(2), par, C.c_int64(self.P), P(self.grads), live, P(self.m), P(self.v),
+                                          c["adam_t"], hp, pk, c["st"])))
+        return self._args
+
+    def _call(self, name):
+        fn, args = (self._args or self._stage_args())[name]
+        self._cells["st"].value = torch.cuda.current_stream(self.device).cuda_stream
+        rc = fn(*args)
+        if rc != 0:
+            raise _lib.CmlplError(fn.__name__, rc)
+
     # ------------------------------------------------------------------ stages (no communication inside)
     def stage_spectral(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True,
                        lab_idx=None, unl_idx=None):
@@ -399,8 +438,7 @@ class DistTrainEngine(TrainEngine):
             raise ValueError("bank smaller than the global batch")
         self._bind(bt_l, btu_l)
         n_l = bt_l + btu_l
-        st = self._stream()
-        self._ensure_packed(st)
+        self._ensure_packed(self._stream())
         keep = None
         noise8 = None
         if noise is not None:
@@ -409,29 +447,31 @@ class DistTrainEngine(TrainEngine):
         if dropmask is not None:
             _chk_f32(dropmask, (2, n_l, s.cls_in), "dropmask")
         self._cur_row = self.step_count % self.hist_rows
-        batch = _lib.Batch(XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), Y.data_ptr(), noise8, bt_l, btu_l,
-                           None if lab_idx is None else lab_idx.data_ptr(), None if unl_idx is None else unl_idx.data_ptr())
-        self._ctx = dict(epoch=epoch, batch_index=batch_index, apply_update=apply_update, dropmask=dropmask,
-                         smooth=1 if self.hp.smooth_gate(epoch, batch_index) else 0,
-                         adap=float(self.hp.thr * self.hp.adap_thr(epoch)),
-                         keep=(keep, XPl, Xl, Y, XPu, Xu, noise, lab_idx, unl_idx), batch=batch)
+        if self._args is None:
+            self._stage_args()
+        c = self._cells
+        b = c["batch"]          # (updated in place: the stage calls hold a reference to this record)
+        b.d_xpl, b.d_xl, b.d_xpu, b.d_xu, b.d_labels = XPl.data_ptr(), Xl.data_ptr(), XPu.data_ptr(), Xu.data_ptr(), Y.data_ptr()
+        b.noise8, b.bt, b.btu = noise8, bt_l, btu_l
+        b.d_lab_idx = None if lab_idx is None else lab_idx.data_ptr()
+        b.d_unl_idx = None if unl_idx is None else unl_idx.data_ptr()
+        c["step"].value = self.step_count
+        c["smooth"].value = 1 if self.hp.smooth_gate(epoch, batch_index) else 0
+        c["adap"].value = float(self.hp.thr * self.hp.adap_thr(epoch))
+        c["dm"].value = None if dropmask is None else dropmask.data_ptr()
+        c["adam_t"].value = self.adam_t + 1
+        c["scal"].value = self.scalar_hist.data_ptr() + 64 * self._cur_row       # this step's row of the logging ring
+        self._banks()           # (the record's pointers: ptr[] of this step)
+        self._ctx = dict(apply_update=apply_update, keep=(keep, XPl, Xl, Y, XPu, Xu, noise, lab_idx, unl_idx, dropmask))
         # the spectral branch of both networks: augmented spectra -> feat_spe -> ReLU -> L2 norm.  feat | labels land
         # directly in this rank's block of the exchange buffer; their all-gather starts behind this stage
-        _lib.check("cmlpl_forward_spectral", lib.cmlpl_forward_spectral(
-            C.byref(self.cshape), C.byref(self._chp), C.byref(batch), C.byref(self.cshard), self.params.data_ptr(),
-            self.seed, self.step_count, self.feat_l.data_ptr(), self.labels_f.data_ptr(), self.workspace.data_ptr(),
-            self.workspace.numel(), st))
+        self._call("spectral")
 
     def stage_spatial(self):
         # augmentation of the patches + the convolution stack + head of both networks -> this rank's logits; the raw rows
         # are handed over as they are (the fused forward leaves the augmented rows in the workspace for the backward
         # stages: no other forward may use this workspace in between)
-        c, st = self._ctx, self._stream()
-        dm = c["dropmask"]
-        _lib.check("cmlpl_forward_spatial", self.lib.cmlpl_forward_spatial(
-            C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard), self.params.data_ptr(),
-            self.packed.data_ptr(), None if dm is None else dm.data_ptr(), 1, self.seed, self.step_count,
-            self.logits_l.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), st))
+        self._call("spatial")
 
     def _gathered(self) -> _lib.Gathered:
         g = self.__dict__.get("_c_gathered")
@@ -442,49 +482,25 @@ class DistTrainEngine(TrainEngine):
 
     def stage_phase1(self):
         # the loss kernels read the global rows where the all-gather left them (rank-major blocks): no re-ordering copy
-        c, st = self._ctx, self._stream()
-        banks, g = self._banks(), self._gathered()
         self._unpacked = False
-        _lib.check("cmlpl_loss_phase1_g", self.lib.cmlpl_loss_phase1_g(
-            C.byref(self.cshape), C.byref(self.cshard), C.byref(g), C.byref(banks), c["smooth"], c["adap"],
-            C.byref(self._chp), self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.probs_l.data_ptr(),
-            self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
+        self._call("phase1")
 
     def stage_phase2(self):
-        c, st = self._ctx, self._stream()
-        banks, g = self._banks(), self._gathered()
-        _lib.check("cmlpl_loss_phase2_g", self.lib.cmlpl_loss_phase2_g(
-            C.byref(self.cshape), C.byref(self.cshard), C.byref(g), C.byref(banks), c["smooth"], c["adap"],
-            C.byref(self._chp), self.probs_g.data_ptr(), self.btu_l, self.scalars.data_ptr(), self.dfeat_l.data_ptr(),
-            self.dfw_part.data_ptr(), self.loss_ws.data_ptr(), self.loss_ws.numel(), st))
+        self._call("phase2")
 
     def stage_backward_data(self):
         # everything of the backward that needs dlogits alone (the reduce-scatter of the column-side feature gradient is
         # still in flight): data-gradient chain, conv0 and 3x3 weight-gradient partials
-        c, st = self._ctx, self._stream()
-        dm = c["dropmask"]
-        _lib.check("cmlpl_backward_data", self.lib.cmlpl_backward_data(
-            C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard), self.params.data_ptr(),
-            self.packed.data_ptr(), None if dm is None else dm.data_ptr(), 1, self.seed, self.step_count,
-            self.dlogits_l.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), st))
+        self._call("backward_data")
 
     def stage_backward_weights(self):
         # dfeat is complete (this rank's slice of the reduce-scatter has arrived): dy takes its share, partials are
         # reduced, classifier / feat_spe weight gradients -> the gradient bucket
-        c, st = self._ctx, self._stream()
-        dm = c["dropmask"]
-        _lib.check("cmlpl_backward_weights", self.lib.cmlpl_backward_weights(
-            C.byref(self.cshape), C.byref(self._chp), C.byref(c["batch"]), C.byref(self.cshard), self.params.data_ptr(),
-            self.packed.data_ptr(), None if dm is None else dm.data_ptr(), 1, self.seed, self.step_count,
-            self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr(), self.grads.data_ptr(), self.live,
-            self.workspace.data_ptr(), self.workspace.numel(), st))
+        self._call("backward_weights")
 
     def stage_update(self):
-        c, st = self._ctx, self._stream()
-        if c["apply_update"]:
-            _lib.check("cmlpl_adam_step", self.lib.cmlpl_adam_step(
-                C.byref(self.cshape), 2, self.params.data_ptr(), self.P, self.grads.data_ptr(), self.live,
-                self.m.data_ptr(), self.v.data_ptr(), self.adam_t + 1, C.byref(self._chp), self.packed.data_ptr(), st))
+        if self._ctx["apply_update"]:
+            self._call("update")
             self.adam_t += 1
         p0 = (self.ptr[0] + self.hp.bank_step) % self.Q                 # train.py:234,237
         self.ptr = [p0, (p0 + self.hp.bank_step) % self.Q]

@@ -301,9 +301,16 @@ class DistTrainEngine(TrainEngine):
         """``alias_single=False`` keeps the REAL collectives at world size 1 (separate send / receive buffers, four
         torch.distributed calls per step): what scripts/dist_overhead.py measures the host cost of the calls with."""
         if comm is None:
+            import os
             import torch.distributed as dist
-            comm = TorchDistComm() if (dist.is_available() and dist.is_initialized()) else NoOpComm()
-        if comm.world == 1 and alias_single and isinstance(comm, (TorchDistComm, SingleComm)):
+            if not (dist.is_available() and dist.is_initialized()):
+                comm = NoOpComm()
+            elif os.environ.get("CMLPL_DIST_COMM", "torch") == "rccl" and (dist.get_world_size() > 1 or not alias_single):
+                from .rccl_comm import RcclComm     # the collectives straight on librccl: a few us of host time each
+                comm = RcclComm(device)
+            else:
+                comm = TorchDistComm()
+        if comm.world == 1 and alias_single and not isinstance(comm, NoOpComm) and hasattr(comm, "all_gather"):
             comm = NoOpComm()      # identity collectives: alias instead of launching RCCL copies
         self.comm = comm
         W = self.world = comm.world

@@ -2,6 +2,7 @@
 the HOST?  At world size 1 on one GPU (RCCL initialised):
   TrainEngine                      one C call per step (the single-GPU engine)
   DistTrainEngine, aliased         seven stage calls, the one-rank collectives aliased away (NoOpComm)
+  DistTrainEngine, RCCL direct     the same with the four collectives as direct librccl calls (cmlpl_amd/rccl_comm.py)
   DistTrainEngine, real calls      the same with the four REAL collectives per step (all_gather_into_tensor x 2,
                                    reduce_scatter_tensor, all_reduce through TorchDistComm; separate send / receive buffers)
 host enqueue = wall time to ENQUEUE a step; wall = steps including the final synchronisation; plus the host time of each
@@ -18,6 +19,8 @@ dist.init_process_group("nccl", device_id=dev)
 from cmlpl_amd import NetShape, HyperParams, TrainEngine
 from cmlpl_amd.distributed import DistTrainEngine, TorchDistComm
 from bench import synth, WORKLOADS
+from cmlpl_amd.rccl_comm import RcclComm
+RCCL = RcclComm(dev)
 
 K = 200
 for wl, bt, btu in (("B2", 128, 128), ("B2", 64, 64), ("B5", 8, 64)):
@@ -27,6 +30,8 @@ for wl, bt, btu in (("B2", 128, 128), ("B2", 64, 64), ("B5", 8, 64)):
     walls = []
     for name, make in (("TrainEngine", lambda: TrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088)),
                        ("DistTrainEngine aliased", lambda: DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088)),
+                       ("DistTrainEngine RCCL direct", lambda: DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088,
+                                                                                comm=RCCL, alias_single=False)),
                        ("DistTrainEngine real calls", lambda: DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088,
                                                                                comm=TorchDistComm(), alias_single=False))):
         eng = make()
@@ -42,7 +47,7 @@ for wl, bt, btu in (("B2", 128, 128), ("B2", 64, 64), ("B5", 8, 64)):
         t2 = time.perf_counter()
         walls.append(t2 - t0)
         print(f"  {name:28s} host enqueue {1e6 * (t1 - t0) / K:7.1f} us/step   wall {1e6 * (t2 - t0) / K:7.1f} us/step", flush=True)
-    print(f"  real calls / TrainEngine wall: {walls[2] / walls[0]:.3f}")
+    print(f"  real calls / TrainEngine wall: {walls[3] / walls[0]:.3f}   RCCL direct / TrainEngine wall: {walls[2] / walls[0]:.3f}")
     # ... and the same engine replaying its seven stage graphs (DistStepGraph), the four real calls eager between them
     li, ui = torch.arange(bt, device=dev), torch.arange(btu, device=dev)
     gr = eng.capture(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], li, ui, bt, btu, capacity=K + 20)

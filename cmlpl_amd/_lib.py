@@ -33,7 +33,7 @@ EXPORTS = (
     "cmlpl_source_hash", "cmlpl_dyn_adam", "cmlpl_step_graph_create", "cmlpl_step_graph_launch",
     "cmlpl_step_graph_destroy", "cmlpl_infer_workspace_bytes", "cmlpl_infer_cube", "cmlpl_dist_stage_graph_create",
     "cmlpl_debug_reload_switches", "cmlpl_forward_spectral", "cmlpl_forward_spatial", "cmlpl_backward_data",
-    "cmlpl_backward_weights",
+    "cmlpl_backward_weights", "cmlpl_dist_step", "cmlpl_rccl_bind", "cmlpl_rccl_unbind",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -47,8 +47,8 @@ class CmlplLibraryError(RuntimeError):
 
 class CmlplError(RuntimeError):
     def __init__(self, fn, rc):
-        names = {-1: "CMLPL_E_ARG", -2: "CMLPL_E_SHAPE", -3: "CMLPL_E_WORKSPACE"}
-        what = names.get(rc, f"hipError_t {rc}" if rc > 0 else str(rc))
+        names = {-1: "CMLPL_E_ARG", -2: "CMLPL_E_SHAPE", -3: "CMLPL_E_WORKSPACE", -4: "CMLPL_E_COMM"}
+        what = names.get(rc, f"hipError_t {rc}" if rc > 0 else (f"CMLPL_E_COMM (ncclResult_t {-4 - rc})" if rc < -4 else str(rc)))
         super().__init__(f"{fn} failed: {what}")
         self.rc = rc
 
@@ -146,6 +146,19 @@ class DistIO(C.Structure):
     ]
 
 
+class Collectives(C.Structure):
+    """cmlpl_collectives: a rank's communicator as three C functions + the side stream / events of the asynchronous
+    exchanges (filled by cmlpl_rccl_bind)"""
+    _fields_ = [("ctx", C.c_void_p), ("all_gather", C.c_void_p), ("reduce_scatter", C.c_void_p), ("all_reduce", C.c_void_p),
+                ("side_stream", C.c_void_p), ("events", C.c_void_p * 4)]
+
+
+class DistStepArgs(C.Structure):
+    """cmlpl_dist_step_args: what changes from step to step, by value"""
+    _fields_ = [("step", C.c_uint64), ("adam_t", C.c_int64), ("d_dropmask", C.c_void_p), ("smooth", C.c_int32),
+                ("adap_mask", C.c_float), ("apply_update", C.c_int32), ("scalars_row", C.c_int32)]
+
+
 STAGE_IDS = {"spectral": 0, "spatial": 1, "phase1": 2, "phase2": 3, "backward_data": 4, "backward_weights": 5, "update": 6}
 
 _lib = None
@@ -230,6 +243,9 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_dyn_adam.argtypes = [HP, i64, C.POINTER(f32), C.POINTER(f32)]
     lib.cmlpl_step_graph_create.argtypes = [SP, HP, C.POINTER(StepIO), vp, C.POINTER(vp)]
     lib.cmlpl_dist_stage_graph_create.argtypes = [SP, HP, C.POINTER(DistIO), i32, vp, C.POINTER(vp)]
+    lib.cmlpl_dist_step.argtypes = [SP, HP, C.POINTER(DistIO), C.POINTER(DistStepArgs), C.POINTER(Collectives), vp]
+    lib.cmlpl_rccl_bind.argtypes = [C.c_char_p, vp, C.POINTER(Collectives)]
+    lib.cmlpl_rccl_unbind.argtypes = [C.POINTER(Collectives)]
     lib.cmlpl_step_graph_launch.argtypes = [vp, vp]
     lib.cmlpl_step_graph_destroy.argtypes = [vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]

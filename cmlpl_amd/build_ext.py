@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcmlpl_hip.so")
-SOURCES = ["api.hip", "augment.hip", "conv0.hip", "conv3x3.hip", "dense.hip", "head.hip", "loss.hip", "memobank.hip", "ntxent.hip", "optim.hip", "wgrad3x3.hip"]
+SOURCES = ["api.hip", "augment.hip", "conv0.hip", "conv3x3.hip", "dense.hip", "dist.hip", "head.hip", "loss.hip", "memobank.hip", "ntxent.hip", "optim.hip", "wgrad3x3.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -66,7 +66,7 @@ def build(force=False, verbose=True, jobs=4):
         if len(procs) >= jobs:
             _drain(procs, verbose)
     _drain(procs, verbose)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)

@@ -32,6 +32,7 @@ same global batch up to fp32 summation order (tests/test_distributed_*.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -142,6 +143,58 @@ def init_distributed(backend: str = "nccl", device: Optional[torch.device] = Non
                                        "local rank its own device (device = cuda:LOCAL_RANK)")
             seen[key] = r
     return dist
+
+
+def pick_comm(device, timeout_s: float = 120.0):
+    """The communicator of a sharded engine on an initialised process group.  Backend nccl: the collectives straight
+    on RCCL (``RcclComm``: the whole step then runs as ONE C call, cmlpl_dist_step) -- after a checked start-up: every
+    rank builds it under a watchdog and runs its three collectives on random data against torch.distributed's; all
+    ranks must agree that they match (an all-reduce(MIN) through torch.distributed), otherwise every rank falls back to
+    ``TorchDistComm`` (the step driven stage by stage from Python) and says so on stderr.  CMLPL_DIST_COMM=torch skips
+    the attempt, =rccl makes a failed check an error.  Any other backend (gloo rehearsals): ``TorchDistComm``."""
+    import sys
+    import torch.distributed as dist
+    want = os.environ.get("CMLPL_DIST_COMM", "auto")
+    if want == "torch" or dist.get_backend() != "nccl":
+        return TorchDistComm()
+    W, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device(device)
+    rc, ok, why = None, 1.0, ""
+    guard = _fail_after(timeout_s, "the start-up of the direct RCCL communicator (CMLPL_DIST_COMM=torch skips it)")
+    try:
+        try:
+            from .rccl_comm import RcclComm
+            rc = RcclComm(dev)
+            g = torch.Generator(device="cpu").manual_seed(77 + rank)
+            a = torch.randn(1024 * W, generator=g).to(dev)
+            o1, o2 = torch.empty(1024 * W * W, device=dev), torch.empty(1024 * W * W, device=dev)
+            rc.all_gather(o1, a); dist.all_gather_into_tensor(o2, a)
+            s1, s2 = torch.empty(1024, device=dev), torch.empty(1024, device=dev)
+            h = rc.reduce_scatter(s1, a, async_op=True); h.wait(); dist.reduce_scatter_tensor(s2, a.clone())
+            r1, r2 = a.clone(), a.clone()
+            rc.all_reduce(r1); dist.all_reduce(r2)
+            torch.cuda.synchronize(dev)
+            if not (torch.equal(o1, o2) and torch.allclose(s1, s2, rtol=1e-5, atol=1e-5) and torch.allclose(r1, r2, rtol=1e-5, atol=1e-5)):
+                ok, why = 0.0, "its collectives differ from torch.distributed's"
+        except Exception as e:       # noqa: BLE001  (a missing symbol, an RCCL error: the fallback is the answer)
+            ok, why = 0.0, f"{type(e).__name__}: {e}"
+        t = torch.tensor([ok], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        all_ok = float(t.item()) == 1.0
+    finally:
+        guard.cancel()
+    if all_ok:
+        return rc
+    if want == "rccl":
+        raise DistStartupError(f"rank {rank}: CMLPL_DIST_COMM=rccl but the direct RCCL communicator failed its check ({why or 'on another rank'})")
+    sys.stderr.write(f"cmlpl_amd.distributed: rank {rank}: direct RCCL communicator not used ({why or 'failed on another rank'}); "
+                     "collectives go through torch.distributed\n")
+    if rc is not None:
+        try:
+            rc.close()
+        except Exception:            # noqa: BLE001
+            pass
+    return TorchDistComm()
 
 
 class TorchDistComm:
@@ -301,18 +354,18 @@ class DistTrainEngine(TrainEngine):
         """``alias_single=False`` keeps the REAL collectives at world size 1 (separate send / receive buffers, four
         torch.distributed calls per step): what scripts/dist_overhead.py measures the host cost of the calls with."""
         if comm is None:
-            import os
             import torch.distributed as dist
             if not (dist.is_available() and dist.is_initialized()):
                 comm = NoOpComm()
-            elif os.environ.get("CMLPL_DIST_COMM", "torch") == "rccl" and (dist.get_world_size() > 1 or not alias_single):
-                from .rccl_comm import RcclComm     # the collectives straight on librccl: a few us of host time each
-                comm = RcclComm(device)
+            elif dist.get_world_size() == 1 and alias_single:
+                comm = NoOpComm()
             else:
-                comm = TorchDistComm()
+                comm = pick_comm(device)
         if comm.world == 1 and alias_single and not isinstance(comm, NoOpComm) and hasattr(comm, "all_gather"):
             comm = NoOpComm()      # identity collectives: alias instead of launching RCCL copies
         self.comm = comm
+        self.native_step = os.environ.get("CMLPL_DIST_NATIVE", "1") != "0"
+        self.async_exchanges = None      # the one-call step: None = the communicator's default (RcclComm.native)
         W = self.world = comm.world
         self.rank = comm.rank
         super().__init__(shape, labeled_batch_size, unlabeled_batch_size, hp, device, seed,
@@ -373,6 +426,7 @@ class DistTrainEngine(TrainEngine):
         self.cshard = _lib.Shard(self.bt_g, self.btu_g, self.rank * bt_l, bt_l, self.rank * btu_l, btu_l)
         self._bound = (bt_l, btu_l)
         self._args = None           # the stage calls' ready-made argument tuples (see _stage_args)
+        self._io = None             # cmlpl_dist_step's records (see _step_io)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -430,9 +484,10 @@ class DistTrainEngine(TrainEngine):
             raise _lib.CmlplError(fn.__name__, rc)
 
     # ------------------------------------------------------------------ stages (no communication inside)
-    def stage_spectral(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True,
-                       lab_idx=None, unl_idx=None):
-        s, lib = self.shape, self.lib
+    def _begin_step(self, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise=None, dropmask=None, apply_update=True,
+                    lab_idx=None, unl_idx=None):
+        """checks, the shard's views, and what changes from step to step written into the kept ctypes cells"""
+        s = self.shape
         g = self._graph() if self._graph is not None else None
         if g is not None and g.pending > 0:
             raise RuntimeError(f"{g.pending} programmed graph replays are pending: launch them (or program() anew) "
@@ -470,6 +525,9 @@ class DistTrainEngine(TrainEngine):
         c["scal"].value = self.scalar_hist.data_ptr() + 64 * self._cur_row       # this step's row of the logging ring
         self._banks()           # (the record's pointers: ptr[] of this step)
         self._ctx = dict(apply_update=apply_update, keep=(keep, XPl, Xl, Y, XPu, Xu, noise, lab_idx, unl_idx, dropmask))
+
+    def stage_spectral(self, *args, **kw):
+        self._begin_step(*args, **kw)
         # the spectral branch of both networks: augmented spectra -> feat_spe -> ReLU -> L2 norm.  feat | labels land
         # directly in this rank's block of the exchange buffer; their all-gather starts behind this stage
         self._call("spectral")
@@ -508,6 +566,10 @@ class DistTrainEngine(TrainEngine):
     def stage_update(self):
         if self._ctx["apply_update"]:
             self._call("update")
+        self._end_step()
+
+    def _end_step(self):
+        if self._ctx["apply_update"]:
             self.adam_t += 1
         p0 = (self.ptr[0] + self.hp.bank_step) % self.Q                 # train.py:234,237
         self.ptr = [p0, (p0 + self.hp.bank_step) % self.Q]
@@ -540,8 +602,50 @@ class DistTrainEngine(TrainEngine):
              dropmask: Optional[torch.Tensor] = None, apply_update: bool = True, lab_idx=None, unl_idx=None) -> None:
         """Per-rank inputs: this rank's bt/W labelled and btu/W unlabelled rows (noise / dropmask, when given,
         are this rank's slices too) -- or, with lab_idx / unl_idx, the resident splits and this rank's row indices."""
-        drive_step(self, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update,
-                   lab_idx=lab_idx, unl_idx=unl_idx)
+        coll = self._native_comm()
+        if coll is False:           # a communicator only Python can drive (torch.distributed, the tests' stand-ins)
+            drive_step(self, self.comm, XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update,
+                       lab_idx=lab_idx, unl_idx=unl_idx)
+            return
+        # the whole step as ONE C call: stages and collectives enqueued back to back (cmlpl_dist_step, csrc/dist.hip)
+        self._begin_step(XPl, Xl, Y, XPu, Xu, epoch, batch_index, noise, dropmask, apply_update, lab_idx=lab_idx, unl_idx=unl_idx)
+        io, a, c = self._step_io()
+        io.batch, io.banks = c["batch"], self._c_banks
+        a.step, a.adam_t, a.d_dropmask = c["step"].value, c["adam_t"].value, c["dm"].value
+        a.smooth, a.adap_mask, a.apply_update, a.scalars_row = c["smooth"].value, c["adap"].value, 1 if apply_update else 0, self._cur_row
+        self._unpacked = False
+        _lib.check("cmlpl_dist_step", self.lib.cmlpl_dist_step(
+            C.byref(self.cshape), C.byref(self._chp), C.byref(io), C.byref(a), coll, self._stream()))
+        self._end_step()
+
+    def _native_comm(self):
+        """the communicator as cmlpl_dist_step takes it: a cmlpl_collectives record (RcclComm), None for the aliased
+        one-rank step -- or False: not available (or switched off: ``native_step = False`` / CMLPL_DIST_NATIVE=0)"""
+        if not self.native_step:
+            return False
+        if isinstance(self.comm, NoOpComm):
+            return None
+        nat = getattr(self.comm, "native", None)
+        return C.byref(nat(self.async_exchanges)) if nat is not None else False
+
+    def _step_io(self):
+        """cmlpl_dist_io of the bound shard in by-value mode + the per-step record, built once per shard"""
+        if self._args is None:
+            self._stage_args()
+        if self._io is None:
+            io = _lib.DistIO()
+            io.shard, io.gathered = self.cshard, self._gathered()
+            io.d_params, io.d_m, io.d_v, io.d_packed = self.params.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.packed.data_ptr()
+            io.d_grads, io.grad_stride = self.grads.data_ptr(), self.live
+            io.d_logits_l, io.d_feat_l, io.d_labels_f = self.logits_l.data_ptr(), self.feat_l.data_ptr(), self.labels_f.data_ptr()
+            io.d_dlogits, io.d_dfeat = self.dlogits_l.data_ptr(), self.dfeat_l.data_ptr()
+            io.d_probs_l, io.d_probs_g, io.probs_shard_rows = self.probs_l.data_ptr(), self.probs_g.data_ptr(), self.btu_l
+            io.d_scalars, io.d_dfeat_w_partial = self.scalar_hist.data_ptr(), self.dfw_part.data_ptr()
+            io.d_workspace, io.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
+            io.d_loss_workspace, io.loss_workspace_bytes = self.loss_ws.data_ptr(), self.loss_ws.numel()
+            io.seed = self.seed
+            self._io = (io, _lib.DistStepArgs())
+        return self._io[0], self._io[1], self._cells
 
     def capture(self, XPl, Xl, Y, XPu, Xu, lab_idx, unl_idx, bt: int, btu: int, capacity: int = 1024) -> "DistStepGraph":
         """The sharded step as FIVE captured graphs, one per stage, with the four collectives eager between them

@@ -31,9 +31,14 @@ class _UniqueId(C.Structure):
     _fields_ = [("internal", C.c_ubyte * 128)]
 
 
-def _load():
+def rccl_path() -> str:
+    """the librccl.so this process uses: torch's own copy"""
     path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-    rccl = C.CDLL(path if os.path.exists(path) else "librccl.so")
+    return path if os.path.exists(path) else "librccl.so"
+
+
+def _load():
+    rccl = C.CDLL(rccl_path())
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     rccl.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
     rccl.ncclCommInitRank.argtypes = [C.POINTER(vp), i32, _UniqueId, i32]
@@ -87,6 +92,7 @@ class RcclComm:
             self._hip_ok(self.hip.hipEventCreateWithFlags(C.byref(ev), 2), "hipEventCreateWithFlags")   # hipEventDisableTiming
             self._events.append(ev)
         self._next = 0
+        self._native = None
 
     # ---- plumbing
     def _ok(self, rc, what):
@@ -141,7 +147,32 @@ class RcclComm:
         return self._issue(lambda st: self._ok(self.rccl.ncclAllReduce(
             t.data_ptr(), t.data_ptr(), t.numel(), NCCL_FLOAT32, NCCL_SUM, self.comm, st), "ncclAllReduce"), async_op)
 
+    def native(self, async_exchanges=None):
+        """this communicator as a ``cmlpl_collectives`` record (cmlpl_rccl_bind): what ``cmlpl_dist_step`` -- the whole
+        sharded step as ONE C call -- issues its four collectives through.  ``async_exchanges``: the embedding all-gather
+        and the column-gradient reduce-scatter on the side stream, under the convolutions (a fork + join costs the step's
+        stream ~10 us on this runtime whatever is forked: profiles/r06_event_hop_probe.txt -- it pays when the exchange
+        itself takes longer than that on the wire); False: all four in order on the step's stream.  Default
+        (CMLPL_DIST_ASYNC=0/1 overrides): asynchronous when there is a wire, in order at world size 1."""
+        if self._native is None:
+            from . import _lib
+            rec = _lib.Collectives()
+            with torch.cuda.device(self.device):
+                _lib.check("cmlpl_rccl_bind", _lib.load().cmlpl_rccl_bind(rccl_path().encode(), self.comm, C.byref(rec)))
+            self._native = rec
+            self._native_inorder = _lib.Collectives.from_buffer_copy(rec)
+            self._native_inorder.side_stream = None
+        if async_exchanges is None:
+            env = os.environ.get("CMLPL_DIST_ASYNC")
+            async_exchanges = (self.world > 1) if env is None else env != "0"
+        return self._native if async_exchanges else self._native_inorder
+
     def close(self):
+        if getattr(self, "_native", None) is not None:
+            from . import _lib
+            torch.cuda.synchronize(self.device)
+            _lib.load().cmlpl_rccl_unbind(C.byref(self._native))
+            self._native = None
         if getattr(self, "comm", None):
             torch.cuda.synchronize(self.device)
             self.rccl.ncclCommDestroy(self.comm)

@@ -39,7 +39,8 @@ extern "C" {
 enum {
   CMLPL_E_ARG = -1,      /* null pointer / bad size */
   CMLPL_E_SHAPE = -2,    /* unsupported shape (e.g. K > 64, window too large for LDS) */
-  CMLPL_E_WORKSPACE = -3 /* workspace too small */
+  CMLPL_E_WORKSPACE = -3,/* workspace too small */
+  CMLPL_E_COMM = -4      /* cmlpl_dist_step: a collective failed (RCCL's ncclResult_t r > 0 comes back as -4 - r) */
 };
 
 /* Shape of one BaseNet2 (tools/models.py:98-128, generalised per SURVEY.md section 0). */
@@ -388,6 +389,45 @@ enum { CMLPL_STAGE_SPECTRAL = 0, CMLPL_STAGE_SPATIAL = 1, CMLPL_STAGE_PHASE1 = 2
        CMLPL_STAGE_BACKWARD_DATA = 4, CMLPL_STAGE_BACKWARD_WEIGHTS = 5, CMLPL_STAGE_UPDATE = 6 };
 int cmlpl_dist_stage_graph_create(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_dist_io* io, int stage,
                                   void* stream, void** graph_out);
+
+/* The SHARDED step as ONE call: the seven stages above, eagerly, with the four collectives issued between them from
+ * inside (train.py:150-278 for a rank's shard; the staging of cmlpl_amd/distributed.py's drive_step: embedding
+ * all-gather asynchronously behind the spectral stage and waited for in front of phase 1, probability all-gather,
+ * reduce-scatter of d_dfeat_w_partial into net 1's unlabelled rows of d_dfeat asynchronously behind phase 2 and waited
+ * for in front of the backward-weights stage, all-reduce of the gradient bucket).  A rank's step driven stage by stage
+ * from Python is bound by the host (profiles/r06_dist_trace_b2_64.txt); this entry point is ~25 enqueues back to back.
+ *   io    : as for the stage graphs, with d_dyn_table = d_dyn_cursor = NULL (scalars by value: `args`); batch by rows
+ *           or by index, noise8 / banks.ptr[] as in the eager stage calls; d_labels_f must follow d_feat_l directly (the
+ *           rank's block of the exchange buffer [2*n_l*1024 feat | bt_l labels] is sent as one piece), gathered.
+ *           d_logits_local == d_logits_l, probs_shard_rows == btu_local; d_scalars = ring base, row args->scalars_row.
+ *   coll  : the rank's communicator as three C functions over float32 buffers (sum), the side stream the two
+ *           asynchronous exchanges run on and four hipEvent_t created with hipEventDisableTiming (side_stream NULL:
+ *           all four collectives in order on `stream`, no events).  Each function
+ *           enqueues on `stream` and returns 0 or an error code.  cmlpl_rccl_bind fills one from an initialised
+ *           ncclComm_t and the path of the librccl.so the process uses (dlopen: this library does not link RCCL; it
+ *           also creates the side stream and the events); _unbind frees what _bind made (not the ncclComm_t).
+ *           NULL = one rank whose exchange buffers alias its own blocks (d_recv_feat == d_feat_l, d_probs_g ==
+ *           d_probs_l, d_dfeat_w_partial == d_dfeat + (n_l + bt_l) * 1024): no collective is issued. */
+typedef struct cmlpl_collectives {
+  void* ctx;
+  int (*all_gather)(void* ctx, const float* send, float* recv, size_t send_count, void* stream);
+  int (*reduce_scatter)(void* ctx, const float* send, float* recv, size_t recv_count, void* stream);
+  int (*all_reduce)(void* ctx, float* buf, size_t count, void* stream);
+  void* side_stream;            /* hipStream_t */
+  void* events[4];              /* hipEvent_t  */
+} cmlpl_collectives;
+typedef struct cmlpl_dist_step_args {
+  uint64_t step;                /* counter of the in-kernel random streams                                          */
+  int64_t adam_t;               /* 1-based                                                                          */
+  const float* d_dropmask;      /* NULL = Philox mask; else this rank's [2][n_l][cls_in]                            */
+  int32_t smooth; float adap_mask;
+  int32_t apply_update;         /* 0 = stop after the gradient all-reduce                                           */
+  int32_t scalars_row;
+} cmlpl_dist_step_args;
+int cmlpl_rccl_bind(const char* librccl_path, void* nccl_comm, cmlpl_collectives* out);
+int cmlpl_rccl_unbind(cmlpl_collectives* coll);
+int cmlpl_dist_step(const cmlpl_shape* shape, const cmlpl_hparams* hp, const cmlpl_dist_io* io,
+                    const cmlpl_dist_step_args* args, const cmlpl_collectives* coll, void* stream);
 
 /* Caller-side row N3: w x w patch windows gathered on device from the z-scored / PCA'd
  * scene cube instead of materialising XP.npy (tools/hyper_tools.py:35-55 MirrowCut, :226-243

@@ -1,6 +1,7 @@
 """Does the re-staged sharded step put its two large collectives UNDER the convolutions on the device?  One rank with the
 four REAL torch.distributed calls (RCCL at world size 1: its collectives are device copies on RCCL's own stream), a few
-dozen steps; run it under `rocprofv3 --kernel-trace` and read the trace with `--summarise`:
+dozen steps (CMLPL_DIST_COMM=rccl: the one-call step over RcclComm instead); run it under `rocprofv3 --kernel-trace` and
+read the trace with `--summarise`:
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d OUT -o t -- python3 scripts/dist_trace_probe.py [B2 64 64]
     python3 scripts/dist_trace_probe.py --summarise OUT/.../t_kernel_trace.csv
 The summary lists one steady-state step in start order: every kernel with its start / end relative to the step's first
@@ -25,7 +26,12 @@ def run(wl, bt, btu, steps=40):
     from bench import synth, WORKLOADS
     shape = WORKLOADS[wl]
     b = synth(shape, bt, btu, 1, dev)
-    eng = DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088, comm=TorchDistComm(), alias_single=False)
+    if os.environ.get("CMLPL_DIST_COMM") == "rccl":      # the one-call step (cmlpl_dist_step) with the collectives issued from C
+        from cmlpl_amd.rccl_comm import RcclComm
+        comm = RcclComm(dev)
+    else:
+        comm = TorchDistComm()
+    eng = DistTrainEngine(NetShape(*shape), bt, btu, HyperParams(), device=dev, seed=1088, comm=comm, alias_single=False)
     eng.init_params_default(1088)
     for i in range(steps):
         eng.step(b["XPl"], b["Xl"], b["Y"], b["XPu"], b["Xu"], 1, i)

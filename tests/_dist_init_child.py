@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from cmlpl_amd.distributed import TorchDistComm, init_distributed  # noqa: E402
+from cmlpl_amd.distributed import TorchDistComm, init_distributed, pick_comm  # noqa: E402
 
 mode = sys.argv[1]
 if mode == "hang":                       # rank 1 never joins: rank 0's watchdog must end it with code 3
@@ -17,6 +17,7 @@ if mode == "hang":                       # rank 1 never joins: rank 0's watchdog
     init_distributed("gloo", None, timeout_s=4.0)
     sys.exit(0)
 dist = init_distributed("gloo", None, timeout_s=60.0)
+assert isinstance(pick_comm("cpu"), TorchDistComm)       # a gloo job: never the direct RCCL communicator
 comm = TorchDistComm(debug=True)
 W, r = comm.world, comm.rank
 inp = torch.arange(6, dtype=torch.float32) + 100 * r

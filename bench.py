@@ -411,7 +411,11 @@ def run_rank(args):
                                f"spectrum {shape[3]}, {shape[4]} classes, {bt} labelled + {btu} unlabelled "
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
                                f"bank + Adam, epoch 1 (memory-bank smoothing active), in-kernel PCG4D noise / Philox dropout",
-                   "global_batch": n_local * world, "parallelism": f"dp{world}"},
+                   "global_batch": n_local * world, "parallelism": f"dp{world}",
+                   # how a rank's step is driven at N > 1: one C call with the collectives on RCCL directly, or the stages
+                   # from Python over torch.distributed (the fallback of cmlpl_amd.distributed.pick_comm)
+                   **({"collectives": type(eng.comm).__name__ + (", one C call per step" if eng._native_comm() is not False else ", stages driven from Python")}
+                      if dist is not None else {})},
         "roofline": {"bound": "mfma", "kernel": labels[dom_name],
                      "achieved": achieved, "peak": kpeak[dom_name], "unit": "TFLOP/s",
                      "frac": achieved / kpeak[dom_name],

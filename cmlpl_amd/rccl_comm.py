@@ -1,22 +1,23 @@
-"""The sharded step's four collectives straight on RCCL (librccl through ctypes), for a host-bound rank.
+"""The sharded step's collectives straight on RCCL (librccl through ctypes), for a host-bound rank.
 
-Why.  At a rank's shard the sharded step is bound by the HOST: seven stage calls and four torch.distributed calls per
-step leave the GPU waiting between launches (profiles/r06_dist_trace_b2_64.txt: 150 us of kernels spread over a 234-us
-step).  A torch.distributed collective costs 13-35 us of host time inside the step (Python -> c10d -> ProcessGroupNCCL:
-work object, watchdog enqueue, two event records, two stream waits, the RCCL call); the RCCL call itself is a few
-microseconds.  ``RcclComm`` has the interface of ``TorchDistComm`` (all_gather / reduce_scatter / all_reduce with
-``async_op`` handles, as ``drive_step`` uses them) and issues
+Why.  Driven over torch.distributed a rank of the sharded step is bound by the HOST: a torch.distributed collective
+costs 13-35 us of host time inside the step (Python -> c10d -> ProcessGroupNCCL: work object, watchdog enqueue, event
+records, stream waits, the RCCL call) and the device idles 80 us of a 234-us step
+(profiles/r06_dist_trace_b2_64.txt).  ``RcclComm`` owns an RCCL communicator of its own (``ncclCommInitRank``; the
+unique id travels through the already initialised torch.distributed group, whatever its backend) and is used two ways:
 
-  * a synchronous collective as ONE ``nccl*`` call on the current stream (in order behind the producer kernels, in
-    front of the consumers: nothing else to say to the device);
-  * an asynchronous one on its own side stream between two hipEvents (record on the current stream -> side stream waits
-    -> collective -> record on the side stream; ``handle.wait()`` makes the current stream wait for the second event).
+  * ``native()``: as a ``cmlpl_collectives`` record (cmlpl_rccl_bind) -- ``DistTrainEngine.step`` then runs the WHOLE
+    sharded step as one C call (cmlpl_dist_step, csrc/dist.hip), stages and collectives enqueued back to back: the
+    product path (profiles/r06_dist_overhead_native.txt: host 53-58 us, wall 1.06-1.08 x the one-GPU engine);
+  * with the interface of ``TorchDistComm`` (all_gather / reduce_scatter / all_reduce with ``async_op`` handles, as
+    ``drive_step`` uses them; read_scalars / loss windows use these too): a synchronous collective is ONE ``nccl*``
+    call on the current stream, an asynchronous one runs on a side stream between two hipEvents
+    (``handle.wait()`` makes the current stream wait for the second).
 
-The communicator is RCCL's own (``ncclCommInitRank``; the unique id travels through the already initialised
-torch.distributed group, whatever its backend).  Opt-in: ``CMLPL_DIST_COMM=rccl`` (``DistTrainEngine`` then builds one);
-the default stays ``TorchDistComm``.  This pool has one GPU per box and RCCL refuses two ranks on one device, so this
-class has run at world size 1 only (tests/test_gpu_rccl_comm.py: bit-identical to the torch.distributed path); the
-engine logic around it is what the gloo / lockstep tests cover."""
+``cmlpl_amd.distributed.pick_comm`` builds one for every engine on an RCCL process group, after a checked start-up
+with a fallback to ``TorchDistComm``.  This pool has one GPU per box and RCCL refuses two ranks on one device, so this
+class has RUN at world size 1 only (tests/test_gpu_rccl_comm.py: bit-identical to the torch.distributed path); the
+staging around it is what the gloo / lockstep tests cover at W = 2, 4, 8."""
 from __future__ import annotations
 
 import ctypes as C

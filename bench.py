@@ -352,7 +352,7 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     scal = eng.read_scalars()
-    if not all(v == v and abs(v) != float("inf") for v in scal.values()):
+    if not all(v == v and abs(v) != float("inf") for v in scal.values()) and not os.environ.get("CMLPL_BENCH_ALLOW_NONFINITE"):   # (ablation builds)
         raise SystemExit(f"bench.py: non-finite loss after the timed region: {scal}")
 
     n_local = bt + btu

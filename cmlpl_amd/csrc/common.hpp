@@ -244,6 +244,24 @@ __device__ __forceinline__ void a_split(const float4& x0, const float4& x1, uint
   A3 = A1;
   return;
 #endif
+#if defined(CMLPL_ABL) && CMLPL_ABL == 60         // ablation: the instruction mix of a TWO-piece fp16 product (x = h1 + 2^-11 h2)
+  {                                                 // against the weight fragments as they are -- wrong results, right timing
+    const float w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t h1[4], h2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+      const half2v p = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(w[2 * j], w[2 * j + 1]));
+      const float r0 = (w[2 * j] - (float)p[0]) * 2048.f, r1 = (w[2 * j + 1] - (float)p[1]) * 2048.f;
+      h1[j] = __builtin_bit_cast(uint32_t, p);
+      h2[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    }
+    A1 = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+    A2 = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+    A3 = A1;
+    return;
+  }
+#endif
   const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
   uint32_t u0[8], u1[8], u2[8];
 #pragma unroll
@@ -261,6 +279,15 @@ __device__ __forceinline__ void a_split(const float4& x0, const float4& x1, uint
 // one 32 x 32 x 16 step of the split product; b1..b3 = the weight pieces of this n tile
 __device__ __forceinline__ f32x16 mfma_b3(const uint4& A1, const uint4& A2, const uint4& A3, const uint4& b1,
                                           const uint4& b2, const uint4& b3, f32x16 acc) {
+#if defined(CMLPL_ABL) && CMLPL_ABL == 60
+  {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A2), __builtin_bit_cast(f16x8, b1), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), __builtin_bit_cast(f16x8, b2), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), __builtin_bit_cast(f16x8, b1), acc, 0, 0, 0);
+    return acc;
+  }
+#endif
   acc = mfma_b16(A1, b3, acc);
   acc = mfma_b16(A2, b2, acc);
   acc = mfma_b16(A3, b1, acc);

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../cmlpl_amd"
 HASH=$(cd .. && python3 -c "from cmlpl_amd.build_ext import source_hash; print(source_hash())")
 SFX=${ABL_SUFFIX:-}
 mkdir -p build_abl$N$SFX
-for f in api augment conv0 conv3x3 dense head loss memobank ntxent optim wgrad3x3; do
+for f in api augment conv0 conv3x3 dense dist head loss memobank ntxent optim wgrad3x3; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DCMLPL_ABL=$N $ABL_FLAGS -DCMLPL_SOURCE_HASH=\"$HASH\" -c csrc/$f.hip -o build_abl$N$SFX/$f.o &
 done
 wait

@@ -1,0 +1,100 @@
+"""VERDICT r05 item 8, taken to its kill criterion on the CPU: would a fp32 product made of TWO fp16 pieces (x = h1 +
+2^-11 h2; a.w ~ h1 g1 + 2^-11 (h1 g2 + h2 g1): three MFMAs instead of the six of the three-piece bf16 split) pass
+tests/test_gpu_ops.py::test_split_bf16_conv1_error_bound_per_element -- |err_i| <= 2^-18 S_i, S_i = sum |a||w| (+ |bias| +
+|residual|) -- including its mixed case (64 channels of a0 spread over 1e-6 .. 1e3, conv1's input channels scaled
+inversely)?  conv1's forward is emulated with exact (fp64) accumulation of the piece products, so only the operand
+representation is judged (the real kernel adds fp32 accumulation rounding on top).  Variants:
+  bf16 x 3            what the kernels do today (reference point)
+  fp16 x 2            pieces as they are
+  fp16 x 2, w-exp     per-input-channel power-of-two exponents folded into the packed weights (weights of channel c scaled
+                      to [1, 2)), the activations of channel c scaled inversely in the kernel
+  fp16 x 2, a-exp     exponents taken from the ACTIVATIONS' per-channel maximum instead (needs a pass over a0 per step)
+No GPU.   python scripts/fp16_two_piece_bound.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import cmlpl_oracle as O
+
+
+def bf16_round(x):
+    """round-to-nearest-even to bf16, as float64 values"""
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def split_bf16(x):
+    p1 = bf16_round(x); r = x - p1
+    p2 = bf16_round(r); r = r - p2
+    return p1, p2, bf16_round(r)
+
+
+def split_fp16(x):
+    with np.errstate(over="ignore"):
+        h1 = x.astype(np.float16).astype(np.float64)
+        h2 = ((x - h1) * 2048.0).astype(np.float16).astype(np.float64)
+    return h1, h2
+
+
+def conv_terms(a0, w1):
+    """im2col: cols [n, 576, HW] (k = ci * 9 + tap), wm [64, 576]"""
+    n, C, H, W = a0.shape
+    cols = F.unfold(torch.from_numpy(a0), 3, padding=1).numpy()
+    return cols, w1.reshape(64, 576)
+
+
+def run(mixed, n=8):
+    shape = O.NetShape(103, 11, 11, 103, 9)
+    params = O.closed_form_params(shape, 9)
+    if mixed:
+        g0 = torch.Generator().manual_seed(5)
+        sc = 10.0 ** (torch.rand(64, generator=g0) * 9.0 - 6.0)
+        params["conv0.weight"] = params["conv0.weight"] * sc.view(64, 1, 1, 1)
+        params["conv0.bias"] = params["conv0.bias"] * sc
+        params["conv1.weight"] = params["conv1.weight"] / sc.view(1, 64, 1, 1)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, shape.C, shape.H, shape.W, generator=g)
+    a0 = F.relu(F.conv2d(x, params["conv0.weight"], params["conv0.bias"])).float().double().numpy()   # fp32 values, as the kernel holds them
+    w1 = params["conv1.weight"].float().double().numpy()
+    b1 = params["conv1.bias"].double().numpy()
+    cols, wm = conv_terms(a0, w1)
+    exact = np.einsum("ok,nkp->nop", wm, cols)
+    S = np.einsum("ok,nkp->nop", np.abs(wm), np.abs(cols)) + np.abs(b1)[None, :, None] + np.abs(a0.reshape(n, 64, -1))
+    out = {}
+    # three bf16 pieces, 6 of 9 products (a1w1 + a1w2 + a2w1 + a1w3 + a2w2 + a3w1)
+    A, Wp = split_bf16(cols), split_bf16(wm)
+    z = sum(np.einsum("ok,nkp->nop", Wp[j], A[i]) for i, j in ((0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)))
+    out["bf16 x 3"] = np.nanmax(np.abs(z - exact) / S)
+
+    def fp16_variant(ea, ew):
+        # ea / ew: per-input-channel exponents applied to activations / weights (2^ea * 2^ew = 1)
+        ka = np.repeat(2.0 ** ea, 9)[None, :, None]; kw = np.repeat(2.0 ** ew, 9)[None, :]
+        a1, a2 = split_fp16(cols * ka)
+        g1, g2 = split_fp16(wm * kw)
+        with np.errstate(invalid="ignore", over="ignore"):
+            zz = np.einsum("ok,nkp->nop", g1, a1) + (np.einsum("ok,nkp->nop", g2, a1) + np.einsum("ok,nkp->nop", g1, a2)) / 2048.0
+            e = np.abs(zz - exact) / S
+        return np.inf if not np.isfinite(e).all() else e.max()
+
+    zero = np.zeros(64)
+    out["fp16 x 2"] = fp16_variant(zero, zero)
+    ew = -np.floor(np.log2(np.abs(w1).reshape(64, 64, 9).transpose(1, 0, 2).reshape(64, -1).max(1)))   # weights of channel c -> [1, 2)
+    out["fp16 x 2, w-exp"] = fp16_variant(-ew, ew)
+    ea = -np.floor(np.log2(np.maximum(np.abs(a0).transpose(1, 0, 2, 3).reshape(64, -1).max(1), 1e-300)))
+    out["fp16 x 2, a-exp"] = fp16_variant(ea, -ea)
+    return out
+
+
+if __name__ == "__main__":
+    print("max over elements of |err| / S, conv1 forward, exact accumulation (the test's bound: 2^-18 = 3.8e-6)")
+    for mixed in (False, True):
+        r = run(mixed)
+        print(("mixed 1e-6..1e3" if mixed else "unit scale") + ":")
+        for k, v in r.items():
+            lg = f"2^{np.log2(v):6.1f}" if np.isfinite(v) and v > 0 else "   inf  "
+            print(f"   {k:18s} {v:10.3e}  ({lg})  {'pass' if v <= 2.0 ** -18 else 'FAIL'}")

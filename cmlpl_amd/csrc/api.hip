@@ -306,6 +306,7 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     t.wc = d_params + L.param_off[8]; t.bc = d_params + L.param_off[9]; t.p_ns = param_stride;
     t.y = w.y; t.dropmask = d_dropmask; t.dropgen = w.dropgen; t.catd = w.catd; t.ynorm = w.ynorm;
     t.logits = d_logits; t.feat = d_feat; t.p2 = w.p2; t.m2 = w.m2; t.dropout_p = dropout_p; t.train = train; t.K = d.K;
+    t.w1h = d_packed + pack_off_h2(d.C, d.bands, 0); t.w1h_ns = pk_ns; t.h2flag = (const uint32_t*)(d_packed + pack_off_h2flag(d.C, d.bands));
     return TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0b3(d.C, d.bands),
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
                                d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, st, xn_save)));
@@ -397,6 +398,8 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     hd.dlogits = d_dlogits; hd.dfeat = d_dfeat_head; hd.mask = mask; hd.wc = d_params + L.param_off[8]; hd.p_ns = param_stride;
     hd.y = w.y; hd.ynorm = w.ynorm; hd.m2 = w.m2; hd.w2d = d_packed + pack_off_b3(d.C, d.bands, 3); hd.w2d_ns = L.packed_total;
     hd.dy = w.dy; hd.dp2 = w.dp2; hd.dp1 = w.dp1; hd.K = d.K;
+    hd.w1h = d_packed + pack_off_h2(d.C, d.bands, 1); hd.w1h_ns = L.packed_total;
+    hd.h2flag = (const uint32_t*)(d_packed + pack_off_h2flag(d.C, d.bands));
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
                                d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,
                                (long long)n * conv0_partial_size(d.C), &hd, st))))) return rc;

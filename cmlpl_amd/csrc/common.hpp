@@ -227,6 +227,45 @@ __device__ __forceinline__ void b3_split(float v, uint32_t (&hi16)[3]) {
   hi16[0] = u0 >> 16; hi16[1] = u1 >> 16; hi16[2] = __float_as_uint(r2) >> 16;
 }
 
+// ---- fp32 as TWO fp16 pieces (conv3x3.hip): x = h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) -- 22 significant bits as
+// long as the residual stays a normal fp16, which is what the operands' power-of-two scales are for (activations: per
+// sample, from the staged image's maximum; weights: 2^H2_WEXP at packing time).  a.w ~ h1 g1 + h2 g1 + h1 g2: three MFMAs.
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_h16(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
+}
+// a weight at the packing scale -> its two pieces (low 16 bits of pcs[0], pcs[1]); true when it does not fit fp16's range
+__device__ __forceinline__ bool h2_split_w(float w, uint32_t (&pcs)[2]) {
+  const float x = w * (float)(1 << 13);                       // (H2_WEXP, kernels.hpp)
+  const _Float16 g1 = (_Float16)x;
+  const _Float16 g2 = (_Float16)(x - (float)g1);
+  pcs[0] = (uint32_t)__builtin_bit_cast(uint16_t, g1); pcs[1] = (uint32_t)__builtin_bit_cast(uint16_t, g2);
+  return !(fabsf(x) <= 65000.f);                               // (also true for NaN)
+}
+// eight consecutive fp32 A elements, scaled by the sample's power of two -> the two fp16 A fragments (round toward zero:
+// the residual of a truncated first piece is exact and has the sign of x)
+__device__ __forceinline__ void h_split(const float4& x0, const float4& x1, float sc, uint4& H1, uint4& H2) {
+  const float w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  uint32_t h1[4], h2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = w[2 * j] * sc, b = w[2 * j + 1] * sc;
+    const f16x2v p = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(a, b));
+    h1[j] = __builtin_bit_cast(uint32_t, p);
+    h2[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - (float)p[0], b - (float)p[1]));
+  }
+  H1 = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+  H2 = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+}
+// one 32 x 32 x 16 step of the two-piece product; g1, g2 = the weight pieces of this n tile
+__device__ __forceinline__ f32x16 mfma_h2(const uint4& H1, const uint4& H2, const uint4& g1, const uint4& g2, f32x16 acc) {
+  acc = mfma_h16(H2, g1, acc);
+  acc = mfma_h16(H1, g2, acc);
+  acc = mfma_h16(H1, g1, acc);
+  return acc;
+}
+
 // ---- split-bf16 MFMA helpers (conv3x3.hip "fp32 on the bf16 MFMA"; shared with wgrad3x3.hip)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_b16(const uint4& a, const uint4& b, f32x16 c) {

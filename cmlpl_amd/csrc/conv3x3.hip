@@ -77,6 +77,28 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
     v = (c < pi.C) ? P[pi.off_w0 + (long long)co * pi.C + c] : 0.f;
   } else if (e < pack_off_w0b3(pi.C, pi.bands)) {
     v = 0.f;                                           // (former k-major copy of feat_spe.weight: unused region)
+  } else if (e >= pack_off_h2flag(pi.C, pi.bands)) {
+    return;                                            // the flag words: zeroed by the launcher, set below
+  } else if (e >= pack_off_h2(pi.C, pi.bands, 0)) {    // conv1 as two fp16 pieces (kernels.hpp: pack_off_h2): two fp16 per float slot
+    const long long r = e - pack_off_h2(pi.C, pi.bands, 0);
+    const int which = (int)(r / PACK_H2);              // 0 forward (n = co, k = ci), 1 data gradient (n = ci, k = co, taps flipped)
+    const int i = (int)(r - (long long)which * PACK_H2) * 2;
+    const int j = i & 7, l31 = (i >> 3) & 31, h = (i >> 8) & 1, nt = (i >> 9) & 1, rest = i >> 10;
+    const int pc = rest & 1, kq = (rest >> 1) & 3, tap = rest >> 3;
+    const int kh = tap / 3, kw = tap - kh * 3, n = nt * 32 + l31;
+    const float* W = P + pi.off_w1;
+    uint32_t out = 0;
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int k = kq * 16 + h * 8 + j + d;
+      const float w = (which == 0) ? W[((n * 64 + k) * 3 + kh) * 3 + kw] : W[((k * 64 + n) * 3 + (2 - kh)) * 3 + (2 - kw)];
+      uint32_t pcs[2];
+      bad |= h2_split_w(w, pcs);
+      out |= pcs[pc] << (16 * d);
+    }
+    if (bad) atomicOr((unsigned int*)(packed + (long long)net * pi.stride + pack_off_h2flag(pi.C, pi.bands)), 1u);
+    v = __uint_as_float(out);
   } else {                                           // conv0 as split-bf16 fragments: conv_b3_index(0, k = band, n = co, piece)
     const int i = (int)(e - pack_off_w0b3(pi.C, pi.bands)) * 2;
     const int j = i & 7, l31 = (i >> 3) & 31, h = (i >> 8) & 1, nt = (i >> 9) & 1, rest = i >> 10;
@@ -97,6 +119,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
 hipError_t launch_pack_weights(int nets, const float* params, long long pstride, const PackInfo& pi, float* packed,
                                hipStream_t st) {
   dim3 grid((unsigned)((pi.stride + 255) / 256), nets);
+  for (int net = 0; net < nets; ++net) {               // the two-piece fp16 sets' range flag: cleared by a FULL pack only
+    hipError_t e = hipMemsetAsync(packed + (long long)net * pi.stride + pack_off_h2flag(pi.C, pi.bands), 0, 64, st);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, params, pstride, pi, packed);
   return hipGetLastError();
 }
@@ -159,6 +185,9 @@ struct Conv3Args {
   // (H / 2)(W / 2), W / 2 -- a 32-bit division by a run-time value is ~40 vector instructions, and those loops did two to
   // four of them per 16-byte item (set by conv3_set_magics on the host)
   uint32_t mg_hw, mg_w, mg_p2, mg_w2;
+  // H2X kernels (conv1's tap loop on two fp16 pieces): this launch's two-piece weight set, the networks' range flags, and
+  // the LDS word (float index into the dynamic allocation) in which the staging leaves the image's largest magnitude
+  const float* wpk16; long long wpk16_ns; const uint32_t* h2flag; long long h2flag_ns; int maxslot;
 };
 
 // x / d == umulhi(x, ceil(2^32 / d)) for x d < 2^32 (every index here is below 2^16); d = 1 is flagged by 0
@@ -536,6 +565,90 @@ __device__ __forceinline__ void conv3_taps_ks(const float* __restrict__ img, con
   ks_tap<TPW>(img, wq, abase, acc, cur, rn0, rn1, ba, bb, 8, kh, PW, active, side);
 }
 
+// conv3_taps_ks on TWO fp16 pieces (common.hpp: h_split / mfma_h2): the same walk -- wave = (pixel half, channel half),
+// fragments L2 -> registers a tap ahead, raw activations two units ahead -- with a unit of two ds_read_b128, a 32-
+// instruction split (scale, truncate to fp16, exact residual, truncate) and SIX MFMAs where the three-piece bf16 unit has
+// 48 and twelve; eight fragments per tap and wave instead of twelve.  `sc` = the sample's power of two (its largest
+// magnitude lands in [2^14, 2^15)); the caller multiplies the folded accumulators by 1 / (sc 2^H2_WEXP).
+constexpr int TAPH = 4 * 2 * 2 * 64;     // uint4 per tap of a two-piece set: k-steps x pieces x n tiles x lanes
+struct HSplit { uint4 p1, p2; };
+template <int I, int TPW>
+__device__ __forceinline__ void ks_unit_h(const float* __restrict__ img, const int (&abase)[TPW], f32x16 (&acc)[TPW][2],
+                                          HSplit& cur, float4& rn0, float4& rn1, const uint4 (&bq)[2][4], int s,
+                                          int kh, int PW, float sc) {
+  constexpr int U = 2 * TPW;
+  constexpr int t = I % TPW, q = I / TPW;
+  float4 rnn0, rnn1;
+  {
+    constexpr int I2 = (I + 2) % U;
+    constexpr int t2 = I2 % TPW, q2 = I2 / TPW;
+    const int s2 = (I + 2 >= U) ? (s + 1 < 9 ? s + 1 : 8) : s;
+    const int kh2 = s2 / 3, kw2 = s2 - kh2 * 3;
+    const float* p = img + abase[t2] + ((kh2 - 1) * PW + (kw2 - 1)) * CS + (2 * kh + q2) * 16;
+    rnn0 = *(const float4*)p; rnn1 = *(const float4*)(p + 4);
+  }
+  acc[t][0] = mfma_h2(cur.p1, cur.p2, bq[q][0], bq[q][2], acc[t][0]);
+  acc[t][1] = mfma_h2(cur.p1, cur.p2, bq[q][1], bq[q][3], acc[t][1]);
+  HSplit nxt;
+  h_split(rn0, rn1, sc, nxt.p1, nxt.p2);
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  SchedInterleave<6>::run();
+  cur = nxt; rn0 = rnn0; rn1 = rnn1;
+}
+template <int TPW, class Side>
+__device__ __forceinline__ void ks_tap_h(const float* __restrict__ img, const uint4* __restrict__ wq, const int (&abase)[TPW],
+                                         f32x16 (&acc)[TPW][2], HSplit& cur, float4& rn0, float4& rn1, const uint4 (&bq)[2][4],
+                                         uint4 (&nb)[2][4], int s, int kh, int PW, bool active, float sc, Side& side) {
+  if (s + 1 < 9) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        nb[q][i] = wq[(size_t)(s + 1) * TAPH + (((2 * kh + q) * 2 + (i >> 1)) * 2 + (i & 1)) * 64];
+  }
+  side(s);
+  if (active) {
+    ks_unit_h<0, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW, sc);
+    ks_unit_h<1, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW, sc);
+    if constexpr (TPW == 2) {
+      ks_unit_h<2, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW, sc);
+      ks_unit_h<3, TPW>(img, abase, acc, cur, rn0, rn1, bq, s, kh, PW, sc);
+    }
+  }
+}
+template <int TPW, class Side = NoSide>
+__device__ __forceinline__ void conv3_taps_ks_h(const float* __restrict__ img, const uint4* __restrict__ wq,
+                                                const int (&abase)[TPW], f32x16 (&acc)[TPW][2], int PW, int wave, bool active,
+                                                float sc, Side side = Side()) {
+  const int kh = wave & 1;
+  uint4 ba[2][4], bb[2][4];                // [k-step q][piece * 2 + n tile]
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ba[q][i] = wq[(((2 * kh + q) * 2 + (i >> 1)) * 2 + (i & 1)) * 64];
+  HSplit cur;
+  float4 rn0, rn1;
+  {
+    const float* p0 = img + abase[0] + (-PW - 1) * CS + (2 * kh) * 16;
+    h_split(*(const float4*)p0, *(const float4*)(p0 + 4), sc, cur.p1, cur.p2);
+    const float* p1 = img + abase[TPW - 1] + (-PW - 1) * CS + (2 * kh + (TPW == 1 ? 1 : 0)) * 16;
+    rn0 = *(const float4*)p1; rn1 = *(const float4*)(p1 + 4);
+  }
+#pragma unroll 1
+  for (int s = 0; s < 8; s += 2) {
+    ks_tap_h<TPW>(img, wq, abase, acc, cur, rn0, rn1, ba, bb, s, kh, PW, active, sc, side);
+    ks_tap_h<TPW>(img, wq, abase, acc, cur, rn0, rn1, bb, ba, s + 1, kh, PW, active, sc, side);
+  }
+  ks_tap_h<TPW>(img, wq, abase, acc, cur, rn0, rn1, ba, bb, 8, kh, PW, active, sc, side);
+}
+// the staging's share of the two-piece path: a thread's largest |value| -> the workgroup's, in the LDS word `slot` (zeroed
+// at kernel start; published by the barrier in front of the tap loop).  NaN never wins a maximum: it meets the pieces as NaN.
+__device__ __forceinline__ void h2_publish_max(float mx, float* slot) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)slot, __float_as_uint(mx));
+}
+
 // Tap loop of the EIGHT-wave per-sample workgroups (one workgroup per CU).  Measured with conv3_taps_ks at eight waves
 // (round 5): a wave = (pixel tile, channel half) still needs its twelve fragments per tap, so eight waves pull 864 KB of
 // weight fragments per sample through the CU's vector-memory path where four pull 432 -- the loop got SLOWER (11.2 us
@@ -679,7 +792,7 @@ struct Conv3Ctx {
 
 // NW = waves of the workgroup: 4 (every MODE), or 8 for the per-sample kernels (MODE >= 2) when one workgroup has a CU
 // to itself (see ks_unit); NT = its threads, TPW = M tiles per wave in the tap loop.
-template <int MODE, int NW = 4, int TPW = 8 / NW, bool CUBE = false>
+template <int MODE, int NW = 4, int TPW = 8 / NW, bool CUBE = false, bool H2X = false>
 __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int lut_entries, Conv3Ctx& c,
                                             const float* dp_lds = nullptr, const uint32_t* mpre = nullptr) {
   constexpr int NT = 64 * NW;
@@ -975,6 +1088,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 #pragma unroll
     for (int nt = 0; nt < C0N; ++nt) bv[nt] = b0[32 * (nt0 + nt) + l31];
     const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for every m of the map (checked on the host)
+    float hmx = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = pt * 32 + acc_row(r, lane);
@@ -982,9 +1096,14 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         const int h = (m * magic) >> 16, w = m - h * W;
         float* d = img + (size_t)((h + 1) * PW + w + 1) * CS + 32 * nt0 + l31;
 #pragma unroll
-        for (int nt = 0; nt < C0N; ++nt) d[32 * nt] = z[nt][r] + bv[nt];
+        for (int nt = 0; nt < C0N; ++nt) {
+          const float v = z[nt][r] + bv[nt];
+          d[32 * nt] = v;
+          if constexpr (H2X) hmx = fmaxf(hmx, fabsf(v));
+        }
       }
     }
+    if constexpr (H2X) h2_publish_max(hmx, smem + a.maxslot);
     if constexpr (NW == 8) {                              // tap 0's fragments into the tap-weight buffer, tap 1's requested
       tap_put8((float4*)wbuf, c.wp8, tid);
       c.wp8 = tap_fetch8(wg, 1, tid);
@@ -1007,6 +1126,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   } else if (dp_lds != nullptr) {
     // fused backward head (S == 1): the pooled gradient was produced by this workgroup and waits in LDS, the ReLU
     // mask words were fetched at kernel start; one (pooled pixel, 4 channels) item -> its 2x2 window
+    float hmx = 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int idx = tid + NT * q;
@@ -1023,9 +1143,11 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
           const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
           *(float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+          if constexpr (H2X) hmx = fmaxf(fmaxf(hmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
       }
     }
+    if constexpr (H2X) h2_publish_max(hmx, smem + a.maxslot);
     if constexpr (NW == 8) {       // (the tap-weight buffer held the head's dz2 image, dead since the head's last barrier)
       tap_put8((float4*)wbuf, c.wp8, tid);
       c.wp8 = tap_fetch8(wg, 1, tid);
@@ -2096,10 +2218,16 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
 //  the per-sample kernels' barrier-free tap loop (conv3_taps_ks: wave = (pixel half, channel half), fragments L2 ->
 //  registers a tap ahead, the halves folded through LDS) instead of the LDS-staged weights with two workgroup barriers
 //  per tap -- what conv2 takes on windows the fused kernels do not reach (the reference's 20 x 20: 10 x 10 maps).
-template <int MODE, int MTW, int TAIL = 0, int NW = 4, int TPW = 8 / NW, bool KSG = false>
+//  H2X (MODE 2 / 3 with tail / head, four waves): conv1's tap loop on TWO fp16 pieces (conv3_taps_ks_h) whenever the
+//  sample's image and the network's weights are inside the ranges that scheme needs -- else, workgroup-uniformly, the
+//  three-piece bf16 loop, which has no range conditions.
+template <int MODE, int MTW, int TAIL = 0, int NW = 4, int TPW = 8 / NW, bool KSG = false, bool H2X = false>
 __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
   static_assert(!KSG || (MODE < 2 && MTW == 1 && TAIL == 0 && NW == 4 && TPW == 2), "KSG: four waves, S = 1, four tiles");
+  static_assert(!H2X || (MODE >= 2 && TAIL == 1 && ((NW == 4 && TPW == 2) || (NW == 8 && TPW == 1))),
+                "H2X: the four-tile per-sample kernels with tail / head");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (H2X) { if (threadIdx.x == 0) smem[a.maxslot] = 0.f; }
   constexpr int NT = 64 * NW;
   constexpr int KMT = NW * TPW / 2;        // pixel tiles of the per-sample kernels
   constexpr int LUTN = (MODE >= 2) ? KMT * 32 : MTW * NW * 32;
@@ -2115,7 +2243,7 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
     if constexpr (BIG) dp_lds = conv3_bwd_head_g(a, smem, mpre);
     else dp_lds = conv3_bwd_head<NW>(a, smem, mpre);
   }
-  conv3_stage<MODE, NW, TPW, INFER>(a, smem, LUTN, c, dp_lds, mpre);
+  conv3_stage<MODE, NW, TPW, INFER, H2X>(a, smem, LUTN, c, dp_lds, mpre);
   STAMPG(MODE & 1, 1);
   const int tid = c.tid, lane = c.lane, l31 = c.l31, hh = c.hh, wave = c.wave, net = c.net, s0 = c.s0;
   const int HW = c.HW, PW = c.PW, S = c.S, PX = c.PX, npx = c.npx;
@@ -2155,6 +2283,21 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
     }
   }
   const uint4* wq = (const uint4*)wg + lane;
+  // H2X: the two-piece loop is taken when the network's weights fit fp16 at the packing scale (flag word, set by the
+  // packing kernels) and the image's largest magnitude is an ordinary number: scale 2^(14 - floor(log2 max)) puts it in
+  // [2^14, 2^15); the folded accumulators are multiplied by hinv = 1 / (scale 2^H2_WEXP).  (Both exact powers of two.)
+  const uint4* wq16 = nullptr;
+  bool h2on = false;
+  float hsc = 1.f, hinv = 1.f;
+  auto h2_decide = [&]() {
+    if constexpr (H2X) {
+      const uint32_t e = __builtin_amdgcn_readfirstlane(((const volatile uint32_t*)smem)[a.maxslot]) >> 23;
+      const uint32_t flag = a.h2flag[(long long)net * a.h2flag_ns];
+      h2on = flag == 0u && e >= 40u && e <= 200u;
+      hsc = __uint_as_float((268u - e) << 23); hinv = __uint_as_float((e - 27u - (uint32_t)(H2_WEXP - 13)) << 23);
+      wq16 = (const uint4*)(a.wpk16 + (long long)net * a.wpk16_ns) + lane;
+    }
+  };
   float* x8 = (float*)(lut + LUTN);        // eight waves: [8][16][64] floats behind the LUT (second tap buffer, then the fold's exchange)
   const bool ks_active = (wave >> 1) * TPW * 32 < npx;
   // What a wave of the per-sample kernels owns after the fold of the two channel halves -- and, in the forward, already
@@ -2181,11 +2324,17 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
         *(float4*)(a0g + (size_t)m * 64 + c4 * 4) = *(const float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4);
       }
     };
-    if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active, side);
+    // (eight waves on two fp16 pieces: a wave's eight fragments per tap straight from L2 as in the four-wave loop -- per CU
+    //  the same 64 KiB per tap as two four-wave workgroups pull; the LDS copy of tap 0 staged above is then not used)
+    if constexpr (H2X) h2_decide();
+    if (h2on) conv3_taps_ks_h<TPW>(img, wq16, ab2, acc2, PW, wave, ks_active, hsc, side);
+    else if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active, side);
     else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active, side);
   } else if constexpr (KS) {
     __syncthreads();   // the staged image is complete (conv3_taps has this barrier in front of its first tap)
-    if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active);
+    if constexpr (H2X) h2_decide();
+    if (h2on) conv3_taps_ks_h<TPW>(img, wq16, ab2, acc2, PW, wave, ks_active, hsc);
+    else if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active);
     else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
   }
   else if constexpr (NW == 8) {   // the general kernels with eight waves (one workgroup per CU: 20 x 20 windows): two waves per SIMD
@@ -2204,6 +2353,14 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
   //  the LUT -- where the backward's head kept its hand-off buffers, dead since the staging; one workgroup per CU, LDS
   //  is plentiful: conv3_ks8_lds)
   if constexpr (KS) conv3_ks_fold<TPW>(acc2, own, NW == 8 ? x8 : wbuf, wave, lane);
+  if constexpr (H2X) {
+    if (h2on) {
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) own[i][r] *= hinv;
+    }
+  }
   STAMPG(MODE & 1, 2);
 
   if (!(MODE & 1)) {
@@ -2660,6 +2817,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
   if (pl.ks) {
     static DevOnce attr_ks;
@@ -2803,6 +2961,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   conv3_set_magics(a);
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -2817,14 +2976,33 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
       hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_fwd_lds(bg, C), st, a);
       return hipGetLastError();
     }
+    const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 2) && tail->w1h != nullptr && tail->h2flag != nullptr;
+    if (h2x) { a.wpk16 = tail->w1h; a.wpk16_ns = tail->w1h_ns; a.h2flag = tail->h2flag; a.h2flag_ns = tail->w1h_ns; }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_lds(H, W, C, conv3_ks8_lds(pl.lds), 8);
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;
+      if (h2x && lds8 + 64 <= LDS_MAX) {
+        static DevOnce attr_h8;
+        hipError_t eh = ensure_max_lds(attr_h8, conv3x3_kernel<2, 1, 1, 8, 1, false, true>);
+        if (eh != hipSuccess) return eh;
+        a.maxslot = (int)(lds8 / 4);
+        hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8, 1, false, true>), dim3(n, nets), dim3(512), lds8 + 64, st, a);
+        return hipGetLastError();
+      }
       hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8>), dim3(n, nets), dim3(512), lds8, st, a);
       return hipGetLastError();
     }
-    hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), dim3(n, nets), dim3(256),
-                       conv3_fused_lds(H, W, C, pl.lds), st, a);
+    const size_t lds = conv3_fused_lds(H, W, C, pl.lds);
+    if (h2x && 2 * (lds + 64) <= LDS_MAX) {
+      // conv1's taps on two fp16 pieces; one more LDS word (the image's largest magnitude) behind everything else
+      static DevOnce attr_h;
+      hipError_t eh = ensure_max_lds(attr_h, conv3x3_kernel<2, 1, 1, 4, 2, false, true>);
+      if (eh != hipSuccess) return eh;
+      a.maxslot = (int)(lds / 4);
+      hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 4, 2, false, true>), dim3(n, nets), dim3(256), lds + 64, st, a);
+      return hipGetLastError();
+    }
+    hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1>), dim3(n, nets), dim3(256), lds, st, a);
     return hipGetLastError();
   }
   return launch_conv3_t<2, 1>(a, dim3(n, nets), conv3_fused_lds(H, W, C, pl.lds), st);
@@ -2945,6 +3123,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0;
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
@@ -2957,14 +3136,32 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
       hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_bwd_lds(bg, C), st, a);
       return hipGetLastError();
     }
+    const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 3) && head->w1h != nullptr && head->h2flag != nullptr;
+    if (h2x) { a.wpk16 = head->w1h; a.wpk16_ns = head->w1h_ns; a.h2flag = head->h2flag; a.h2flag_ns = head->w1h_ns; }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pl.lds));
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;
+      if (h2x && lds8 + 64 <= LDS_MAX) {
+        static DevOnce attr_h8;
+        hipError_t eh = ensure_max_lds(attr_h8, conv3x3_kernel<3, 1, 1, 8, 1, false, true>);
+        if (eh != hipSuccess) return eh;
+        a.maxslot = (int)(lds8 / 4);
+        hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8, 1, false, true>), dim3(n, nets), dim3(512), lds8 + 64, st, a);
+        return hipGetLastError();
+      }
       hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8>), dim3(n, nets), dim3(512), lds8, st, a);
       return hipGetLastError();
     }
-    hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), dim3(n, nets), dim3(256),
-                       conv3_fused_bwd_lds(H, W, C, pl.lds), st, a);
+    const size_t lds = conv3_fused_bwd_lds(H, W, C, pl.lds);
+    if (h2x && 2 * (lds + 64) <= LDS_MAX) {
+      static DevOnce attr_h;
+      hipError_t eh = ensure_max_lds(attr_h, conv3x3_kernel<3, 1, 1, 4, 2, false, true>);
+      if (eh != hipSuccess) return eh;
+      a.maxslot = (int)(lds / 4);
+      hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 4, 2, false, true>), dim3(n, nets), dim3(256), lds + 64, st, a);
+      return hipGetLastError();
+    }
+    hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1>), dim3(n, nets), dim3(256), lds, st, a);
     return hipGetLastError();
   }
   return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);

@@ -39,7 +39,21 @@ __host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET +
 // ... and conv0.weight as split-bf16 B fragments [k16 step][piece][n tile][lane][8 bf16] (= conv_b3_index with tap 0,
 // k = band, n = co; bands beyond C are zero) for the conv0 stage of the fused forward
 __host__ __device__ inline long long pack_off_w0b3(int C, int bands) { return pack_off_wst(C) + (long long)bands * 1024; }
-__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_w0b3(C, bands) + (long long)((C + 15) / 16) * 1536; }
+__host__ __device__ inline long long pack_off_w0b3_end(int C, int bands) { return pack_off_w0b3(C, bands) + (long long)((C + 15) / 16) * 1536; }
+// ... and conv1's forward / data-gradient weights as TWO fp16 pieces for the three-MFMA product of the per-sample kernels
+// (conv3x3.hip "fp32 as two fp16 pieces"): w 2^H2_WEXP = g1 + g2, g1 = fp16(w 2^H2_WEXP), g2 = fp16 of the residual
+// (unscaled: the 2^-11 of the cross terms lives in the operands), fragments [tap][k16 step][piece][n tile][lane][8 fp16];
+// behind the two sets one flag word per network: != 0 when a weight left fp16's range at that scale (set by the packing
+// kernels, sticky until the next full pack) -- the kernels then take the three-piece bf16 loop
+constexpr int H2_WEXP = 13;                 // |w| < 8 keeps w 2^13 under fp16's 65504
+constexpr int PACK_H2 = PACK_CONV;          // floats occupied by one two-piece fp16 set (2 pieces x 2 bytes per weight)
+__host__ __device__ inline long long pack_off_h2(int C, int bands, int which) { return pack_off_w0b3_end(C, bands) + (long long)which * PACK_H2; }
+__host__ __device__ inline long long pack_off_h2flag(int C, int bands) { return pack_off_w0b3_end(C, bands) + 2LL * PACK_H2; }
+__host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_h2flag(C, bands) + 16; }
+// fp16 element index of (tap, k, n, piece) inside one two-piece set
+__host__ __device__ inline int conv_h2_index(int tap, int k, int n, int p) {
+  return ((((tap * 4 + (k >> 4)) * 2 + p) * 2 + (n >> 5)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7);
+}
 struct PackInfo { long long stride, off_w0, off_w1, off_w2, off_ws; int C, bands; };
 constexpr int PART3 = 9 * 4096 + 64;         // conv3x3 wgrad partial: dW[s][ci][co] + db[co]
 constexpr size_t LDS_MAX = 160 * 1024;
@@ -90,6 +104,7 @@ struct FwdTail {
   const float* w2f; long long w2f_ns; const float* b2; const float* wc; const float* bc; long long p_ns;
   const float* y; const float* dropmask; float* dropgen; float* catd; float* ynorm; float* logits; float* feat;
   float* p2; uint8_t* m2; float dropout_p; int train, K;
+  const float* w1h = nullptr; long long w1h_ns = 0; const uint32_t* h2flag = nullptr;   // conv1's two-piece fp16 set (pack_off_h2(.., 0)) + its flag words, or null
 };
 bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
@@ -106,6 +121,7 @@ struct BwdHead {
   const float* dlogits; const float* dfeat; const float* mask; const float* wc; long long p_ns;
   const float* y; const float* ynorm; const uint8_t* m2; const float* w2d; long long w2d_ns;
   float* dy; float* dp2; float* dp1; int K;
+  const float* w1h = nullptr; long long w1h_ns = 0; const uint32_t* h2flag = nullptr;   // conv1's data-gradient two-piece fp16 set (pack_off_h2(.., 1)), or null
 };
 bool conv3_fused_head_ok(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
@@ -190,6 +206,7 @@ struct Switches {
   int fuse_big;                                               // CMLPL_FUSE_BIG: 0 = windows of 129 .. 256 pixels on the general kernels (default 1: eight-tile per-sample kernels)
   int conv3_nw8;                                              // CMLPL_CONV3_NW8: 0 = the general 3x3 kernels always with four waves (default 1)
   int conv0a;                                                 // CMLPL_CONV0A: 0 = augment_kernel + conv0_fwd_kernel (f32 MFMA) on the general path (default 1: one fused split-bf16 launch)
+  int f16x2;                                                  // CMLPL_F16X2: 1 = conv1's tap loops of the four-wave per-sample kernels on TWO fp16 pieces (three MFMAs per product; 2 / 3: the forward / the backward kernel only; default 0: three bf16 pieces, six)
   int conv3_ks;                                               // CMLPL_CONV3_KS: 0 = the general 3x3 kernels always with LDS-staged tap weights (default 1: barrier-free loop at S = 1, one tile per wave)
   int ks8;                                                    // CMLPL_KS8: eight-wave per-sample workgroups never (0) / always (1) / when the grid fits the CUs (-1)
   int conv3_s, conv0_dma, conv0_ps;                           // CMLPL_CONV3_S (0 = planner), CMLPL_CONV0_DMA (default 1), CMLPL_CONV0_PS (0 = planner)
@@ -204,7 +221,7 @@ inline Switches read_switches() {
     Switches w;
     w.fuse_conv0 = env("CMLPL_FUSE_CONV0", 1); w.fuse_conv0_bwd = env("CMLPL_FUSE_CONV0_BWD", 1);
     w.fuse_tail = env("CMLPL_FUSE_TAIL", 1); w.fuse_spe = env("CMLPL_FUSE_SPE", 1);
-    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1); w.conv3_nw8 = env("CMLPL_CONV3_NW8", 1); w.conv3_ks = env("CMLPL_CONV3_KS", 1); w.conv0a = env("CMLPL_CONV0A", 1);
+    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1); w.conv3_nw8 = env("CMLPL_CONV3_NW8", 1); w.conv3_ks = env("CMLPL_CONV3_KS", 1); w.conv0a = env("CMLPL_CONV0A", 1); w.f16x2 = env("CMLPL_F16X2", 0);
     w.conv3_s = env("CMLPL_CONV3_S", 0); w.conv0_dma = env("CMLPL_CONV0_DMA", 1); w.conv0_ps = env("CMLPL_CONV0_PS", 0);
     w.wgrad3_u = env("CMLPL_WGRAD3_U", 0); w.wgrad3_cspl = env("CMLPL_WGRAD3_CSPL", 0); w.wgrad3_r = env("CMLPL_WGRAD3_R", 1);
     w.wgrad3_ru = env("CMLPL_WGRAD3_RU", 0); w.wgrad3_rg = env("CMLPL_WGRAD3_RG", 0);

@@ -13,6 +13,7 @@ BTU = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 WIN = int(os.environ.get("CMLPL_TL_WIN", "11"))           # window side: 11 = B2 / B4, 15 = B5
 shape = NetShape(C, WIN, WIN, C, K)
 eng = TrainEngine(shape, BT, BTU, HyperParams(), device="cuda:0", seed=1)
+eng.init_params_default(1)          # (zero parameters give zero images: the two-piece loop would not be taken)
 g = torch.Generator(device="cuda:0").manual_seed(0)
 XPl = torch.randn(BT, C, WIN, WIN, device="cuda:0", generator=g)
 XPu = torch.randn(BTU, C, WIN, WIN, device="cuda:0", generator=g)

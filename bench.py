@@ -36,13 +36,16 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0      # same guide, "BF16/F16 ~2.5 PF dense"
 # The 3x3 convolutions compute fp32 products as six bf16 MFMAs (three exact bf16 pieces per operand, fp32 accumulate;
 # cmlpl_amd/csrc/conv3x3.hip): their ceiling in fp32-equivalent FLOP/s is the bf16 peak / 6.
 SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+SPLIT2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0      # fp32 as two fp16 pieces: three 16-bit MFMAs per product (f16 rate = bf16 rate)
 
 
 def blended_peak(segments):
     """fp32-equivalent MFMA peak of a kernel that mixes f32-input and split-bf16 MFMA segments:
-    total FLOPs / sum(FLOPs_i / peak_i).  segments: {"f32": flops, "split": flops}."""
-    tot = segments.get("f32", 0.0) + segments.get("split", 0.0)
-    floor_s = segments.get("f32", 0.0) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + segments.get("split", 0.0) / (SPLIT_PEAK_TFLOPS * 1e12)
+    total FLOPs / sum(FLOPs_i / peak_i).  segments: {"f32": flops, "split": flops (three bf16 pieces, six MFMAs per
+    product), "split2": flops (two fp16 pieces, three MFMAs per product)}."""
+    tot = segments.get("f32", 0.0) + segments.get("split", 0.0) + segments.get("split2", 0.0)
+    floor_s = (segments.get("f32", 0.0) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + segments.get("split", 0.0) / (SPLIT_PEAK_TFLOPS * 1e12) +
+               segments.get("split2", 0.0) / (SPLIT2_PEAK_TFLOPS * 1e12))
     return (tot / floor_s / 1e12) if floor_s > 0 else FP32_MFMA_PEAK_TFLOPS
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # written by scripts/pmc_summary.py --json
 CONV1_KERNELS = {     # labels of the unfused launches; the fused ones are named where the calibration window finds them
@@ -383,6 +386,13 @@ def run_rank(args):
         kvar = "8,1"
     else:
         kvar = "4,2"
+    # conv1's tap loops of the four-tile per-sample kernels run on TWO fp16 pieces (three MFMAs per product) unless switched
+    # off; conv0, conv2 and the weight gradients stay on three bf16 pieces (six)
+    f16x2 = os.environ.get("CMLPL_F16X2", "1")
+    if tail_fwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "2"):
+        kseg["conv1_fwd"]["split"] -= c1; kseg["conv1_fwd"]["split2"] = c1
+    if head_bwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "3"):
+        kseg["conv1_dgrad"]["split"] -= c1; kseg["conv1_dgrad"]["split2"] = c1
     if tail_fwd:
         kseg["conv1_fwd"]["split"] += conv2_flops                                       # tail: split-bf16 too (16x16x32 MFMA)
         labels["conv1_fwd"] = (f"conv3x3_kernel<2,1,1,{kvar}> (per-sample fused forward: augmentation + conv0 1x1 + conv1 3x3 + "
@@ -405,8 +415,10 @@ def run_rank(args):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32 (convolutions: f32 operands as 3 exact bf16 pieces on the bf16 MFMA, 6 of 9 piece products, f32 "
-                 "accumulate: max-norm error measured at f32 level against f64, per-product worst case 2^-21; "
-                 "everything else f32 MFMA / f32 VALU)", "data": "synthetic",
+                 "accumulate, per-product worst case 2^-21 -- conv1's tap loops of the per-sample kernels as 2 fp16 pieces with "
+                 "power-of-two operand scales, 3 piece products, worst case 2^-20.7, falling back to the 3-piece loop "
+                 "outside fp16's range; max-norm error measured at f32 level against f64; everything else f32 MFMA / "
+                 "f32 VALU)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic PaviaU-shaped patches {shape[1]}x{shape[2]}x{shape[0]}, "
                                f"spectrum {shape[3]}, {shape[4]} classes, {bt} labelled + {btu} unlabelled "
                                f"rows per GPU (batch {n_local}), dual BaseNet2 fwd/bwd + contrastive/mutual losses + "
@@ -420,8 +432,9 @@ def run_rank(args):
                      "achieved": achieved, "peak": kpeak[dom_name], "unit": "TFLOP/s",
                      "frac": achieved / kpeak[dom_name],
                      "peak_note": "fp32-equivalent MFMA ceiling of this kernel's own instruction mix: algorithmic "
-                                  "FLOPs / (f32-segment FLOPs / 157.3 T + split-segment FLOPs / (2500 T / 6)); "
-                                  "a split-bf16 product costs six bf16 MFMAs (history of the mix: DESIGN.md section 4)",
+                                  "FLOPs / (f32-segment FLOPs / 157.3 T + split-segment FLOPs / (2500 T / 6) + "
+                                  "split2-segment FLOPs / (2500 T / 3)); a three-piece bf16 product costs six 16-bit "
+                                  "MFMAs, a two-piece fp16 product three (history of the mix: DESIGN.md section 4)",
                      "flops_by_mfma_kind": kseg[dom_name],
                      "frac_of_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": traffic.get(dom_name),

@@ -192,6 +192,17 @@ def test_unfused_spectral_branch_passes_step_parity():
     _run(J_UNFSPE)
 
 
+J_B3ONLY = _job("conv", "three-piece-conv1", {"CMLPL_F16X2": "0"},
+                ["tests/test_gpu_ops.py", "tests/test_gpu_step.py", "-k", "(forward_backward and (B2 or B4)) or error_bound or b2_b256 or b2_64"])
+
+
+def test_three_piece_tap_loops_of_the_per_sample_kernels_pass_parity():
+    """CMLPL_F16X2=0: conv1's tap loops of the four-tile per-sample kernels on three bf16 pieces (the loop every sample
+    whose operands leave the two-piece scheme's ranges still takes: tests/test_gpu_f16x2.py) against the oracle, the
+    reference fixture and the per-element error bounds"""
+    _run(J_B3ONLY)
+
+
 _UNFUSED = {"CMLPL_FUSE_CONV0": "0", "CMLPL_FUSE_TAIL": "0", "CMLPL_FUSE_SPE": "0"}
 J_NOISE = [_traj("traj", "noise-fused", {}, "B2", 64, 64), _traj("traj", "noise-unfused", _UNFUSED, "B2", 64, 64),
            _traj("traj", "noise-fused-again", {}, "B2", 64, 64)]

@@ -29,11 +29,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
-    # peak: the MFMA ceiling of the kernel's own mix of f32-input and split-bf16 segments, between the two pure cases
-    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 157.3 <= rf["peak"] <= 2500.0 / 6 + 1e-6
+    # peak: the MFMA ceiling of the kernel's own mix of f32-input, three-piece bf16 (six MFMAs per product) and
+    # two-piece fp16 (three) segments, between the pure cases
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 157.3 <= rf["peak"] <= 2500.0 / 3 + 1e-6
     seg = rf["flops_by_mfma_kind"]
     assert abs(sum(seg.values()) - rf["flops_per_launch"]) < 1.0
-    want_peak = sum(seg.values()) / (seg.get("f32", 0.0) / 157.3 + seg.get("split", 0.0) / (2500.0 / 6))
+    assert seg.get("split2", 0.0) > 0.0 and seg.get("split", 0.0) > 0.0        # conv1's taps | conv0 + conv2 of the fused launch
+    want_peak = sum(seg.values()) / (seg.get("f32", 0.0) / 157.3 + seg.get("split", 0.0) / (2500.0 / 6) +
+                                     seg.get("split2", 0.0) / (2500.0 / 3))
     assert abs(rf["peak"] - want_peak) < 1e-6 * want_peak
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
     assert rf["launches_timed"] == 12

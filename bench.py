@@ -389,9 +389,9 @@ def run_rank(args):
     # conv1's tap loops of the four-tile per-sample kernels run on TWO fp16 pieces (three MFMAs per product) unless switched
     # off; conv0, conv2 and the weight gradients stay on three bf16 pieces (six)
     f16x2 = os.environ.get("CMLPL_F16X2", "1")
-    if tail_fwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "2"):
+    if tail_fwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "2", "4"):
         kseg["conv1_fwd"]["split"] -= c1; kseg["conv1_fwd"]["split2"] = c1
-    if head_bwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "3"):
+    if head_bwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "3", "4"):
         kseg["conv1_dgrad"]["split"] -= c1; kseg["conv1_dgrad"]["split2"] = c1
     if tail_fwd:
         kseg["conv1_fwd"]["split"] += conv2_flops                                       # tail: split-bf16 too (16x16x32 MFMA)
@@ -450,6 +450,11 @@ def run_rank(args):
              "traffic": traffic.get(k)}
             for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
+        # The fused backward skips conv1's tap loop for a sample whose gradient image is zero everywhere (exact: zeros
+        # times finite weights) -- an unlabelled row no loss term reaches through the convolutions, i.e. one under the
+        # confidence threshold (train.py:221).  How many of the last step's unlabelled rows were ABOVE it, per network:
+        # (btu - that) x 2 workgroups of the backward launch skipped; CMLPL_F16X2=4 measures without skipping.
+        "backward_zero_images": {"unlabelled_rows": btu * world, "confident_s": scal["n_mask_s"], "confident_w": scal["n_mask_w"]},
         # did the container's CPU quota freeze this process inside the timed region?  (a throttled period stops every
         # thread for up to a CFS period, ~100 ms: profiles/r06_stall_rootcause.txt)  null where cpu.stat is not readable
         "host_throttled": None if thr0 is None or thr1 is None else

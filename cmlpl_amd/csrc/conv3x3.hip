@@ -188,6 +188,7 @@ struct Conv3Args {
   // H2X kernels (conv1's tap loop on two fp16 pieces): this launch's two-piece weight set, the networks' range flags, and
   // the LDS word (float index into the dynamic allocation) in which the staging leaves the image's largest magnitude
   const float* wpk16; long long wpk16_ns; const uint32_t* h2flag; long long h2flag_ns; int maxslot;
+  int h2_noskip;      // measurement aid (CMLPL_F16X2=4): an all-zero image runs the two-piece loop instead of skipping it
 };
 
 // x / d == umulhi(x, ceil(2^32 / d)) for x d < 2^32 (every index here is below 2^16); d = 1 is flagged by 0
@@ -2286,15 +2287,21 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
   // H2X: the two-piece loop is taken when the network's weights fit fp16 at the packing scale (flag word, set by the
   // packing kernels) and the image's largest magnitude is an ordinary number: scale 2^(14 - floor(log2 max)) puts it in
   // [2^14, 2^15); the folded accumulators are multiplied by hinv = 1 / (scale 2^H2_WEXP).  (Both exact powers of two.)
+  // An image that is ZERO everywhere (the data gradient of a row no loss term reaches: a masked-out unlabelled row -- a
+  // third of a step's workgroups in the backward) meets finite weights (flag clear): its products are exact zeros on
+  // either loop; the backward skips the tap loop (hzero), the forward runs the two-piece one at scale 1.
   const uint4* wq16 = nullptr;
-  bool h2on = false;
+  bool h2on = false, hzero = false;
   float hsc = 1.f, hinv = 1.f;
   auto h2_decide = [&]() {
     if constexpr (H2X) {
-      const uint32_t e = __builtin_amdgcn_readfirstlane(((const volatile uint32_t*)smem)[a.maxslot]) >> 23;
+      const uint32_t mxb = __builtin_amdgcn_readfirstlane(((const volatile uint32_t*)smem)[a.maxslot]);
+      const uint32_t e = mxb >> 23;
       const uint32_t flag = a.h2flag[(long long)net * a.h2flag_ns];
-      h2on = flag == 0u && e >= 40u && e <= 200u;
-      hsc = __uint_as_float((268u - e) << 23); hinv = __uint_as_float((e - 27u - (uint32_t)(H2_WEXP - 13)) << 23);
+      hzero = flag == 0u && mxb == 0u;
+      h2on = flag == 0u && ((e >= 40u && e <= 200u) || hzero);
+      hsc = hzero ? 1.f : __uint_as_float((268u - e) << 23);
+      hinv = hzero ? 1.f : __uint_as_float((e - 27u - (uint32_t)(H2_WEXP - 13)) << 23);
       wq16 = (const uint4*)(a.wpk16 + (long long)net * a.wpk16_ns) + lane;
     }
   };
@@ -2333,7 +2340,7 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
   } else if constexpr (KS) {
     __syncthreads();   // the staged image is complete (conv3_taps has this barrier in front of its first tap)
     if constexpr (H2X) h2_decide();
-    if (h2on) conv3_taps_ks_h<TPW>(img, wq16, ab2, acc2, PW, wave, ks_active, hsc);
+    if (h2on) { if (!hzero || a.h2_noskip) conv3_taps_ks_h<TPW>(img, wq16, ab2, acc2, PW, wave, ks_active, hsc); }
     else if constexpr (NW == 8) conv3_taps_lds8<TPW>(img, wbuf, x8, wg, c.wp8, ab2, acc2, PW, tid, wave, lane, ks_active);
     else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
   }
@@ -2817,7 +2824,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
   if (pl.ks) {
     static DevOnce attr_ks;
@@ -2961,7 +2968,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   conv3_set_magics(a);
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -2976,7 +2983,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
       hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_fwd_lds(bg, C), st, a);
       return hipGetLastError();
     }
-    const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 2) && tail->w1h != nullptr && tail->h2flag != nullptr;
+    const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 2 || switches().f16x2 == 4) && tail->w1h != nullptr && tail->h2flag != nullptr;
     if (h2x) { a.wpk16 = tail->w1h; a.wpk16_ns = tail->w1h_ns; a.h2flag = tail->h2flag; a.h2flag_ns = tail->w1h_ns; }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_lds(H, W, C, conv3_ks8_lds(pl.lds), 8);
@@ -3123,7 +3130,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4;
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
@@ -3136,7 +3143,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
       hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_bwd_lds(bg, C), st, a);
       return hipGetLastError();
     }
-    const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 3) && head->w1h != nullptr && head->h2flag != nullptr;
+    const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 3 || switches().f16x2 == 4) && head->w1h != nullptr && head->h2flag != nullptr;
     if (h2x) { a.wpk16 = head->w1h; a.wpk16_ns = head->w1h_ns; a.h2flag = head->h2flag; a.h2flag_ns = head->w1h_ns; }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pl.lds));

@@ -206,7 +206,7 @@ struct Switches {
   int fuse_big;                                               // CMLPL_FUSE_BIG: 0 = windows of 129 .. 256 pixels on the general kernels (default 1: eight-tile per-sample kernels)
   int conv3_nw8;                                              // CMLPL_CONV3_NW8: 0 = the general 3x3 kernels always with four waves (default 1)
   int conv0a;                                                 // CMLPL_CONV0A: 0 = augment_kernel + conv0_fwd_kernel (f32 MFMA) on the general path (default 1: one fused split-bf16 launch)
-  int f16x2;                                                  // CMLPL_F16X2: 0 = conv1's tap loops of the four-tile per-sample kernels on three bf16 pieces like every other product (default 1: TWO fp16 pieces, three MFMAs per product, wherever the operands' ranges allow; 2 / 3: in the forward / the backward kernel only)
+  int f16x2;                                                  // CMLPL_F16X2: 0 = conv1's tap loops of the four-tile per-sample kernels on three bf16 pieces like every other product (default 1: TWO fp16 pieces, three MFMAs per product, wherever the operands' ranges allow; 2 / 3: in the forward / the backward kernel only; 4: as 1, but an all-zero gradient image runs the loop instead of skipping it -- a measurement aid)
   int conv3_ks;                                               // CMLPL_CONV3_KS: 0 = the general 3x3 kernels always with LDS-staged tap weights (default 1: barrier-free loop at S = 1, one tile per wave)
   int ks8;                                                    // CMLPL_KS8: eight-wave per-sample workgroups never (0) / always (1) / when the grid fits the CUs (-1)
   int conv3_s, conv0_dma, conv0_ps;                           // CMLPL_CONV3_S (0 = planner), CMLPL_CONV0_DMA (default 1), CMLPL_CONV0_PS (0 = planner)

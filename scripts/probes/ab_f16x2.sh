@@ -1,5 +1,5 @@
 # same-box A/B of conv1's tap loops on two fp16 pieces (CMLPL_F16X2=1) against the three-piece bf16 default
-for X in 0 1 0 1; do
+for X in ${AB_MODES:-0 1 0 1}; do
   echo "== CMLPL_F16X2=$X"
   CMLPL_F16X2=$X python bench.py --workload ${1:-B2} --steps 300 --warmup 30 --no-cpu-baseline --breakdown 2>/tmp/ab.err | python -c "
 import sys, json

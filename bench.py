@@ -404,6 +404,10 @@ def run_rank(args):
     if wgrad_pair:
         key = "split" if wgrad_split else "f32"
         kseg["conv1_wgrad"][key] += conv2_flops
+        # ... and the pair weight-gradient launch both its maps (planes of two fp16 pieces), when both fused launches ran the
+        # two-piece kernels (they leave the operands' maxima it scales by)
+        if wgrad_split and tail_fwd and head_bwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "4"):
+            kseg["conv1_wgrad"] = {"split2": kseg["conv1_wgrad"]["split"]}
         labels["conv1_wgrad"] = "wgrad3b_pair_kernel (conv1 + conv2 weight gradients in one launch, both networks)"
     kflops = {k: sum(v.values()) for k, v in kseg.items()}
     kpeak = {k: blended_peak(v) for k, v in kseg.items()}

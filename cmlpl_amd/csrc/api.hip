@@ -34,6 +34,7 @@ bool make_dims(const cmlpl_shape* s, Dims* d) {
 struct NetWs {
   float *a0, *p1, *p2, *y, *ynorm, *catd, *dropgen, *dy, *dp2, *dp1, *da0, *part1, *part2, *part0;
   uint8_t *m1, *m2;
+  uint32_t* hstat;      // [4 kinds][2 networks][n] per-sample maxima the fused kernels leave for the two-piece weight gradient
   size_t bytes;
 };
 
@@ -69,6 +70,7 @@ bool carve_net(const Dims& d, int nets, int n, char* base, NetWs* w) {
   w->part1 = (float*)take((size_t)nets * w1.G * PART3 * 4);
   w->part2 = (float*)take((size_t)nets * w2.G * PART3 * 4);
   w->part0 = (float*)take((size_t)nets * G0 * (size_t)conv0_partial_size(d.C) * 4);
+  w->hstat = (uint32_t*)take((size_t)4 * 2 * n * 4);
   w->bytes = off;
   return true;
 }
@@ -307,6 +309,9 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     t.y = w.y; t.dropmask = d_dropmask; t.dropgen = w.dropgen; t.catd = w.catd; t.ynorm = w.ynorm;
     t.logits = d_logits; t.feat = d_feat; t.p2 = w.p2; t.m2 = w.m2; t.dropout_p = dropout_p; t.train = train; t.K = d.K;
     t.w1h = d_packed + pack_off_h2(d.C, d.bands, 0); t.w1h_ns = pk_ns; t.h2flag = (const uint32_t*)(d_packed + pack_off_h2flag(d.C, d.bands));
+    // every sample's largest |a0| / |p1| (this launch) and gradient operands (the backward's), for the two-piece
+    // weight-gradient launch of the same step
+    if (conv3_h2x_both(d.H, d.W, d.C, nets * n, d.K)) t.hstat = w.hstat;
     return TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3_fused(nets, n, d.C, d.H, d.W, xs, d_packed + pack_off_w0b3(d.C, d.bands),
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
                                d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, st, xn_save)));
@@ -400,13 +405,15 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     hd.dy = w.dy; hd.dp2 = w.dp2; hd.dp1 = w.dp1; hd.K = d.K;
     hd.w1h = d_packed + pack_off_h2(d.C, d.bands, 1); hd.w1h_ns = L.packed_total;
     hd.h2flag = (const uint32_t*)(d_packed + pack_off_h2flag(d.C, d.bands));
+    const bool h2w = conv3_h2x_both(d.H, d.W, d.C, nets * n, d.K);
+    if (h2w) hd.hstat = w.hstat;
     if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
                                d_packed + pack_off_b3(d.C, d.bands, 1), L.packed_total, xs, w.part0,
                                (long long)n * conv0_partial_size(d.C), &hd, st))))) return rc;
     // conv1's and conv2's weight gradients: one launch where the pair kernel exists (timed as the conv1 kernel)
     bool merged = false;
     if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3_pair(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, d.H2, d.W2,
-                                  w.p1, w.dp2, w.m2, w.part2, &merged, st))))) return rc;
+                                  w.p1, w.dp2, w.m2, w.part2, &merged, st, h2w ? w.hstat : nullptr, hd.h2flag, L.packed_total))))) return rc;
     (void)merged;
   } else {
     // General path (windows the per-sample kernels do not take: P 20x20, B5 15x15): one launch per stage.  Round 4:

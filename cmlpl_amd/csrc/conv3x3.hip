@@ -189,6 +189,10 @@ struct Conv3Args {
   // the LDS word (float index into the dynamic allocation) in which the staging leaves the image's largest magnitude
   const float* wpk16; long long wpk16_ns; const uint32_t* h2flag; long long h2flag_ns; int maxslot;
   int h2_noskip;      // measurement aid (CMLPL_F16X2=4): an all-zero image runs the two-piece loop instead of skipping it
+  // statistics for the two-piece WEIGHT-GRADIENT kernel (wgrad3x3.hip), [kind][2 networks][n samples] words: every
+  // workgroup leaves its sample's largest magnitude (float bits) of a0, p1 (forward) and of conv1's / conv2's masked
+  // up-sampled pooled gradients (backward) -- plain stores, every slot rewritten every step; null = not collected
+  uint32_t* hstat;
 };
 
 // x / d == umulhi(x, ceil(2^32 / d)) for x d < 2^32 (every index here is below 2^16); d = 1 is flagged by 0
@@ -1190,8 +1194,9 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 }
 
 // avgpool2 + ReLU-mask epilogue shared by the forward kernels (img holds relu(z) at the pixel centres)
-template <int NT = 256, bool STORE = true>
-__device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c, float* img2 = nullptr) {
+template <int NT = 256, bool STORE = true, bool STAT = false>
+__device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c, float* img2 = nullptr, float* statslot = nullptr) {
+  float pmx = 0.f;
   float* out = STORE ? a.out + (long long)c.net * a.out_ns : nullptr;
   uint8_t* mo = STORE ? a.mask_out + (long long)c.net * a.mask_out_ns : nullptr;
   // one (pooled pixel, 4 channels) item per thread and pass: four ds_read_b128, one 16-B and one 4-B store
@@ -1211,6 +1216,7 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
       o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
       o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
       if constexpr (STORE) *(float4*)(out + g) = o;
+      if constexpr (STAT) pmx = fmaxf(fmaxf(pmx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
       // fused tail: the pooled map also becomes the zero-bordered conv2 input image, in LDS
       if (img2 != nullptr) *(float4*)(img2 + (size_t)((ph + 1) * (c.W2 + 2) + pw + 1) * CS + c4 * 4) = o;
 #define CMLPL_NIB(A, B, C, D) ((uint32_t)((relu_open(A) ? 1 : 0) | (relu_open(B) ? 2 : 0) | (relu_open(C) ? 4 : 0) | (relu_open(D) ? 8 : 0)))
@@ -1220,6 +1226,7 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
       if constexpr (STORE) *(uint32_t*)(mo + g) = m;
     }
   }
+  if constexpr (STAT) { if (statslot != nullptr) h2_publish_max(pmx, statslot); }
 }
 
 // The rest of BaseNet2.forward for this workgroup's sample (S == 1), entered right after conv1's pooled map p1 has
@@ -1668,6 +1675,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     const int c4 = tid & 15, pp = tid >> 4, ph = pp >> 1, pw = pp & 1;
     const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
     const uint32_t m = m2pre;
+    float zmx = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       float4 v;
@@ -1677,6 +1685,12 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
       v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
       const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
       *(float4*)(img2 + (size_t)((h + 1) * PW2 + w + 1) * CS + c4 * 4) = v;
+      zmx = fmaxf(fmaxf(zmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (a.hstat != nullptr) {       // (wave 0 whole: the batch-level maximum of conv2's gradient operand, for its weight gradient)
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) zmx = fmaxf(zmx, __shfl_xor(zmx, o, 64));
+      if (tid == 0) a.hstat[(3 * 2 + net) * a.n + sample] = __float_as_uint(zmx);
     }
   }
   __syncthreads();
@@ -2228,7 +2242,7 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
   static_assert(!H2X || (MODE >= 2 && TAIL == 1 && ((NW == 4 && TPW == 2) || (NW == 8 && TPW == 1))),
                 "H2X: the four-tile per-sample kernels with tail / head");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if constexpr (H2X) { if (threadIdx.x == 0) smem[a.maxslot] = 0.f; }
+  if constexpr (H2X) { if (threadIdx.x == 0) { smem[a.maxslot] = 0.f; smem[a.maxslot + 1] = 0.f; } }
   constexpr int NT = 64 * NW;
   constexpr int KMT = NW * TPW / 2;        // pixel tiles of the per-sample kernels
   constexpr int LUTN = (MODE >= 2) ? KMT * 32 : MTW * NW * 32;
@@ -2303,6 +2317,7 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
       hsc = hzero ? 1.f : __uint_as_float((268u - e) << 23);
       hinv = hzero ? 1.f : __uint_as_float((e - 27u - (uint32_t)(H2_WEXP - 13)) << 23);
       wq16 = (const uint4*)(a.wpk16 + (long long)net * a.wpk16_ns) + lane;
+      if (a.hstat != nullptr && tid == 0) a.hstat[((MODE == 2 ? 0 : 2) * 2 + net) * a.n + s0] = mxb;
     }
   };
   float* x8 = (float*)(lut + LUTN);        // eight waves: [8][16][64] floats behind the LUT (second tap buffer, then the fold's exchange)
@@ -2432,11 +2447,16 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
     STAMP(0, 10);
     __syncthreads();
     STAMP(0, 11);
-    conv3_pool_store<NT, !INFER>(a, c, TAIL ? wbuf : nullptr);
+    // (H2X: the pooled map's largest magnitude goes into the second statistics word of the LDS slot -- dead since the tap
+    //  loop was chosen -- and from there, behind the tail's barriers, into the batch-level word the weight gradient reads)
+    conv3_pool_store<NT, !INFER, H2X>(a, c, TAIL ? wbuf : nullptr, (H2X && a.hstat != nullptr) ? smem + a.maxslot + 1 : nullptr);
     STAMP(0, 7);
     if constexpr (TAIL != 0) {
       if constexpr (BIG) conv3_fwd_tail_g<INFER>(a, c, smem);
       else conv3_fwd_tail<NW, INFER>(a, c, smem);
+    }
+    if constexpr (H2X) {
+      if (a.hstat != nullptr && tid == 0) a.hstat[(1 * 2 + net) * a.n + s0] = ((const volatile uint32_t*)smem)[a.maxslot + 1];
     }
   } else if (MODE == 3) {
     // conv0 weight gradient fused in (S == 1, MTW == 1):  dW0[c][co] = sum_pix xn[c][pix] * da0[pix][co].
@@ -2824,7 +2844,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
   if (pl.ks) {
     static DevOnce attr_ks;
@@ -2968,7 +2988,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   conv3_set_magics(a);
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -2984,7 +3004,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
       return hipGetLastError();
     }
     const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 2 || switches().f16x2 == 4) && tail->w1h != nullptr && tail->h2flag != nullptr;
-    if (h2x) { a.wpk16 = tail->w1h; a.wpk16_ns = tail->w1h_ns; a.h2flag = tail->h2flag; a.h2flag_ns = tail->w1h_ns; }
+    if (h2x) { a.wpk16 = tail->w1h; a.wpk16_ns = tail->w1h_ns; a.h2flag = tail->h2flag; a.h2flag_ns = tail->w1h_ns; a.hstat = tail->hstat; }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_lds(H, W, C, conv3_ks8_lds(pl.lds), 8);
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;
@@ -3130,7 +3150,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr;
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
@@ -3144,7 +3164,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
       return hipGetLastError();
     }
     const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 3 || switches().f16x2 == 4) && head->w1h != nullptr && head->h2flag != nullptr;
-    if (h2x) { a.wpk16 = head->w1h; a.wpk16_ns = head->w1h_ns; a.h2flag = head->h2flag; a.h2flag_ns = head->w1h_ns; }
+    if (h2x) { a.wpk16 = head->w1h; a.wpk16_ns = head->w1h_ns; a.h2flag = head->h2flag; a.h2flag_ns = head->w1h_ns; a.hstat = head->hstat; }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pl.lds));
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;
@@ -3172,6 +3192,20 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
     return hipGetLastError();
   }
   return launch_conv3_t<3, 1>(a, dim3(n, nets), conv3_fused_bwd_lds(H, W, C, pl.lds), st);
+}
+
+// do the fused forward AND backward launches of this shape / batch take the two-piece kernels (which also collect the
+// batch statistics the two-piece weight gradient needs)?  Mirrors the launchers below.
+bool conv3_h2x_both(int H, int W, int C, int rows, int K) {
+  if (switches().f16x2 != 1 && switches().f16x2 != 4) return false;
+  BigGeom bg;
+  if (conv3_big_fwd_ok(H, W, C, &bg) || conv3_big_bwd_ok(H, W, C, &bg)) return false;
+  if (!conv3_fused_tail_ok(H, W, C, rows, K) || !conv3_fused_head_ok(H, W, C, rows, K)) return false;
+  Conv3Plan pf, pb;
+  if (!plan_conv3(0, H, W, rows, &pf) || !plan_conv3(1, H, W, rows, &pb)) return false;
+  if (conv3_ks8(rows))
+    return conv3_fused_lds(H, W, C, conv3_ks8_lds(pf.lds), 8) + 64 <= LDS_MAX && conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pb.lds)) + 64 <= LDS_MAX;
+  return 2 * (conv3_fused_lds(H, W, C, pf.lds) + 64) <= LDS_MAX && 2 * (conv3_fused_bwd_lds(H, W, C, pb.lds) + 64) <= LDS_MAX;
 }
 
 }  // namespace cmlpl

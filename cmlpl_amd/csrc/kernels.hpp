@@ -105,6 +105,7 @@ struct FwdTail {
   const float* y; const float* dropmask; float* dropgen; float* catd; float* ynorm; float* logits; float* feat;
   float* p2; uint8_t* m2; float dropout_p; int train, K;
   const float* w1h = nullptr; long long w1h_ns = 0; const uint32_t* h2flag = nullptr;   // conv1's two-piece fp16 set (pack_off_h2(.., 0)) + its flag words, or null
+  uint32_t* hstat = nullptr;        // [4 kinds][2 networks][n] per-sample maxima for the two-piece weight gradient, or null
 };
 bool conv3_fused_tail_ok(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& xs, const float* w0t, long long w0t_ns,
@@ -122,8 +123,10 @@ struct BwdHead {
   const float* y; const float* ynorm; const uint8_t* m2; const float* w2d; long long w2d_ns;
   float* dy; float* dp2; float* dp1; int K;
   const float* w1h = nullptr; long long w1h_ns = 0; const uint32_t* h2flag = nullptr;   // conv1's data-gradient two-piece fp16 set (pack_off_h2(.., 1)), or null
+  uint32_t* hstat = nullptr;
 };
 bool conv3_fused_head_ok(int H, int W, int C, int rows, int K);
+bool conv3_h2x_both(int H, int W, int C, int rows, int K);
 hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const float* dpool, const uint8_t* mask,
                                   const float* wpk, long long wpk_ns, const XSrc& xs, float* part0, long long part0_ns,
                                   const BwdHead* head /* or null */, hipStream_t st);
@@ -135,7 +138,9 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
                          float* part, hipStream_t st);
 hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1, const float* dpool1,
                               const uint8_t* mask1, float* part1, int H2, int W2, const float* in2,
-                              const float* dpool2, const uint8_t* mask2, float* part2, bool* merged, hipStream_t st);
+                              const float* dpool2, const uint8_t* mask2, float* part2, bool* merged, hipStream_t st,
+                              const uint32_t* hstat = nullptr /* this step's per-sample maxima (conv3x3.hip: [4][2][n]), or null */,
+                              const uint32_t* h2flag = nullptr, long long h2flag_ns = 0);
 
 // ---- conv0.hip
 hipError_t launch_conv0_fwd(int nets, int n, int C, int HW, const float* xn, const float* w0t, long long w0t_ns,

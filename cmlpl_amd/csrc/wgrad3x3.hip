@@ -36,6 +36,11 @@ struct Wgrad3Args {
   const float* in; const float* dpool; const uint8_t* mask; float* part;
   long long in_ns, dpool_ns, part_ns;
   int n, H, W, RU, U, G, UPG;
+  // two-piece fp16 planes (wgrad3b_body<CPR, true>): per network and sample the largest magnitude (float bits) of the
+  // activation operand and of the masked up-sampled pooled gradient, left by the fused forward / backward kernels of this
+  // step (conv3x3.hip: Conv3Args::hstat, [2 networks][n]); the networks' weight-range flags (two-piece packing, kernels.hpp);
+  // null = three-piece bf16 planes
+  const uint32_t* stat_a; const uint32_t* stat_g; const uint32_t* h2flag; long long h2flag_ns;
 };
 
 // CSPL = 1: one workgroup produces all 64 output channels (wave = (co tile, ci tile), 9 taps each).
@@ -491,6 +496,16 @@ __device__ __forceinline__ void plane_put(char* plane0, int plane_stride, int by
   *(uint2*)(plane0 + plane_stride + byte) = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
   *(uint2*)(plane0 + 2 * plane_stride + byte) = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
 }
+// ... and as TWO fp16 pieces of x * sc (common.hpp: h_split): truncated first piece, exact residual truncated
+__device__ __forceinline__ void plane_put_h(char* plane0, int plane_stride, int byte, const float4& v, float sc) {
+  const float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+  const f16x2v p0 = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+  const f16x2v p1 = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(x[2], x[3]));
+  *(uint2*)(plane0 + byte) = make_uint2(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
+  *(uint2*)(plane0 + plane_stride + byte) =
+      make_uint2(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x[0] - (float)p0[0], x[1] - (float)p0[1])),
+                 __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x[2] - (float)p1[0], x[3] - (float)p1[1])));
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -502,11 +517,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CPR>
-__device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, const int net, const int kh, float* smem) {
+// HP: both operands as TWO fp16 pieces of (value x its batch-level power-of-two scale) -- two planes each where the
+// three-piece scheme has three, three MFMAs per product where it has six, a 12-instruction split per four elements
+// where it has 22; the partial is multiplied by 1 / (sa sg) = `inv` (exact) when it is written.
+template <int CPR, bool HP = false>
+__device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, const int net, const int kh, float* smem,
+                                             const float sa = 1.f, const float sg = 1.f, const float inv = 1.f) {
   constexpr int NT = 512, U = wg3b_U(CPR), R = 2 * U, CO = 2 * CPR;
   constexpr int APOS = wg3b_apos(CPR), KP = wg3b_kp(CPR), NST = KP / 16;
-  constexpr int APL = APOS * 128, BPL = KP * 128, BUF = wg3b_buf(CPR);
+  constexpr int NP = HP ? 2 : 3;                                   // pieces = planes per operand
+  constexpr int APL = APOS * 128, BPL = KP * 128, BUF = NP * (APOS + KP) * 128;
+  static_assert(BUF <= wg3b_buf(CPR), "the launch sizes LDS for three-piece planes");
   constexpr int NRA = (R * (CO + 1) * 16 + NT - 1) / NT;          // activation items per thread and stage
   static_assert(U >= 2 && U * CPR * 16 <= NT, "stage geometry");
   char* lds = (char*)smem;
@@ -525,12 +546,12 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const int tail0 = (W + 1) * R, ntail = APOS - tail0;          // positions of the right halo (and beyond)
     const int nz = R + ntail + (KP - CO * R);                      // positions to clear per (buffer, piece)
-    for (int i = tid; i < 6 * nz * 8; i += NT) {                   // 8 float4 per position
-      const int f = i & 7, q = (i >> 3) % nz, bp = (i >> 3) / nz, buf = bp / 3, pc = bp - 3 * buf;
+    for (int i = tid; i < 2 * NP * nz * 8; i += NT) {              // 8 float4 per position
+      const int f = i & 7, q = (i >> 3) % nz, bp = (i >> 3) / nz, buf = bp / NP, pc = bp - NP * buf;
       char* base = lds + buf * BUF;
       char* dst = q < R ? base + pc * APL + q * 128
                 : q < R + ntail ? base + pc * APL + (tail0 + q - R) * 128
-                : base + 3 * APL + pc * BPL + (CO * R + q - R - ntail) * 128;
+                : base + NP * APL + pc * BPL + (CO * R + q - R - ntail) * 128;
       *(float4*)(dst + f * 16) = z;
     }
   }
@@ -598,24 +619,37 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   auto commit = [&](char* buf) {
 #pragma unroll
     for (int q = 0; q < NRA; ++q)
-      if (a_u[q] < (1 << 28)) plane_put(buf, APL, a_dst[q], pa[q]);
+      if (a_u[q] < (1 << 28)) {
+        if constexpr (HP) plane_put_h(buf, APL, a_dst[q], pa[q], sa);
+        else plane_put(buf, APL, a_dst[q], pa[q]);
+      }
     if (d_u < (1 << 28)) {
       // the four positions of a pooled item's 2x2 window carry the SAME value d / 4, each behind its own gate bit:
       // split once, then gate the packed pieces (a 16-bit lane mask per channel) -- 4 x (gate, scale, split) before
       const float q[4] = {pdd.x * 0.25f, pdd.y * 0.25f, pdd.z * 0.25f, pdd.w * 0.25f};
-      uint32_t u0[4], u1[4], u2[4];
+      uint2 p0, p1, p2 = make_uint2(0u, 0u);
+      if constexpr (HP) {
+        const float x[4] = {q[0] * sg, q[1] * sg, q[2] * sg, q[3] * sg};
+        const f16x2v h0 = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+        const f16x2v h1 = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(x[2], x[3]));
+        p0 = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+        p1 = make_uint2(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x[0] - (float)h0[0], x[1] - (float)h0[1])),
+                        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x[2] - (float)h1[0], x[3] - (float)h1[1])));
+      } else {
+        uint32_t u0[4], u1[4], u2[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        u0[j] = __float_as_uint(q[j]);
-        const float r1 = q[j] - __uint_as_float(u0[j] & 0xffff0000u);
-        u1[j] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(u1[j] & 0xffff0000u);
-        u2[j] = __float_as_uint(r2);
+        for (int j = 0; j < 4; ++j) {
+          u0[j] = __float_as_uint(q[j]);
+          const float r1 = q[j] - __uint_as_float(u0[j] & 0xffff0000u);
+          u1[j] = __float_as_uint(r1);
+          const float r2 = r1 - __uint_as_float(u1[j] & 0xffff0000u);
+          u2[j] = __float_as_uint(r2);
+        }
+        p0 = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
+        p1 = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
+        p2 = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
       }
-      const uint2 p0 = make_uint2(hi_pair(u0[0], u0[1]), hi_pair(u0[2], u0[3]));
-      const uint2 p1 = make_uint2(hi_pair(u1[0], u1[1]), hi_pair(u1[2], u1[3]));
-      const uint2 p2 = make_uint2(hi_pair(u2[0], u2[1]), hi_pair(u2[2], u2[3]));
-      char* bpl = buf + 3 * APL;
+      char* bpl = buf + NP * APL;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         // gate bit of channel j and window position sub: bit 8 j + sub of the mask word -> all-ones / zero
@@ -624,7 +658,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
         const uint32_t m01 = (s0 & 0xffffu) | (s1 & 0xffff0000u), m23 = (s2 & 0xffffu) | (s3 & 0xffff0000u);
         *(uint2*)(bpl + d_dst[sub]) = make_uint2(p0.x & m01, p0.y & m23);
         *(uint2*)(bpl + BPL + d_dst[sub]) = make_uint2(p1.x & m01, p1.y & m23);
-        *(uint2*)(bpl + 2 * BPL + d_dst[sub]) = make_uint2(p2.x & m01, p2.y & m23);
+        if constexpr (!HP) *(uint2*)(bpl + 2 * BPL + d_dst[sub]) = make_uint2(p2.x & m01, p2.y & m23);
       }
       // bias gradient: the value times the number of open gates of its window
       // (a closed window contributes 0 whatever its value, as the per-position gate did)
@@ -652,7 +686,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   const int rowb = (8 * (gq >> 1) + qq) * 128 + 32 * (gq & 1) + 8 * pp;
   const int sw = (qq >> 1) & 1;
   const int a_lane = rowb + ((it ^ sw) << 6);
-  const int b_lane = 3 * APL + rowb + ((ct ^ sw) << 6);
+  const int b_lane = NP * APL + rowb + ((ct ^ sw) << 6);
   int cur = 0;
   for (int ub = ubeg; ub < uend; ub += U) {
     const bool more = ub + U < uend;            // workgroup-uniform
@@ -667,6 +701,17 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
       const int step = 2 * st + kg;             // wave-uniform
       if (step < NST && CMLPL_ABL != 32) {
         const char* pbs = pb_ + step * 2048;
+        if constexpr (HP) {
+          const f16x8v b1 = __builtin_bit_cast(f16x8v, tr_frag(pbs)), b2 = __builtin_bit_cast(f16x8v, tr_frag(pbs + BPL));
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const char* pas = pa_ + step * 2048 + kw * (R * 128);
+            const f16x8v a1 = __builtin_bit_cast(f16x8v, tr_frag(pas)), a2 = __builtin_bit_cast(f16x8v, tr_frag(pas + APL));
+            acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc[kw], 0, 0, 0);
+            acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[kw], 0, 0, 0);
+            acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[kw], 0, 0, 0);
+          }
+        } else {
         const bf16x8 b1 = tr_frag(pbs), b2 = tr_frag(pbs + BPL), b3 = tr_frag(pbs + 2 * BPL);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
@@ -678,6 +723,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
           acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[kw], 0, 0, 0);
           acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[kw], 0, 0, 0);
           acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[kw], 0, 0, 0);
+        }
         }
       }
     }
@@ -705,7 +751,8 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = it * 32 + acc_row(r, lane);
-        part[(3 * kh + s) * 4096 + ci * 64 + ct * 32 + l31] = acc[s][r] + red[(s * 16 + r) * 64];
+        const float v = acc[s][r] + red[(s * 16 + r) * 64];
+        part[(3 * kh + s) * 4096 + ci * 64 + ct * 32 + l31] = HP ? v * inv : v;
       }
     }
   }
@@ -720,10 +767,47 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   STAMP(2, 3);
 }
 
+// three-piece planes, or two-piece ones when this step's fused kernels left both operands' per-sample maxima: the
+// workgroup first folds them to the BATCH maxima (the accumulators sum over samples: one scale per operand), and takes the
+// two-piece planes when both are ordinary numbers and the network's weights were inside the two-piece range (the flag
+// marks a numerically extreme network: everything of it stays on three pieces).  Workgroup-uniform.
+template <int CPR>
+__device__ __forceinline__ void wgrad3b_run(const Wgrad3Args& a, const int g, const int net, const int kh, float* smem) {
+  if (a.stat_a != nullptr && a.stat_g != nullptr) {
+    uint32_t* s_stat = (uint32_t*)smem;          // (two words of the plane region, handed back behind the third barrier)
+    const int tid = threadIdx.x;
+    if (tid < 2) s_stat[tid] = 0u;
+    uint32_t ma = 0u, mg = 0u;
+    for (int i = tid; i < a.n; i += 512) {
+      const uint32_t x = a.stat_a[(long long)net * a.n + i], y = a.stat_g[(long long)net * a.n + i];
+      ma = x > ma ? x : ma; mg = y > mg ? y : mg;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const uint32_t x = (uint32_t)__shfl_xor((int)ma, o, 64), y = (uint32_t)__shfl_xor((int)mg, o, 64);
+      ma = x > ma ? x : ma; mg = y > mg ? y : mg;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicMax(&s_stat[0], ma); atomicMax(&s_stat[1], mg); }
+    __syncthreads();
+    const uint32_t ea = __builtin_amdgcn_readfirstlane(s_stat[0]) >> 23, eg = __builtin_amdgcn_readfirstlane(s_stat[1]) >> 23;
+    __syncthreads();
+    const uint32_t flag = a.h2flag != nullptr ? a.h2flag[(long long)net * a.h2flag_ns] : 0u;
+    if (flag == 0u && ea >= 40u && ea <= 200u && eg >= 40u && eg <= 200u && ea + eg >= 160u) {
+      // scales 2^(14 - floor(log2 max)): the largest magnitude of either operand lands in [2^14, 2^15)
+      const float sa = __uint_as_float((268u - ea) << 23), sg = __uint_as_float((268u - eg) << 23);
+      const float inv = __uint_as_float((ea + eg - 155u) << 23);
+      wgrad3b_body<CPR, true>(a, g, net, kh, smem, sa, sg, inv);
+      return;
+    }
+  }
+  wgrad3b_body<CPR, false>(a, g, net, kh, smem);
+}
+
 template <int CPR>
 __global__ __launch_bounds__(512) void wgrad3b_kernel(Wgrad3Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  wgrad3b_body<CPR>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+  wgrad3b_run<CPR>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 // conv1's and conv2's weight gradients of one backward pass in ONE launch (one ramp and one drain instead of two).
 // A workgroup fills a CU and workgroups go to the XCDs round-robin in launch order, so ALL of conv1's long
@@ -735,8 +819,8 @@ __global__ __launch_bounds__(512) void wgrad3b_pair_kernel(Wgrad3Args a, Wgrad3A
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int na = a.G * nets * 3;
   int id = (int)blockIdx.x;
-  if (id < na) { const int g = id % a.G, r = id / a.G; wgrad3b_body<CPRA>(a, g, r % nets, r / nets, smem); }
-  else { id -= na; const int g = id % b.G, r = id / b.G; wgrad3b_body<CPRB>(b, g, r % nets, r / nets, smem); }
+  if (id < na) { const int g = id % a.G, r = id / a.G; wgrad3b_run<CPRA>(a, g, r % nets, r / nets, smem); }
+  else { id -= na; const int g = id % b.G, r = id / b.G; wgrad3b_run<CPRB>(b, g, r % nets, r / nets, smem); }
 }
 
 static size_t wgrad3_lds(int RU, int U, int W, int cspl = 1) {
@@ -860,6 +944,7 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G; a.UPG = pl.UPG;
+  a.stat_a = nullptr; a.stat_g = nullptr; a.h2flag = nullptr; a.h2flag_ns = 0;
   if (pl.rsplit && pl.b3) {
 #define WG3B_CASE(CPR_)                                                                              \
     case CPR_: {                                                                                     \
@@ -903,6 +988,7 @@ static void wgrad3_args(Wgrad3Args& a, const Wgrad3Plan& pl, int n, int H, int W
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G; a.UPG = pl.UPG;
+  a.stat_a = nullptr; a.stat_g = nullptr; a.h2flag = nullptr; a.h2flag_ns = 0;
 }
 
 // Plans of both 3x3 weight gradients of a backward pass.  *pair: one launch (wgrad3b_pair_kernel) -- then the two plans
@@ -930,7 +1016,8 @@ bool plan_wgrad3_both(int nets, int n, int H1, int W1, int H2, int W2, bool want
 // both 3x3 weight gradients of a backward pass: one launch where a pair kernel exists, else two
 hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1, const float* dpool1,
                               const uint8_t* mask1, float* part1, int H2, int W2, const float* in2,
-                              const float* dpool2, const uint8_t* mask2, float* part2, bool* merged, hipStream_t st) {
+                              const float* dpool2, const uint8_t* mask2, float* part2, bool* merged, hipStream_t st,
+                              const uint32_t* hstat, const uint32_t* h2flag, long long h2flag_ns) {
   Wgrad3Plan p1, p2;
   *merged = false;
   bool pair = false;
@@ -939,6 +1026,10 @@ hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1,
     Wgrad3Args a, b;
     wgrad3_args(a, p1, n, H1, W1, in1, dpool1, mask1, part1);
     wgrad3_args(b, p2, n, H2, W2, in2, dpool2, mask2, part2);
+    if (hstat != nullptr) {     // [kind][2 networks][n]: a0, p1, conv1's gradient operand, conv2's
+      a.stat_a = hstat + 0 * 2 * n; a.stat_g = hstat + 2 * 2 * n; b.stat_a = hstat + 1 * 2 * n; b.stat_g = hstat + 3 * 2 * n;
+      a.h2flag = b.h2flag = h2flag; a.h2flag_ns = b.h2flag_ns = h2flag_ns;
+    }
     const size_t lds = p1.lds > p2.lds ? p1.lds : p2.lds;
     const dim3 grid((p1.G + p2.G) * nets * 3);
 #define WG3P_CASE(CA_, CB_)                                                                          \

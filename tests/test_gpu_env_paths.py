@@ -76,11 +76,13 @@ def test_tall_pair_exp_kernel_passes_loss_parity():
 WIDE = [("0", "0"), ("4", "1"), ("4", "2"), ("4", "3"), ("4", "4"), ("2", "2")]
 # the planner's tile shape also runs the eight-rank configuration and the headline batch against the reference fixture;
 # every other forced tile shape runs the loss block (plain buffers) and the sharded steps (packed exchange buffers) -- local
-# row counts from 4 to 128 through the 64-row (one or two row blocks of workgroups) and 128-row instantiations
+# row counts from 4 to 128 through the 64-row (one or two row blocks of workgroups) and 128-row instantiations (the last
+# three shapes: the four- and eight-rank B2 cases of the sharded steps)
 J_WIDE = {(mb, nbw): _job("pair", f"wide-{mb}-{nbw}", {"CMLPL_PAIR_WIDE": "1", "CMLPL_PAIR_MB": mb, "CMLPL_PAIR_NBW": nbw},
                           ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "tests/test_gpu_step.py", "-k",
                            "loss_block or sharded_step_equals or (eight_rank and B3) or b2_b256" if (mb, nbw) == ("0", "0")
-                           else "loss_block or sharded_step_equals"])
+                           else "loss_block or sharded_step_equals" if (mb, nbw) in (("4", "1"), ("4", "2"))
+                           else "loss_block or (sharded_step_equals and (8-B2 or 4-B2))"])
           for mb, nbw in WIDE}
 
 

@@ -389,9 +389,9 @@ def run_rank(args):
     # conv1's tap loops of the four-tile per-sample kernels run on TWO fp16 pieces (three MFMAs per product) unless switched
     # off; conv0, conv2 and the weight gradients stay on three bf16 pieces (six)
     f16x2 = os.environ.get("CMLPL_F16X2", "1")
-    if tail_fwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "2", "4"):
+    if tail_fwd and kvar in ("4,2", "8,1", "8,2") and f16x2 in ("1", "2", "4"):
         kseg["conv1_fwd"]["split"] -= c1; kseg["conv1_fwd"]["split2"] = c1
-    if head_bwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "3", "4"):
+    if head_bwd and kvar in ("4,2", "8,1", "8,2") and f16x2 in ("1", "3", "4"):
         kseg["conv1_dgrad"]["split"] -= c1; kseg["conv1_dgrad"]["split2"] = c1
     if tail_fwd:
         kseg["conv1_fwd"]["split"] += conv2_flops                                       # tail: split-bf16 too (16x16x32 MFMA)
@@ -406,7 +406,7 @@ def run_rank(args):
         kseg["conv1_wgrad"][key] += conv2_flops
         # ... and the pair weight-gradient launch both its maps (planes of two fp16 pieces), when both fused launches ran the
         # two-piece kernels (they leave the operands' maxima it scales by)
-        if wgrad_split and tail_fwd and head_bwd and kvar in ("4,2", "8,1") and f16x2 in ("1", "4"):
+        if wgrad_split and tail_fwd and head_bwd and kvar in ("4,2", "8,1", "8,2") and f16x2 in ("1", "4"):
             kseg["conv1_wgrad"] = {"split2": kseg["conv1_wgrad"]["split"]}
         labels["conv1_wgrad"] = "wgrad3b_pair_kernel (conv1 + conv2 weight gradients in one launch, both networks)"
     kflops = {k: sum(v.values()) for k, v in kseg.items()}

@@ -2127,6 +2127,7 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
       for (int pc = 0; pc < 3; ++pc) bq[t0][3 * q + pc] = wq[(size_t)t0 * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
   __syncthreads();                                                 // dp2s complete, img2 zeroed
   STAMP(1, 4);
+  float zmx = 0.f;
   if (tid < P4 * 16) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
     const int c4 = tid & 15, pp = tid >> 4, ph = pp / W4, pw = pp - ph * W4;
     const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
@@ -2140,9 +2141,14 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
       v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
       const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
       *(float4*)(img2 + (size_t)((h + 1) * PW2 + w + 1) * CS + c4 * 4) = v;
+      zmx = fmaxf(fmaxf(zmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
   }
+  // (two-piece weight gradient: this sample's largest |dz2| -- whole waves take part in the reduction; the second word of
+  //  the statistics slot was zeroed at kernel start, in front of the barrier above)
+  if (a.hstat != nullptr && (tid >> 6) * 64 < P4 * 16) h2_publish_max(zmx, smem + a.maxslot + 1);
   __syncthreads();
+  if (a.hstat != nullptr && tid == 0) a.hstat[(3 * 2 + net) * a.n + sample] = ((const volatile uint32_t*)smem)[a.maxslot + 1];
   STAMP(1, 5);
   // ---- conv2 data gradient (split-bf16, 32x32x16): this wave's pixel tile x input-channel tile x output-channel half
   const int pA = mtile * 32 + l31;
@@ -2239,8 +2245,7 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
 template <int MODE, int MTW, int TAIL = 0, int NW = 4, int TPW = 8 / NW, bool KSG = false, bool H2X = false>
 __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
   static_assert(!KSG || (MODE < 2 && MTW == 1 && TAIL == 0 && NW == 4 && TPW == 2), "KSG: four waves, S = 1, four tiles");
-  static_assert(!H2X || (MODE >= 2 && TAIL == 1 && ((NW == 4 && TPW == 2) || (NW == 8 && TPW == 1))),
-                "H2X: the four-tile per-sample kernels with tail / head");
+  static_assert(!H2X || (MODE >= 2 && TAIL == 1 && (NW == 8 || TPW == 2)), "H2X: the per-sample kernels with tail / head");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if constexpr (H2X) { if (threadIdx.x == 0) { smem[a.maxslot] = 0.f; smem[a.maxslot + 1] = 0.f; } }
   constexpr int NT = 64 * NW;
@@ -2999,12 +3004,22 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
     static DevOnce attr_once;
     hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<2, 1, 1>, conv3x3_kernel<2, 1, 1, 8>, conv3x3_kernel<2, 1, 1, 8, 2>);
     if (e != hipSuccess) return e;
-    if (big) {
-      hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_fwd_lds(bg, C), st, a);
-      return hipGetLastError();
-    }
     const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 2 || switches().f16x2 == 4) && tail->w1h != nullptr && tail->h2flag != nullptr;
     if (h2x) { a.wpk16 = tail->w1h; a.wpk16_ns = tail->w1h_ns; a.h2flag = tail->h2flag; a.h2flag_ns = tail->w1h_ns; a.hstat = tail->hstat; }
+    if (big) {
+      const size_t ldsb = conv3_big_fwd_lds(bg, C);
+      if (h2x && ldsb + 64 <= LDS_MAX) {
+        static DevOnce attr_hb;
+        hipError_t eh = ensure_max_lds(attr_hb, conv3x3_kernel<2, 1, 1, 8, 2, false, true>);
+        if (eh != hipSuccess) return eh;
+        a.maxslot = (int)(ldsb / 4);
+        hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8, 2, false, true>), dim3(n, nets), dim3(512), ldsb + 64, st, a);
+        return hipGetLastError();
+      }
+      a.hstat = nullptr;
+      hipLaunchKernelGGL((conv3x3_kernel<2, 1, 1, 8, 2>), dim3(n, nets), dim3(512), ldsb, st, a);
+      return hipGetLastError();
+    }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_lds(H, W, C, conv3_ks8_lds(pl.lds), 8);
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;
@@ -3159,12 +3174,22 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
     static DevOnce attr_once;
     hipError_t e = ensure_max_lds(attr_once, conv3x3_kernel<3, 1, 1>, conv3x3_kernel<3, 1, 1, 8>, conv3x3_kernel<3, 1, 1, 8, 2>);
     if (e != hipSuccess) return e;
-    if (big) {
-      hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8, 2>), dim3(n, nets), dim3(512), conv3_big_bwd_lds(bg, C), st, a);
-      return hipGetLastError();
-    }
     const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 3 || switches().f16x2 == 4) && head->w1h != nullptr && head->h2flag != nullptr;
     if (h2x) { a.wpk16 = head->w1h; a.wpk16_ns = head->w1h_ns; a.h2flag = head->h2flag; a.h2flag_ns = head->w1h_ns; a.hstat = head->hstat; }
+    if (big) {
+      const size_t ldsb = conv3_big_bwd_lds(bg, C);
+      if (h2x && ldsb + 64 <= LDS_MAX) {
+        static DevOnce attr_hb;
+        hipError_t eh = ensure_max_lds(attr_hb, conv3x3_kernel<3, 1, 1, 8, 2, false, true>);
+        if (eh != hipSuccess) return eh;
+        a.maxslot = (int)(ldsb / 4);
+        hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8, 2, false, true>), dim3(n, nets), dim3(512), ldsb + 64, st, a);
+        return hipGetLastError();
+      }
+      a.hstat = nullptr;
+      hipLaunchKernelGGL((conv3x3_kernel<3, 1, 1, 8, 2>), dim3(n, nets), dim3(512), ldsb, st, a);
+      return hipGetLastError();
+    }
     if (conv3_ks8(nets * n)) {
       const size_t lds8 = conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pl.lds));
       if (lds8 > LDS_MAX) return hipErrorInvalidValue;
@@ -3199,8 +3224,10 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
 bool conv3_h2x_both(int H, int W, int C, int rows, int K) {
   if (switches().f16x2 != 1 && switches().f16x2 != 4) return false;
   BigGeom bg;
-  if (conv3_big_fwd_ok(H, W, C, &bg) || conv3_big_bwd_ok(H, W, C, &bg)) return false;
   if (!conv3_fused_tail_ok(H, W, C, rows, K) || !conv3_fused_head_ok(H, W, C, rows, K)) return false;
+  if (conv3_big_fwd_ok(H, W, C, &bg) || conv3_big_bwd_ok(H, W, C, &bg))           // the eight-tile kernels (windows of 129 .. 256 pixels)
+    return conv3_big_fwd_ok(H, W, C, &bg) && conv3_big_bwd_ok(H, W, C, &bg) && conv3_big_fwd_lds(bg, C) + 64 <= LDS_MAX &&
+           conv3_big_bwd_lds(bg, C) + 64 <= LDS_MAX;
   Conv3Plan pf, pb;
   if (!plan_conv3(0, H, W, rows, &pf) || !plan_conv3(1, H, W, rows, &pb)) return false;
   if (conv3_ks8(rows))

@@ -38,6 +38,14 @@ struct NetWs {
   size_t bytes;
 };
 
+// do ALL FOUR general 3x3 launches of a step (conv1 / conv2, forward / data gradient) take two-piece kernels?  Then each
+// leaves its samples' image maxima in the statistics table and the weight-gradient pair launch can scale by them.
+bool general_h2_stats(const Dims& d, int rows) {
+  return !conv3_fused_ok(d.H, d.W, d.C, rows) && !conv3_fused_bwd_ok(d.H, d.W, d.C, rows) &&
+         conv3_h2x_general(0, d.H, d.W, rows) && conv3_h2x_general(1, d.H, d.W, rows) &&
+         conv3_h2x_general(0, d.H2, d.W2, rows) && conv3_h2x_general(1, d.H2, d.W2, rows);
+}
+
 // per-net conv0 weight-gradient partials: one per sample when the fused data-gradient kernel produces them
 int conv0_partials(const Dims& d, int nets, int n) {
   return conv3_fused_bwd_ok(d.H, d.W, d.C, nets * n) ? n : plan_conv0_wgrad_G(n, d.C, d.HW);
@@ -316,6 +324,10 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
                                pk_ns, d_params + L.param_off[1], param_stride, w.a0, d_packed + pack_off_b3(d.C, d.bands, 0), pk_ns,
                                d_params + L.param_off[3], param_stride, w.p1, w.m1, &t, st, xn_save)));
   }
+  // the general 3x3 launches on two fp16 pieces where their plans allow; when all four of a step do, each leaves its
+  // samples' image maxima for the two-piece weight gradient (general_h2_stats)
+  const uint32_t* h2flag = (const uint32_t*)(d_packed + pack_off_h2flag(d.C, d.bands));
+  const bool gen_stats = general_h2_stats(d, nets * n);
   if (conv3_fused_ok(d.H, d.W, d.C, nets * n)) {
     // conv0 + conv1 in one launch, input rows taken where they lie and augmented in LDS: neither an augmented
     // copy of the input nor a0's round trip between the two convolutions touches HBM (a0 is still written once,
@@ -334,11 +346,13 @@ int fwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
       if ((rc = TIMED(CMLPL_K_CONV0_FWD, chk(launch_conv0_fwd(nets, n, d.C, d.HW, d_xn, d_packed + pack_off_w0t(), pk_ns,
                                      d_params + L.param_off[1], param_stride, w.a0, st))))) return rc;
     }
+    const Conv3H2 h1 = {d_packed + pack_off_h2(d.C, d.bands, 0), pk_ns, h2flag, gen_stats ? w.hstat : nullptr, 0};
     if ((rc = TIMED(CMLPL_K_CONV1_FWD, chk(launch_conv3(0, nets, n, d.H, d.W, w.a0, nullptr, d_packed + pack_off_b3(d.C, d.bands, 0),
-                               pk_ns, d_params + L.param_off[3], param_stride, w.p1, w.m1, st))))) return rc;
+                               pk_ns, d_params + L.param_off[3], param_stride, w.p1, w.m1, st, &h1))))) return rc;
   }
+  const Conv3H2 h2 = {d_packed + pack_off_h2(d.C, d.bands, 2), pk_ns, h2flag, gen_stats ? w.hstat : nullptr, 1};
   if ((rc = TIMED(CMLPL_K_CONV2_FWD, chk(launch_conv3(0, nets, n, d.H2, d.W2, w.p1, nullptr, d_packed + pack_off_b3(d.C, d.bands, 2),
-                             pk_ns, d_params + L.param_off[5], param_stride, w.p2, w.m2, st))))) return rc;
+                             pk_ns, d_params + L.param_off[5], param_stride, w.p2, w.m2, st, &h2))))) return rc;
   const int nlab = shard ? shard->nlab : n, lab0 = shard ? shard->lab0 : 0;
   const int unl_base = shard ? shard->bt_g + shard->unl0 : n;
   return TIMED(CMLPL_K_HEAD_FWD, chk(launch_head_fwd(nets, n, d.P4, d.K, w.p2, w.y, d_dropmask, w.dropgen, dropout_p,
@@ -423,12 +437,13 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
     // feat is re-formed inside head_bwd as y / ||y|| (the forward's own division), so it is not an input here
     if ((rc = TIMED(CMLPL_K_HEAD_BWD, chk(launch_head_bwd(nets, n, d.P4, d.K, d_dlogits, d_dfeat_head, mask,
                                   d_params + L.param_off[8], param_stride, w.y, w.ynorm, w.dy, w.dp2, st))))) return rc;
+    const uint32_t* h2flag = (const uint32_t*)(d_packed + pack_off_h2flag(d.C, d.bands));
+    const bool gen_stats = general_h2_stats(d, nets * n);
+    const Conv3H2 h3 = {d_packed + pack_off_h2(d.C, d.bands, 3), L.packed_total, h2flag, gen_stats ? w.hstat : nullptr, 3};
     if ((rc = TIMED(CMLPL_K_CONV2_DGRAD, chk(launch_conv3(1, nets, n, d.H2, d.W2, w.dp2, w.m2, d_packed + pack_off_b3(d.C, d.bands, 3),
-                               L.packed_total, nullptr, 0, w.dp1, nullptr, st))))) return rc;
-    bool merged = false;
-    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3_pair(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, d.H2, d.W2,
-                                  w.p1, w.dp2, w.m2, w.part2, &merged, st))))) return rc;
-    (void)merged;
+                               L.packed_total, nullptr, 0, w.dp1, nullptr, st, &h3))))) return rc;
+    // (round 6: conv1's data gradient in FRONT of the weight-gradient pair launch -- it leaves the maxima of conv1's
+    //  gradient operand that the two-piece weight gradient scales by; neither reads what the other writes)
     if (conv3_fused_bwd_ok(d.H, d.W, d.C, nets * n)) {
       // conv1 data gradient + conv0 weight gradient in one launch: da0 never goes to HBM
       if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3_fused_bwd(nets, n, d.C, d.H, d.W, w.dp1, w.m1,
@@ -436,11 +451,17 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
                                  (long long)n * conv0_partial_size(d.C), nullptr, st))))) return rc;
     } else {
       if (!d_xn) return CMLPL_E_ARG;
+      const Conv3H2 h1 = {d_packed + pack_off_h2(d.C, d.bands, 1), L.packed_total, h2flag, gen_stats ? w.hstat : nullptr, 2};
       if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + pack_off_b3(d.C, d.bands, 1),
-                                 L.packed_total, nullptr, 0, w.da0, nullptr, st))))) return rc;
+                                 L.packed_total, nullptr, 0, w.da0, nullptr, st, &h1))))) return rc;
       if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
         return rc;
     }
+    bool merged = false;
+    if ((rc = TIMED(CMLPL_K_CONV1_WGRAD, chk(launch_wgrad3_pair(nets, n, d.H, d.W, w.a0, w.dp1, w.m1, w.part1, d.H2, d.W2,
+                                  w.p1, w.dp2, w.m2, w.part2, &merged, st, gen_stats ? w.hstat : nullptr, h2flag,
+                                  L.packed_total))))) return rc;
+    (void)merged;
   }
   if (!(parts & 2)) return 0;
   if (parts == 2) {

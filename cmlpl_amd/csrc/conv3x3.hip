@@ -81,18 +81,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, long long 
     return;                                            // the flag words: zeroed by the launcher, set below
   } else if (e >= pack_off_h2(pi.C, pi.bands, 0)) {    // conv1 as two fp16 pieces (kernels.hpp: pack_off_h2): two fp16 per float slot
     const long long r = e - pack_off_h2(pi.C, pi.bands, 0);
-    const int which = (int)(r / PACK_H2);              // 0 forward (n = co, k = ci), 1 data gradient (n = ci, k = co, taps flipped)
+    const int which = (int)(r / PACK_H2);              // 0 / 2: conv1 / conv2 forward (n = co, k = ci), 1 / 3: data gradient (n = ci, k = co, taps flipped)
     const int i = (int)(r - (long long)which * PACK_H2) * 2;
     const int j = i & 7, l31 = (i >> 3) & 31, h = (i >> 8) & 1, nt = (i >> 9) & 1, rest = i >> 10;
     const int pc = rest & 1, kq = (rest >> 1) & 3, tap = rest >> 3;
     const int kh = tap / 3, kw = tap - kh * 3, n = nt * 32 + l31;
-    const float* W = P + pi.off_w1;
+    const float* W = P + ((which < 2) ? pi.off_w1 : pi.off_w2);
     uint32_t out = 0;
     bool bad = false;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       const int k = kq * 16 + h * 8 + j + d;
-      const float w = (which == 0) ? W[((n * 64 + k) * 3 + kh) * 3 + kw] : W[((k * 64 + n) * 3 + (2 - kh)) * 3 + (2 - kw)];
+      const float w = ((which & 1) == 0) ? W[((n * 64 + k) * 3 + kh) * 3 + kw] : W[((k * 64 + n) * 3 + (2 - kh)) * 3 + (2 - kw)];
       uint32_t pcs[2];
       bad |= h2_split_w(w, pcs);
       out |= pcs[pc] << (16 * d);
@@ -189,6 +189,7 @@ struct Conv3Args {
   // the LDS word (float index into the dynamic allocation) in which the staging leaves the image's largest magnitude
   const float* wpk16; long long wpk16_ns; const uint32_t* h2flag; long long h2flag_ns; int maxslot;
   int h2_noskip;      // measurement aid (CMLPL_F16X2=4): an all-zero image runs the two-piece loop instead of skipping it
+  int hkind;          // general kernels (MODE 0 / 1): which statistic this launch's image is (0 a0, 1 p1, 2 / 3 conv1's / conv2's gradient operand)
   // statistics for the two-piece WEIGHT-GRADIENT kernel (wgrad3x3.hip), [kind][2 networks][n samples] words: every
   // workgroup leaves its sample's largest magnitude (float bits) of a0, p1 (forward) and of conv1's / conv2's masked
   // up-sampled pooled gradients (backward) -- plain stores, every slot rewritten every step; null = not collected
@@ -646,6 +647,121 @@ __device__ __forceinline__ void conv3_taps_ks_h(const float* __restrict__ img, c
   }
   ks_tap_h<TPW>(img, wq, abase, acc, cur, rn0, rn1, ba, bb, 8, kh, PW, active, sc, side);
 }
+// The LDS-staged tap loop (conv3_taps) on two fp16 pieces, for the eight-wave general kernels (windows beyond 256 pixels:
+// the reference's 20 x 20): a tap's fragments are 16 KiB (4 k-steps x 2 pieces x 2 n tiles x 1 KiB) -- two 16-byte pieces
+// per thread global -> registers -> LDS, a tap ahead --, a k-step of a tile is six MFMAs and a 32-instruction split.
+struct TapRegs8H { float4 w0, w1; };
+__device__ __forceinline__ TapRegs8H tap_fetch8h(const float4* wg, int tap, int tid) {
+  TapRegs8H t;
+  const float4* wn = wg + tap * TAPH + tid;
+  t.w0 = wn[0]; t.w1 = wn[512];
+  return t;
+}
+__device__ __forceinline__ void tap_put8h(float4* wl, const TapRegs8H& t, int tid) { wl[tid] = t.w0; wl[tid + 512] = t.w1; }
+
+template <int NTA, int KQ, int MTW, int HALF = 0>
+__device__ __forceinline__ void tap_step_h(const float* __restrict__ img, const uint4* __restrict__ bl,
+                                           const int (&abase)[MTW], f32x16 (&acc)[MTW][2], HSplit (&cur)[NTA],
+                                           float4 (&rn0)[NTA], float4 (&rn1)[NTA], uint4 (&b)[4], int step, int PW, float sc) {
+  uint4 nb[4];                     // [piece * 2 + n tile] of the next k-step
+  float4 rnn0[NTA], rnn1[NTA];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nb[i] = b[i];
+  if (KQ < 3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nb[i] = bl[((KQ + 1) * 4 + i) * 64];
+  }
+  {
+    const int o2 = tap_step_off(step + 2 < 36 ? step + 2 : 35, PW);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) {
+      rnn0[t] = *(const float4*)(img + abase[t] + o2);
+      rnn1[t] = *(const float4*)(img + abase[t] + o2 + 4);
+    }
+  }
+  HSplit nxt[NTA];
+  // one MFMA, then one PAIR of the next step's split (scale, truncate, exact residual, truncate: 8 vector instructions),
+  // with plain scheduling fences between them -- as the three-piece loop for several tiles per wave does it
+#define CMLPL_HPAIR(j) { const float a_ = v[2 * (j)] * sc, b_ = v[2 * (j) + 1] * sc; \
+                         const f16x2v p_ = __builtin_bit_cast(f16x2v, __builtin_amdgcn_cvt_pkrtz(a_, b_)); \
+                         h1[j] = __builtin_bit_cast(uint32_t, p_); \
+                         h2[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_ - (float)p_[0], b_ - (float)p_[1])); }
+#define CMLPL_FENCE __builtin_amdgcn_sched_barrier(0);
+  constexpr int NFULL = NTA - (HALF != 0 ? 1 : 0);
+#pragma unroll
+  for (int t = 0; t < NFULL; ++t) {
+    const uint4 H1 = cur[t].p1, H2 = cur[t].p2;
+    const float v[8] = {rn0[t].x, rn0[t].y, rn0[t].z, rn0[t].w, rn1[t].x, rn1[t].y, rn1[t].z, rn1[t].w};
+    uint32_t h1[4], h2[4];
+    f32x16 c0 = acc[t][0], c1 = acc[t][1];
+    CMLPL_FENCE
+    c0 = mfma_h16(H2, b[0], c0); CMLPL_FENCE CMLPL_HPAIR(0) CMLPL_FENCE
+    c0 = mfma_h16(H1, b[2], c0); CMLPL_FENCE CMLPL_HPAIR(1) CMLPL_FENCE
+    c0 = mfma_h16(H1, b[0], c0); CMLPL_FENCE CMLPL_HPAIR(2) CMLPL_FENCE
+    c1 = mfma_h16(H2, b[1], c1); CMLPL_FENCE CMLPL_HPAIR(3) CMLPL_FENCE
+    c1 = mfma_h16(H1, b[3], c1); CMLPL_FENCE
+    nxt[t].p1 = make_uint4(h1[0], h1[1], h1[2], h1[3]); nxt[t].p2 = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+    CMLPL_FENCE
+    c1 = mfma_h16(H1, b[1], c1); CMLPL_FENCE
+    acc[t][0] = c0; acc[t][1] = c1;
+  }
+  if constexpr (HALF != 0) {     // the shared tile: three MFMAs of ONE channel tile, in the order a full tile runs them
+    constexpr int t = NTA - 1, h = HALF == 2 ? 1 : 0;
+    const uint4 H1 = cur[t].p1, H2 = cur[t].p2;
+    const float v[8] = {rn0[t].x, rn0[t].y, rn0[t].z, rn0[t].w, rn1[t].x, rn1[t].y, rn1[t].z, rn1[t].w};
+    uint32_t h1[4], h2[4];
+    f32x16 ch = acc[t][h];
+    CMLPL_FENCE
+    ch = mfma_h16(H2, b[0 + h], ch); CMLPL_FENCE CMLPL_HPAIR(0) CMLPL_HPAIR(1) CMLPL_FENCE
+    ch = mfma_h16(H1, b[2 + h], ch); CMLPL_FENCE CMLPL_HPAIR(2) CMLPL_HPAIR(3) CMLPL_FENCE
+    ch = mfma_h16(H1, b[0 + h], ch); CMLPL_FENCE
+    nxt[t].p1 = make_uint4(h1[0], h1[1], h1[2], h1[3]); nxt[t].p2 = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+    acc[t][h] = ch;
+  }
+#undef CMLPL_HPAIR
+#undef CMLPL_FENCE
+#pragma unroll
+  for (int t = 0; t < NTA; ++t) { cur[t] = nxt[t]; rn0[t] = rnn0[t]; rn1[t] = rnn1[t]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = nb[i];
+}
+
+template <int MTW, int NTA, int HALF = 0>
+__device__ __forceinline__ void conv3_taps_h(const float* __restrict__ img, float* __restrict__ wbuf,
+                                             const float4* __restrict__ wg, TapRegs8H w, const int (&abase)[MTW],
+                                             f32x16 (&acc)[MTW][2], int PW, int tid, int lane, float sc) {
+  float4* wl = (float4*)wbuf;
+  const uint4* bl = (const uint4*)wbuf + lane;
+  constexpr int NT = NTA > 0 ? NTA : 1;
+  HSplit cur[NT];
+  float4 rn0[NT], rn1[NT];
+#pragma unroll 1
+  for (int s = 0; s < 9; ++s) {
+    __syncthreads();  // everyone done with wbuf of tap s-1
+    tap_put8h(wl, w, tid);
+    __syncthreads();
+    if (s + 1 < 9) w = tap_fetch8h(wg, s + 1, tid);
+    if constexpr (NTA > 0) {
+      uint4 b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = bl[i * 64];
+      if (s == 0) {               // pipeline fill: steps 0 and 1
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) {
+          const float* p0 = img + abase[t] + tap_step_off(0, PW);
+          h_split(*(const float4*)p0, *(const float4*)(p0 + 4), sc, cur[t].p1, cur[t].p2);
+          const float* p1 = img + abase[t] + tap_step_off(1, PW);
+          rn0[t] = *(const float4*)p1; rn1[t] = *(const float4*)(p1 + 4);
+        }
+      }
+      tap_step_h<NTA, 0, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 0, PW, sc);
+      tap_step_h<NTA, 1, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 1, PW, sc);
+      tap_step_h<NTA, 2, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 2, PW, sc);
+      tap_step_h<NTA, 3, MTW, HALF>(img, bl, abase, acc, cur, rn0, rn1, b, s * 4 + 3, PW, sc);
+    }
+  }
+}
+
 // the staging's share of the two-piece path: a thread's largest |value| -> the workgroup's, in the LDS word `slot` (zeroed
 // at kernel start; published by the barrier in front of the tap loop).  NaN never wins a maximum: it meets the pieces as NaN.
 __device__ __forceinline__ void h2_publish_max(float mx, float* slot) {
@@ -793,6 +909,7 @@ struct Conv3Ctx {
   float* img; float* wbuf; int* lut; const float4* wg;
   TapRegs wp;
   TapRegs8 wp8;           // eight-wave workgroups: tap 1's fragments (tap 0's are in LDS when conv3_stage returns)
+  TapRegs8H wp8h;         // H2X general kernels: tap 0's two-piece fragments (requested beside wp8: which loop runs is known later)
 };
 
 // NW = waves of the workgroup: 4 (every MODE), or 8 for the per-sample kernels (MODE >= 2) when one workgroup has a CU
@@ -832,6 +949,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
   // tap-0 weights: issued now so the HBM/L2 latency overlaps the image staging below
   if constexpr (MODE < 2 && NW == 4) c.wp = tap_fetch(wg, 0, tid);   // (the four-wave per-sample kernels fetch their fragments themselves)
   if constexpr (NW == 8 && (MODE == 3 || MODE < 2)) c.wp8 = tap_fetch8(wg, 0, tid);
+  if constexpr (H2X && NW == 8 && MODE < 2) c.wp8h = tap_fetch8h((const float4*)(a.wpk16 + (long long)net * a.wpk16_ns), 0, tid);
   __syncthreads();
 
   if (MODE == 2) {
@@ -1117,6 +1235,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     __syncthreads();                                      // the LUT (and the image) are complete
   } else if (MODE == 0) {
     const float* src = a.in + (long long)net * a.in_ns;
+    float hmx = 0.f;
     staged_copy<8, float4, NT>(S * HW * 16, tid,
         [&](int idx) {
           const int c4 = idx & 15, p = idx >> 4, s = fdiv(p, a.mg_hw), pix = p - s * HW, sample = s0 + s;
@@ -1127,7 +1246,9 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         [&](int idx, float4 v) {
           const int c4 = idx & 15, p = idx >> 4, s = fdiv(p, a.mg_hw), pix = p - s * HW, h = fdiv(pix, a.mg_w), w = pix - h * W;
           *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+          if constexpr (H2X) hmx = fmaxf(fmaxf(hmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         });
+    if constexpr (H2X) h2_publish_max(hmx, smem + a.maxslot);
   } else if (dp_lds != nullptr) {
     // fused backward head (S == 1): the pooled gradient was produced by this workgroup and waits in LDS, the ReLU
     // mask words were fetched at kernel start; one (pooled pixel, 4 channels) item -> its 2x2 window
@@ -1161,6 +1282,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const float* dp = a.in + (long long)net * a.in_ns;
     const uint8_t* mk = a.mask_in + (long long)net * a.mask_in_ns;
     struct DM { float4 d; uint32_t m; };
+    float hmx = 0.f;
     // one (pooled pixel, 4 channels) item feeds the 4 full-resolution positions of its 2x2 window
     staged_copy<8, DM, NT>(S * P2 * 16, tid,
         [&](int idx) {
@@ -1183,8 +1305,10 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             v.w = ((r.m >> (24 + sub)) & 1u) ? r.d.w * 0.25f : 0.f;
             const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
             *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
+            if constexpr (H2X) hmx = fmaxf(fmaxf(hmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
           }
         });
+    if constexpr (H2X) h2_publish_max(hmx, smem + a.maxslot);
   }
 
   c.tid = tid; c.lane = lane; c.l31 = l31; c.hh = hh; c.wave = wave; c.net = net; c.s0 = s0;
@@ -2245,7 +2369,8 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
 template <int MODE, int MTW, int TAIL = 0, int NW = 4, int TPW = 8 / NW, bool KSG = false, bool H2X = false>
 __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) void conv3x3_kernel(Conv3Args a) {
   static_assert(!KSG || (MODE < 2 && MTW == 1 && TAIL == 0 && NW == 4 && TPW == 2), "KSG: four waves, S = 1, four tiles");
-  static_assert(!H2X || (MODE >= 2 && TAIL == 1 && (NW == 8 || TPW == 2)), "H2X: the per-sample kernels with tail / head");
+  static_assert(!H2X || (MODE >= 2 && TAIL == 1 && (NW == 8 || TPW == 2)) || (MODE < 2 && TAIL == 0 && (KSG || NW == 8)),
+                "H2X: the per-sample kernels with tail / head; the general kernels with one sample per workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if constexpr (H2X) { if (threadIdx.x == 0) { smem[a.maxslot] = 0.f; smem[a.maxslot + 1] = 0.f; } }
   constexpr int NT = 64 * NW;
@@ -2317,12 +2442,12 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
       const uint32_t mxb = __builtin_amdgcn_readfirstlane(((const volatile uint32_t*)smem)[a.maxslot]);
       const uint32_t e = mxb >> 23;
       const uint32_t flag = a.h2flag[(long long)net * a.h2flag_ns];
-      hzero = flag == 0u && mxb == 0u;
-      h2on = flag == 0u && ((e >= 40u && e <= 200u) || hzero);
-      hsc = hzero ? 1.f : __uint_as_float((268u - e) << 23);
-      hinv = hzero ? 1.f : __uint_as_float((e - 27u - (uint32_t)(H2_WEXP - 13)) << 23);
+      hzero = flag == 0u && mxb == 0u && (MODE & 1) != 0;      // (a zero GRADIENT image: its products are skipped)
+      h2on = flag == 0u && ((e >= 40u && e <= 200u) || mxb == 0u);
+      hsc = mxb == 0u ? 1.f : __uint_as_float((268u - e) << 23);
+      hinv = mxb == 0u ? 1.f : __uint_as_float((e - 27u - (uint32_t)(H2_WEXP - 13)) << 23);
       wq16 = (const uint4*)(a.wpk16 + (long long)net * a.wpk16_ns) + lane;
-      if (a.hstat != nullptr && tid == 0) a.hstat[((MODE == 2 ? 0 : 2) * 2 + net) * a.n + s0] = mxb;
+      if (a.hstat != nullptr && tid == 0) a.hstat[((MODE == 2 ? 0 : MODE == 3 ? 2 : a.hkind) * 2 + net) * a.n + s0] = mxb;
     }
   };
   float* x8 = (float*)(lut + LUTN);        // eight waves: [8][16][64] floats behind the LUT (second tap buffer, then the fold's exchange)
@@ -2365,7 +2490,23 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
     else conv3_taps_ks<TPW>(img, wq, ab2, acc2, PW, wave, ks_active);
   }
   else if constexpr (NW == 8) {   // the general kernels with eight waves (one workgroup per CU: 20 x 20 windows): two waves per SIMD
-    if (last_tile >= MT) conv3_taps<MTW, MTW - 1, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
+    if constexpr (H2X) { __syncthreads(); h2_decide(); }      // (the staged image's maximum is complete behind this barrier)
+    if (h2on) {
+      if (!hzero || a.h2_noskip) {
+        const float4* wg16 = (const float4*)(a.wpk16 + (long long)net * a.wpk16_ns);
+        if (last_tile >= MT) conv3_taps_h<MTW, MTW - 1>(img, wbuf, wg16, c.wp8h, abase, acc, PW, tid, lane, hsc);
+        else if (nmask == 3) conv3_taps_h<MTW, MTW>(img, wbuf, wg16, c.wp8h, abase, acc, PW, tid, lane, hsc);
+        else if constexpr (MTW >= 2) {
+          if (nmask == 1) conv3_taps_h<MTW, MTW, 1>(img, wbuf, wg16, c.wp8h, abase, acc, PW, tid, lane, hsc);
+          else            conv3_taps_h<MTW, MTW, 2>(img, wbuf, wg16, c.wp8h, abase, acc, PW, tid, lane, hsc);
+        }
+#pragma unroll
+        for (int t = 0; t < MTW; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[t][0][r] *= hinv; acc[t][1][r] *= hinv; }
+      }
+    }
+    else if (last_tile >= MT) conv3_taps<MTW, MTW - 1, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
     else if (nmask == 3) conv3_taps<MTW, MTW, NoSide, 1, TapRegs8>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
     else if constexpr (MTW >= 2) {
       if (nmask == 1) conv3_taps<MTW, MTW, NoSide, 1, TapRegs8, 1>(img, wbuf, wg, c.wp8, abase, acc, PW, tid, lane);
@@ -2836,7 +2977,7 @@ static hipError_t launch_conv3_t(const Conv3Args& a, dim3 grid, size_t lds, hipS
 
 hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in, const uint8_t* mask_in,
                         const float* wpk, long long wpk_ns, const float* bias, long long bias_ns,
-                        float* out, uint8_t* mask_out, hipStream_t st) {
+                        float* out, uint8_t* mask_out, hipStream_t st, const Conv3H2* h2) {
   Conv3Plan pl;
   if (!plan_conv3(mode, H, W, nets * n, &pl)) return hipErrorInvalidValue;
   const int HW = H * W, P2 = (H / 2) * (W / 2);
@@ -2849,8 +2990,25 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
+  // the two-piece tap loops (one sample per workgroup: the barrier-free loop, or eight waves with staged tap weights)
+  const bool h2x = h2 != nullptr && conv3_h2x_general(mode, H, W, nets * n);
+  if (h2x) {
+    a.wpk16 = h2->wpk16; a.wpk16_ns = h2->wpk16_ns; a.h2flag = h2->h2flag; a.h2flag_ns = h2->wpk16_ns; a.hstat = h2->hstat;
+    a.hkind = h2->kind; a.maxslot = (int)(pl.lds / 4);
+    const size_t lds = pl.lds + 64;
+#define CMLPL_H2_LAUNCH(...)                                                                       \
+    { static DevOnce attr_h;                                                                         \
+      hipError_t eh = ensure_max_lds(attr_h, conv3x3_kernel<__VA_ARGS__>);                           \
+      if (eh != hipSuccess) return eh;                                                               \
+      hipLaunchKernelGGL((conv3x3_kernel<__VA_ARGS__>), grid, dim3(pl.ks ? 256 : 512), lds, st, a);  \
+      return hipGetLastError(); }
+    if (pl.ks) { if (mode == 0) CMLPL_H2_LAUNCH(0, 1, 0, 4, 2, true, true) else CMLPL_H2_LAUNCH(1, 1, 0, 4, 2, true, true) }
+    if (pl.MTW == 1) { if (mode == 0) CMLPL_H2_LAUNCH(0, 1, 0, 8, 1, false, true) else CMLPL_H2_LAUNCH(1, 1, 0, 8, 1, false, true) }
+    if (mode == 0) CMLPL_H2_LAUNCH(0, 2, 0, 8, 1, false, true) else CMLPL_H2_LAUNCH(1, 2, 0, 8, 1, false, true)
+#undef CMLPL_H2_LAUNCH
+  }
   if (pl.ks) {
     static DevOnce attr_ks;
     hipError_t e = ensure_max_lds(attr_ks, conv3x3_kernel<0, 1, 0, 4, 2, true>, conv3x3_kernel<1, 1, 0, 4, 2, true>);
@@ -2993,7 +3151,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   conv3_set_magics(a);
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -3165,7 +3323,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0;
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
@@ -3233,6 +3391,16 @@ bool conv3_h2x_both(int H, int W, int C, int rows, int K) {
   if (conv3_ks8(rows))
     return conv3_fused_lds(H, W, C, conv3_ks8_lds(pf.lds), 8) + 64 <= LDS_MAX && conv3_fused_bwd_lds(H, W, C, conv3_ks8_lds(pb.lds)) + 64 <= LDS_MAX;
   return 2 * (conv3_fused_lds(H, W, C, pf.lds) + 64) <= LDS_MAX && 2 * (conv3_fused_bwd_lds(H, W, C, pb.lds) + 64) <= LDS_MAX;
+}
+
+// would launch_conv3 run this map on a two-piece kernel?  (one sample per workgroup: the barrier-free loop of at most four
+// tiles, or the eight-wave kernels with one or two tiles per wave; LDS for one more word)
+bool conv3_h2x_general(int mode, int H, int W, int rows) {
+  if (switches().f16x2 != 1 && switches().f16x2 != 4) return false;
+  Conv3Plan pl;
+  if (!plan_conv3(mode, H, W, rows, &pl) || pl.S != 1) return false;
+  if (pl.ks) return 2 * (pl.lds + 64) <= LDS_MAX;
+  return pl.nw == 8 && pl.MTW >= 1 && pl.MTW <= 2 && pl.lds + 64 <= LDS_MAX;
 }
 
 }  // namespace cmlpl

@@ -40,7 +40,8 @@ __host__ __device__ inline long long pack_off_wst(int C) { return PACK_PER_NET +
 // k = band, n = co; bands beyond C are zero) for the conv0 stage of the fused forward
 __host__ __device__ inline long long pack_off_w0b3(int C, int bands) { return pack_off_wst(C) + (long long)bands * 1024; }
 __host__ __device__ inline long long pack_off_w0b3_end(int C, int bands) { return pack_off_w0b3(C, bands) + (long long)((C + 15) / 16) * 1536; }
-// ... and conv1's forward / data-gradient weights as TWO fp16 pieces for the three-MFMA product of the per-sample kernels
+// ... and the 3x3 weights (conv1 forward / data gradient, conv2 forward / data gradient: `which` as for the split-bf16
+// sets) as TWO fp16 pieces for the three-MFMA product
 // (conv3x3.hip "fp32 as two fp16 pieces"): w 2^H2_WEXP = g1 + g2, g1 = fp16(w 2^H2_WEXP), g2 = fp16 of the residual
 // (unscaled: the 2^-11 of the cross terms lives in the operands), fragments [tap][k16 step][piece][n tile][lane][8 fp16];
 // behind the two sets one flag word per network: != 0 when a weight left fp16's range at that scale (set by the packing
@@ -48,7 +49,7 @@ __host__ __device__ inline long long pack_off_w0b3_end(int C, int bands) { retur
 constexpr int H2_WEXP = 13;                 // |w| < 8 keeps w 2^13 under fp16's 65504
 constexpr int PACK_H2 = PACK_CONV;          // floats occupied by one two-piece fp16 set (2 pieces x 2 bytes per weight)
 __host__ __device__ inline long long pack_off_h2(int C, int bands, int which) { return pack_off_w0b3_end(C, bands) + (long long)which * PACK_H2; }
-__host__ __device__ inline long long pack_off_h2flag(int C, int bands) { return pack_off_w0b3_end(C, bands) + 2LL * PACK_H2; }
+__host__ __device__ inline long long pack_off_h2flag(int C, int bands) { return pack_off_w0b3_end(C, bands) + 4LL * PACK_H2; }
 __host__ __device__ inline long long pack_total(int C, int bands) { return pack_off_h2flag(C, bands) + 16; }
 // fp16 element index of (tap, k, n, piece) inside one two-piece set
 __host__ __device__ inline int conv_h2_index(int tap, int k, int n, int p) {
@@ -95,9 +96,13 @@ struct Conv3Plan { int S, MTW; size_t lds; int nw; int ks; };   // nw: waves of 
 bool plan_conv3(int mode, int H, int W, int rows, Conv3Plan* p);
 // mode 0: out = avgpool2(relu(conv(in)+bias+in)), mask_out = relu bits; in [nets][n][H*W][64]
 // mode 1: in = dpool [nets][n][(H/2)*(W/2)][64] + mask_in; out = dgrad(dz) + dz, [nets][n][H*W][64]
+// what a general 3x3 launch needs for the two-piece tap loop: this map's two-piece weight set (pack_off_h2), the
+// networks' range flags, the per-sample statistics table ([4][2][n], or null) and which of its rows this launch's image is
+struct Conv3H2 { const float* wpk16; long long wpk16_ns; const uint32_t* h2flag; uint32_t* hstat; int kind; };
+bool conv3_h2x_general(int mode, int H, int W, int rows);
 hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in, const uint8_t* mask_in,
                         const float* wpk, long long wpk_nstride, const float* bias, long long bias_nstride,
-                        float* out, uint8_t* mask_out, hipStream_t st);
+                        float* out, uint8_t* mask_out, hipStream_t st, const Conv3H2* h2 = nullptr /* two-piece tap loop where the plan allows, or null */);
 bool conv3_fused_ok(int H, int W, int C, int rows);
 // the rest of the forward (conv2 + pool + head) in the same per-sample workgroup: see conv3_fwd_tail
 struct FwdTail {

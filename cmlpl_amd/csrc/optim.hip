@@ -91,13 +91,12 @@ __device__ __forceinline__ void adam_conv_chunk(const AdamArgs& a, int chunk, in
     for (int pcs = 0; pcs < 3; ++pcs)
       bd[conv_b3_index(8 - tap, co0, ci, pcs) >> 2] = make_uint2(pc[0][pcs] | (pc[1][pcs] << 16), pc[2][pcs] | (pc[3][pcs] << 16));
   }
-  // conv1 also as TWO fp16 pieces (kernels.hpp: pack_off_h2; same items, same threads): forward set 16-byte pieces,
+  // ... and as TWO fp16 pieces (kernels.hpp: pack_off_h2; same items, same threads): forward set 16-byte pieces,
   // data-gradient set 8-byte pieces; a weight outside fp16's range at the packing scale raises the network's flag
-  if (which != 0) return;
   static_assert(H2_WEXP == 13, "h2_split_w scales by 2^13");
   bool bad = false;
   if (tid < 72) {
-    uint4* hf = (uint4*)(pkn + pack_off_h2(a.pi.C, a.pi.bands, 0));
+    uint4* hf = (uint4*)(pkn + pack_off_h2(a.pi.C, a.pi.bands, which));
     const int h = tid & 1, tap = (tid >> 1) % 9, cl = tid / 18, co = co0 + cl;
     uint32_t pc[8][2];
 #pragma unroll
@@ -108,7 +107,7 @@ __device__ __forceinline__ void adam_conv_chunk(const AdamArgs& a, int chunk, in
           make_uint4(pc[0][pcs] | (pc[1][pcs] << 16), pc[2][pcs] | (pc[3][pcs] << 16),
                      pc[4][pcs] | (pc[5][pcs] << 16), pc[6][pcs] | (pc[7][pcs] << 16));
   } else if (tid < 72 + 144) {
-    uint2* hd = (uint2*)(pkn + pack_off_h2(a.pi.C, a.pi.bands, 1));
+    uint2* hd = (uint2*)(pkn + pack_off_h2(a.pi.C, a.pi.bands, which + 1));
     const int it = tid - 72, tap = it % 9, cil = it / 9, ci = ci0 + cil;
     uint32_t pc[4][2];
 #pragma unroll

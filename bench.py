@@ -386,12 +386,15 @@ def run_rank(args):
         kvar = "8,1"
     else:
         kvar = "4,2"
-    # conv1's tap loops of the four-tile per-sample kernels run on TWO fp16 pieces (three MFMAs per product) unless switched
-    # off; conv0, conv2 and the weight gradients stay on three bf16 pieces (six)
-    f16x2 = os.environ.get("CMLPL_F16X2", "1")
-    if tail_fwd and kvar in ("4,2", "8,1", "8,2") and f16x2 in ("1", "2", "4"):
+    # which products run on TWO fp16 pieces (three MFMAs per product) is the planners' decision: asked of the library
+    # (conv1's tap loops, the weight gradients; on the general path also conv2's launches); the rest on three bf16 pieces
+    cs_ = _lib.Shape(*shape)
+    tp = lib.cmlpl_debug_two_piece(C.byref(cs_), 2, n_local)
+    if tp < 0:
+        raise SystemExit(f"bench.py: cmlpl_debug_two_piece: {tp}")
+    if tp & 1:
         kseg["conv1_fwd"]["split"] -= c1; kseg["conv1_fwd"]["split2"] = c1
-    if head_bwd and kvar in ("4,2", "8,1", "8,2") and f16x2 in ("1", "3", "4"):
+    if tp & 2:
         kseg["conv1_dgrad"]["split"] -= c1; kseg["conv1_dgrad"]["split2"] = c1
     if tail_fwd:
         kseg["conv1_fwd"]["split"] += conv2_flops                                       # tail: split-bf16 too (16x16x32 MFMA)
@@ -404,11 +407,10 @@ def run_rank(args):
     if wgrad_pair:
         key = "split" if wgrad_split else "f32"
         kseg["conv1_wgrad"][key] += conv2_flops
-        # ... and the pair weight-gradient launch both its maps (planes of two fp16 pieces), when both fused launches ran the
-        # two-piece kernels (they leave the operands' maxima it scales by)
-        if wgrad_split and tail_fwd and head_bwd and kvar in ("4,2", "8,1", "8,2") and f16x2 in ("1", "4"):
+        # ... and the pair weight-gradient launch both its maps (planes of two fp16 pieces) when the step's 3x3 launches
+        # leave the operands' maxima it scales by
+        if wgrad_split and (tp & 4):
             kseg["conv1_wgrad"] = {"split2": kseg["conv1_wgrad"]["split"]}
-        labels["conv1_wgrad"] = "wgrad3b_pair_kernel (conv1 + conv2 weight gradients in one launch, both networks)"
     kflops = {k: sum(v.values()) for k, v in kseg.items()}
     kpeak = {k: blended_peak(v) for k, v in kseg.items()}
     traffic, traffic_src = recorded_traffic(args.workload, n_local)

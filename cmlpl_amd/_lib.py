@@ -33,7 +33,7 @@ EXPORTS = (
     "cmlpl_source_hash", "cmlpl_dyn_adam", "cmlpl_step_graph_create", "cmlpl_step_graph_launch",
     "cmlpl_step_graph_destroy", "cmlpl_infer_workspace_bytes", "cmlpl_infer_cube", "cmlpl_dist_stage_graph_create",
     "cmlpl_debug_reload_switches", "cmlpl_forward_spectral", "cmlpl_forward_spatial", "cmlpl_backward_data",
-    "cmlpl_backward_weights", "cmlpl_dist_step", "cmlpl_rccl_bind", "cmlpl_rccl_unbind",
+    "cmlpl_backward_weights", "cmlpl_dist_step", "cmlpl_rccl_bind", "cmlpl_rccl_unbind", "cmlpl_debug_two_piece",
 )
 
 KERNEL_NAMES = ("augment", "conv0_fwd", "conv1_fwd", "conv2_fwd", "spe_fwd", "head_fwd", "loss", "head_bwd",
@@ -246,6 +246,7 @@ def load(path: str = LIB_PATH):
     lib.cmlpl_dist_step.argtypes = [SP, HP, C.POINTER(DistIO), C.POINTER(DistStepArgs), C.POINTER(Collectives), vp]
     lib.cmlpl_rccl_bind.argtypes = [C.c_char_p, vp, C.POINTER(Collectives)]
     lib.cmlpl_rccl_unbind.argtypes = [C.POINTER(Collectives)]
+    lib.cmlpl_debug_two_piece.argtypes = [SP, i32, i32]
     lib.cmlpl_step_graph_launch.argtypes = [vp, vp]
     lib.cmlpl_step_graph_destroy.argtypes = [vp]
     lib.cmlpl_debug_region.argtypes = [SP, i32, i32, C.c_char_p, C.POINTER(sz), C.POINTER(sz)]

@@ -1194,4 +1194,21 @@ int cmlpl_debug_reload_switches(void) {
   return 0;
 }
 
+int cmlpl_debug_two_piece(const cmlpl_shape* shape, int nets, int n) {
+  Dims d;
+  if (!make_dims(shape, &d) || nets < 1 || nets > 2 || n < 1) return CMLPL_E_SHAPE;
+  const int rows = nets * n, f = switches().f16x2;
+  int bits = 0;
+  if (conv3_fused_tail_ok(d.H, d.W, d.C, rows, d.K) && conv3_fused_head_ok(d.H, d.W, d.C, rows, d.K)) {   // the per-sample kernels
+    if (conv3_h2x_both(d.H, d.W, d.C, rows, d.K)) return 1 | 2 | 4;
+    return f == 2 ? 1 : f == 3 ? 2 : 0;    // (the switch's forward-only / backward-only modes: weight gradients on three pieces)
+  }
+  if (conv3_fused_ok(d.H, d.W, d.C, rows) || conv3_fused_bwd_ok(d.H, d.W, d.C, rows)) return 0;   // (mixed paths: switch-forced variants)
+  if (conv3_h2x_general(0, d.H, d.W, rows)) bits |= 1;
+  if (conv3_h2x_general(1, d.H, d.W, rows)) bits |= 2;
+  if (general_h2_stats(d, rows)) bits |= 4;
+  if (conv3_h2x_general(0, d.H2, d.W2, rows) && conv3_h2x_general(1, d.H2, d.W2, rows)) bits |= 8;
+  return bits;
+}
+
 }  // extern "C"

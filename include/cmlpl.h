@@ -561,6 +561,13 @@ int cmlpl_debug_region(const cmlpl_shape* shape, int nets, int n, const char* na
  * The reference has no counterpart (it has no native code). */
 int cmlpl_debug_reload_switches(void);
 
+/* Measurement aid (bench.py's roofline accounting): which products of a step on `nets` networks x n rows run as TWO
+ * fp16 pieces (three MFMAs per product) under the current switches -- bit 0: conv1's forward tap loop, bit 1: conv1's
+ * data-gradient tap loop, bit 2: both weight gradients, bit 3: conv2's forward and data-gradient tap loops (general
+ * path only).  What the planners decide; a sample or network outside the scheme's ranges still takes the three-piece loop
+ * at run time.  Negative: CMLPL_E_*. */
+int cmlpl_debug_two_piece(const cmlpl_shape* shape, int nets, int n);
+
 #ifdef __cplusplus
 }
 #endif

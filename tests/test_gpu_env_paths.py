@@ -241,7 +241,10 @@ def test_eight_wave_per_sample_kernels_are_bit_identical_to_the_four_wave_ones(s
 
 
 NW8_CASES = [("P", 32, 48, {}), ("W12", 20, 30, {"CMLPL_FUSE_BIG": "0", "CMLPL_CONV3_S": "2"})]
-J_NW8 = {c[0]: [_traj("traj", f"nw8-{nw8}-{c[0]}", dict(c[3], CMLPL_CONV3_NW8=nw8), *c[:3]) for nw8 in ("0", "1")] for c in NW8_CASES}
+# (both on the three-piece tap loop: the four-wave general plan has no two-piece kernels, the eight-wave one takes them by
+#  default -- what is compared here is the wave arrangement)
+J_NW8 = {c[0]: [_traj("traj", f"nw8-{nw8}-{c[0]}", dict(c[3], CMLPL_CONV3_NW8=nw8, CMLPL_F16X2="0"), *c[:3]) for nw8 in ("0", "1")]
+         for c in NW8_CASES}
 
 
 @pytest.mark.parametrize("shape,bt,btu,extra", NW8_CASES)
@@ -250,7 +253,7 @@ def test_eight_wave_general_kernels_are_bit_identical_to_the_four_wave_plan(shap
     fills a CU and a wave would carry two or more pixel tiles -- the reference's own 20x20x60 windows) against the
     four-wave plan (CMLPL_CONV3_NW8=0): the same tiles on other waves, the odd tile of a last round of 1 or 5 tiles shared
     by two waves (one output-channel tile each: 13 tiles at 20x20, 9 at two 12x12 windows per workgroup), every
-    accumulator fed in the same order -- three steps agree bit for bit."""
+    accumulator fed in the same order -- three steps agree bit for bit (on the three-piece loop, CMLPL_F16X2=0)."""
     outs = [_lines(j) for j in J_NW8[shape]]
     assert outs[0][-1].startswith("sha ") and outs[0] == outs[1], (outs[0][-2:], outs[1][-2:])
 

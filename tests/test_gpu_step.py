@@ -65,8 +65,12 @@ def test_step_matches_golden_and_oracle(name):
         report("logits", lo, lo_ref, 2e-4, 5e-6 * float(lo_ref.abs().max()) + 2e-5)
         report_after_updates("feat", fe, torch.stack(ref["feats"]), 1e-5, 3e-6, s, g.hp.lr)
         # ReLU masks saved by the HIP forward vs the oracle's pre-activation signs: a mismatch is only
-        # tolerated exactly at the activation boundary (|z| < 2e-5), where fp32 summation order decides
-        flips = relu_mask_audit(eng, ref["taps"], g.shape, n, ztol_y=2e-5 + 0.25 * g.hp.lr * s)
+        # tolerated exactly at the activation boundary (|z| < 2e-5), where fp32 summation order decides -- at step 0.
+        # After s Adam updates a weight whose gradient is ~eps-sized may sit O(lr) away from the oracle's (Adam moves it
+        # by ~lr whatever the gradient's size; its SIGN is decided by rounding: see report_params), which shifts the
+        # pre-activations it feeds by O(lr * |a|): the boundary widens by 0.1 lr per step for the convolutions' masks
+        # as it does by 0.25 lr for the spectral branch's
+        flips = relu_mask_audit(eng, ref["taps"], g.shape, n, ztol=2e-5 + 0.1 * g.hp.lr * s, ztol_y=2e-5 + 0.25 * g.hp.lr * s)
         total_flips += sum(sum(f.values()) for f in flips)
         for net in range(2):
             for k in O.LIVE_KEYS:
@@ -172,7 +176,7 @@ def test_b5_1to8_single_gpu_runs_on_with_modulo_bank_writes():
             assert rel_err(row, g.z["hist"][0], 1e-7) < LOSS_RTOL, (row, g.z["hist"][0])     # the reference itself
         assert rel_err(row, ref["hist"], 1e-7) < LOSS_RTOL, (s, row, ref["hist"])
         assert eng.ptr == list(st.ptr), (s, eng.ptr, st.ptr)
-        relu_mask_audit(eng, ref["taps"], g.shape, n, ztol_y=2e-5 + 0.25 * g.hp.lr * s)
+        relu_mask_audit(eng, ref["taps"], g.shape, n, ztol=2e-5 + 0.1 * g.hp.lr * s, ztol_y=2e-5 + 0.25 * g.hp.lr * s)
         for net in range(2):
             for k in O.LIVE_KEYS:
                 gr = ref["grads"][net][k]
@@ -380,7 +384,7 @@ def test_step_by_index_where_forward_and_backward_plans_differ(win, C):
         for k in ("ctr_s", "total_s", "cls_s", "con_s", "total_w", "cls_w", "con_w", "ctr_w"):
             want = float(ref[k].detach())
             assert abs(sc[k] - want) <= LOSS_RTOL * abs(want) + 1e-6, (s, k, sc[k], want)
-        relu_mask_audit(eng, ref["taps"], shape, n, ztol_y=2e-5 + 0.25 * hp.lr * s)
+        relu_mask_audit(eng, ref["taps"], shape, n, ztol=2e-5 + 0.1 * hp.lr * s, ztol_y=2e-5 + 0.25 * hp.lr * s)
         for net in range(2):
             for k in O.LIVE_KEYS:
                 gr = ref["grads"][net][k]

@@ -38,9 +38,12 @@ def test_hot_kernels_have_no_scratch(tmp_path):
             assert occ >= 2, (name, occ)
         seen += 1
     assert seen >= 20
-    # the per-sample kernels with conv1's taps on two fp16 pieces (and the three-piece loop beside them): forward and
-    # backward: four waves, eight waves, eight waves with eight tiles
-    assert sum(1 for b in blocks if "conv3x3_kernel" in b.split()[0] and b.split()[0].endswith("Lb0ELb1EEEvNS_9Conv3ArgsE")) == 6
+    # the kernels with a two-piece fp16 tap loop (and the three-piece loop beside it): the per-sample ones -- forward and
+    # backward: four waves, eight waves, eight waves with eight tiles -- and the one-sample general ones -- forward and
+    # data gradient: eight waves with one / two tiles per wave, four waves with the barrier-free loop
+    names = [b.split()[0] for b in blocks if "conv3x3_kernel" in b.split()[0]]
+    assert sum(1 for n in names if n.endswith("Lb0ELb1EEEvNS_9Conv3ArgsE")) == 10, names
+    assert sum(1 for n in names if n.endswith("Lb1ELb1EEEvNS_9Conv3ArgsE")) == 2, names
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

@@ -422,7 +422,7 @@ def run_rank(args):
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32 (convolutions: f32 operands as 3 exact bf16 pieces on the bf16 MFMA, 6 of 9 piece products, f32 "
                  "accumulate, per-product worst case 2^-21 -- conv1's tap loops of the per-sample kernels as 2 fp16 pieces with "
-                 "power-of-two operand scales, 3 piece products, worst case 2^-20.7, falling back to the 3-piece loop "
+                 "power-of-two operand scales, 3 piece products, worst case 2^-20 / mean 2^-23, falling back to the 3-piece loop "
                  "outside fp16's range; max-norm error measured at f32 level against f64; everything else f32 MFMA / "
                  "f32 VALU)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic PaviaU-shaped patches {shape[1]}x{shape[2]}x{shape[0]}, "

@@ -227,7 +227,7 @@ __device__ __forceinline__ void b3_split(float v, uint32_t (&hi16)[3]) {
   hi16[0] = u0 >> 16; hi16[1] = u1 >> 16; hi16[2] = __float_as_uint(r2) >> 16;
 }
 
-// ---- fp32 as TWO fp16 pieces (conv3x3.hip): x = h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) -- 22 significant bits as
+// ---- fp32 as TWO fp16 pieces (conv3x3.hip): x = h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) -- 21-22 significant bits (tests/test_split_f16_math.py) as
 // long as the residual stays a normal fp16, which is what the operands' power-of-two scales are for (activations: per
 // sample, from the staged image's maximum; weights: 2^H2_WEXP at packing time).  a.w ~ h1 g1 + h2 g1 + h1 g2: three MFMAs.
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));

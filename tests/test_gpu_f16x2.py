@@ -115,3 +115,44 @@ def test_images_outside_the_scale_range_fall_back_bit_for_bit(scale):
     else:
         both_nan = torch.isnan(lo1) & torch.isnan(lo0)
         assert torch.equal(torch.where(both_nan, torch.zeros_like(lo1), lo1), torch.where(both_nan, torch.zeros_like(lo0), lo0))
+
+
+def test_the_library_reports_which_products_run_on_two_pieces():
+    """cmlpl_debug_two_piece (bench.py's roofline mix): per-sample kernels -> conv1's two tap loops + the weight gradients;
+    the general path (the reference's 20 x 20 window) -> also conv2's launches; nothing with the switch off"""
+    import ctypes as C
+    from cmlpl_amd import _lib
+    lib = _lib.load()
+    ask = lambda shape, n: lib.cmlpl_debug_two_piece(C.byref(_lib.Shape(*shape)), 2, n)
+    old = os.environ.get("CMLPL_F16X2")
+    try:
+        os.environ.pop("CMLPL_F16X2", None)
+        lib.cmlpl_debug_reload_switches()
+        assert ask((103, 11, 11, 103, 9), 256) == 7 and ask((103, 11, 11, 103, 9), 128) == 7      # four waves | eight waves
+        assert ask((48, 15, 15, 48, 20), 256) == 7                                                 # eight-tile kernels
+        assert ask((60, 20, 20, 103, 9), 256) == 15                                                # general path
+        os.environ["CMLPL_F16X2"] = "2"
+        lib.cmlpl_debug_reload_switches()
+        assert ask((103, 11, 11, 103, 9), 256) == 1
+        os.environ["CMLPL_F16X2"] = "0"
+        lib.cmlpl_debug_reload_switches()
+        assert ask((103, 11, 11, 103, 9), 256) == 0 and ask((60, 20, 20, 103, 9), 256) == 0
+    finally:
+        if old is None:
+            os.environ.pop("CMLPL_F16X2", None)
+        else:
+            os.environ["CMLPL_F16X2"] = old
+        lib.cmlpl_debug_reload_switches()
+
+
+def test_general_path_two_piece_loops_run_and_stay_at_fp32_level():
+    """the reference's own 20 x 20 x 60 window: all four 3x3 launches and the weight gradients on two pieces against the
+    three-piece run of the same step"""
+    shape = O.NetShape(60, 20, 20, 103, 9)
+    params = O.closed_form_params(shape, 9)
+    lo1, g1, f1 = _run(shape, params, 8, 8, f16x2="1")
+    lo0, g0, _ = _run(shape, params, 8, 8, f16x2="0")
+    assert f1 == [0, 0]
+    assert not torch.equal(lo1, lo0) and not torch.equal(g1, g0), "the two-piece loops did not run"
+    assert (lo1 - lo0).abs().max() <= 4e-6 * lo0.abs().max(), ((lo1 - lo0).abs().max(), lo0.abs().max())
+    assert (g1 - g0).abs().max() <= 4e-6 * g0.abs().max(), ((g1 - g0).abs().max(), g0.abs().max())

@@ -443,6 +443,9 @@ def run_rank(args):
                                   "MFMAs, a two-piece fp16 product three (history of the mix: DESIGN.md section 4)",
                      "flops_by_mfma_kind": kseg[dom_name],
                      "frac_of_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     # continuity with rounds 2-5, whose kernels ran every product on three bf16 pieces: the same achieved
+                     # rate against THAT mix's ceiling (2500 T / 6) -- `frac` above is against this kernel's own, higher one
+                     "frac_of_three_piece_ceiling": achieved / SPLIT_PEAK_TFLOPS,
                      "traffic": traffic.get(dom_name),
                      "traffic_unit": "bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; recorded in "
                                      f"{traffic_src or 'profiles/'}, null when the kernel sources changed since)",

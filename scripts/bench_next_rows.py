@@ -64,7 +64,7 @@ def n4():
         def step():
             ei.grad = ej.grad = None
             crit(ei, ej).backward()
-        dt = min(timeit(step) for _ in range(3))
+        dt = min(timeit(step, warm=30, reps=300) for _ in range(5))     # (host-bound call: short windows catch the box's CPU hiccups)
         print(f"N4 NT-Xent forward+backward, B={B}, D={D}: {dt * 1e6:.1f} us/call wall")
 
 

@@ -189,6 +189,7 @@ struct Conv3Args {
   // the LDS word (float index into the dynamic allocation) in which the staging leaves the image's largest magnitude
   const float* wpk16; long long wpk16_ns; const uint32_t* h2flag; long long h2flag_ns; int maxslot;
   int h2_noskip;      // measurement aid (CMLPL_F16X2=4): an all-zero image runs the two-piece loop instead of skipping it
+  int pairshift;      // see wg_decode
   int hkind;          // general kernels (MODE 0 / 1): which statistic this launch's image is (0 a0, 1 p1, 2 / 3 conv1's / conv2's gradient operand)
   // statistics for the two-piece WEIGHT-GRADIENT kernel (wgrad3x3.hip), [kind][2 networks][n samples] words: every
   // workgroup leaves its sample's largest magnitude (float bits) of a0, p1 (forward) and of conv1's / conv2's masked
@@ -206,8 +207,13 @@ static inline void conv3_set_magics(Conv3Args& a) {
 
 // Workgroup -> (network, first sample).  (Measured, round 3: numbering the workgroups so that the two a CU holds belong
 // to the same network -- hoping their weight-fragment streams would meet in L1 -- changed nothing: 0.2129 vs 0.2128 ms.)
+// pairshift (fused backward, S == 1): network 1's workgroup b takes sample (b + n / 2) % n, so that the two workgroups a CU
+// holds (b of network 0 and b of network 1, by launch order) are a labelled and an unlabelled row where the batch is
+// [labelled ; unlabelled] halves -- an unlabelled row under the confidence threshold has an all-zero gradient image and
+// skips most of its work: paired with a working row instead of with its own twin it leaves that row the CU.
 __device__ __forceinline__ void wg_decode(const Conv3Args& a, int& net, int& s0) {
   net = (int)blockIdx.y; s0 = (int)blockIdx.x * a.S;
+  if (a.pairshift != 0 && net == 1) { s0 += a.n >> 1; if (s0 >= a.n) s0 -= a.n; }
 }
 // Inference from the cube: workgroup b takes pixel (b % 8) * ceil(n / 8) + b / 8 of the launch's range, so that each XCD
 // (own L2, workgroups dealt round-robin) walks one contiguous eighth in raster order and overlapping windows are re-read
@@ -2990,7 +2996,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
   // the two-piece tap loops (one sample per workgroup: the barrier-free loop, or eight waves with staged tap weights)
   const bool h2x = h2 != nullptr && conv3_h2x_general(mode, H, W, nets * n);
@@ -3151,7 +3157,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   conv3_set_magics(a);
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -3323,7 +3329,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;
@@ -3334,6 +3340,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
     if (e != hipSuccess) return e;
     const bool h2x = (switches().f16x2 == 1 || switches().f16x2 == 3 || switches().f16x2 == 4) && head->w1h != nullptr && head->h2flag != nullptr;
     if (h2x) { a.wpk16 = head->w1h; a.wpk16_ns = head->w1h_ns; a.h2flag = head->h2flag; a.h2flag_ns = head->w1h_ns; a.hstat = head->hstat; }
+    a.pairshift = (nets == 2 && switches().bwd_pair != 0) ? 1 : 0;
     if (big) {
       const size_t ldsb = conv3_big_bwd_lds(bg, C);
       if (h2x && ldsb + 64 <= LDS_MAX) {

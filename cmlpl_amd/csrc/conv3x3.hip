@@ -769,11 +769,24 @@ __device__ __forceinline__ void conv3_taps_h(const float* __restrict__ img, floa
 }
 
 // the staging's share of the two-piece path: a thread's largest |value| -> the workgroup's, in the LDS word `slot` (zeroed
-// at kernel start; published by the barrier in front of the tap loop).  NaN never wins a maximum: it meets the pieces as NaN.
-__device__ __forceinline__ void h2_publish_max(float mx, float* slot) {
+// at kernel start; published by the barrier in front of the tap loop).  Magnitudes are compared as their BIT PATTERNS
+// (sign cleared): the order of the non-negative floats, with every NaN above infinity -- an image that holds a NaN is
+// "out of range" (it takes the three-piece loop, where the NaN travels as in fp32), never "all zero".
+__device__ __forceinline__ uint32_t mag_max(uint32_t m, float v) {
+  const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+  return b > m ? b : m;
+}
+__device__ __forceinline__ uint32_t mag_max4(uint32_t m, const float4& v) {
+  return mag_max(mag_max(mag_max(mag_max(m, v.x), v.y), v.z), v.w);
+}
+__device__ __forceinline__ uint32_t wave_mag_max(uint32_t mx) {
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)slot, __float_as_uint(mx));
+  for (int o = 32; o >= 1; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)mx, o, 64); mx = x > mx ? x : mx; }
+  return mx;
+}
+__device__ __forceinline__ void h2_publish_max(uint32_t mx, float* slot) {
+  mx = wave_mag_max(mx);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)slot, mx);
 }
 
 // Tap loop of the EIGHT-wave per-sample workgroups (one workgroup per CU).  Measured with conv3_taps_ks at eight waves
@@ -1217,7 +1230,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 #pragma unroll
     for (int nt = 0; nt < C0N; ++nt) bv[nt] = b0[32 * (nt0 + nt) + l31];
     const int magic = (65536 + W - 1) / W;                // m / W == (m * magic) >> 16 for every m of the map (checked on the host)
-    float hmx = 0.f;
+    uint32_t hmx = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = pt * 32 + acc_row(r, lane);
@@ -1228,7 +1241,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         for (int nt = 0; nt < C0N; ++nt) {
           const float v = z[nt][r] + bv[nt];
           d[32 * nt] = v;
-          if constexpr (H2X) hmx = fmaxf(hmx, fabsf(v));
+          if constexpr (H2X) hmx = mag_max(hmx, v);
         }
       }
     }
@@ -1241,7 +1254,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     __syncthreads();                                      // the LUT (and the image) are complete
   } else if (MODE == 0) {
     const float* src = a.in + (long long)net * a.in_ns;
-    float hmx = 0.f;
+    uint32_t hmx = 0u;
     staged_copy<8, float4, NT>(S * HW * 16, tid,
         [&](int idx) {
           const int c4 = idx & 15, p = idx >> 4, s = fdiv(p, a.mg_hw), pix = p - s * HW, sample = s0 + s;
@@ -1252,13 +1265,13 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
         [&](int idx, float4 v) {
           const int c4 = idx & 15, p = idx >> 4, s = fdiv(p, a.mg_hw), pix = p - s * HW, h = fdiv(pix, a.mg_w), w = pix - h * W;
           *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
-          if constexpr (H2X) hmx = fmaxf(fmaxf(hmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          if constexpr (H2X) hmx = mag_max4(hmx, v);
         });
     if constexpr (H2X) h2_publish_max(hmx, smem + a.maxslot);
   } else if (dp_lds != nullptr) {
     // fused backward head (S == 1): the pooled gradient was produced by this workgroup and waits in LDS, the ReLU
     // mask words were fetched at kernel start; one (pooled pixel, 4 channels) item -> its 2x2 window
-    float hmx = 0.f;
+    uint32_t hmx = 0u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int idx = tid + NT * q;
@@ -1275,7 +1288,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
           v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
           const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
           *(float4*)(img + (size_t)((h + 1) * PW + w + 1) * CS + c4 * 4) = v;
-          if constexpr (H2X) hmx = fmaxf(fmaxf(hmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          if constexpr (H2X) hmx = mag_max4(hmx, v);
         }
       }
     }
@@ -1288,7 +1301,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
     const float* dp = a.in + (long long)net * a.in_ns;
     const uint8_t* mk = a.mask_in + (long long)net * a.mask_in_ns;
     struct DM { float4 d; uint32_t m; };
-    float hmx = 0.f;
+    uint32_t hmx = 0u;
     // one (pooled pixel, 4 channels) item feeds the 4 full-resolution positions of its 2x2 window
     staged_copy<8, DM, NT>(S * P2 * 16, tid,
         [&](int idx) {
@@ -1311,7 +1324,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
             v.w = ((r.m >> (24 + sub)) & 1u) ? r.d.w * 0.25f : 0.f;
             const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
             *(float4*)(img + (size_t)(s * IMG + (h + 1) * PW + w + 1) * CS + c4 * 4) = v;
-            if constexpr (H2X) hmx = fmaxf(fmaxf(hmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            if constexpr (H2X) hmx = mag_max4(hmx, v);
           }
         });
     if constexpr (H2X) h2_publish_max(hmx, smem + a.maxslot);
@@ -1326,7 +1339,7 @@ __device__ __forceinline__ void conv3_stage(const Conv3Args& a, float* smem, int
 // avgpool2 + ReLU-mask epilogue shared by the forward kernels (img holds relu(z) at the pixel centres)
 template <int NT = 256, bool STORE = true, bool STAT = false>
 __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3Ctx& c, float* img2 = nullptr, float* statslot = nullptr) {
-  float pmx = 0.f;
+  uint32_t pmx = 0u;
   float* out = STORE ? a.out + (long long)c.net * a.out_ns : nullptr;
   uint8_t* mo = STORE ? a.mask_out + (long long)c.net * a.mask_out_ns : nullptr;
   // one (pooled pixel, 4 channels) item per thread and pass: four ds_read_b128, one 16-B and one 4-B store
@@ -1346,7 +1359,7 @@ __device__ __forceinline__ void conv3_pool_store(const Conv3Args& a, const Conv3
       o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
       o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
       if constexpr (STORE) *(float4*)(out + g) = o;
-      if constexpr (STAT) pmx = fmaxf(fmaxf(pmx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      if constexpr (STAT) pmx = mag_max4(pmx, o);
       // fused tail: the pooled map also becomes the zero-bordered conv2 input image, in LDS
       if (img2 != nullptr) *(float4*)(img2 + (size_t)((ph + 1) * (c.W2 + 2) + pw + 1) * CS + c4 * 4) = o;
 #define CMLPL_NIB(A, B, C, D) ((uint32_t)((relu_open(A) ? 1 : 0) | (relu_open(B) ? 2 : 0) | (relu_open(C) ? 4 : 0) | (relu_open(D) ? 8 : 0)))
@@ -1805,7 +1818,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     const int c4 = tid & 15, pp = tid >> 4, ph = pp >> 1, pw = pp & 1;
     const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
     const uint32_t m = m2pre;
-    float zmx = 0.f;
+    uint32_t zmx = 0u;
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       float4 v;
@@ -1815,12 +1828,11 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
       v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
       const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
       *(float4*)(img2 + (size_t)((h + 1) * PW2 + w + 1) * CS + c4 * 4) = v;
-      zmx = fmaxf(fmaxf(zmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      zmx = mag_max4(zmx, v);
     }
     if (a.hstat != nullptr) {       // (wave 0 whole: the batch-level maximum of conv2's gradient operand, for its weight gradient)
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) zmx = fmaxf(zmx, __shfl_xor(zmx, o, 64));
-      if (tid == 0) a.hstat[(3 * 2 + net) * a.n + sample] = __float_as_uint(zmx);
+      zmx = wave_mag_max(zmx);
+      if (tid == 0) a.hstat[(3 * 2 + net) * a.n + sample] = zmx;
     }
   }
   __syncthreads();
@@ -2257,7 +2269,7 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
       for (int pc = 0; pc < 3; ++pc) bq[t0][3 * q + pc] = wq[(size_t)t0 * TAPW + (((kh2 * 2 + q) * 3 + pc) * 2 + nt) * 64];
   __syncthreads();                                                 // dp2s complete, img2 zeroed
   STAMP(1, 4);
-  float zmx = 0.f;
+  uint32_t zmx = 0u;
   if (tid < P4 * 16) {   // dz2 = mask2 * upsample(dp2) / 4: (pooled pixel, 4 channels) -> its 2x2 window
     const int c4 = tid & 15, pp = tid >> 4, ph = pp / W4, pw = pp - ph * W4;
     const float4 d = *(const float4*)(dp2s + pp * 64 + c4 * 4);
@@ -2271,7 +2283,7 @@ __device__ __forceinline__ const float* conv3_bwd_head_g(const Conv3Args& a, flo
       v.w = ((m >> (24 + sub)) & 1u) ? d.w * 0.25f : 0.f;
       const int h = 2 * ph + (sub >> 1), w = 2 * pw + (sub & 1);
       *(float4*)(img2 + (size_t)((h + 1) * PW2 + w + 1) * CS + c4 * 4) = v;
-      zmx = fmaxf(fmaxf(zmx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      zmx = mag_max4(zmx, v);
     }
   }
   // (two-piece weight gradient: this sample's largest |dz2| -- whole waves take part in the reduction; the second word of

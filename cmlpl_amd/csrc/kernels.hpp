@@ -216,6 +216,7 @@ struct Switches {
   int fuse_big;                                               // CMLPL_FUSE_BIG: 0 = windows of 129 .. 256 pixels on the general kernels (default 1: eight-tile per-sample kernels)
   int conv3_nw8;                                              // CMLPL_CONV3_NW8: 0 = the general 3x3 kernels always with four waves (default 1)
   int conv0a;                                                 // CMLPL_CONV0A: 0 = augment_kernel + conv0_fwd_kernel (f32 MFMA) on the general path (default 1: one fused split-bf16 launch)
+  int zero_skip;                                              // CMLPL_ZERO_SKIP: 0 = the two-piece weight gradients walk every sample (default 1: samples whose gradient operand is zero everywhere -- rows no loss term reaches -- are left out)
   int bwd_pair;                                               // CMLPL_BWD_PAIR: 0 = the fused backward's workgroup b of network 1 takes sample b (default 1: sample (b + n / 2) % n, see wg_decode in conv3x3.hip)
   int f16x2;                                                  // CMLPL_F16X2: 0 = conv1's tap loops of the four-tile per-sample kernels on three bf16 pieces like every other product (default 1: TWO fp16 pieces, three MFMAs per product, wherever the operands' ranges allow; 2 / 3: in the forward / the backward kernel only; 4: as 1, but an all-zero gradient image runs the loop instead of skipping it -- a measurement aid)
   int conv3_ks;                                               // CMLPL_CONV3_KS: 0 = the general 3x3 kernels always with LDS-staged tap weights (default 1: barrier-free loop at S = 1, one tile per wave)
@@ -232,7 +233,7 @@ inline Switches read_switches() {
     Switches w;
     w.fuse_conv0 = env("CMLPL_FUSE_CONV0", 1); w.fuse_conv0_bwd = env("CMLPL_FUSE_CONV0_BWD", 1);
     w.fuse_tail = env("CMLPL_FUSE_TAIL", 1); w.fuse_spe = env("CMLPL_FUSE_SPE", 1);
-    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1); w.conv3_nw8 = env("CMLPL_CONV3_NW8", 1); w.conv3_ks = env("CMLPL_CONV3_KS", 1); w.conv0a = env("CMLPL_CONV0A", 1); w.f16x2 = env("CMLPL_F16X2", 1); w.bwd_pair = env("CMLPL_BWD_PAIR", 1);
+    w.ks8 = env("CMLPL_KS8", -1); w.fuse_big = env("CMLPL_FUSE_BIG", 1); w.conv3_nw8 = env("CMLPL_CONV3_NW8", 1); w.conv3_ks = env("CMLPL_CONV3_KS", 1); w.conv0a = env("CMLPL_CONV0A", 1); w.f16x2 = env("CMLPL_F16X2", 1); w.bwd_pair = env("CMLPL_BWD_PAIR", 1); w.zero_skip = env("CMLPL_ZERO_SKIP", 1);
     w.conv3_s = env("CMLPL_CONV3_S", 0); w.conv0_dma = env("CMLPL_CONV0_DMA", 1); w.conv0_ps = env("CMLPL_CONV0_PS", 0);
     w.wgrad3_u = env("CMLPL_WGRAD3_U", 0); w.wgrad3_cspl = env("CMLPL_WGRAD3_CSPL", 0); w.wgrad3_r = env("CMLPL_WGRAD3_R", 1);
     w.wgrad3_ru = env("CMLPL_WGRAD3_RU", 0); w.wgrad3_rg = env("CMLPL_WGRAD3_RG", 0);

@@ -41,6 +41,10 @@ struct Wgrad3Args {
   // step (conv3x3.hip: Conv3Args::hstat, [2 networks][n]); the networks' weight-range flags (two-piece packing, kernels.hpp);
   // null = three-piece bf16 planes
   const uint32_t* stat_a; const uint32_t* stat_g; const uint32_t* h2flag; long long h2flag_ns;
+  // ... and for skipping the samples whose gradient operand is zero everywhere (stat_g word 0: a row no loss term reaches):
+  // byte offset of the LDS list of the other samples (behind the stage buffers; 0 = no room, nothing is skipped), x / UPS
+  // as a multiply
+  int slist_off; uint32_t mg_ups;
 };
 
 // CSPL = 1: one workgroup produces all 64 output channels (wave = (co tile, ci tile), 9 taps each).
@@ -520,9 +524,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
 // HP: both operands as TWO fp16 pieces of (value x its batch-level power-of-two scale) -- two planes each where the
 // three-piece scheme has three, three MFMAs per product where it has six, a 12-instruction split per four elements
 // where it has 22; the partial is multiplied by 1 / (sa sg) = `inv` (exact) when it is written.
-template <int CPR, bool HP = false>
+// CP: the units are those of the `nnz` samples listed in `slist` (ascending), dealt to the G workgroups in equal contiguous
+// shares: a sample whose gradient operand is zero everywhere contributes nothing and is not read.  An item's address is
+// then formed from its unit through the list, stage by stage, instead of being carried.
+template <int CPR, bool HP = false, bool CP = false>
 __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, const int net, const int kh, float* smem,
-                                             const float sa = 1.f, const float sg = 1.f, const float inv = 1.f) {
+                                             const float sa = 1.f, const float sg = 1.f, const float inv = 1.f,
+                                             const uint16_t* slist = nullptr, const int nnz = 0) {
   constexpr int NT = 512, U = wg3b_U(CPR), R = 2 * U, CO = 2 * CPR;
   constexpr int APOS = wg3b_apos(CPR), KP = wg3b_kp(CPR), NST = KP / 16;
   constexpr int NP = HP ? 2 : 3;                                   // pieces = planes per operand
@@ -536,9 +544,9 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   const int H = a.H, W = a.W, HW = H * W;
   const int H2 = H >> 1, W2 = W >> 1;
   const int UPS = H2;                       // units (pooled rows) per sample
-  const int NU = a.n * UPS;
-  const int UPG = a.UPG;
-  const int ubeg = g * UPG, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
+  const int NU = (CP ? nnz : a.n) * UPS;
+  const int UPG = CP ? ((NU + a.G - 1) / a.G + U - 1) / U * U : a.UPG;      // (CP: equal shares of what is left, whole stages)
+  const int ubeg = (g * UPG < NU) ? g * UPG : NU, uend = (ubeg + UPG < NU) ? ubeg + UPG : NU;
   STAMP(2, 0);
   {  // What staging never writes must read as zero, in both buffers and all three pieces: the activation halo
      // columns x = 0 and x >= W + 1, and the gradient rows of the k padding.  (Everything else is rewritten by every
@@ -567,6 +575,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   const int qU = U / UPS, rU = U - qU * UPS;
   const int dStep = (qU * HW + 2 * rU * W) * 64, dWrap = (HW - 2 * UPS * W) * 64;
   int a_u[NRA], a_dst[NRA], a_off[NRA], a_row[NRA], a_lim[NRA];
+  int a_ir[NRA], a_in[NRA];                 // CP: row of the item inside its unit's row pair (+ kernel row - 1), offset inside an image row
 #pragma unroll
   for (int q = 0; q < NRA; ++q) {
     const int t = tid + NT * q;
@@ -575,6 +584,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
     const bool ex = rho < R;
     const int ir = (rho & 1) + kh - 1;
     a_u[q] = ex ? (rho >> 1) : (1 << 28);
+    a_ir[q] = ir; a_in[q] = px * 64 + c4 * 4;
     a_dst[q] = plane_byte((px + 1) * R + (ex ? rho : 0), c4 * 4);
     const int smp = (ubeg + (rho >> 1)) / UPS, j = (ubeg + (rho >> 1)) - smp * UPS;
     a_row[q] = 2 * j + ir;                                 // image row of the item (-1 .. H: outside rows read as zero)
@@ -591,6 +601,7 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) d_dst[sub] = plane_byte((2 * pw + (sub & 1)) * R + 2 * u + (sub >> 1), c4 * 4);
     d_off = (ubeg + u) * (W2 * 64) + pw * 64 + c4 * 4;    // pooled rows of consecutive samples are consecutive: linear
+    if constexpr (CP) d_off = pw * 64 + c4 * 4;           // (the offset inside a pooled row; the row comes from the list)
   }
   float4 pa[NRA];
   float4 pdd = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -599,6 +610,25 @@ __device__ __forceinline__ void wgrad3b_body(const Wgrad3Args& a, const int g, c
   // fetch(ub): the global loads of the stage that begins at unit ub (in order: it advances the carried offsets)
   auto fetch = [&](int ub) {
     const int left = uend - ub;                          // units of this workgroup from ub on (uniform)
+    if constexpr (CP) {
+#pragma unroll
+      for (int q = 0; q < NRA; ++q) {
+        const bool in = a_u[q] < left;                     // (a_u of an item that does not exist is huge)
+        const int v = in ? ub + a_u[q] : 0;
+        const int si = (int)__umulhi((uint32_t)v, a.mg_ups), j = v - si * UPS;
+        const int smp = slist[si], row = 2 * j + a_ir[q];
+        const bool ok = in && (unsigned)row < (unsigned)H;
+        const float4 x = *(const float4*)(src + (ok ? (smp * HW + row * W) * 64 + a_in[q] : 0));
+        pa[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const bool ok = d_u < left;
+      const int v = ok ? ub + d_u : 0;
+      const int si = (int)__umulhi((uint32_t)v, a.mg_ups), j = v - si * UPS;
+      const int gi = ok ? ((int)slist[si] * UPS + j) * (W2 * 64) + d_off : 0;
+      pdd = *(const float4*)(dp + gi);
+      pdm = ok ? *(const uint32_t*)(mk + gi) : 0u;
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NRA; ++q) {
       const bool ok = a_u[q] < left && (unsigned)a_row[q] < (unsigned)H;      // (a_u of an item that does not exist is huge)
@@ -797,6 +827,31 @@ __device__ __forceinline__ void wgrad3b_run(const Wgrad3Args& a, const int g, co
       // scales 2^(14 - floor(log2 max)): the largest magnitude of either operand lands in [2^14, 2^15)
       const float sa = __uint_as_float((268u - ea) << 23), sg = __uint_as_float((268u - eg) << 23);
       const float inv = __uint_as_float((ea + eg - 155u) << 23);
+      if (a.slist_off > 0) {
+        // the samples with a non-zero gradient operand, in ascending order (a ballot prefix per wave, the waves' counts
+        // through LDS): when some are missing, only these are walked
+        uint16_t* slist = (uint16_t*)((char*)smem + a.slist_off);
+        int* wcnt = (int*)smem + 4;
+        const int lane = tid & 63, wave = tid >> 6;
+        int nnz = 0;
+        for (int i0 = 0; i0 < a.n; i0 += 512) {
+          const int i = i0 + tid;
+          const bool nzf = i < a.n && a.stat_g[(long long)net * a.n + i] != 0u;
+          const unsigned long long bal = __ballot(nzf);
+          if (lane == 0) wcnt[wave] = __popcll(bal);
+          __syncthreads();
+          int woff = 0, tot = 0;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) { const int c = wcnt[w]; woff += (w < wave) ? c : 0; tot += c; }
+          if (nzf) slist[nnz + woff + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+          nnz += tot;
+          __syncthreads();
+        }
+        if (nnz < a.n) {
+          wgrad3b_body<CPR, true, true>(a, g, net, kh, smem, sa, sg, inv, slist, nnz);
+          return;
+        }
+      }
       wgrad3b_body<CPR, true>(a, g, net, kh, smem, sa, sg, inv);
       return;
     }
@@ -944,7 +999,7 @@ hipError_t launch_wgrad3(int nets, int n, int H, int W, const float* in, const f
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G; a.UPG = pl.UPG;
-  a.stat_a = nullptr; a.stat_g = nullptr; a.h2flag = nullptr; a.h2flag_ns = 0;
+  a.stat_a = nullptr; a.stat_g = nullptr; a.h2flag = nullptr; a.h2flag_ns = 0; a.slist_off = 0; a.mg_ups = 0;
   if (pl.rsplit && pl.b3) {
 #define WG3B_CASE(CPR_)                                                                              \
     case CPR_: {                                                                                     \
@@ -988,7 +1043,7 @@ static void wgrad3_args(Wgrad3Args& a, const Wgrad3Plan& pl, int n, int H, int W
   a.dpool_ns = (long long)n * (H / 2) * (W / 2) * 64;
   a.part_ns = (long long)pl.G * PART3;
   a.n = n; a.H = H; a.W = W; a.RU = pl.RU; a.U = pl.U; a.G = pl.G; a.UPG = pl.UPG;
-  a.stat_a = nullptr; a.stat_g = nullptr; a.h2flag = nullptr; a.h2flag_ns = 0;
+  a.stat_a = nullptr; a.stat_g = nullptr; a.h2flag = nullptr; a.h2flag_ns = 0; a.slist_off = 0; a.mg_ups = 0;
 }
 
 // Plans of both 3x3 weight gradients of a backward pass.  *pair: one launch (wgrad3b_pair_kernel) -- then the two plans
@@ -1030,7 +1085,16 @@ hipError_t launch_wgrad3_pair(int nets, int n, int H1, int W1, const float* in1,
       a.stat_a = hstat + 0 * 2 * n; a.stat_g = hstat + 2 * 2 * n; b.stat_a = hstat + 1 * 2 * n; b.stat_g = hstat + 3 * 2 * n;
       a.h2flag = b.h2flag = h2flag; a.h2flag_ns = b.h2flag_ns = h2flag_ns;
     }
-    const size_t lds = p1.lds > p2.lds ? p1.lds : p2.lds;
+    size_t lds = p1.lds > p2.lds ? p1.lds : p2.lds;
+    // room for the list of samples with a non-zero gradient operand behind the stage buffers: zero samples are skipped
+    // (CMLPL_ZERO_SKIP=0: never)
+    const size_t lbytes = ((size_t)2 * n + 15) & ~(size_t)15;
+    if (hstat != nullptr && switches().zero_skip != 0 && n <= 65535 && H1 / 2 >= 2 && H2 / 2 >= 2 && lds + lbytes <= LDS_MAX) {
+      a.slist_off = b.slist_off = (int)lds;
+      a.mg_ups = (uint32_t)((0x100000000ULL + (uint32_t)(H1 / 2) - 1) / (uint32_t)(H1 / 2));
+      b.mg_ups = (uint32_t)((0x100000000ULL + (uint32_t)(H2 / 2) - 1) / (uint32_t)(H2 / 2));
+      lds += lbytes;
+    }
     const dim3 grid((p1.G + p2.G) * nets * 3);
 #define WG3P_CASE(CA_, CB_)                                                                          \
     if (p1.rsplit == CA_ && p2.rsplit == CB_) {                                                      \

@@ -311,7 +311,9 @@ def test_eight_rank_baseline_configs_match_the_oracle(cfg):
         for r, e in enumerate(engines):      # every rank's masks sit on the oracle's signs (its own rows)
             rows = list(range(r * bt_l, (r + 1) * bt_l)) + list(range(bt + r * btu_l, bt + (r + 1) * btu_l))
             taps = [{k: v[rows] for k, v in ref["taps"][net].items()} for net in range(2)]
-            relu_mask_audit(e, taps, shape, bt_l + btu_l)
+            # (after s Adam updates the boundary widens as in tests/test_gpu_step.py: a weight with an eps-sized gradient may
+            #  sit O(lr) away from the oracle's)
+            relu_mask_audit(e, taps, shape, bt_l + btu_l, ztol=2e-5 + 0.1 * hp.lr * s, ztol_y=2e-5 + 0.25 * hp.lr * s)
         for net in range(2):
             for k in O.LIVE_KEYS:
                 gr = ref["grads"][net][k]

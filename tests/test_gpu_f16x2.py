@@ -16,12 +16,14 @@ DEV = "cuda:0"
 SHAPES = {"B2": O.NetShape(103, 11, 11, 103, 9), "B4": O.NetShape(200, 11, 11, 200, 16)}
 
 
-def _run(shape, params, bt, btu, scale=1.0, steps=1, lr=None, f16x2="1", noise=None):
+def _run(shape, params, bt, btu, scale=1.0, steps=1, lr=None, f16x2="1", noise=None, env=None):
     """`steps` training steps from `params` (both networks) under CMLPL_F16X2 = f16x2 -> (logits, grads, packed flag words)"""
     from cmlpl_amd import HyperParams, NetShape, TrainEngine, _lib
     lib = _lib.load()
     old = os.environ.get("CMLPL_F16X2")
     os.environ["CMLPL_F16X2"] = f16x2
+    old_env = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
     lib.cmlpl_debug_reload_switches()
     try:
         hp = HyperParams(**{k: v for k, v in (("lr", lr), ("noise", noise)) if v is not None})
@@ -45,6 +47,11 @@ def _run(shape, params, bt, btu, scale=1.0, steps=1, lr=None, f16x2="1", noise=N
             os.environ.pop("CMLPL_F16X2", None)
         else:
             os.environ["CMLPL_F16X2"] = old
+        for k, v in old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         lib.cmlpl_debug_reload_switches()
 
 
@@ -156,3 +163,19 @@ def test_general_path_two_piece_loops_run_and_stay_at_fp32_level():
     assert not torch.equal(lo1, lo0) and not torch.equal(g1, g0), "the two-piece loops did not run"
     assert (lo1 - lo0).abs().max() <= 4e-6 * lo0.abs().max(), ((lo1 - lo0).abs().max(), lo0.abs().max())
     assert (g1 - g0).abs().max() <= 4e-6 * g0.abs().max(), ((g1 - g0).abs().max(), g0.abs().max())
+
+
+@pytest.mark.parametrize("name", ["B2", "P"])
+def test_weight_gradients_skip_samples_without_gradient(name):
+    """At the default threshold no unlabelled row of a freshly initialised pair of networks is confident (train.py:221):
+    their gradient images are zero everywhere and the two-piece weight-gradient launch leaves those samples out
+    (CMLPL_ZERO_SKIP=0: walks them) -- the same sums, grouped differently: equal to fp32 rounding; so do the fused
+    backward's workgroup pairing (CMLPL_BWD_PAIR) and zero-image skip."""
+    shape = SHAPES[name] if name in SHAPES else O.NetShape(60, 20, 20, 103, 9)
+    params = O.closed_form_params(shape, 9)
+    lo1, g1, _ = _run(shape, params, 24, 40)
+    lo0, g0, _ = _run(shape, params, 24, 40, env={"CMLPL_ZERO_SKIP": "0", "CMLPL_BWD_PAIR": "0"})
+    assert torch.equal(lo1, lo0)                              # (the forward is not touched)
+    assert (g1 - g0).abs().max() <= 2e-6 * g0.abs().max(), ((g1 - g0).abs().max(), g0.abs().max())
+    if name == "B2":
+        assert not torch.equal(g1, g0), "no sample was skipped: were the unlabelled rows confident?"

@@ -1832,10 +1832,14 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     }
     if (a.hstat != nullptr) {       // (wave 0 whole: the batch-level maximum of conv2's gradient operand, for its weight gradient)
       zmx = wave_mag_max(zmx);
-      if (tid == 0) a.hstat[(3 * 2 + net) * a.n + sample] = zmx;
+      if (tid == 0) { a.hstat[(3 * 2 + net) * a.n + sample] = zmx; ((uint32_t*)smem)[a.maxslot + 1] = zmx; }
     }
   }
   __syncthreads();
+  // a gradient image that is zero everywhere (a row no loss term reaches through the convolutions) meets finite weights
+  // (range flag clear): conv2's data gradient is zero -- its MFMA loop is skipped, the epilogue writes the zeros
+  const bool z2skip = a.hstat != nullptr && a.h2_noskip == 0 && ((const volatile uint32_t*)smem)[a.maxslot + 1] == 0u &&
+                      a.h2flag[(long long)net * a.h2flag_ns] == 0u;
   STAMP(1, 5);
   // ---- conv2 data gradient, split-bf16 on the 32x32x16 MFMA: the P2 <= 32 output pixels are ONE tile (row p = l31,
   // rows >= P2 read the zero corner); this wave multiplies its half of the input channels of every tap into its
@@ -1859,6 +1863,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
   };
   ASplit cur;
   float4 rn0, rn1;
+  if (!z2skip) {
   {
     const float* p0 = raw_ptr(0);
     a_split(*(const float4*)p0, *(const float4*)(p0 + 4), cur.p1, cur.p2, cur.p3);
@@ -1889,6 +1894,7 @@ __device__ __forceinline__ const float* conv3_bwd_head(const Conv3Args& a, float
     if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     SchedInterleave<6>::run();                             // (6 VALU, 1 MFMA) x 6; the rest of the split behind them
     cur = nxt; rn0 = rnn0; rn1 = rnn1;
+  }
   }
   STAMP(1, 6);
   // ---- fold the two channel halves through LDS (the dz2 image region, once every wave is done reading it) and
@@ -2653,8 +2659,11 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
     float* dal = smem + (C < BP ? C : BP) * HW;           // [HW + 1][64]
     const int Cw = conv0_partial_rows(C);                 // rows of the partial (kernels.hpp)
     float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Cw * 64 + 64);
+    // a sample whose gradient image was zero everywhere (hzero) has da0 = 0: its partial is zero -- neither the slab nor
+    // the MFMAs are needed, the stores below write the zeros
+    const bool zskip = H2X && hzero && a.h2_noskip == 0;
     SlabRange rg = slab_range(a.xs, net, s0, C * HW, 0, (C < BP ? C : BP) * HW);
-    slab_issue<NW>(rg, slab, wave, lane);                 // the forward's input again (first pass)
+    if (!zskip) slab_issue<NW>(rg, slab, wave, lane);     // the forward's input again (first pass)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = ot * 32 + acc_row(r, lane);
@@ -2675,9 +2684,9 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
       if (cb > 0) {
         __syncthreads();                                  // every wave is done reading the previous pass's rows
         rg = slab_range(a.xs, net, s0, C * HW, (cb * HW) >> 2, nb * HW);   // (BP * HW is a multiple of 4)
-        slab_issue<NW>(rg, slab, wave, lane);
+        if (!zskip) slab_issue<NW>(rg, slab, wave, lane);
       }
-      slab_tail(rg, slab, tid);
+      if (!zskip) slab_tail(rg, slab, tid);
       if (cb == 0) STAMP(1, 13);
       __syncthreads();                                    // range landed (the barrier waits for the DMA), da0 complete
       // dW0 tile of this wave on the split-bf16 MFMA: k-steps of 16 pixels; lane (row = band c, half h) takes pixels
@@ -2708,7 +2717,7 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
             const float* bp = dal + 32 * cn0 + l31;
 #pragma unroll 1
             for (int kq = kq0; kq < NS; kq += kqs) {        // (rolled: three variants of sixteen unrolled k-steps spilled addresses)
-              {
+              if (!zskip) {
                 float ra[8], rb[NCT][8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -2779,7 +2788,7 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
         const int NS = (HWl + 15) >> 4;
 #pragma unroll
         for (int kq = 0; kq < 2 * KMT; ++kq) {            // HW <= 32 KMT (conv3_fused_bwd_ok)
-          if (kq < NS) {                                  // uniform
+          if (kq < NS && !zskip) {                        // uniform
             float ra[8], rb[TPW][8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -3008,7 +3017,7 @@ hipError_t launch_conv3(int mode, int nets, int n, int H, int W, const float* in
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = 0; a.xn_out = nullptr;
   a.xs = XSrc(); a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4 || switches().zero_skip == 0; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
   dim3 grid((n + pl.S - 1) / pl.S, nets);
   // the two-piece tap loops (one sample per workgroup: the barrier-free loop, or eight waves with staged tap weights)
   const bool h2x = h2 != nullptr && conv3_h2x_general(mode, H, W, nets * n);
@@ -3169,7 +3178,7 @@ hipError_t launch_conv3_fused(int nets, int n, int C, int H, int W, const XSrc& 
   conv3_set_magics(a);
   a.w0t = w0t; a.w0t_ns = w0t_ns; a.b0 = b0; a.b0_ns = b0_ns; a.a0out = a0out; a.C = C; a.xn_out = xn_out;
   a.xs = xs; a.part0 = nullptr; a.part0_ns = 0; a.bp = 0;
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4 || switches().zero_skip == 0; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
   (void)HW;
   if (tail != nullptr) {
     if (!conv3_fused_tail_ok(H, W, C, nets * n, tail->K)) return hipErrorInvalidValue;
@@ -3341,7 +3350,7 @@ hipError_t launch_conv3_fused_bwd(int nets, int n, int C, int H, int W, const fl
   conv3_set_magics(a);
   a.w0t = nullptr; a.b0 = nullptr; a.a0out = nullptr; a.w0t_ns = a.b0_ns = 0; a.C = C; a.xn_out = nullptr;
   a.xs = xs; a.part0 = part0; a.part0_ns = part0_ns; a.bp = big ? conv3_big_bp(bg, C) : conv3_bwd_bp(H, W, C);
-  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
+  a.wpk16 = nullptr; a.wpk16_ns = 0; a.h2flag = nullptr; a.h2flag_ns = 0; a.maxslot = 0; a.h2_noskip = switches().f16x2 == 4 || switches().zero_skip == 0; a.hstat = nullptr; a.hkind = 0; a.pairshift = 0;
   if (head != nullptr) {
     if (!conv3_fused_head_ok(H, W, C, nets * n, head->K)) return hipErrorInvalidValue;
     a.dlogits = head->dlogits; a.dfeat = head->dfeat; a.hmask = head->mask; a.wc = head->wc; a.p_ns = head->p_ns;

@@ -216,7 +216,7 @@ struct Switches {
   int fuse_big;                                               // CMLPL_FUSE_BIG: 0 = windows of 129 .. 256 pixels on the general kernels (default 1: eight-tile per-sample kernels)
   int conv3_nw8;                                              // CMLPL_CONV3_NW8: 0 = the general 3x3 kernels always with four waves (default 1)
   int conv0a;                                                 // CMLPL_CONV0A: 0 = augment_kernel + conv0_fwd_kernel (f32 MFMA) on the general path (default 1: one fused split-bf16 launch)
-  int zero_skip;                                              // CMLPL_ZERO_SKIP: 0 = the two-piece weight gradients walk every sample (default 1: samples whose gradient operand is zero everywhere -- rows no loss term reaches -- are left out)
+  int zero_skip;                                              // CMLPL_ZERO_SKIP: 0 = nothing is skipped (default 1: a sample whose gradient image is zero everywhere -- a row no loss term reaches through the convolutions -- skips conv2's / conv1's data-gradient loops and conv0's weight gradient in the fused backward and is left out of the two-piece weight gradients: exact)
   int bwd_pair;                                               // CMLPL_BWD_PAIR: 0 = the fused backward's workgroup b of network 1 takes sample b (default 1: sample (b + n / 2) % n, see wg_decode in conv3x3.hip)
   int f16x2;                                                  // CMLPL_F16X2: 0 = conv1's tap loops of the four-tile per-sample kernels on three bf16 pieces like every other product (default 1: TWO fp16 pieces, three MFMAs per product, wherever the operands' ranges allow; 2 / 3: in the forward / the backward kernel only; 4: as 1, but an all-zero gradient image runs the loop instead of skipping it -- a measurement aid)
   int conv3_ks;                                               // CMLPL_CONV3_KS: 0 = the general 3x3 kernels always with LDS-staged tap weights (default 1: barrier-free loop at S = 1, one tile per wave)

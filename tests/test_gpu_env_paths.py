@@ -81,7 +81,7 @@ WIDE = [("0", "0"), ("4", "1"), ("4", "2"), ("4", "3"), ("4", "4"), ("2", "2")]
 J_WIDE = {(mb, nbw): _job("pair", f"wide-{mb}-{nbw}", {"CMLPL_PAIR_WIDE": "1", "CMLPL_PAIR_MB": mb, "CMLPL_PAIR_NBW": nbw},
                           ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "tests/test_gpu_step.py", "-k",
                            "loss_block or sharded_step_equals or (eight_rank and B3) or b2_b256" if (mb, nbw) == ("0", "0")
-                           else "loss_block or sharded_step_equals" if (mb, nbw) in (("4", "1"), ("4", "2"))
+                           else "loss_block or (sharded_step_equals and (8-B2 or 4-B2 or 2-P))" if (mb, nbw) in (("4", "1"), ("4", "2"))
                            else "loss_block or (sharded_step_equals and (8-B2 or 4-B2))"])
           for mb, nbw in WIDE}
 
@@ -93,7 +93,8 @@ def test_wide_pair_exp_kernel_passes_loss_parity(mb, nbw):
     _run(J_WIDE[(mb, nbw)])
 
 
-J_DFEAT = _job("pair", "dfeat-direct", {"CMLPL_DFEAT_LDS": "0"}, _PAIR_SEL)
+J_DFEAT = _job("pair", "dfeat-direct", {"CMLPL_DFEAT_LDS": "0"},
+               ["tests/test_gpu_ops.py", "tests/test_gpu_distributed.py", "-k", "loss_block or sharded_step_equals"])
 
 
 def test_direct_load_feature_gradient_gemms_pass_loss_parity():
@@ -111,7 +112,8 @@ def test_32_row_pair_exp_kernel_passes_loss_parity():
 
 
 J_NTX = [_job("next", "ntx-vector", {"CMLPL_NTX_MFMA": "0"}, ["tests/test_ntxent.py", "-k", "not (512-1024 or 256-1024)"])] + [
-    _job("next", f"ntx-ncw{ncw}", {"CMLPL_NTX_NCW": ncw}, ["tests/test_ntxent.py", "-k", "512-1024 or 300-516 or 150-300 or 32-128"])
+    _job("next", f"ntx-ncw{ncw}", {"CMLPL_NTX_NCW": ncw},
+         ["tests/test_ntxent.py", "-k", ("512-1024 or " if ncw == "4" else "") + "300-516 or 150-300 or 32-128"])
     for ncw in ("1", "2", "4")]
 
 
@@ -147,14 +149,16 @@ def test_one_workgroup_unsupervised_loss_up_to_8192_rows():
     _run(J_UNSUP_1)
 
 
-J_WG_GEN = _job("conv", "wgrad-general", {"CMLPL_WGRAD3_R": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
+J_WG_GEN = _job("conv", "wgrad-general", {"CMLPL_WGRAD3_R": "0"},
+                ["tests/test_gpu_ops.py", "-k", "forward_backward and not (W12 or W16 or B4 or B5)"])
 
 
 def test_general_wgrad_fallback_passes_backward_parity():
     _run(J_WG_GEN)
 
 
-J_WG_F32 = _job("conv", "wgrad-f32", {"CMLPL_WGRAD3_B3": "0"}, ["tests/test_gpu_ops.py", "-k", "forward_backward"])
+J_WG_F32 = _job("conv", "wgrad-f32", {"CMLPL_WGRAD3_B3": "0"},
+                ["tests/test_gpu_ops.py", "-k", "forward_backward and (B2 or B4 or P or W8 or W13 or W18)"])
 
 
 def test_f32_mfma_row_split_wgrad_passes_backward_parity():

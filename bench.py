@@ -459,10 +459,12 @@ def run_rank(args):
              "traffic": traffic.get(k)}
             for k in CONV1_KERNELS if k != dom_name],
         "final_losses": {k: scal[k] for k in ("total_s", "total_w", "cls_s", "ctr_s", "con_s")},
-        # The fused backward skips conv1's tap loop for a sample whose gradient image is zero everywhere (exact: zeros
-        # times finite weights) -- an unlabelled row no loss term reaches through the convolutions, i.e. one under the
-        # confidence threshold (train.py:221).  How many of the last step's unlabelled rows were ABOVE it, per network:
-        # (btu - that) x 2 workgroups of the backward launch skipped; CMLPL_F16X2=4 measures without skipping.
+        # A sample whose gradient image is zero everywhere -- an unlabelled row no loss term reaches through the
+        # convolutions, i.e. one under the confidence threshold (train.py:221: 0.999 in the first epochs) -- skips its
+        # data-gradient loops and conv0 weight gradient in the fused backward and is left out of the weight-gradient
+        # launch (exact: zeros times finite operands).  How many of the last step's unlabelled rows were ABOVE the
+        # threshold, per network: the others were skipped.  CMLPL_ZERO_SKIP=0 measures with nothing skipped; the
+        # algorithmic FLOPs of the backward / weight-gradient lines in roofline_others count the skipped rows as done.
         "backward_zero_images": {"unlabelled_rows": btu * world, "confident_s": scal["n_mask_s"], "confident_w": scal["n_mask_w"]},
         # did the container's CPU quota freeze this process inside the timed region?  (a throttled period stops every
         # thread for up to a CFS period, ~100 ms: profiles/r06_stall_rootcause.txt)  null where cpu.stat is not readable

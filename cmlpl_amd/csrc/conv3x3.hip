@@ -2661,7 +2661,12 @@ __global__ __launch_bounds__(64 * NW, ((MODE >= 2 || KSG) && NW == 4 ? 2 : 1)) v
     float* pp = a.part0 + (long long)net * a.part0_ns + (size_t)s0 * ((size_t)Cw * 64 + 64);
     // a sample whose gradient image was zero everywhere (hzero) has da0 = 0: its partial is zero -- neither the slab nor
     // the MFMAs are needed, the stores below write the zeros
-    const bool zskip = H2X && hzero && a.h2_noskip == 0;
+    // (not when the sample's activations were not finite -- the forward left their largest magnitude: 0 times a
+    //  non-finite input is NaN in fp32, and stays so)
+    bool zskip = false;
+    if constexpr (H2X) {
+      if (a.hstat != nullptr) zskip = hzero && a.h2_noskip == 0 && (a.hstat[(0 * 2 + net) * a.n + s0] >> 23) < 255u;
+    }
     SlabRange rg = slab_range(a.xs, net, s0, C * HW, 0, (C < BP ? C : BP) * HW);
     if (!zskip) slab_issue<NW>(rg, slab, wave, lane);     // the forward's input again (first pass)
 #pragma unroll

@@ -836,7 +836,8 @@ __device__ __forceinline__ void wgrad3b_run(const Wgrad3Args& a, const int g, co
         int nnz = 0;
         for (int i0 = 0; i0 < a.n; i0 += 512) {
           const int i = i0 + tid;
-          const bool nzf = i < a.n && a.stat_g[(long long)net * a.n + i] != 0u;
+          // (a sample with a zero gradient operand stays in when its activations were not finite: 0 x inf is NaN)
+          const bool nzf = i < a.n && (a.stat_g[(long long)net * a.n + i] != 0u || (a.stat_a[(long long)net * a.n + i] >> 23) == 255u);
           const unsigned long long bal = __ballot(nzf);
           if (lane == 0) wcnt[wave] = __popcll(bal);
           __syncthreads();

@@ -411,6 +411,8 @@ def run_rank(args):
         # leave the operands' maxima it scales by
         if wgrad_split and (tp & 4):
             kseg["conv1_wgrad"] = {"split2": kseg["conv1_wgrad"]["split"]}
+        labels["conv1_wgrad"] = ("wgrad3b_pair_kernel (conv1 + conv2 weight gradients in one launch, both networks" +
+                                 (", two-piece fp16 planes)" if wgrad_split and (tp & 4) else ")"))
     kflops = {k: sum(v.values()) for k, v in kseg.items()}
     kpeak = {k: blended_peak(v) for k, v in kseg.items()}
     traffic, traffic_src = recorded_traffic(args.workload, n_local)

@@ -454,7 +454,8 @@ int bwd_core(const Dims& d, const cmlpl_layout_t& L, int nets, int n, const floa
       const Conv3H2 h1 = {d_packed + pack_off_h2(d.C, d.bands, 1), L.packed_total, h2flag, gen_stats ? w.hstat : nullptr, 2};
       if ((rc = TIMED(CMLPL_K_CONV1_DGRAD, chk(launch_conv3(1, nets, n, d.H, d.W, w.dp1, w.m1, d_packed + pack_off_b3(d.C, d.bands, 1),
                                  L.packed_total, nullptr, 0, w.da0, nullptr, st, &h1))))) return rc;
-      if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st)))))
+      if ((rc = TIMED(CMLPL_K_CONV0_WGRAD, chk(launch_conv0_wgrad(nets, n, d.C, d.HW, d_xn, w.da0, w.part0, st, gen_stats ? w.hstat : nullptr, h2flag,
+                                                                         L.packed_total)))))
         return rc;
     }
     bool merged = false;

@@ -250,10 +250,14 @@ typedef __attribute__((address_space(1))) const void c0_gbl_void;
 // PS > 1 (no DMA): a sample's pixels are walked in PS equal ranges, one slab of [Ct][HW / PS] at a time -- the 20 x 20
 // window's whole slab is 103 KB, i.e. ONE workgroup per CU whose staging and MFMA phases cannot overlap with anything;
 // half slabs let three workgroups share a CU.
+// zstat (or null): the step's per-sample maxima table ([kind][2][n]: conv3x3.hip Conv3Args::hstat) + the networks' weight
+// range flags: a sample whose conv1 gradient image was zero everywhere (a row no loss term reaches) has da0 = 0 -- it is not
+// walked (unless its activations were not finite, or the weights were: 0 x inf stays NaN).
 template <bool DMA>
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ xn, const float* __restrict__ da0,
                                                           float* __restrict__ part, int n, int C, int HWfull, int G,
-                                                          int PS) {
+                                                          int PS, const uint32_t* __restrict__ zstat,
+                                                          const uint32_t* __restrict__ h2flag, long long h2flag_ns) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // xs[Ct][HWp] (+ 64 zero floats)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,8 +277,10 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   for (int i = (DMA ? C * HW : 0) + tid; i < Ct * HWp + 64; i += 256) smem[i] = 0.f;
   const int pairs = (HW + 1) >> 1;
 
+  const bool zflag = zstat != nullptr && h2flag[(long long)net * h2flag_ns] == 0u;
   for (int su = sbeg * PS; su < send * PS; ++su) {
     const int s = su / PS, p0 = (su - s * PS) * HW;              // sample, first pixel of this slab
+    if (zflag && zstat[(2 * 2 + net) * n + s] == 0u && (zstat[(0 * 2 + net) * n + s] >> 23) < 255u) continue;   // (uniform)
     const float* brow = da0 + (((long long)net * n + s) * HWfull + p0) * 64 + ct * 32 + l31;
     float bq[4][C0_PB];             // ring of four batches: three requested ahead of the one being multiplied
     auto fetch = [&](float (&buf)[C0_PB], int t0) {
@@ -477,7 +483,8 @@ int plan_conv0_wgrad_G(int n, int C, int HW) {
 }
 
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
-                              hipStream_t st) {
+                              hipStream_t st, const uint32_t* zstat, const uint32_t* h2flag, long long h2flag_ns) {
+  if (switches().zero_skip == 0 || h2flag == nullptr) zstat = nullptr;
   const int NT = (C + 31) / 32, Ct = NT * 32;
   if (NT > 2 * C0_MAXT) return hipErrorInvalidValue;
   const bool dma_off = switches().conv0_dma == 0;
@@ -496,8 +503,8 @@ hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, c
     if (e != hipSuccess) return e;
   }
   const int G = plan_conv0_wgrad_G(n, C, HW);
-  if (dma) hipLaunchKernelGGL(conv0_wgrad_kernel<true>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G, 1);
-  else     hipLaunchKernelGGL(conv0_wgrad_kernel<false>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G, PS);
+  if (dma) hipLaunchKernelGGL(conv0_wgrad_kernel<true>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G, 1, zstat, h2flag, h2flag_ns);
+  else     hipLaunchKernelGGL(conv0_wgrad_kernel<false>, dim3(G, nets), dim3(256), lds, st, xn, da0, part, n, C, HW, G, PS, zstat, h2flag, h2flag_ns);
   return hipGetLastError();
 }
 

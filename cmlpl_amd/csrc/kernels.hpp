@@ -169,7 +169,8 @@ hipError_t launch_reduce_gemm(int nets, const ReduceTable& t, const GemmTN& g0, 
 __host__ __device__ inline int conv0_partial_rows(int C) { return (C + 3) & ~3; }
 int conv0_partial_size(int C);
 hipError_t launch_conv0_wgrad(int nets, int n, int C, int HW, const float* xn, const float* da0, float* part,
-                              hipStream_t st);
+                              hipStream_t st, const uint32_t* zstat = nullptr /* per-sample maxima table: zero-gradient rows are not walked */,
+                              const uint32_t* h2flag = nullptr, long long h2flag_ns = 0);
 
 // ---- dense.hip
 bool spe_fused_ok(int bands);

@@ -153,8 +153,9 @@ class RcclComm:
         sharded step as ONE C call -- issues its four collectives through.  ``async_exchanges``: the embedding all-gather
         and the column-gradient reduce-scatter on the side stream, under the convolutions (a fork + join costs the step's
         stream ~10 us on this runtime whatever is forked: profiles/r06_event_hop_probe.txt -- it pays when the exchange
-        itself takes longer than that on the wire); False: all four in order on the step's stream.  Default
-        (CMLPL_DIST_ASYNC=0/1 overrides): asynchronous when there is a wire, in order at world size 1."""
+        itself takes longer than that on the wire -- at 8 GPUs the embedding all-gather should gain ~10 us, the reduce-scatter
+        nothing: never measured, this pool has one GPU per box); False: all four in order on the step's stream, ONE stream for
+        the communicator as torch.distributed itself uses it.  Default: in order; CMLPL_DIST_ASYNC=1 forks the two."""
         if self._native is None:
             from . import _lib
             rec = _lib.Collectives()
@@ -165,7 +166,7 @@ class RcclComm:
             self._native_inorder.side_stream = None
         if async_exchanges is None:
             env = os.environ.get("CMLPL_DIST_ASYNC")
-            async_exchanges = (self.world > 1) if env is None else env != "0"
+            async_exchanges = env is not None and env != "0"
         return self._native if async_exchanges else self._native_inorder
 
     def close(self):
